@@ -1,0 +1,218 @@
+/*
+ * mmf_hip.h -- C ABI of the MI355X (gfx950) dense-tracking hot path of MultiMotionFusion.
+ *
+ * This is the drop-in boundary: plain C, raw device/host pointers and sizes, no C++ / torch /
+ * Eigen / OpenCV types.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference tree).  The C++ shim classes with the reference's own
+ * names (multimotionfusion_amd/cpp/) and the Python ctypes mirror
+ * (multimotionfusion_amd/_capi.py) are thin forwards onto this header.
+ *
+ * Conventions
+ *   - every `*_dev` / "device" pointer is HBM memory of the context's device; everything else
+ *     is host memory.  2-D images are passed as (pointer, step_bytes) like the reference's
+ *     DeviceArray2D / PtrStep (Core/Cuda/containers/kernel_containers.hpp:48-91); step 0
+ *     means dense (step = cols * sizeof(element)).
+ *   - vertex / normal maps are planar float32 [3*rows][cols] (x plane, y plane, z plane;
+ *     Core/Cuda/reduce.cu:261-263), invalid = NaN in the x plane.
+ *   - 3x3 matrices are row major float[9] (types.cuh:61-73), poses row major float[16].
+ *   - all work is enqueued on the context's stream; functions that return results in host
+ *     memory synchronise that stream before returning (the reference's *Step functions do the
+ *     same, reduce.cu:452-456); the others are asynchronous on the stream -- call
+ *     mmf_ctx_synchronize() (the reference relies on the default stream's ordering).
+ *   - return value: MMF_OK (0) or a negative mmf_status; mmf_last_error() gives the message for
+ *     the calling thread.  (The reference prints and exit(-1)s, convenience.cuh:74-83; the C++
+ *     shims reproduce that on a non-zero status.)
+ */
+#ifndef MMF_HIP_H_
+#define MMF_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMF_ABI_VERSION 1
+
+typedef enum {
+    MMF_OK = 0,
+    MMF_ERR_INVALID = -1, /* bad argument (null pointer, size, alignment) */
+    MMF_ERR_HIP = -2,     /* a HIP runtime call failed                     */
+    MMF_ERR_NO_DEVICE = -3,
+    MMF_ERR_STATE = -4 /* call order violated (e.g. initRGB before initICP) */
+} mmf_status;
+
+typedef struct mmf_ctx mmf_ctx;   /* device + stream + reduction scratch              */
+typedef struct mmf_odom mmf_odom; /* replaces class RGBDOdometry (RGBDOdometry.h:31)  */
+
+/* types.cuh:75-81 (DataTerm), 16 bytes */
+typedef struct {
+    int16_t zero_x, zero_y;
+    int16_t one_x, one_y;
+    float diff;
+    uint8_t valid;
+    uint8_t pad_[3];
+} mmf_dataterm;
+
+/* types.cuh:83-99 (CameraModel) */
+typedef struct {
+    float fx, fy, cx, cy;
+} mmf_camera;
+
+int mmf_abi_version(void);
+const char *mmf_last_error(void);
+
+/* `stream` is a hipStream_t to run on (e.g. the caller's), or NULL to create a private one. */
+int mmf_ctx_create(int device, void *stream, mmf_ctx **out);
+void mmf_ctx_destroy(mmf_ctx *ctx);
+int mmf_ctx_synchronize(mmf_ctx *ctx);
+void *mmf_ctx_stream(mmf_ctx *ctx);
+/* name of the device the context runs on, e.g. "gfx950:sramecc+:xnack-" */
+int mmf_ctx_device_name(mmf_ctx *ctx, char *buf, size_t buflen);
+
+/* ---------------------------------------------------------------------------------------
+ * Device entry points: one per host function of Core/Cuda/cudafuncs.cuh:64-193.
+ * (`pyrDown(ushort)` cudafuncs.cuh:167 has no caller in the reference and is not provided.)
+ * `threads, blocks` of the reference signatures are chosen internally for gfx950.
+ * ------------------------------------------------------------------------------------- */
+
+/* icpStep, cudafuncs.cuh:64-82 / reduce.cu:399-473.
+ * A_host[36] row major symmetric, b_host[6], residual_host[2] = {sum r^2, inliers}.
+ * err_map_dev: optional cols x rows float32 image standing in for icpErrorSurface. */
+int mmf_icp_step(mmf_ctx *ctx, const float Rcurr[9], const float tcurr[3], const float *vmap_curr,
+                 size_t vmap_curr_step, const float *nmap_curr, size_t nmap_curr_step,
+                 const float Rprev_inv[9], const float tprev[3], const mmf_camera *intr,
+                 const float *vmap_g_prev, size_t vmap_g_prev_step, const float *nmap_g_prev,
+                 size_t nmap_g_prev_step, float dist_thres, float angle_thres, int cols, int rows,
+                 float *A_host, float *b_host, float *residual_host, float *err_map_dev,
+                 size_t err_map_step);
+
+/* computeRgbResidual, cudafuncs.cuh:113-132 / reduce.cu:867-945.  last/next masks are not
+ * read by the reference (MASK_RGB_RESIDUAL undefined) and are not taken. */
+int mmf_compute_rgb_residual(mmf_ctx *ctx, float min_scale, const int16_t *dIdx, size_t dIdx_step,
+                             const int16_t *dIdy, size_t dIdy_step, const float *last_depth,
+                             size_t last_depth_step, const float *next_depth,
+                             size_t next_depth_step, const uint8_t *last_image,
+                             size_t last_image_step, const uint8_t *next_image,
+                             size_t next_image_step, mmf_dataterm *corres_dev,
+                             float max_depth_delta, const float kt[3], const float krkinv[9],
+                             int cols, int rows, int *sigma_sum_host, int *count_host,
+                             float *err_map_dev, size_t err_map_step);
+
+/* rgbStep, cudafuncs.cuh:84-97 / reduce.cu:609-661.  cloud = AoS float3 (dense). */
+int mmf_rgb_step(mmf_ctx *ctx, const mmf_dataterm *corres_dev, float sigma, const float *cloud_dev,
+                 float fx, float fy, const int16_t *dIdx, size_t dIdx_step, const int16_t *dIdy,
+                 size_t dIdy_step, float sobel_scale, int cols, int rows, float *A_host,
+                 float *b_host);
+
+/* so3Step, cudafuncs.cuh:99-110 / reduce.cu:1092-1150.  A_host[9], b_host[3], residual[2]. */
+int mmf_so3_step(mmf_ctx *ctx, const uint8_t *last_image, size_t last_image_step,
+                 const uint8_t *next_image, size_t next_image_step, const float image_basis[9],
+                 const float kinv[9], const float krlr[9], int cols, int rows, float *A_host,
+                 float *b_host, float *residual_host);
+
+/* createVMap / createNMap, cudafuncs.cuh:134-142 / cudafuncs.cu:136-205 (mask unused, :119) */
+int mmf_create_vmap(mmf_ctx *ctx, const mmf_camera *intr, const float *depth, size_t depth_step,
+                    int cols, int rows, float *vmap, size_t vmap_step, float depth_cutoff);
+int mmf_create_nmap(mmf_ctx *ctx, const float *vmap, size_t vmap_step, int cols, int rows,
+                    float *nmap, size_t nmap_step);
+/* tranformMaps (sic), cudafuncs.cuh:144-149; src may equal dst */
+int mmf_transform_maps(mmf_ctx *ctx, const float *vmap_src, const float *nmap_src, size_t src_step,
+                       int cols, int rows, const float R[9], const float t[3], float *vmap_dst,
+                       float *nmap_dst, size_t dst_step);
+/* copyMaps, cudafuncs.cuh:151-154: RGBA32F interleaved (dense) -> planar */
+int mmf_copy_maps(mmf_ctx *ctx, const float *vmap_rgba, const float *nmap_rgba, int cols, int rows,
+                  float *vmap_dst, float *nmap_dst, size_t dst_step);
+/* resizeVMap / resizeNMap, cudafuncs.cuh:156-160; output is (in_cols/2) x (in_rows/2) */
+int mmf_resize_vmap(mmf_ctx *ctx, const float *in, size_t in_step, int in_cols, int in_rows,
+                    float *out, size_t out_step);
+int mmf_resize_nmap(mmf_ctx *ctx, const float *in, size_t in_step, int in_cols, int in_rows,
+                    float *out, size_t out_step);
+/* imageBGRToIntensity, cudafuncs.cuh:162-163; `channels` = 3 or 4 interleaved u8 */
+int mmf_image_bgr_to_intensity(mmf_ctx *ctx, const uint8_t *img, size_t img_step, int channels,
+                               int cols, int rows, uint8_t *dst, size_t dst_step);
+/* verticesToDepth, cudafuncs.cuh:165-167; vmap_rgba dense RGBA32F */
+int mmf_vertices_to_depth(mmf_ctx *ctx, const float *vmap_rgba, int cols, int rows, float cutoff,
+                          float *dst, size_t dst_step);
+/* projectToPointCloud, cudafuncs.cuh:170-173; cloud dense AoS float3 */
+int mmf_project_to_point_cloud(mmf_ctx *ctx, const float *depth, size_t depth_step, int cols,
+                               int rows, const mmf_camera *intr, int level, float *cloud);
+/* pyrDownGaussF / pyrDownUcharGauss, cudafuncs.cuh:182-186; dst is (cols/2) x (rows/2) */
+int mmf_pyr_down_gauss_f(mmf_ctx *ctx, const float *src, size_t src_step, int src_cols,
+                         int src_rows, float *dst, size_t dst_step);
+int mmf_pyr_down_uchar_gauss(mmf_ctx *ctx, const uint8_t *src, size_t src_step, int src_cols,
+                             int src_rows, uint8_t *dst, size_t dst_step);
+/* computeDerivativeImages, cudafuncs.cuh:191-193 */
+int mmf_compute_derivative_images(mmf_ctx *ctx, const uint8_t *src, size_t src_step, int cols,
+                                  int rows, int16_t *dx, size_t dx_step, int16_t *dy,
+                                  size_t dy_step);
+
+/* ---------------------------------------------------------------------------------------
+ * RGBDOdometry (Core/Utils/RGBDOdometry.h:31-137).  GPUTexture* arguments of the reference
+ * become dense device images; Eigen types become float arrays.
+ * ------------------------------------------------------------------------------------- */
+#define MMF_NUM_PYRS 3 /* RGBDOdometry.h:72 */
+
+/* RGBDOdometry::RGBDOdometry, RGBDOdometry.h:34-36 (maskID is unused by the kernels) */
+int mmf_odom_create(mmf_ctx *ctx, int width, int height, float cx, float cy, float fx, float fy,
+                    float dist_thresh, float angle_thresh, mmf_odom **out);
+void mmf_odom_destroy(mmf_odom *o);
+
+/* Model::generateCUDATextures (Core/Model/Model.cpp:359-388): level-0 filtered depth ->
+ * 3-level pyramid owned by the odometry object (returned for sharing between models). */
+int mmf_odom_build_depth_pyramid(mmf_odom *o, const float *depth_l0, size_t step);
+/* RGBDOdometry::initICP(depthPyramid, maskPyramid, cutoff), RGBDOdometry.h:41-43.  depth_pyr
+ * may be NULL to use the pyramid built by mmf_odom_build_depth_pyramid. */
+int mmf_odom_init_icp(mmf_odom *o, const float *const depth_pyr[MMF_NUM_PYRS],
+                      const size_t steps[MMF_NUM_PYRS], float depth_cutoff);
+/* RGBDOdometry::initICP(GPUTexture*,GPUTexture*,cutoff), RGBDOdometry.h:44 */
+int mmf_odom_init_icp_from_prediction(mmf_odom *o, const float *vert_rgba, const float *norm_rgba,
+                                      float depth_cutoff);
+/* RGBDOdometry::initICPModel, RGBDOdometry.h:47 */
+int mmf_odom_init_icp_model(mmf_odom *o, const float *vert_rgba, const float *norm_rgba,
+                            float depth_cutoff, const float pose[16]);
+/* RGBDOdometry::initRGB / initRGBModel / initFirstRGB, RGBDOdometry.h:49-53.
+ * Must follow the matching initICP* call (RGBDOdometry.cpp:197,202). */
+int mmf_odom_init_rgb(mmf_odom *o, const uint8_t *rgb, size_t step, int channels);
+int mmf_odom_init_rgb_model(mmf_odom *o, const uint8_t *rgb, size_t step, int channels);
+int mmf_odom_init_first_rgb(mmf_odom *o, const uint8_t *rgb, size_t step, int channels);
+
+/* RGBDOdometry::getIncrementalTransformation, RGBDOdometry.h:56-58.
+ * trans[3] / rot[9] in-out (host).  icp_err_dev / rgb_err_dev: width x height float32 device
+ * images (dense) standing in for the two cudaSurfaceObject_t, or NULL.
+ * The whole Gauss-Newton schedule runs device-resident (no host round trip per iteration);
+ * the call returns after the stream has drained and trans/rot/stats are valid. */
+int mmf_odom_get_incremental_transformation(mmf_odom *o, float trans[3], float rot[9],
+                                            int rgb_only, float icp_weight, int pyramid,
+                                            int fast_odom, int so3, float *icp_err_dev,
+                                            float *rgb_err_dev);
+
+/* public result members, RGBDOdometry.h:62-69 */
+typedef struct {
+    float lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
+    double lastA[36];
+    double lastb[6];
+    int iterations_run;
+    int so3_iterations_run;
+} mmf_odom_stats;
+int mmf_odom_get_stats(mmf_odom *o, mmf_odom_stats *out);
+/* RGBDOdometry::getCovariance, RGBDOdometry.h:60: inverse of lastA (6x6, row major) */
+int mmf_odom_get_covariance(mmf_odom *o, double cov[36]);
+
+/* Introspection for parity tests: device pointer of an internal pyramid buffer.
+ * names: vmaps_curr nmaps_curr vmaps_g_prev nmaps_g_prev last_depth next_depth depth_pyr cloud
+ *        last_image next_image last_next_image dIdx dIdy corres */
+int mmf_odom_buffer(mmf_odom *o, const char *name, int level, void **dev_ptr, size_t *bytes);
+/* synchronous copy of that buffer into host memory (host_bytes must equal its size) */
+int mmf_odom_download(mmf_odom *o, const char *name, int level, void *host_dst, size_t host_bytes);
+
+/* Timing hook for bench.py: enqueue `reps` back-to-back launches of the level-`level` ICP
+ * reduction kernel on the odometry object's current maps and pose (no host work in
+ * between), bracketed by HIP events on the context's stream; returns the mean time per launch. */
+int mmf_odom_time_icp_kernel(mmf_odom *o, int level, int reps, float *mean_us_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMF_HIP_H_ */

@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI in include/mmf_hip.h (libmmf_hip.so).
+
+This module is plumbing: it declares argument types and turns a non-zero status into a Python
+exception carrying mmf_last_error().  There is NO fallback: if the library is missing or fails
+to load the import raises, so a GPU box can never silently run something else.
+"""
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libmmf_hip.so")
+
+MMF_NUM_PYRS = 3
+
+
+class MmfError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"mmf status {status}: {message}")
+        self.status = status
+
+
+class mmf_camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+
+class mmf_dataterm(C.Structure):
+    _fields_ = [("zero_x", C.c_int16), ("zero_y", C.c_int16), ("one_x", C.c_int16), ("one_y", C.c_int16),
+                ("diff", C.c_float), ("valid", C.c_uint8), ("pad_", C.c_uint8 * 3)]
+
+
+class mmf_odom_stats(C.Structure):
+    _fields_ = [("lastICPError", C.c_float), ("lastICPCount", C.c_float), ("lastRGBError", C.c_float),
+                ("lastRGBCount", C.c_float), ("lastSO3Error", C.c_float), ("lastSO3Count", C.c_float),
+                ("lastA", C.c_double * 36), ("lastb", C.c_double * 6), ("iterations_run", C.c_int),
+                ("so3_iterations_run", C.c_int)]
+
+
+_vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_cam = C.POINTER(mmf_camera)
+
+# name -> (restype, argtypes); must list every function declared in include/mmf_hip.h
+SIGNATURES = {
+    "mmf_abi_version": (_i, []),
+    "mmf_last_error": (C.c_char_p, []),
+    "mmf_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "mmf_ctx_destroy": (None, [_vp]),
+    "mmf_ctx_synchronize": (_i, [_vp]),
+    "mmf_ctx_stream": (_vp, [_vp]),
+    "mmf_ctx_device_name": (_i, [_vp, C.c_char_p, _sz]),
+    "mmf_icp_step": (_i, [_vp, _fp, _fp, _vp, _sz, _vp, _sz, _fp, _fp, _cam, _vp, _sz, _vp, _sz, _f, _f, _i, _i,
+                          _fp, _fp, _fp, _vp, _sz]),
+    "mmf_compute_rgb_residual": (_i, [_vp, _f, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _f,
+                                      _fp, _fp, _i, _i, _ip, _ip, _vp, _sz]),
+    "mmf_rgb_step": (_i, [_vp, _vp, _f, _vp, _f, _f, _vp, _sz, _vp, _sz, _f, _i, _i, _fp, _fp]),
+    "mmf_so3_step": (_i, [_vp, _vp, _sz, _vp, _sz, _fp, _fp, _fp, _i, _i, _fp, _fp, _fp]),
+    "mmf_create_vmap": (_i, [_vp, _cam, _vp, _sz, _i, _i, _vp, _sz, _f]),
+    "mmf_create_nmap": (_i, [_vp, _vp, _sz, _i, _i, _vp, _sz]),
+    "mmf_transform_maps": (_i, [_vp, _vp, _vp, _sz, _i, _i, _fp, _fp, _vp, _vp, _sz]),
+    "mmf_copy_maps": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz]),
+    "mmf_resize_vmap": (_i, [_vp, _vp, _sz, _i, _i, _vp, _sz]),
+    "mmf_resize_nmap": (_i, [_vp, _vp, _sz, _i, _i, _vp, _sz]),
+    "mmf_image_bgr_to_intensity": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp, _sz]),
+    "mmf_vertices_to_depth": (_i, [_vp, _vp, _i, _i, _f, _vp, _sz]),
+    "mmf_project_to_point_cloud": (_i, [_vp, _vp, _sz, _i, _i, _cam, _i, _vp]),
+    "mmf_pyr_down_gauss_f": (_i, [_vp, _vp, _sz, _i, _i, _vp, _sz]),
+    "mmf_pyr_down_uchar_gauss": (_i, [_vp, _vp, _sz, _i, _i, _vp, _sz]),
+    "mmf_compute_derivative_images": (_i, [_vp, _vp, _sz, _i, _i, _vp, _sz, _vp, _sz]),
+    "mmf_odom_create": (_i, [_vp, _i, _i, _f, _f, _f, _f, _f, _f, C.POINTER(_vp)]),
+    "mmf_odom_destroy": (None, [_vp]),
+    "mmf_odom_build_depth_pyramid": (_i, [_vp, _vp, _sz]),
+    "mmf_odom_init_icp": (_i, [_vp, C.POINTER(_vp), C.POINTER(_sz), _f]),
+    "mmf_odom_init_icp_from_prediction": (_i, [_vp, _vp, _vp, _f]),
+    "mmf_odom_init_icp_model": (_i, [_vp, _vp, _vp, _f, _fp]),
+    "mmf_odom_init_rgb": (_i, [_vp, _vp, _sz, _i]),
+    "mmf_odom_init_rgb_model": (_i, [_vp, _vp, _sz, _i]),
+    "mmf_odom_init_first_rgb": (_i, [_vp, _vp, _sz, _i]),
+    "mmf_odom_get_incremental_transformation": (_i, [_vp, _fp, _fp, _i, _f, _i, _i, _i, _vp, _vp]),
+    "mmf_odom_get_stats": (_i, [_vp, C.POINTER(mmf_odom_stats)]),
+    "mmf_odom_get_covariance": (_i, [_vp, C.POINTER(C.c_double)]),
+    "mmf_odom_buffer": (_i, [_vp, C.c_char_p, _i, C.POINTER(_vp), C.POINTER(_sz)]),
+    "mmf_odom_download": (_i, [_vp, C.c_char_p, _i, _vp, _sz]),
+    "mmf_odom_time_icp_kernel": (_i, [_vp, _i, _i, _fp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmmf_hip.so (once).  Raises if it is missing: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m multimotionfusion_amd.build` "
+            "(hipcc, gfx950). multimotionfusion_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        raise MmfError(status, load().mmf_last_error().decode("utf-8", "replace"))
+
+
+def fptr(arr):
+    """float32 numpy array -> POINTER(c_float) (no copy; caller keeps the array alive)."""
+    return arr.ctypes.data_as(_fp)

@@ -1,0 +1,50 @@
+// device_math.hpp -- float3 / mat33 helpers for the gfx950 tracking kernels.
+//
+// The operation ORDER mirrors the reference's operators (Core/Cuda/operators.cuh:56-91) and the
+// translation unit is built with -ffp-contract=off, so a pixel's Jacobian row is bit-identical
+// to the CPU oracle's (oracle/mmf_oracle.c).  `/` and sqrtf are IEEE correctly rounded under
+// hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmf {
+
+struct f3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ f3 make_f3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+    return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float norm(f3 a) { return sqrtf(dot(a, a)); }
+// reference: rsqrtf (approximate on CUDA); here the correctly rounded 1/sqrt so the oracle and
+// the kernel agree bit-for-bit.
+__device__ __forceinline__ f3 normalized(f3 a) {
+    const float rn = 1.0f / sqrtf(dot(a, a));
+    return f3{a.x * rn, a.y * rn, a.z * rn};
+}
+
+// row-major 3x3 (types.cuh:61-73)
+struct m33 {
+    float m[9];
+};
+__device__ __forceinline__ f3 operator*(const m33& M, f3 a) {
+    return f3{dot(f3{M.m[0], M.m[1], M.m[2]}, a), dot(f3{M.m[3], M.m[4], M.m[5]}, a),
+              dot(f3{M.m[6], M.m[7], M.m[8]}, a)};
+}
+
+__device__ __forceinline__ float qnan() { return __int_as_float(0x7fffffff); }  // cudafuncs.cu:131
+
+// CUDA's __float2int_rn: nearest-even, NaN -> 0, saturating.
+__device__ __forceinline__ int float2int_rn(float x) {
+    if (x != x) return 0;
+    x = fminf(fmaxf(x, -2147483648.0f), 2147483520.0f);
+    return (int)rintf(x);
+}
+
+}  // namespace mmf

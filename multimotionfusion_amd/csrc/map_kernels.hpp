@@ -1,0 +1,253 @@
+// map_kernels.hpp -- vertex/normal map and image-pyramid kernels for gfx950
+// (replacing Core/Cuda/cudafuncs.cu:109-762).  All are one-touch streaming kernels:
+// a workgroup is 64 x 4 pixels so a wave64 reads/writes one contiguous 256-byte row segment
+// per plane (the reference's 32 x 8 blocks are shaped for 32-wide warps).
+#pragma once
+#include "device_math.hpp"
+
+namespace mmf {
+
+constexpr int kTileX = 64, kTileY = 4;
+
+#define MMF_PIXEL_XY()                                        \
+    const int x = blockIdx.x * kTileX + threadIdx.x;          \
+    const int y = blockIdx.y * kTileY + threadIdx.y
+
+// cudafuncs.cu:109-134 (computeVmapKernel); the mask test is commented out there (:119)
+__global__ __launch_bounds__(256) void create_vmap_kernel(const float* __restrict__ depth, int d_stride, int cols,
+                                                          int rows, float* __restrict__ vmap, int v_stride,
+                                                          float fx_inv, float fy_inv, float cx, float cy,
+                                                          float cutoff) {
+    MMF_PIXEL_XY();
+    if (x >= cols || y >= rows) return;
+    const float z = depth[(size_t)y * d_stride + x];
+    if (z != 0 && z < cutoff) {
+        vmap[(size_t)y * v_stride + x] = z * (x - cx) * fx_inv;
+        vmap[(size_t)(y + rows) * v_stride + x] = z * (y - cy) * fy_inv;
+        vmap[(size_t)(y + 2 * rows) * v_stride + x] = z;
+    } else {
+        vmap[(size_t)y * v_stride + x] = qnan();
+    }
+}
+
+// cudafuncs.cu:152-189 (computeNmapKernel)
+__global__ __launch_bounds__(256) void create_nmap_kernel(int rows, int cols, const float* __restrict__ vmap,
+                                                          int v_stride, float* __restrict__ nmap, int n_stride) {
+    MMF_PIXEL_XY();
+    if (x >= cols || y >= rows) return;
+    if (x == cols - 1 || y == rows - 1) {
+        nmap[(size_t)y * n_stride + x] = qnan();
+        return;
+    }
+    f3 v00, v01, v10;
+    v00.x = vmap[(size_t)y * v_stride + x];
+    v01.x = vmap[(size_t)y * v_stride + x + 1];
+    v10.x = vmap[(size_t)(y + 1) * v_stride + x];
+    if (!(v00.x != v00.x) && !(v01.x != v01.x) && !(v10.x != v10.x)) {
+        v00.y = vmap[(size_t)(y + rows) * v_stride + x];
+        v01.y = vmap[(size_t)(y + rows) * v_stride + x + 1];
+        v10.y = vmap[(size_t)(y + 1 + rows) * v_stride + x];
+        v00.z = vmap[(size_t)(y + 2 * rows) * v_stride + x];
+        v01.z = vmap[(size_t)(y + 2 * rows) * v_stride + x + 1];
+        v10.z = vmap[(size_t)(y + 1 + 2 * rows) * v_stride + x];
+        const f3 r = normalized(cross(v01 - v00, v10 - v00));
+        nmap[(size_t)y * n_stride + x] = r.x;
+        nmap[(size_t)(y + rows) * n_stride + x] = r.y;
+        nmap[(size_t)(y + 2 * rows) * n_stride + x] = r.z;
+    } else {
+        nmap[(size_t)y * n_stride + x] = qnan();
+    }
+}
+
+// cudafuncs.cu:207-249 (tranformMapsKernel); in place is fine (one pixel per lane)
+__global__ __launch_bounds__(256) void transform_maps_kernel(int rows, int cols, const float* vsrc, const float* nsrc,
+                                                             int s_stride, m33 R, f3 t, float* vdst, float* ndst,
+                                                             int d_stride) {
+    MMF_PIXEL_XY();
+    if (x >= cols || y >= rows) return;
+    f3 vs, vd = make_f3(qnan(), qnan(), qnan());
+    vs.x = vsrc[(size_t)y * s_stride + x];
+    if (!(vs.x != vs.x)) {
+        vs.y = vsrc[(size_t)(y + rows) * s_stride + x];
+        vs.z = vsrc[(size_t)(y + 2 * rows) * s_stride + x];
+        vd = R * vs + t;
+        vdst[(size_t)(y + rows) * d_stride + x] = vd.y;
+        vdst[(size_t)(y + 2 * rows) * d_stride + x] = vd.z;
+    }
+    vdst[(size_t)y * d_stride + x] = vd.x;
+
+    f3 ns, nd = make_f3(qnan(), qnan(), qnan());
+    ns.x = nsrc[(size_t)y * s_stride + x];
+    if (!(ns.x != ns.x)) {
+        ns.y = nsrc[(size_t)(y + rows) * s_stride + x];
+        ns.z = nsrc[(size_t)(y + 2 * rows) * s_stride + x];
+        nd = R * ns;
+        ndst[(size_t)(y + rows) * d_stride + x] = nd.y;
+        ndst[(size_t)(y + 2 * rows) * d_stride + x] = nd.z;
+    }
+    ndst[(size_t)y * d_stride + x] = nd.x;
+}
+
+// cudafuncs.cu:271-311 (copyMapsKernel): one float4 load per map per pixel (RGBA32F texel)
+__global__ __launch_bounds__(256) void copy_maps_kernel(int rows, int cols, const float4* __restrict__ vsrc,
+                                                        const float4* __restrict__ nsrc, float* __restrict__ vdst,
+                                                        float* __restrict__ ndst, int d_stride) {
+    MMF_PIXEL_XY();
+    if (x >= cols || y >= rows) return;
+    const float4 v = vsrc[(size_t)y * cols + x];
+    const float4 n = nsrc[(size_t)y * cols + x];
+    f3 vd = make_f3(qnan(), qnan(), qnan()), nd = vd;
+    if (!(v.z == 0)) {
+        vd = make_f3(v.x, v.y, v.z);
+        nd = make_f3(n.x, n.y, n.z);
+    }
+    vdst[(size_t)y * d_stride + x] = vd.x;
+    vdst[(size_t)(y + rows) * d_stride + x] = vd.y;
+    vdst[(size_t)(y + 2 * rows) * d_stride + x] = vd.z;
+    ndst[(size_t)y * d_stride + x] = nd.x;
+    ndst[(size_t)(y + rows) * d_stride + x] = nd.y;
+    ndst[(size_t)(y + 2 * rows) * d_stride + x] = nd.z;
+}
+
+// cudafuncs.cu:366-417 (resizeMapKernel<normalize>): float2 loads cover the 2x2 footprint
+template <bool NORMALIZE>
+__global__ __launch_bounds__(256) void resize_map_kernel(int drows, int dcols, int srows, const float* __restrict__ in,
+                                                         int i_stride, float* __restrict__ out, int o_stride) {
+    MMF_PIXEL_XY();
+    if (x >= dcols || y >= drows) return;
+    const int xs = x * 2, ys = y * 2;
+    const float x00 = in[(size_t)(ys + 0) * i_stride + xs + 0];
+    const float x01 = in[(size_t)(ys + 0) * i_stride + xs + 1];
+    const float x10 = in[(size_t)(ys + 1) * i_stride + xs + 0];
+    const float x11 = in[(size_t)(ys + 1) * i_stride + xs + 1];
+    if ((x00 != x00) || (x01 != x01) || (x10 != x10) || (x11 != x11)) {
+        out[(size_t)y * o_stride + x] = qnan();
+        return;
+    }
+    f3 n;
+    n.x = (x00 + x01 + x10 + x11) / 4;
+    const float y00 = in[(size_t)(ys + srows + 0) * i_stride + xs + 0];
+    const float y01 = in[(size_t)(ys + srows + 0) * i_stride + xs + 1];
+    const float y10 = in[(size_t)(ys + srows + 1) * i_stride + xs + 0];
+    const float y11 = in[(size_t)(ys + srows + 1) * i_stride + xs + 1];
+    n.y = (y00 + y01 + y10 + y11) / 4;
+    const float z00 = in[(size_t)(ys + 2 * srows + 0) * i_stride + xs + 0];
+    const float z01 = in[(size_t)(ys + 2 * srows + 0) * i_stride + xs + 1];
+    const float z10 = in[(size_t)(ys + 2 * srows + 1) * i_stride + xs + 0];
+    const float z11 = in[(size_t)(ys + 2 * srows + 1) * i_stride + xs + 1];
+    n.z = (z00 + z01 + z10 + z11) / 4;
+    if (NORMALIZE) n = normalized(n);
+    out[(size_t)y * o_stride + x] = n.x;
+    out[(size_t)(y + drows) * o_stride + x] = n.y;
+    out[(size_t)(y + 2 * drows) * o_stride + x] = n.z;
+}
+
+// 5x5 binomial weights (cudafuncs.cu:517-521).  The reference cudaMallocs, uploads and frees
+// this table on every call (:523-531); here it is a compile-time constant.
+__device__ __forceinline__ float gauss5(int idx) {
+    constexpr float w[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
+    return w[idx];
+}
+
+// cudafuncs.cu:333-364 (pyrDownKernelGaussF), quirks kept: int `count`, clipped asymmetric window
+__global__ __launch_bounds__(256) void pyrdown_gauss_f_kernel(const float* __restrict__ src, int s_stride, int scols,
+                                                              int srows, float* __restrict__ dst, int d_stride,
+                                                              int dcols, int drows) {
+    MMF_PIXEL_XY();
+    if (x >= dcols || y >= drows) return;
+    const int D = 5;
+    const int tx = min(2 * x - D / 2 + D, scols - 1);
+    const int ty = min(2 * y - D / 2 + D, srows - 1);
+    float sum = 0;
+    int count = 0;
+    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+            const float s = src[(size_t)cy * s_stride + cx];
+            if (!(s != s)) {
+                const float w = gauss5((ty - cy - 1) * 5 + (tx - cx - 1));
+                sum += s * w;
+                count = (int)((float)count + w);
+            }
+        }
+    dst[(size_t)y * d_stride + x] = (float)(sum / (float)count);
+}
+
+// cudafuncs.cu:534-564 (pyrDownKernelIntensityGauss)
+__global__ __launch_bounds__(256) void pyrdown_uchar_gauss_kernel(const uint8_t* __restrict__ src, int s_stride,
+                                                                  int scols, int srows, uint8_t* __restrict__ dst,
+                                                                  int d_stride, int dcols, int drows) {
+    MMF_PIXEL_XY();
+    if (x >= dcols || y >= drows) return;
+    const int D = 5;
+    const int tx = min(2 * x - D / 2 + D, scols - 1);
+    const int ty = min(2 * y - D / 2 + D, srows - 1);
+    float sum = 0;
+    int count = 0;
+    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+            const uint8_t s = src[(size_t)cy * s_stride + cx];
+            if (s > 0) {
+                const float w = gauss5((ty - cy - 1) * 5 + (tx - cx - 1));
+                sum += s * w;
+                count = (int)((float)count + w);
+            }
+        }
+    const float q = sum / (float)count;
+    dst[(size_t)y * d_stride + x] = (q != q) ? (uint8_t)0 : (uint8_t)(unsigned)q;
+}
+
+// cudafuncs.cu:602-613 (verticesToDepthKernel)
+__global__ __launch_bounds__(256) void vertices_to_depth_kernel(const float4* __restrict__ vmap_rgba, int cols, int rows,
+                                                                float* __restrict__ dst, int d_stride, float cutoff) {
+    MMF_PIXEL_XY();
+    if (x >= cols || y >= rows) return;
+    const float z = vmap_rgba[(size_t)y * cols + x].z;
+    dst[(size_t)y * d_stride + x] = (z > cutoff || z <= 0) ? qnan() : z;
+}
+
+// cudafuncs.cu:624-637 (bgr2IntensityKernel): channel order as uploaded
+__global__ __launch_bounds__(256) void image_to_intensity_kernel(const uint8_t* __restrict__ img, int i_stride,
+                                                                 int channels, int cols, int rows,
+                                                                 uint8_t* __restrict__ dst, int d_stride) {
+    MMF_PIXEL_XY();
+    if (x >= cols || y >= rows) return;
+    const uint8_t* p = img + (size_t)y * i_stride + (size_t)x * channels;
+    const int value = (int)((float)p[0] * 0.114f + (float)p[1] * 0.299f + (float)p[2] * 0.587f);
+    dst[(size_t)y * d_stride + x] = (uint8_t)value;
+}
+
+// cudafuncs.cu:669-694 (applyKernel) with the tables of :702-708; border quirk kept
+__global__ __launch_bounds__(256) void derivative_kernel(const uint8_t* __restrict__ src, int s_stride, int cols,
+                                                         int rows, int16_t* __restrict__ dx, int dx_stride,
+                                                         int16_t* __restrict__ dy, int dy_stride) {
+    MMF_PIXEL_XY();
+    if (x >= cols || y >= rows) return;
+    constexpr float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+    constexpr float gy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+    float dxv = 0, dyv = 0;
+    int k = 8;
+    for (int j = max(y - 1, 0); j <= min(y + 1, rows - 1); ++j)
+        for (int i = max(x - 1, 0); i <= min(x + 1, cols - 1); ++i) {
+            const float s = (float)src[(size_t)j * s_stride + i];
+            dxv += s * gx[k];
+            dyv += s * gy[k];
+            --k;
+        }
+    dx[(size_t)y * dx_stride + x] = (int16_t)dxv;
+    dy[(size_t)y * dy_stride + x] = (int16_t)dyv;
+}
+
+// cudafuncs.cu:729-747 (projectPointsKernel); AoS float3 output, dense
+__global__ __launch_bounds__(256) void project_points_kernel(const float* __restrict__ depth, int d_stride, int cols,
+                                                             int rows, float* __restrict__ cloud, float inv_fx,
+                                                             float inv_fy, float cx, float cy) {
+    MMF_PIXEL_XY();
+    if (x >= cols || y >= rows) return;
+    const float z = depth[(size_t)y * d_stride + x];
+    float* c = cloud + ((size_t)y * cols + x) * 3;
+    c[0] = (float)((x - cx) * z * inv_fx);
+    c[1] = (float)((y - cy) * z * inv_fy);
+    c[2] = z;
+}
+
+}  // namespace mmf

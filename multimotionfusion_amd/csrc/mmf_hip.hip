@@ -1,0 +1,1061 @@
+// mmf_hip.hip -- C ABI (include/mmf_hip.h) over the gfx950 tracking kernels.
+// Built only for gfx950 with -ffp-contract=off (see multimotionfusion_amd/build.py).
+#include "../../include/mmf_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "map_kernels.hpp"
+#include "track_kernels.hpp"
+
+using namespace mmf;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define MMF_HIP_TRY(expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return fail(MMF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__) + " (" +  \
+                                         __FILE__ + ":" + std::to_string(__LINE__) + ")");        \
+    } while (0)
+
+#define MMF_REQUIRE(cond, msg)                                  \
+    do {                                                        \
+        if (!(cond)) return fail(MMF_ERR_INVALID, (msg));       \
+    } while (0)
+
+extern "C" int mmf_abi_version(void) { return MMF_ABI_VERSION; }
+extern "C" const char* mmf_last_error(void) { return g_last_error.c_str(); }
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxGrid = 2048;  // workgroups per reduction launch (grid-stride beyond)
+
+struct mmf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float* partials_f = nullptr;  // kMaxGrid * kPartialStride
+    unsigned* ticket = nullptr;
+    OdomState* scratch_state = nullptr;  // for the stand-alone *Step entry points
+    OdomState* host_state = nullptr;     // pinned staging
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    char arch[64] = {0};
+};
+
+extern "C" int mmf_ctx_create(int device, void* stream, mmf_ctx** out) {
+    MMF_REQUIRE(out != nullptr, "mmf_ctx_create: out is null");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(MMF_ERR_NO_DEVICE, "mmf_ctx_create: no HIP device visible");
+    MMF_REQUIRE(device >= 0 && device < count, "mmf_ctx_create: device index out of range");
+    MMF_HIP_TRY(hipSetDevice(device));
+    mmf_ctx* c = new (std::nothrow) mmf_ctx();
+    MMF_REQUIRE(c != nullptr, "mmf_ctx_create: out of host memory");
+    c->device = device;
+    hipDeviceProp_t prop;
+    MMF_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    std::snprintf(c->arch, sizeof(c->arch), "%s", prop.gcnArchName);
+    if (std::strncmp(c->arch, "gfx950", 6) != 0) {
+        std::string m = std::string("mmf_ctx_create: this library is built for gfx950 only, device is ") + c->arch;
+        delete c;
+        return fail(MMF_ERR_NO_DEVICE, m);
+    }
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        MMF_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    MMF_HIP_TRY(hipMalloc(&c->partials_f, sizeof(float) * kMaxGrid * kPartialStride));
+    MMF_HIP_TRY(hipMalloc(&c->ticket, 64));
+    MMF_HIP_TRY(hipMemsetAsync(c->ticket, 0, 64, c->stream));
+    MMF_HIP_TRY(hipMalloc(&c->scratch_state, sizeof(OdomState)));
+    MMF_HIP_TRY(hipMemsetAsync(c->scratch_state, 0, sizeof(OdomState), c->stream));
+    MMF_HIP_TRY(hipHostMalloc(&c->host_state, sizeof(OdomState), hipHostMallocDefault));
+    MMF_HIP_TRY(hipEventCreate(&c->ev0));
+    MMF_HIP_TRY(hipEventCreate(&c->ev1));
+    MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = c;
+    return MMF_OK;
+}
+
+extern "C" void mmf_ctx_destroy(mmf_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->partials_f);
+    (void)hipFree(c->ticket);
+    (void)hipFree(c->scratch_state);
+    (void)hipHostFree(c->host_state);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mmf_ctx_synchronize(mmf_ctx* c) {
+    MMF_REQUIRE(c != nullptr, "mmf_ctx_synchronize: ctx is null");
+    MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    return MMF_OK;
+}
+
+extern "C" void* mmf_ctx_stream(mmf_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int mmf_ctx_device_name(mmf_ctx* c, char* buf, size_t buflen) {
+    MMF_REQUIRE(c && buf && buflen > 0, "mmf_ctx_device_name: bad arguments");
+    std::snprintf(buf, buflen, "%s", c->arch);
+    return MMF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------
+static inline dim3 tile_grid(int cols, int rows) {
+    return dim3((cols + kTileX - 1) / kTileX, (rows + kTileY - 1) / kTileY);
+}
+static inline dim3 tile_block() { return dim3(kTileX, kTileY); }
+
+static inline int stride_elems(size_t step_bytes, int cols, size_t elem) {
+    return step_bytes ? (int)(step_bytes / elem) : cols;
+}
+
+static inline int reduce_grid(int n, int per_block) {
+    int g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return g;
+}
+
+static inline LevelIntr level_intr(float fx, float fy, float cx, float cy, int level) {
+    const int div = 1 << level;  // types.cuh:94-98
+    return LevelIntr{fx / div, fy / div, cx / div, cy / div};
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ICP reduction launch: 4 pixels per lane when the layout allows 16-byte row loads
+template <int MODE>
+static hipError_t launch_icp(mmf_ctx* c, OdomState* st, const IcpArgs& a) {
+    const int n = a.cols * a.rows;
+    const bool vec4 = (a.cols % 4 == 0) && (a.vmap_curr.stride % 4 == 0) && (a.nmap_curr.stride % 4 == 0) &&
+                      aligned16(a.vmap_curr.base) && aligned16(a.nmap_curr.base) &&
+                      (!a.err_map || (aligned16(a.err_map) && a.err_stride % 4 == 0));
+    if (vec4) {
+        const int grid = reduce_grid(n, kBlock * 4);
+        hipLaunchKernelGGL((icp_kernel<4, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, st, a, c->partials_f, c->ticket);
+    } else {
+        const int grid = reduce_grid(n, kBlock);
+        hipLaunchKernelGGL((icp_kernel<1, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, st, a, c->partials_f, c->ticket);
+    }
+    return hipGetLastError();
+}
+
+static void unpack_se3_host(const float* tot, float* A, float* b) {  // reduce.cu:458-472
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const float v = tot[shift++];
+            if (j == 6)
+                b[i] = v;
+            else
+                A[j * 6 + i] = A[i * 6 + j] = v;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone device entry points (cudafuncs.cuh)
+// ---------------------------------------------------------------------------------------------
+extern "C" int mmf_icp_step(mmf_ctx* c, const float Rcurr[9], const float tcurr[3], const float* vmap_curr,
+                            size_t vmap_curr_step, const float* nmap_curr, size_t nmap_curr_step,
+                            const float Rprev_inv[9], const float tprev[3], const mmf_camera* intr,
+                            const float* vmap_g_prev, size_t vmap_g_prev_step, const float* nmap_g_prev,
+                            size_t nmap_g_prev_step, float dist_thres, float angle_thres, int cols, int rows,
+                            float* A_host, float* b_host, float* residual_host, float* err_map_dev,
+                            size_t err_map_step) {
+    MMF_REQUIRE(c && Rcurr && tcurr && Rprev_inv && tprev && intr, "mmf_icp_step: null argument");
+    MMF_REQUIRE(vmap_curr && nmap_curr && vmap_g_prev && nmap_g_prev, "mmf_icp_step: null map");
+    MMF_REQUIRE(A_host && b_host && residual_host, "mmf_icp_step: null output");
+    MMF_REQUIRE(cols > 0 && rows > 0 && (long long)cols * rows * 3 < (1ll << 31), "mmf_icp_step: bad size");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    OdomState* h = c->host_state;
+    std::memcpy(h->Rcurr, Rcurr, sizeof(float) * 9);
+    std::memcpy(h->tcurr, tcurr, sizeof(float) * 3);
+    std::memcpy(h->Rprev_inv, Rprev_inv, sizeof(float) * 9);
+    std::memcpy(h->tprev, tprev, sizeof(float) * 3);
+    // Rprev .. tcurr are contiguous at the head of the struct
+    MMF_HIP_TRY(hipMemcpyAsync(c->scratch_state, h, offsetof(OdomState, resultRt), hipMemcpyHostToDevice, c->stream));
+    IcpArgs a;
+    a.vmap_curr = MapView{vmap_curr, stride_elems(vmap_curr_step, cols, 4)};
+    a.nmap_curr = MapView{nmap_curr, stride_elems(nmap_curr_step, cols, 4)};
+    a.vmap_g_prev = MapView{vmap_g_prev, stride_elems(vmap_g_prev_step, cols, 4)};
+    a.nmap_g_prev = MapView{nmap_g_prev, stride_elems(nmap_g_prev_step, cols, 4)};
+    a.intr = LevelIntr{intr->fx, intr->fy, intr->cx, intr->cy};
+    a.dist_thres = dist_thres;
+    a.angle_thres = angle_thres;
+    a.cols = cols;
+    a.rows = rows;
+    a.err_map = err_map_dev;
+    a.err_stride = stride_elems(err_map_step, cols, 4);
+    MMF_HIP_TRY(launch_icp<FINISH_RAW>(c, c->scratch_state, a));
+    float tot[32];
+    MMF_HIP_TRY(hipMemcpyAsync(tot, c->scratch_state->out_f, sizeof(float) * 32, hipMemcpyDeviceToHost, c->stream));
+    MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    unpack_se3_host(tot, A_host, b_host);
+    residual_host[0] = tot[27];
+    residual_host[1] = tot[28];
+    return MMF_OK;
+}
+
+static RgbResidualArgs make_residual_args(float min_scale, const int16_t* dIdx, size_t dIdx_step, const int16_t* dIdy,
+                                          size_t dIdy_step, const float* last_depth, size_t ld_step,
+                                          const float* next_depth, size_t nd_step, const uint8_t* last_image,
+                                          size_t li_step, const uint8_t* next_image, size_t ni_step,
+                                          mmf_dataterm* corres, float max_depth_delta, int cols, int rows,
+                                          float* err_map, size_t err_step) {
+    RgbResidualArgs a;
+    a.min_scale = min_scale;
+    a.max_depth_delta = max_depth_delta;
+    a.dIdx = dIdx;
+    a.dIdy = dIdy;
+    a.d_stride = stride_elems(dIdx_step, cols, 2);
+    (void)dIdy_step;
+    a.last_depth = last_depth;
+    a.next_depth = next_depth;
+    a.ld_stride = stride_elems(ld_step, cols, 4);
+    a.nd_stride = stride_elems(nd_step, cols, 4);
+    a.last_image = last_image;
+    a.next_image = next_image;
+    a.li_stride = stride_elems(li_step, cols, 1);
+    a.ni_stride = stride_elems(ni_step, cols, 1);
+    a.corres = corres;
+    a.cols = cols;
+    a.rows = rows;
+    a.err_map = err_map;
+    a.err_stride = stride_elems(err_step, cols, 4);
+    a.intr = LevelIntr{0, 0, 0, 0};
+    return a;
+}
+
+extern "C" int mmf_compute_rgb_residual(mmf_ctx* c, float min_scale, const int16_t* dIdx, size_t dIdx_step,
+                                        const int16_t* dIdy, size_t dIdy_step, const float* last_depth,
+                                        size_t last_depth_step, const float* next_depth, size_t next_depth_step,
+                                        const uint8_t* last_image, size_t last_image_step, const uint8_t* next_image,
+                                        size_t next_image_step, mmf_dataterm* corres_dev, float max_depth_delta,
+                                        const float kt[3], const float krkinv[9], int cols, int rows,
+                                        int* sigma_sum_host, int* count_host, float* err_map_dev,
+                                        size_t err_map_step) {
+    MMF_REQUIRE(c && dIdx && dIdy && last_depth && next_depth && last_image && next_image && corres_dev && kt &&
+                    krkinv && sigma_sum_host && count_host,
+                "mmf_compute_rgb_residual: null argument");
+    MMF_REQUIRE(cols > 0 && rows > 0 && cols < 32768 && rows < 32768, "mmf_compute_rgb_residual: bad size");
+    MMF_REQUIRE(dIdx_step == dIdy_step, "mmf_compute_rgb_residual: dIdx/dIdy steps differ");
+    MMF_REQUIRE(aligned16(corres_dev), "mmf_compute_rgb_residual: corres must be 16-byte aligned");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    OdomState* h = c->host_state;
+    std::memcpy(h->krkinv, krkinv, sizeof(float) * 9);
+    std::memcpy(h->kt, kt, sizeof(float) * 3);
+    MMF_HIP_TRY(hipMemcpyAsync(c->scratch_state->krkinv, h->krkinv, sizeof(float) * 12, hipMemcpyHostToDevice, c->stream));
+    RgbResidualArgs a = make_residual_args(min_scale, dIdx, dIdx_step, dIdy, dIdy_step, last_depth, last_depth_step,
+                                           next_depth, next_depth_step, last_image, last_image_step, next_image,
+                                           next_image_step, corres_dev, max_depth_delta, cols, rows, err_map_dev,
+                                           err_map_step);
+    const int grid = reduce_grid(cols * rows, kBlock);
+    hipLaunchKernelGGL((rgb_residual_kernel<FINISH_RAW>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state, a,
+                       reinterpret_cast<int*>(c->partials_f), c->ticket);
+    MMF_HIP_TRY(hipGetLastError());
+    int tot[2];
+    MMF_HIP_TRY(hipMemcpyAsync(tot, c->scratch_state->out_i, sizeof(tot), hipMemcpyDeviceToHost, c->stream));
+    MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    *count_host = tot[0];
+    *sigma_sum_host = tot[1];
+    return MMF_OK;
+}
+
+extern "C" int mmf_rgb_step(mmf_ctx* c, const mmf_dataterm* corres_dev, float sigma, const float* cloud_dev, float fx,
+                            float fy, const int16_t* dIdx, size_t dIdx_step, const int16_t* dIdy, size_t dIdy_step,
+                            float sobel_scale, int cols, int rows, float* A_host, float* b_host) {
+    MMF_REQUIRE(c && corres_dev && cloud_dev && dIdx && dIdy && A_host && b_host, "mmf_rgb_step: null argument");
+    MMF_REQUIRE(cols > 0 && rows > 0, "mmf_rgb_step: bad size");
+    MMF_REQUIRE(dIdx_step == dIdy_step, "mmf_rgb_step: dIdx/dIdy steps differ");
+    MMF_REQUIRE(aligned16(corres_dev), "mmf_rgb_step: corres must be 16-byte aligned");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    c->host_state->sigmaVal = sigma;
+    MMF_HIP_TRY(hipMemcpyAsync(&c->scratch_state->sigmaVal, &c->host_state->sigmaVal, sizeof(float),
+                               hipMemcpyHostToDevice, c->stream));
+    RgbStepArgs a;
+    a.corres = corres_dev;
+    a.cloud = cloud_dev;
+    a.fx = fx;
+    a.fy = fy;
+    a.dIdx = dIdx;
+    a.dIdy = dIdy;
+    a.d_stride = stride_elems(dIdx_step, cols, 2);
+    a.sobel_scale = sobel_scale;
+    a.cols = cols;
+    a.rows = rows;
+    a.intr = LevelIntr{0, 0, 0, 0};
+    const int grid = reduce_grid(cols * rows, kBlock);
+    hipLaunchKernelGGL((rgb_step_kernel<FINISH_RAW>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state, a,
+                       c->partials_f, c->ticket);
+    MMF_HIP_TRY(hipGetLastError());
+    float tot[32];
+    MMF_HIP_TRY(hipMemcpyAsync(tot, c->scratch_state->out_f, sizeof(float) * 32, hipMemcpyDeviceToHost, c->stream));
+    MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    unpack_se3_host(tot, A_host, b_host);
+    return MMF_OK;
+}
+
+extern "C" int mmf_so3_step(mmf_ctx* c, const uint8_t* last_image, size_t last_image_step, const uint8_t* next_image,
+                            size_t next_image_step, const float image_basis[9], const float kinv[9],
+                            const float krlr[9], int cols, int rows, float* A_host, float* b_host,
+                            float* residual_host) {
+    MMF_REQUIRE(c && last_image && next_image && image_basis && kinv && krlr && A_host && b_host && residual_host,
+                "mmf_so3_step: null argument");
+    MMF_REQUIRE(cols > 2 && rows > 2, "mmf_so3_step: bad size");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    OdomState* h = c->host_state;
+    std::memcpy(h->imageBasis, image_basis, sizeof(float) * 9);
+    std::memcpy(h->kinv, kinv, sizeof(float) * 9);
+    std::memcpy(h->krlr, krlr, sizeof(float) * 9);
+    MMF_HIP_TRY(hipMemcpyAsync(c->scratch_state->imageBasis, h->imageBasis, sizeof(float) * 27, hipMemcpyHostToDevice,
+                               c->stream));
+    So3Args a;
+    a.last_image = last_image;
+    a.next_image = next_image;
+    a.l_stride = stride_elems(last_image_step, cols, 1);
+    a.n_stride = stride_elems(next_image_step, cols, 1);
+    a.cols = cols;
+    a.rows = rows;
+    a.intr = LevelIntr{0, 0, 0, 0};
+    const int grid = reduce_grid(cols * rows, kBlock);
+    hipLaunchKernelGGL((so3_kernel<FINISH_RAW>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state, a,
+                       c->partials_f, c->ticket);
+    MMF_HIP_TRY(hipGetLastError());
+    float tot[32];
+    MMF_HIP_TRY(hipMemcpyAsync(tot, c->scratch_state->out_f, sizeof(float) * 32, hipMemcpyDeviceToHost, c->stream));
+    MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    int shift = 0;  // reduce.cu:1135-1149
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) {
+            const float v = tot[shift++];
+            if (j == 3)
+                b_host[i] = v;
+            else
+                A_host[j * 3 + i] = A_host[i * 3 + j] = v;
+        }
+    residual_host[0] = tot[9];
+    residual_host[1] = tot[10];
+    return MMF_OK;
+}
+
+// ---- map / pyramid entry points ---------------------------------------------------------------
+static int launch_create_vmap(mmf_ctx* c, LevelIntr in, const float* depth, int d_stride, int cols, int rows,
+                              float* vmap, int v_stride, float cutoff) {
+    hipLaunchKernelGGL(create_vmap_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, depth, d_stride, cols,
+                       rows, vmap, v_stride, 1.f / in.fx, 1.f / in.fy, in.cx, in.cy, cutoff);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_create_vmap(mmf_ctx* c, const mmf_camera* intr, const float* depth, size_t depth_step, int cols,
+                               int rows, float* vmap, size_t vmap_step, float depth_cutoff) {
+    MMF_REQUIRE(c && intr && depth && vmap && cols > 0 && rows > 0, "mmf_create_vmap: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_create_vmap(c, LevelIntr{intr->fx, intr->fy, intr->cx, intr->cy}, depth,
+                              stride_elems(depth_step, cols, 4), cols, rows, vmap, stride_elems(vmap_step, cols, 4),
+                              depth_cutoff);
+}
+
+static int launch_create_nmap(mmf_ctx* c, const float* vmap, int v_stride, int cols, int rows, float* nmap,
+                              int n_stride) {
+    hipLaunchKernelGGL(create_nmap_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, rows, cols, vmap,
+                       v_stride, nmap, n_stride);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_create_nmap(mmf_ctx* c, const float* vmap, size_t vmap_step, int cols, int rows, float* nmap,
+                               size_t nmap_step) {
+    MMF_REQUIRE(c && vmap && nmap && cols > 0 && rows > 0, "mmf_create_nmap: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_create_nmap(c, vmap, stride_elems(vmap_step, cols, 4), cols, rows, nmap,
+                              stride_elems(nmap_step, cols, 4));
+}
+
+static int launch_transform(mmf_ctx* c, const float* vs, const float* ns, int s_stride, int cols, int rows,
+                            const float R[9], const float t[3], float* vd, float* nd, int d_stride) {
+    m33 Rm;
+    std::memcpy(Rm.m, R, sizeof(float) * 9);
+    hipLaunchKernelGGL(transform_maps_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, rows, cols, vs, ns,
+                       s_stride, Rm, f3{t[0], t[1], t[2]}, vd, nd, d_stride);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_transform_maps(mmf_ctx* c, const float* vmap_src, const float* nmap_src, size_t src_step, int cols,
+                                  int rows, const float R[9], const float t[3], float* vmap_dst, float* nmap_dst,
+                                  size_t dst_step) {
+    MMF_REQUIRE(c && vmap_src && nmap_src && R && t && vmap_dst && nmap_dst && cols > 0 && rows > 0,
+                "mmf_transform_maps: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_transform(c, vmap_src, nmap_src, stride_elems(src_step, cols, 4), cols, rows, R, t, vmap_dst,
+                            nmap_dst, stride_elems(dst_step, cols, 4));
+}
+
+static int launch_copy_maps(mmf_ctx* c, const float* v_rgba, const float* n_rgba, int cols, int rows, float* vd,
+                            float* nd, int d_stride) {
+    hipLaunchKernelGGL(copy_maps_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, rows, cols,
+                       reinterpret_cast<const float4*>(v_rgba), reinterpret_cast<const float4*>(n_rgba), vd, nd,
+                       d_stride);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_copy_maps(mmf_ctx* c, const float* vmap_rgba, const float* nmap_rgba, int cols, int rows,
+                             float* vmap_dst, float* nmap_dst, size_t dst_step) {
+    MMF_REQUIRE(c && vmap_rgba && nmap_rgba && vmap_dst && nmap_dst && cols > 0 && rows > 0,
+                "mmf_copy_maps: bad argument");
+    MMF_REQUIRE(aligned16(vmap_rgba) && aligned16(nmap_rgba), "mmf_copy_maps: RGBA images must be 16-byte aligned");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_copy_maps(c, vmap_rgba, nmap_rgba, cols, rows, vmap_dst, nmap_dst, stride_elems(dst_step, cols, 4));
+}
+
+template <bool NORMALIZE>
+static int launch_resize(mmf_ctx* c, const float* in, int i_stride, int in_cols, int in_rows, float* out,
+                         int o_stride) {
+    const int dcols = in_cols / 2, drows = in_rows / 2;
+    hipLaunchKernelGGL((resize_map_kernel<NORMALIZE>), tile_grid(dcols, drows), tile_block(), 0, c->stream, drows,
+                       dcols, in_rows, in, i_stride, out, o_stride);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_resize_vmap(mmf_ctx* c, const float* in, size_t in_step, int in_cols, int in_rows, float* out,
+                               size_t out_step) {
+    MMF_REQUIRE(c && in && out && in_cols > 1 && in_rows > 1, "mmf_resize_vmap: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_resize<false>(c, in, stride_elems(in_step, in_cols, 4), in_cols, in_rows, out,
+                                stride_elems(out_step, in_cols / 2, 4));
+}
+
+extern "C" int mmf_resize_nmap(mmf_ctx* c, const float* in, size_t in_step, int in_cols, int in_rows, float* out,
+                               size_t out_step) {
+    MMF_REQUIRE(c && in && out && in_cols > 1 && in_rows > 1, "mmf_resize_nmap: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_resize<true>(c, in, stride_elems(in_step, in_cols, 4), in_cols, in_rows, out,
+                               stride_elems(out_step, in_cols / 2, 4));
+}
+
+static int launch_intensity(mmf_ctx* c, const uint8_t* img, int i_stride, int channels, int cols, int rows,
+                            uint8_t* dst, int d_stride) {
+    hipLaunchKernelGGL(image_to_intensity_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, img, i_stride,
+                       channels, cols, rows, dst, d_stride);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_image_bgr_to_intensity(mmf_ctx* c, const uint8_t* img, size_t img_step, int channels, int cols,
+                                          int rows, uint8_t* dst, size_t dst_step) {
+    MMF_REQUIRE(c && img && dst && cols > 0 && rows > 0, "mmf_image_bgr_to_intensity: bad argument");
+    MMF_REQUIRE(channels == 3 || channels == 4, "mmf_image_bgr_to_intensity: channels must be 3 or 4");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_intensity(c, img, img_step ? (int)img_step : cols * channels, channels, cols, rows, dst,
+                            stride_elems(dst_step, cols, 1));
+}
+
+static int launch_vertices_to_depth(mmf_ctx* c, const float* vmap_rgba, int cols, int rows, float cutoff, float* dst,
+                                    int d_stride) {
+    hipLaunchKernelGGL(vertices_to_depth_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream,
+                       reinterpret_cast<const float4*>(vmap_rgba), cols, rows, dst, d_stride, cutoff);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_vertices_to_depth(mmf_ctx* c, const float* vmap_rgba, int cols, int rows, float cutoff, float* dst,
+                                     size_t dst_step) {
+    MMF_REQUIRE(c && vmap_rgba && dst && cols > 0 && rows > 0, "mmf_vertices_to_depth: bad argument");
+    MMF_REQUIRE(aligned16(vmap_rgba), "mmf_vertices_to_depth: RGBA image must be 16-byte aligned");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_vertices_to_depth(c, vmap_rgba, cols, rows, cutoff, dst, stride_elems(dst_step, cols, 4));
+}
+
+static int launch_project(mmf_ctx* c, const float* depth, int d_stride, int cols, int rows, LevelIntr in,
+                          float* cloud) {
+    hipLaunchKernelGGL(project_points_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, depth, d_stride, cols,
+                       rows, cloud, 1.0f / in.fx, 1.0f / in.fy, in.cx, in.cy);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_project_to_point_cloud(mmf_ctx* c, const float* depth, size_t depth_step, int cols, int rows,
+                                          const mmf_camera* intr, int level, float* cloud) {
+    MMF_REQUIRE(c && depth && intr && cloud && cols > 0 && rows > 0 && level >= 0 && level < 16,
+                "mmf_project_to_point_cloud: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_project(c, depth, stride_elems(depth_step, cols, 4), cols, rows,
+                          level_intr(intr->fx, intr->fy, intr->cx, intr->cy, level), cloud);
+}
+
+static int launch_pyrdown_f(mmf_ctx* c, const float* src, int s_stride, int scols, int srows, float* dst,
+                            int d_stride) {
+    const int dcols = scols / 2, drows = srows / 2;
+    hipLaunchKernelGGL(pyrdown_gauss_f_kernel, tile_grid(dcols, drows), tile_block(), 0, c->stream, src, s_stride,
+                       scols, srows, dst, d_stride, dcols, drows);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_pyr_down_gauss_f(mmf_ctx* c, const float* src, size_t src_step, int src_cols, int src_rows,
+                                    float* dst, size_t dst_step) {
+    MMF_REQUIRE(c && src && dst && src_cols > 1 && src_rows > 1, "mmf_pyr_down_gauss_f: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_pyrdown_f(c, src, stride_elems(src_step, src_cols, 4), src_cols, src_rows, dst,
+                            stride_elems(dst_step, src_cols / 2, 4));
+}
+
+static int launch_pyrdown_u8(mmf_ctx* c, const uint8_t* src, int s_stride, int scols, int srows, uint8_t* dst,
+                             int d_stride) {
+    const int dcols = scols / 2, drows = srows / 2;
+    hipLaunchKernelGGL(pyrdown_uchar_gauss_kernel, tile_grid(dcols, drows), tile_block(), 0, c->stream, src, s_stride,
+                       scols, srows, dst, d_stride, dcols, drows);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_pyr_down_uchar_gauss(mmf_ctx* c, const uint8_t* src, size_t src_step, int src_cols, int src_rows,
+                                        uint8_t* dst, size_t dst_step) {
+    MMF_REQUIRE(c && src && dst && src_cols > 1 && src_rows > 1, "mmf_pyr_down_uchar_gauss: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_pyrdown_u8(c, src, stride_elems(src_step, src_cols, 1), src_cols, src_rows, dst,
+                             stride_elems(dst_step, src_cols / 2, 1));
+}
+
+static int launch_derivative(mmf_ctx* c, const uint8_t* src, int s_stride, int cols, int rows, int16_t* dx,
+                             int dx_stride, int16_t* dy, int dy_stride) {
+    hipLaunchKernelGGL(derivative_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, src, s_stride, cols, rows,
+                       dx, dx_stride, dy, dy_stride);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_compute_derivative_images(mmf_ctx* c, const uint8_t* src, size_t src_step, int cols, int rows,
+                                             int16_t* dx, size_t dx_step, int16_t* dy, size_t dy_step) {
+    MMF_REQUIRE(c && src && dx && dy && cols > 0 && rows > 0, "mmf_compute_derivative_images: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    return launch_derivative(c, src, stride_elems(src_step, cols, 1), cols, rows, dx, stride_elems(dx_step, cols, 2),
+                             dy, stride_elems(dy_step, cols, 2));
+}
+
+// ---------------------------------------------------------------------------------------------
+// RGBDOdometry object
+// ---------------------------------------------------------------------------------------------
+struct mmf_odom {
+    mmf_ctx* ctx = nullptr;
+    int width = 0, height = 0;
+    float cx = 0, cy = 0, fx = 0, fy = 0;
+    float dist_thres = 0, angle_thres = 0;
+    float sobel_scale = 0.125f;         // RGBDOdometry.cpp:31-32
+    float max_depth_delta_rgb = 0.07f;  // :33
+    float max_depth_rgb = 6.0f;         // :34
+    float min_grad[MMF_NUM_PYRS] = {5, 3, 1};  // :103-105
+
+    // one slab of HBM; every buffer below points into it
+    void* slab = nullptr;
+    size_t slab_bytes = 0;
+    float *vmaps_tmp = nullptr, *nmaps_tmp = nullptr;
+    float *vmaps_g_prev[MMF_NUM_PYRS], *nmaps_g_prev[MMF_NUM_PYRS];
+    float *vmaps_curr[MMF_NUM_PYRS], *nmaps_curr[MMF_NUM_PYRS];
+    float *last_depth[MMF_NUM_PYRS], *next_depth[MMF_NUM_PYRS], *depth_pyr[MMF_NUM_PYRS];
+    uint8_t *last_image[MMF_NUM_PYRS], *next_image[MMF_NUM_PYRS], *last_next_image[MMF_NUM_PYRS];
+    int16_t *dIdx[MMF_NUM_PYRS], *dIdy[MMF_NUM_PYRS];
+    float* cloud[MMF_NUM_PYRS];
+    mmf_dataterm* corres[MMF_NUM_PYRS];
+    OdomState* state = nullptr;  // device
+    OdomState* host_result = nullptr;  // pinned
+    bool have_tmp = false;  // vmaps_tmp filled by an initICP* call (ordering contract)
+    mmf_odom_stats stats;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, float cy, float fx, float fy,
+                               float dist_thresh, float angle_thresh, mmf_odom** out) {
+    MMF_REQUIRE(c && out, "mmf_odom_create: null argument");
+    MMF_REQUIRE(width >= 32 && height >= 32 && width % 4 == 0 && height % 4 == 0 && width < 32768 && height < 32768,
+                "mmf_odom_create: width/height must be multiples of 4, >= 32");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    mmf_odom* o = new (std::nothrow) mmf_odom();
+    MMF_REQUIRE(o != nullptr, "mmf_odom_create: out of host memory");
+    o->ctx = c;
+    o->width = width;
+    o->height = height;
+    o->cx = cx;
+    o->cy = cy;
+    o->fx = fx;
+    o->fy = fy;
+    o->dist_thres = dist_thresh;
+    o->angle_thres = angle_thresh;
+    std::memset(&o->stats, 0, sizeof(o->stats));
+    o->stats.lastICPCount = o->stats.lastRGBCount = o->stats.lastSO3Count = (float)(width * height);  // :24-28
+
+    // carve every pyramid buffer out of one allocation, each 256-byte aligned
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    const size_t n0 = (size_t)width * height;
+    size_t o_vt = carve(4 * n0 * 4), o_nt = carve(4 * n0 * 4);
+    size_t o_vgp[3], o_ngp[3], o_vc[3], o_nc[3], o_ld[3], o_nd[3], o_dp[3], o_li[3], o_ni[3], o_lni[3], o_dx[3],
+        o_dy[3], o_cl[3], o_co[3];
+    for (int i = 0; i < MMF_NUM_PYRS; ++i) {
+        const size_t n = (size_t)(width >> i) * (height >> i);
+        o_vgp[i] = carve(3 * n * 4);
+        o_ngp[i] = carve(3 * n * 4);
+        o_vc[i] = carve(3 * n * 4);
+        o_nc[i] = carve(3 * n * 4);
+        o_ld[i] = carve(n * 4);
+        o_nd[i] = carve(n * 4);
+        o_dp[i] = carve(n * 4);
+        o_li[i] = carve(n);
+        o_ni[i] = carve(n);
+        o_lni[i] = carve(n);
+        o_dx[i] = carve(n * 2);
+        o_dy[i] = carve(n * 2);
+        o_cl[i] = carve(3 * n * 4);
+        o_co[i] = carve(n * sizeof(mmf_dataterm));
+    }
+    size_t o_state = carve(sizeof(OdomState));
+    o->slab_bytes = off;
+    hipError_t e = hipMalloc(&o->slab, o->slab_bytes);
+    if (e != hipSuccess) {
+        delete o;
+        return fail(MMF_ERR_HIP, std::string("mmf_odom_create: hipMalloc: ") + hipGetErrorString(e));
+    }
+    MMF_HIP_TRY(hipMemsetAsync(o->slab, 0, o->slab_bytes, c->stream));
+    char* base = static_cast<char*>(o->slab);
+    o->vmaps_tmp = (float*)(base + o_vt);
+    o->nmaps_tmp = (float*)(base + o_nt);
+    for (int i = 0; i < MMF_NUM_PYRS; ++i) {
+        o->vmaps_g_prev[i] = (float*)(base + o_vgp[i]);
+        o->nmaps_g_prev[i] = (float*)(base + o_ngp[i]);
+        o->vmaps_curr[i] = (float*)(base + o_vc[i]);
+        o->nmaps_curr[i] = (float*)(base + o_nc[i]);
+        o->last_depth[i] = (float*)(base + o_ld[i]);
+        o->next_depth[i] = (float*)(base + o_nd[i]);
+        o->depth_pyr[i] = (float*)(base + o_dp[i]);
+        o->last_image[i] = (uint8_t*)(base + o_li[i]);
+        o->next_image[i] = (uint8_t*)(base + o_ni[i]);
+        o->last_next_image[i] = (uint8_t*)(base + o_lni[i]);
+        o->dIdx[i] = (int16_t*)(base + o_dx[i]);
+        o->dIdy[i] = (int16_t*)(base + o_dy[i]);
+        o->cloud[i] = (float*)(base + o_cl[i]);
+        o->corres[i] = (mmf_dataterm*)(base + o_co[i]);
+    }
+    o->state = (OdomState*)(base + o_state);
+    MMF_HIP_TRY(hipHostMalloc(&o->host_result, sizeof(OdomState), hipHostMallocDefault));
+    MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = o;
+    return MMF_OK;
+}
+
+extern "C" void mmf_odom_destroy(mmf_odom* o) {
+    if (!o) return;
+    (void)hipSetDevice(o->ctx->device);
+    (void)hipStreamSynchronize(o->ctx->stream);
+    (void)hipFree(o->slab);
+    (void)hipHostFree(o->host_result);
+    delete o;
+}
+
+extern "C" int mmf_odom_build_depth_pyramid(mmf_odom* o, const float* depth_l0, size_t step) {
+    MMF_REQUIRE(o && depth_l0, "mmf_odom_build_depth_pyramid: null argument");
+    mmf_ctx* c = o->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const size_t s = step ? step : (size_t)o->width * 4;
+    MMF_HIP_TRY(hipMemcpy2DAsync(o->depth_pyr[0], (size_t)o->width * 4, depth_l0, s, (size_t)o->width * 4, o->height,
+                                 hipMemcpyDeviceToDevice, c->stream));
+    for (int i = 1; i < MMF_NUM_PYRS; ++i) {  // Model.cpp:378-382
+        int rc = launch_pyrdown_f(c, o->depth_pyr[i - 1], o->width >> (i - 1), o->width >> (i - 1),
+                                  o->height >> (i - 1), o->depth_pyr[i], o->width >> i);
+        if (rc) return rc;
+    }
+    return MMF_OK;
+}
+
+extern "C" int mmf_odom_init_icp(mmf_odom* o, const float* const depth_pyr[MMF_NUM_PYRS],
+                                 const size_t steps[MMF_NUM_PYRS], float depth_cutoff) {
+    MMF_REQUIRE(o != nullptr, "mmf_odom_init_icp: null odometry");
+    mmf_ctx* c = o->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < MMF_NUM_PYRS; ++i) {  // RGBDOdometry.cpp:112-115
+        const int cols = o->width >> i, rows = o->height >> i;
+        const float* d = depth_pyr ? depth_pyr[i] : o->depth_pyr[i];
+        MMF_REQUIRE(d != nullptr, "mmf_odom_init_icp: null pyramid level");
+        const int ds = (depth_pyr && steps && steps[i]) ? (int)(steps[i] / 4) : cols;
+        int rc = launch_create_vmap(c, level_intr(o->fx, o->fy, o->cx, o->cy, i), d, ds, cols, rows, o->vmaps_curr[i],
+                                    cols, depth_cutoff);
+        if (rc) return rc;
+        rc = launch_create_nmap(c, o->vmaps_curr[i], cols, cols, rows, o->nmaps_curr[i], cols);
+        if (rc) return rc;
+    }
+    return MMF_OK;
+}
+
+static int odom_take_prediction(mmf_odom* o, const float* vert_rgba, const float* norm_rgba, float** vdst,
+                                float** ndst) {
+    mmf_ctx* c = o->ctx;
+    const size_t bytes = (size_t)4 * o->width * o->height * sizeof(float);
+    // the reference copies both textures into vmaps_tmp / nmaps_tmp (RGBDOdometry.cpp:125,130);
+    // vmaps_tmp is read again by initRGB*/populateRGBDData (:179)
+    MMF_HIP_TRY(hipMemcpyAsync(o->vmaps_tmp, vert_rgba, bytes, hipMemcpyDeviceToDevice, c->stream));
+    MMF_HIP_TRY(hipMemcpyAsync(o->nmaps_tmp, norm_rgba, bytes, hipMemcpyDeviceToDevice, c->stream));
+    o->have_tmp = true;
+    int rc = launch_copy_maps(c, o->vmaps_tmp, o->nmaps_tmp, o->width, o->height, vdst[0], ndst[0], o->width);
+    if (rc) return rc;
+    for (int i = 1; i < MMF_NUM_PYRS; ++i) {
+        rc = launch_resize<false>(c, vdst[i - 1], o->width >> (i - 1), o->width >> (i - 1), o->height >> (i - 1),
+                                  vdst[i], o->width >> i);
+        if (rc) return rc;
+        rc = launch_resize<true>(c, ndst[i - 1], o->width >> (i - 1), o->width >> (i - 1), o->height >> (i - 1),
+                                 ndst[i], o->width >> i);
+        if (rc) return rc;
+    }
+    return MMF_OK;
+}
+
+extern "C" int mmf_odom_init_icp_from_prediction(mmf_odom* o, const float* vert_rgba, const float* norm_rgba,
+                                                 float depth_cutoff) {
+    (void)depth_cutoff;  // unused by the reference as well (RGBDOdometry.cpp:120-141)
+    MMF_REQUIRE(o && vert_rgba && norm_rgba, "mmf_odom_init_icp_from_prediction: null argument");
+    MMF_HIP_TRY(hipSetDevice(o->ctx->device));
+    return odom_take_prediction(o, vert_rgba, norm_rgba, o->vmaps_curr, o->nmaps_curr);
+}
+
+extern "C" int mmf_odom_init_icp_model(mmf_odom* o, const float* vert_rgba, const float* norm_rgba,
+                                       float depth_cutoff, const float pose[16]) {
+    (void)depth_cutoff;  // unused by the reference as well (RGBDOdometry.cpp:143-175)
+    MMF_REQUIRE(o && vert_rgba && norm_rgba && pose, "mmf_odom_init_icp_model: null argument");
+    MMF_HIP_TRY(hipSetDevice(o->ctx->device));
+    int rc = odom_take_prediction(o, vert_rgba, norm_rgba, o->vmaps_g_prev, o->nmaps_g_prev);
+    if (rc) return rc;
+    const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+    const float t[3] = {pose[3], pose[7], pose[11]};
+    for (int i = 0; i < MMF_NUM_PYRS; ++i) {
+        const int cols = o->width >> i, rows = o->height >> i;
+        rc = launch_transform(o->ctx, o->vmaps_g_prev[i], o->nmaps_g_prev[i], cols, cols, rows, R, t,
+                              o->vmaps_g_prev[i], o->nmaps_g_prev[i], cols);
+        if (rc) return rc;
+    }
+    return MMF_OK;
+}
+
+// RGBDOdometry.cpp:177-194 (populateRGBDData); mask pyramids are never read and are omitted
+static int odom_populate_rgbd(mmf_odom* o, const uint8_t* rgb, size_t step, int channels, float** depths,
+                              uint8_t** images) {
+    mmf_ctx* c = o->ctx;
+    if (!o->have_tmp)
+        return fail(MMF_ERR_STATE, "initRGB*/initRGBModel needs a preceding initICPModel / initICP(prediction): "
+                                   "it reads vmaps_tmp (RGBDOdometry.cpp:197,202)");
+    int rc = launch_vertices_to_depth(c, o->vmaps_tmp, o->width, o->height, o->max_depth_rgb, depths[0], o->width);
+    if (rc) return rc;
+    for (int i = 0; i + 1 < MMF_NUM_PYRS; ++i) {
+        rc = launch_pyrdown_f(c, depths[i], o->width >> i, o->width >> i, o->height >> i, depths[i + 1],
+                              o->width >> (i + 1));
+        if (rc) return rc;
+    }
+    rc = launch_intensity(c, rgb, step ? (int)step : o->width * channels, channels, o->width, o->height, images[0],
+                          o->width);
+    if (rc) return rc;
+    for (int i = 0; i + 1 < MMF_NUM_PYRS; ++i) {
+        rc = launch_pyrdown_u8(c, images[i], o->width >> i, o->width >> i, o->height >> i, images[i + 1],
+                               o->width >> (i + 1));
+        if (rc) return rc;
+    }
+    return MMF_OK;
+}
+
+extern "C" int mmf_odom_init_rgb(mmf_odom* o, const uint8_t* rgb, size_t step, int channels) {
+    MMF_REQUIRE(o && rgb && (channels == 3 || channels == 4), "mmf_odom_init_rgb: bad argument");
+    MMF_HIP_TRY(hipSetDevice(o->ctx->device));
+    return odom_populate_rgbd(o, rgb, step, channels, o->next_depth, o->next_image);
+}
+
+extern "C" int mmf_odom_init_rgb_model(mmf_odom* o, const uint8_t* rgb, size_t step, int channels) {
+    MMF_REQUIRE(o && rgb && (channels == 3 || channels == 4), "mmf_odom_init_rgb_model: bad argument");
+    MMF_HIP_TRY(hipSetDevice(o->ctx->device));
+    return odom_populate_rgbd(o, rgb, step, channels, o->last_depth, o->last_image);
+}
+
+extern "C" int mmf_odom_init_first_rgb(mmf_odom* o, const uint8_t* rgb, size_t step, int channels) {
+    MMF_REQUIRE(o && rgb && (channels == 3 || channels == 4), "mmf_odom_init_first_rgb: bad argument");
+    mmf_ctx* c = o->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    int rc = launch_intensity(c, rgb, step ? (int)step : o->width * channels, channels, o->width, o->height,
+                              o->last_next_image[0], o->width);
+    if (rc) return rc;
+    for (int i = 0; i + 1 < MMF_NUM_PYRS; ++i) {  // RGBDOdometry.cpp:212-214
+        rc = launch_pyrdown_u8(c, o->last_next_image[i], o->width >> i, o->width >> i, o->height >> i,
+                               o->last_next_image[i + 1], o->width >> (i + 1));
+        if (rc) return rc;
+    }
+    return MMF_OK;
+}
+
+static IcpArgs odom_icp_args(mmf_odom* o, int level, float* err_map) {
+    const int cols = o->width >> level, rows = o->height >> level;
+    IcpArgs a;
+    a.vmap_curr = MapView{o->vmaps_curr[level], cols};
+    a.nmap_curr = MapView{o->nmaps_curr[level], cols};
+    a.vmap_g_prev = MapView{o->vmaps_g_prev[level], cols};
+    a.nmap_g_prev = MapView{o->nmaps_g_prev[level], cols};
+    a.intr = level_intr(o->fx, o->fy, o->cx, o->cy, level);
+    a.dist_thres = o->dist_thres;
+    a.angle_thres = o->angle_thres;
+    a.cols = cols;
+    a.rows = rows;
+    a.err_map = err_map;
+    a.err_stride = cols;
+    return a;
+}
+
+// RGBDOdometry::getIncrementalTransformation (RGBDOdometry.cpp:217-477), device resident:
+// every kernel below is enqueued back to back on the context's stream; the data-dependent
+// `break`s of the reference (:285-292, :376-378) become flags in the device state that make the
+// remaining launches of that loop return immediately.
+extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[3], float rot[9], int rgb_only,
+                                                       float icp_weight, int pyramid, int fast_odom, int so3,
+                                                       float* icp_err_dev, float* rgb_err_dev) {
+    MMF_REQUIRE(o && trans && rot, "mmf_odom_get_incremental_transformation: null argument");
+    mmf_ctx* c = o->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const bool icp = !rgb_only && icp_weight > 0;  // :221-222
+    const bool rgb = rgb_only || icp_weight < 100;
+
+    if (rgb)
+        for (int i = 0; i < MMF_NUM_PYRS; ++i) {  // :230-235
+            int rc = launch_derivative(c, o->next_image[i], o->width >> i, o->width >> i, o->height >> i, o->dIdx[i],
+                                       o->width >> i, o->dIdy[i], o->width >> i);
+            if (rc) return rc;
+        }
+
+    BeginArgs b;
+    std::memcpy(b.trans, trans, sizeof(b.trans));
+    std::memcpy(b.rot, rot, sizeof(b.rot));
+    b.rgb_only = rgb_only ? 1 : 0;
+    b.icp = icp ? 1 : 0;
+    b.rgb = rgb ? 1 : 0;
+    b.so3 = so3 ? 1 : 0;
+    b.icp_weight = icp_weight;
+    b.so3_intr = level_intr(o->fx, o->fy, o->cx, o->cy, 2);
+    hipLaunchKernelGGL(odom_begin_kernel, dim3(1), dim3(64), 0, c->stream, o->state, b);
+    MMF_HIP_TRY(hipGetLastError());
+
+    if (so3) {  // :239-310
+        const int lvl = 2, cols = o->width >> lvl, rows = o->height >> lvl;
+        So3Args a;
+        a.last_image = o->last_next_image[lvl];
+        a.next_image = o->next_image[lvl];
+        a.l_stride = a.n_stride = cols;
+        a.cols = cols;
+        a.rows = rows;
+        a.intr = b.so3_intr;
+        const int grid = reduce_grid(cols * rows, kBlock);
+        for (int i = 0; i < 10; ++i) {
+            hipLaunchKernelGGL((so3_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), 0, c->stream, o->state, a,
+                               c->partials_f, c->ticket);
+            MMF_HIP_TRY(hipGetLastError());
+        }
+    }
+
+    const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};  // :312-314
+    bool first_level = true;
+    for (int i = MMF_NUM_PYRS - 1; i >= 0; --i) {
+        const int cols = o->width >> i, rows = o->height >> i;
+        const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, i);
+        if (rgb) {  // :332-334
+            int rc = launch_project(c, o->last_depth[i], cols, cols, rows, in, o->cloud[i]);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(gn_level_begin_kernel, dim3(1), dim3(64), 0, c->stream, o->state, first_level ? 1 : 0, in);
+        MMF_HIP_TRY(hipGetLastError());
+        first_level = false;
+
+        for (int j = 0; j < iterations[i]; ++j) {
+            const bool last_l0 = (i == 0 && j == iterations[i] - 1);
+            if (rgb) {  // :363-371
+                const float min_scale = (float)(std::pow((double)o->min_grad[i], 2.0) / std::pow((double)o->sobel_scale, 2.0));
+                RgbResidualArgs a = make_residual_args(min_scale, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0,
+                                                       o->next_depth[i], 0, o->last_image[i], 0, o->next_image[i], 0,
+                                                       o->corres[i], o->max_depth_delta_rgb, cols, rows,
+                                                       last_l0 ? rgb_err_dev : nullptr, 0);
+                a.intr = in;
+                const int grid = reduce_grid(cols * rows, kBlock);
+                hipLaunchKernelGGL((rgb_residual_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), 0, c->stream, o->state,
+                                   a, reinterpret_cast<int*>(c->partials_f), c->ticket);
+                MMF_HIP_TRY(hipGetLastError());
+            }
+            if (icp) {  // :403-410
+                IcpArgs a = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
+                MMF_HIP_TRY(launch_icp<FINISH_GN>(c, o->state, a));
+            }
+            if (rgb) {  // :418-423, then :425-460 in the finishing workgroup
+                RgbStepArgs a;
+                a.corres = o->corres[i];
+                a.cloud = o->cloud[i];
+                a.fx = in.fx;
+                a.fy = in.fy;
+                a.dIdx = o->dIdx[i];
+                a.dIdy = o->dIdy[i];
+                a.d_stride = cols;
+                a.sobel_scale = o->sobel_scale;
+                a.cols = cols;
+                a.rows = rows;
+                a.intr = in;
+                const int grid = reduce_grid(cols * rows, kBlock);
+                hipLaunchKernelGGL((rgb_step_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), 0, c->stream, o->state, a,
+                                   c->partials_f, c->ticket);
+                MMF_HIP_TRY(hipGetLastError());
+            }
+        }
+    }
+
+    hipLaunchKernelGGL(odom_end_kernel, dim3(1), dim3(64), 0, c->stream, o->state);
+    MMF_HIP_TRY(hipGetLastError());
+    MMF_HIP_TRY(hipMemcpyAsync(o->host_result, o->state, sizeof(OdomState), hipMemcpyDeviceToHost, c->stream));
+    MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+
+    if (so3)  // :469-473
+        for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(o->last_next_image[i], o->next_image[i]);
+
+    const OdomState* r = o->host_result;
+    std::memcpy(trans, r->trans_out, sizeof(float) * 3);
+    std::memcpy(rot, r->rot_out, sizeof(float) * 9);
+    // members the reference leaves untouched in a given mode keep their previous values
+    if (icp) {
+        o->stats.lastICPError = r->st.lastICPError;
+        o->stats.lastICPCount = r->st.lastICPCount;
+    }
+    o->stats.lastRGBError = r->st.lastRGBError;
+    o->stats.lastRGBCount = r->st.lastRGBCount;
+    if (so3) {
+        o->stats.lastSO3Error = r->st.lastSO3Error;
+        o->stats.lastSO3Count = r->st.lastSO3Count;
+    }
+    if (r->st.iterations_run > 0) {
+        std::memcpy(o->stats.lastA, r->st.lastA, sizeof(double) * 36);
+        std::memcpy(o->stats.lastb, r->st.lastb, sizeof(double) * 6);
+    }
+    o->stats.iterations_run = r->st.iterations_run;
+    o->stats.so3_iterations_run = r->st.so3_iterations_run;
+    return MMF_OK;
+}
+
+extern "C" int mmf_odom_get_stats(mmf_odom* o, mmf_odom_stats* out) {
+    MMF_REQUIRE(o && out, "mmf_odom_get_stats: null argument");
+    *out = o->stats;
+    return MMF_OK;
+}
+
+// RGBDOdometry.cpp:479 -- lastA.lu().inverse(); Gauss-Jordan with partial pivoting on the host
+extern "C" int mmf_odom_get_covariance(mmf_odom* o, double cov[36]) {
+    MMF_REQUIRE(o && cov, "mmf_odom_get_covariance: null argument");
+    double a[6][12];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            a[i][j] = o->stats.lastA[i * 6 + j];
+            a[i][6 + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int col = 0; col < 6; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 6; ++r)
+            if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (piv != col)
+            for (int k = 0; k < 12; ++k) std::swap(a[piv][k], a[col][k]);
+        const double d = a[col][col];
+        for (int k = 0; k < 12; ++k) a[col][k] /= d;
+        for (int r = 0; r < 6; ++r)
+            if (r != col) {
+                const double f = a[r][col];
+                for (int k = 0; k < 12; ++k) a[r][k] -= f * a[col][k];
+            }
+    }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) cov[i * 6 + j] = a[i][6 + j];
+    return MMF_OK;
+}
+
+extern "C" int mmf_odom_buffer(mmf_odom* o, const char* name, int level, void** dev_ptr, size_t* bytes) {
+    MMF_REQUIRE(o && name && dev_ptr && bytes && level >= 0 && level < MMF_NUM_PYRS, "mmf_odom_buffer: bad argument");
+    const size_t n = (size_t)(o->width >> level) * (o->height >> level);
+    const std::string s(name);
+    void* p = nullptr;
+    size_t b = 0;
+    if (s == "vmaps_curr") p = o->vmaps_curr[level], b = 3 * n * 4;
+    else if (s == "nmaps_curr") p = o->nmaps_curr[level], b = 3 * n * 4;
+    else if (s == "vmaps_g_prev") p = o->vmaps_g_prev[level], b = 3 * n * 4;
+    else if (s == "nmaps_g_prev") p = o->nmaps_g_prev[level], b = 3 * n * 4;
+    else if (s == "last_depth") p = o->last_depth[level], b = n * 4;
+    else if (s == "next_depth") p = o->next_depth[level], b = n * 4;
+    else if (s == "depth_pyr") p = o->depth_pyr[level], b = n * 4;
+    else if (s == "cloud") p = o->cloud[level], b = 3 * n * 4;
+    else if (s == "last_image") p = o->last_image[level], b = n;
+    else if (s == "next_image") p = o->next_image[level], b = n;
+    else if (s == "last_next_image") p = o->last_next_image[level], b = n;
+    else if (s == "dIdx") p = o->dIdx[level], b = n * 2;
+    else if (s == "dIdy") p = o->dIdy[level], b = n * 2;
+    else if (s == "corres") p = o->corres[level], b = n * sizeof(mmf_dataterm);
+    else return fail(MMF_ERR_INVALID, "mmf_odom_buffer: unknown buffer name '" + s + "'");
+    *dev_ptr = p;
+    *bytes = b;
+    return MMF_OK;
+}
+
+extern "C" int mmf_odom_download(mmf_odom* o, const char* name, int level, void* host_dst, size_t host_bytes) {
+    MMF_REQUIRE(host_dst != nullptr, "mmf_odom_download: null destination");
+    void* p = nullptr;
+    size_t b = 0;
+    int rc = mmf_odom_buffer(o, name, level, &p, &b);
+    if (rc) return rc;
+    MMF_REQUIRE(b == host_bytes, "mmf_odom_download: size mismatch");
+    MMF_HIP_TRY(hipSetDevice(o->ctx->device));
+    MMF_HIP_TRY(hipMemcpyAsync(host_dst, p, b, hipMemcpyDeviceToHost, o->ctx->stream));
+    MMF_HIP_TRY(hipStreamSynchronize(o->ctx->stream));
+    return MMF_OK;
+}
+
+extern "C" int mmf_odom_time_icp_kernel(mmf_odom* o, int level, int reps, float* mean_us_out) {
+    MMF_REQUIRE(o && mean_us_out && level >= 0 && level < MMF_NUM_PYRS && reps > 0, "mmf_odom_time_icp_kernel: bad argument");
+    mmf_ctx* c = o->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    IcpArgs a = odom_icp_args(o, level, nullptr);
+    // the state's pose fields are whatever the last getIncrementalTransformation left (or zero);
+    // FINISH_RAW only writes out_f
+    for (int w = 0; w < 3; ++w) MMF_HIP_TRY(launch_icp<FINISH_RAW>(c, o->state, a));
+    MMF_HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; ++r) MMF_HIP_TRY(launch_icp<FINISH_RAW>(c, o->state, a));
+    MMF_HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    MMF_HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    MMF_HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *mean_us_out = ms * 1000.0f / reps;
+    return MMF_OK;
+}

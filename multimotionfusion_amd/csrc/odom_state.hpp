@@ -1,0 +1,338 @@
+// odom_state.hpp -- device-resident Gauss-Newton state of one RGBDOdometry object and the
+// double-precision pose algebra the reference runs on the host between kernel launches.
+//
+// The reference returns to the host after every reduction (2 launches + cudaDeviceSynchronize +
+// a small D2H copy + an Eigen solve, >= 3 x 19 + 10 times per model per frame;
+// Core/Utils/RGBDOdometry.cpp:257-310, 331-462).  Here the state lives in HBM, the workgroup
+// that finishes a reduction also runs the 6x6 solve / SE3 update in double on one lane, and
+// the next kernel on the stream reads the new pose from this struct -- no host round trip
+// inside getIncrementalTransformation.
+//
+// The algebra restates Eigen operations the reference calls (ldlt().solve, inverse(),
+// Isometry3f products; Eigen itself is an unpinned system dependency that is absent here):
+// same formulas as oracle/mmf_oracle.c so both agree to rounding.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+
+namespace mmf {
+
+struct OdomStats {  // mirrors mmf_odom_stats (include/mmf_hip.h)
+    float lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
+    double lastA[36];
+    double lastb[6];
+    int iterations_run;
+    int so3_iterations_run;
+};
+
+struct OdomState {
+    // pose being optimised (RGBDOdometry.cpp:224-228)
+    float Rprev[9], tprev[3], Rprev_inv[9];
+    float Rcurr[9], tcurr[3];
+    double resultRt[16];
+    // SO3 pre-alignment (RGBDOdometry.cpp:237-310)
+    double resultR[9], lastResultR[9];
+    float R_lr[9];
+    float so3_lastError, so3_lastCount;
+    int so3_done;
+    float imageBasis[9], kinv[9], krlr[9];
+    // photometric term
+    float krkinv[9], kt[3];
+    int sigma, rgbCount;
+    float sigmaVal;
+    int level_break;  // rgbOnly divergence `break` of the current level (RGBDOdometry.cpp:376-378)
+    // configuration of this call
+    int rgb_only, icp, rgb, so3;
+    float icp_weight;
+    // last reductions
+    float A_icp[36], b_icp[6], residual_icp[2];
+    float A_rgb[36], b_rgb[6];
+    // raw totals for the stand-alone *Step entry points
+    float out_f[32];
+    int out_i[2];
+    // outputs
+    float trans_out[3], rot_out[9];
+    OdomStats st;
+};
+
+// ---- small dense algebra (double unless suffixed f) -----------------------------------------
+
+__device__ inline void inverse3f(const float* m, float* inv) {  // RGBDOdometry.cpp:316
+    const float c00 = m[4] * m[8] - m[5] * m[7];
+    const float c01 = m[5] * m[6] - m[3] * m[8];
+    const float c02 = m[3] * m[7] - m[4] * m[6];
+    const float det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const float id = 1.0f / det;
+    inv[0] = c00 * id;
+    inv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    inv[3] = c01 * id;
+    inv[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    inv[6] = c02 * id;
+    inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+__device__ inline void inverse3d(const double* m, double* inv) {
+    const double c00 = m[4] * m[8] - m[5] * m[7];
+    const double c01 = m[5] * m[6] - m[3] * m[8];
+    const double c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double id = 1.0 / det;
+    inv[0] = c00 * id;
+    inv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    inv[3] = c01 * id;
+    inv[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    inv[6] = c02 * id;
+    inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+__device__ inline void inverse4d(const double* m, double* inv) {  // RGBDOdometry.cpp:348
+    const double s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2];
+    const double s2 = m[0] * m[7] - m[4] * m[3], s3 = m[1] * m[6] - m[5] * m[2];
+    const double s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+    const double c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11];
+    const double c3 = m[9] * m[14] - m[13] * m[10], c2 = m[8] * m[15] - m[12] * m[11];
+    const double c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    const double id = 1.0 / det;
+    inv[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
+    inv[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
+    inv[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
+    inv[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
+    inv[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
+    inv[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
+    inv[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
+    inv[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
+    inv[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
+    inv[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
+    inv[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
+    inv[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
+    inv[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
+    inv[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
+    inv[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
+    inv[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
+}
+
+template <int N, typename T>
+__device__ inline void matmul(const T* a, const T* b, T* c) {  // c may alias a or b
+    T r[N * N];
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            T s = 0;
+            for (int k = 0; k < N; ++k) s += a[i * N + k] * b[k * N + j];
+            r[i * N + j] = s;
+        }
+    for (int i = 0; i < N * N; ++i) c[i] = r[i];
+}
+
+__device__ inline void rodrigues(const double* src, double* R) {  // OdometryProvider.h:32-67
+    double rx = src[0], ry = src[1], rz = src[2];
+    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    if (theta >= DBL_EPSILON) {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const double c = cos(theta), s = sin(theta), c1 = 1. - c;
+        const double itheta = theta ? 1. / theta : 0.;
+        rx *= itheta;
+        ry *= itheta;
+        rz *= itheta;
+        const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+        const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+        for (int k = 0; k < 9; ++k) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+    }
+}
+
+// LDL^T solve of a symmetric N x N system (what ldlt().solve computes for an SPD matrix up to
+// rounding; RGBDOdometry.cpp:298, 435-443)
+template <int N, typename T>
+__device__ inline void ldlt_solve(const T* A, const T* b, T* x) {
+    T L[N * N], D[N], y[N];
+    for (int j = 0; j < N; ++j) {
+        T d = A[j * N + j];
+        for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k] * D[k];
+        D[j] = d;
+        for (int i = j + 1; i < N; ++i) {
+            T s = A[i * N + j];
+            for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k] * D[k];
+            L[i * N + j] = s / d;
+        }
+    }
+    for (int i = 0; i < N; ++i) {
+        T s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i * N + k] * y[k];
+        y[i] = s;
+    }
+    for (int i = 0; i < N; ++i) y[i] /= D[i];
+    for (int i = N - 1; i >= 0; --i) {
+        T s = y[i];
+        for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k];
+        x[i] = s;
+    }
+}
+
+struct LevelIntr {  // CameraModel::operator()(level), types.cuh:94-98 (computed on the host)
+    float fx, fy, cx, cy;
+};
+
+__device__ inline void k_matrix(const LevelIntr& in, double* K) {  // RGBDOdometry.cpp:336-342
+    for (int i = 0; i < 9; ++i) K[i] = 0;
+    K[0] = in.fx;
+    K[4] = in.fy;
+    K[2] = in.cx;
+    K[5] = in.cy;
+    K[8] = 1;
+}
+
+// SO3 kernel parameters for the next iteration (RGBDOdometry.cpp:261-272)
+__device__ inline void so3_prepare(OdomState* st, const LevelIntr& in) {
+    double K[9], K_inv[9], tmp[9], H[9];
+    k_matrix(in, K);
+    inverse3d(K, K_inv);
+    matmul<3>(K, st->resultR, tmp);
+    for (int k = 0; k < 9; ++k) st->krlr[k] = (float)tmp[k];
+    matmul<3>(tmp, K_inv, H);
+    for (int k = 0; k < 9; ++k) {
+        st->imageBasis[k] = (float)H[k];
+        st->kinv[k] = (float)K_inv[k];
+    }
+}
+
+// after a so3 reduction: RGBDOdometry.cpp:281-308
+__device__ inline void so3_finish(OdomState* st, const float* tot, const LevelIntr& in) {
+    float jtj[9], jtr[3];
+    int shift = 0;  // reduce.cu:1135-1146
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) {
+            const float value = tot[shift++];
+            if (j == 3)
+                jtr[i] = value;
+            else
+                jtj[j * 3 + i] = jtj[i * 3 + j] = value;
+        }
+    const float r0 = tot[9], r1 = tot[10];
+    st->st.so3_iterations_run++;
+    st->st.lastSO3Error = sqrtf(r0) / r1;
+    st->st.lastSO3Count = r1;
+    if (st->st.lastSO3Error < st->so3_lastError && fabsf(st->so3_lastError - st->st.lastSO3Count) < 0.001) {
+        st->so3_done = 1;  // "converged" (the reference compares the error with the COUNT, :285)
+        return;
+    } else if (st->st.lastSO3Error > st->so3_lastError + 0.001) {  // diverging
+        st->st.lastSO3Error = st->so3_lastError;
+        st->st.lastSO3Count = st->so3_lastCount;
+        for (int k = 0; k < 9; ++k) st->resultR[k] = st->lastResultR[k];
+        st->so3_done = 1;
+        return;
+    }
+    st->so3_lastError = st->st.lastSO3Error;
+    st->so3_lastCount = st->st.lastSO3Count;
+    for (int k = 0; k < 9; ++k) st->lastResultR[k] = st->resultR[k];
+    float delta[3];
+    ldlt_solve<3, float>(jtj, jtr, delta);
+    const double dd[3] = {delta[0], delta[1], delta[2]};
+    double rotUpdate[9];
+    float rotUpdatef[9];
+    rodrigues(dd, rotUpdate);
+    for (int k = 0; k < 9; ++k) rotUpdatef[k] = (float)rotUpdate[k];
+    matmul<3, float>(rotUpdatef, st->R_lr, st->R_lr);
+    for (int k = 0; k < 9; ++k) st->resultR[k] = st->R_lr[k];
+    so3_prepare(st, in);
+}
+
+// KRK^-1 and K t of the inverse running transform (RGBDOdometry.cpp:348-358)
+__device__ inline void rgb_prepare(OdomState* st, const LevelIntr& in) {
+    double K[9], K_inv[9], Rt[16], tmp[9], KRK[9];
+    k_matrix(in, K);
+    inverse3d(K, K_inv);
+    inverse4d(st->resultRt, Rt);
+    const double R[9] = {Rt[0], Rt[1], Rt[2], Rt[4], Rt[5], Rt[6], Rt[8], Rt[9], Rt[10]};
+    matmul<3>(K, R, tmp);
+    matmul<3>(tmp, K_inv, KRK);
+    for (int k = 0; k < 9; ++k) st->krkinv[k] = (float)KRK[k];
+    const double t3[3] = {Rt[3], Rt[7], Rt[11]};
+    for (int r = 0; r < 3; ++r)
+        st->kt[r] = (float)(K[r * 3 + 0] * t3[0] + K[r * 3 + 1] * t3[1] + K[r * 3 + 2] * t3[2]);
+}
+
+// unpack 29 sums into the symmetric A and b (reduce.cu:458-472)
+__device__ inline void unpack_se3(const float* tot, float* A, float* b) {
+    int shift = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j) {
+            const float value = tot[shift++];
+            if (j == 6)
+                b[i] = value;
+            else
+                A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+}
+
+// after the photometric correspondence pass: RGBDOdometry.cpp:373-385
+__device__ inline void residual_finish(OdomState* st, int count, int sigma) {
+    st->sigma = sigma;
+    st->rgbCount = count;
+    const float tmpError = (float)(sqrt((double)sigma) / count);
+    float sigmaVal = (tmpError == 0) ? 1 : (float)count;
+    if (st->rgb_only && tmpError > st->st.lastRGBError) {
+        st->level_break = 1;
+        return;
+    }
+    st->st.lastRGBError = tmpError;
+    st->st.lastRGBCount = (float)count;
+    if (st->rgb_only) sigmaVal = -1;
+    st->sigmaVal = sigmaVal;
+}
+
+// combine, solve, update the pose: RGBDOdometry.cpp:425-460 + OdometryProvider.h:69-89
+__device__ inline void solve_and_update(OdomState* st, const LevelIntr& in) {
+    double* A = st->st.lastA;
+    double* b = st->st.lastb;
+    if (st->icp && st->rgb) {
+        const double w = st->icp_weight;
+        for (int k = 0; k < 36; ++k) A[k] = (double)st->A_rgb[k] + w * w * (double)st->A_icp[k];
+        for (int k = 0; k < 6; ++k) b[k] = (double)st->b_rgb[k] + w * (double)st->b_icp[k];
+    } else if (st->icp) {
+        for (int k = 0; k < 36; ++k) A[k] = st->A_icp[k];
+        for (int k = 0; k < 6; ++k) b[k] = st->b_icp[k];
+    } else {
+        for (int k = 0; k < 36; ++k) A[k] = st->A_rgb[k];
+        for (int k = 0; k < 6; ++k) b[k] = st->b_rgb[k];
+    }
+    double result[6];
+    ldlt_solve<6, double>(A, b, result);
+    st->st.iterations_run++;
+
+    double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rup[9];
+    const double rvec[3] = {result[3], result[4], result[5]};
+    rodrigues(rvec, Rup);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) upd[r * 4 + c] = Rup[r * 3 + c];
+        upd[r * 4 + 3] = result[r];
+    }
+    matmul<4>(upd, st->resultRt, st->resultRt);
+
+    float Ro[9], to[3], RoT[9], ti[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) Ro[r * 3 + c] = (float)st->resultRt[r * 4 + c];
+        to[r] = (float)st->resultRt[r * 4 + 3];
+    }
+    // currentT = [Rprev|tprev] * rgbOdom.inverse(); isometry inverse = (R^T, -R^T t)
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) RoT[r * 3 + c] = Ro[c * 3 + r];
+    for (int r = 0; r < 3; ++r)
+        ti[r] = -RoT[r * 3 + 0] * to[0] + -RoT[r * 3 + 1] * to[1] + -RoT[r * 3 + 2] * to[2];
+    matmul<3, float>(st->Rprev, RoT, st->Rcurr);
+    for (int r = 0; r < 3; ++r) {
+        float s = 0;
+        for (int k = 0; k < 3; ++k) s += st->Rprev[r * 3 + k] * ti[k];
+        st->tcurr[r] = s + st->tprev[r];
+    }
+    rgb_prepare(st, in);  // parameters of the next iteration's correspondence pass
+}
+
+}  // namespace mmf

@@ -1,0 +1,46 @@
+"""Per-rigid-body sharding across GPUs (new design -- the reference is single
+GPU and iterates its Model list serially, Core/MultiMotionFusion.cpp:312,793-816).
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the
+CPU tests).  Models never read each other's surfels or pyramids, so the only exchange per frame
+is
+  1. the frame itself: rank 0 broadcasts RGB (u8 x3), depth (f32) and mask (u8) = 8 B/px, and
+     every rank builds its own pyramids (cheaper than shipping them);
+  2. an all_gather of each rank's 4x4 pose + {lastICPError, lastICPCount} (72 B per rank).
+There is no cross-GPU reduction of JtJ: a model's 29-float sum stays on one GPU (a ring
+all-reduce of 116 bytes would be pure latency on point-to-point xGMI links).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def model_owner(model_id: int, world_size: int) -> int:
+    """model m lives on rank m mod G; the global model (id 0) on rank 0."""
+    return model_id % world_size
+
+
+def local_models(num_models: int, rank: int, world_size: int):
+    return [m for m in range(num_models) if model_owner(m, world_size) == rank]
+
+
+def broadcast_frame(rgb: torch.Tensor, depth: torch.Tensor, mask: torch.Tensor, src: int = 0):
+    """Replicate the frame held by `src` into the (pre-allocated) tensors of every rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    # three collectives on one stream; sizes are fixed per frame so RCCL reuses its plan
+    dist.broadcast(rgb, src=src)
+    dist.broadcast(depth, src=src)
+    dist.broadcast(mask, src=src)
+
+
+def gather_poses(pose: np.ndarray, icp_error: float, icp_count: float, device) -> np.ndarray:
+    """all_gather of [16 pose floats, lastICPError, lastICPCount] -> array [world, 18]."""
+    rec = torch.zeros(18, dtype=torch.float32, device=device)
+    rec[:16] = torch.from_numpy(np.asarray(pose, np.float32).reshape(16)).to(device)
+    rec[16], rec[17] = float(icp_error), float(icp_count)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return rec.cpu().numpy()[None]
+    out = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, rec)
+    return torch.stack(out).cpu().numpy()

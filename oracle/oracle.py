@@ -1,0 +1,333 @@
+"""ctypes wrapper of the CPU oracle (oracle/mmf_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module,
+and only as the checker / reported CPU baseline.  PARITY UNPINNED (see mmf_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_DIR, "liboracle.so")
+
+
+def build(force=False, march=None, out=None):
+    """make the oracle library (gcc).  `march`/`out` let bench.py build a -march=native copy."""
+    target = out or "liboracle.so"
+    path = os.path.join(_DIR, target)
+    src_m = max(os.path.getmtime(os.path.join(_DIR, f)) for f in ("mmf_oracle.c", "mmf_oracle.h", "Makefile"))
+    if not force and os.path.exists(path) and os.path.getmtime(path) >= src_m:
+        return path
+    cmd = ["make", "-C", _DIR, f"OUT={target}", "-B"]
+    if march:
+        cmd.append(f"MARCH={march}")
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+    return path
+
+
+class _Dataterm(C.Structure):
+    _fields_ = [("zero_x", C.c_int16), ("zero_y", C.c_int16), ("one_x", C.c_int16), ("one_y", C.c_int16),
+                ("diff", C.c_float), ("valid", C.c_uint8), ("pad_", C.c_uint8 * 3)]
+
+
+class OdomStats(C.Structure):
+    _fields_ = [("lastICPError", C.c_float), ("lastICPCount", C.c_float), ("lastRGBError", C.c_float),
+                ("lastRGBCount", C.c_float), ("lastSO3Error", C.c_float), ("lastSO3Count", C.c_float),
+                ("lastA", C.c_double * 36), ("lastb", C.c_double * 6), ("iterations_run", C.c_int),
+                ("so3_iterations_run", C.c_int)]
+
+
+_lib_cache = {}
+
+
+def lib(path=None):
+    path = path or LIB
+    if path in _lib_cache:
+        return _lib_cache[path]
+    if not os.path.exists(path):
+        build()
+    l = C.CDLL(path)
+    l.orc_odom_create.restype = C.c_void_p
+    l.orc_odom_buffer_f32.restype = C.POINTER(C.c_float)
+    l.orc_odom_buffer_u8.restype = C.POINTER(C.c_uint8)
+    l.orc_odom_buffer_i16.restype = C.POINTER(C.c_int16)
+    l.orc_omp_threads.restype = C.c_int
+    _lib_cache[path] = l
+    return l
+
+
+def _f(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _pf(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _pu8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _pi16(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int16))
+
+
+def _cf(x):
+    return C.c_float(float(x))
+
+
+# ---- map kernels --------------------------------------------------------------------------------
+def create_vmap(depth, fx, fy, cx, cy, cutoff):
+    depth = _f(depth)
+    rows, cols = depth.shape
+    out = np.zeros((3 * rows, cols), np.float32)
+    lib().orc_create_vmap(_pf(depth), cols, rows, _cf(fx), _cf(fy), _cf(cx), _cf(cy), _cf(cutoff), _pf(out))
+    return out
+
+
+def create_nmap(vmap):
+    vmap = _f(vmap)
+    rows, cols = vmap.shape[0] // 3, vmap.shape[1]
+    out = np.zeros_like(vmap)
+    lib().orc_create_nmap(_pf(vmap), cols, rows, _pf(out))
+    return out
+
+
+def transform_maps(vmap, nmap, R, t):
+    vmap, nmap = _f(vmap), _f(nmap)
+    rows, cols = vmap.shape[0] // 3, vmap.shape[1]
+    vd, nd = vmap.copy(), nmap.copy()
+    R, t = _f(np.reshape(R, 9)), _f(np.reshape(t, 3))
+    lib().orc_transform_maps(_pf(vmap), _pf(nmap), cols, rows, _pf(R), _pf(t), _pf(vd), _pf(nd))
+    return vd, nd
+
+
+def copy_maps(v_rgba, n_rgba):
+    v_rgba, n_rgba = _f(v_rgba), _f(n_rgba)
+    rows, cols = v_rgba.shape[:2]
+    vd = np.zeros((3 * rows, cols), np.float32)
+    nd = np.zeros((3 * rows, cols), np.float32)
+    lib().orc_copy_maps(_pf(v_rgba), _pf(n_rgba), cols, rows, _pf(vd), _pf(nd))
+    return vd, nd
+
+
+def resize_map(m, normalize):
+    m = _f(m)
+    rows, cols = m.shape[0] // 3, m.shape[1]
+    out = np.zeros((3 * (rows // 2), cols // 2), np.float32)
+    lib().orc_resize_map(_pf(m), cols, rows, int(normalize), _pf(out))
+    return out
+
+
+def pyrdown_gauss_f(src):
+    src = _f(src)
+    rows, cols = src.shape
+    out = np.zeros((rows // 2, cols // 2), np.float32)
+    lib().orc_pyrdown_gauss_f(_pf(src), cols, rows, _pf(out))
+    return out
+
+
+def pyrdown_uchar_gauss(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    rows, cols = src.shape
+    out = np.zeros((rows // 2, cols // 2), np.uint8)
+    lib().orc_pyrdown_uchar_gauss(_pu8(src), cols, rows, _pu8(out))
+    return out
+
+
+def vertices_to_depth(v_rgba, cutoff):
+    v_rgba = _f(v_rgba)
+    rows, cols = v_rgba.shape[:2]
+    out = np.zeros((rows, cols), np.float32)
+    lib().orc_vertices_to_depth(_pf(v_rgba), cols, rows, _cf(cutoff), _pf(out))
+    return out
+
+
+def image_to_intensity(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    rows, cols, ch = img.shape
+    out = np.zeros((rows, cols), np.uint8)
+    lib().orc_image_to_intensity(_pu8(img), ch, cols, rows, _pu8(out))
+    return out
+
+
+def derivative_images(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    rows, cols = src.shape
+    dx = np.zeros((rows, cols), np.int16)
+    dy = np.zeros((rows, cols), np.int16)
+    lib().orc_derivative_images(_pu8(src), cols, rows, _pi16(dx), _pi16(dy))
+    return dx, dy
+
+
+def project_to_cloud(depth, fx, fy, cx, cy):
+    depth = _f(depth)
+    rows, cols = depth.shape
+    out = np.zeros((rows, cols, 3), np.float32)
+    lib().orc_project_to_cloud(_pf(depth), cols, rows, _cf(fx), _cf(fy), _cf(cx), _cf(cy), _pf(out))
+    return out
+
+
+# ---- reductions -----------------------------------------------------------------------------------
+def icp_step(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, fx, fy, cx, cy, vmap_g_prev, nmap_g_prev,
+             dist_thres, angle_thres, want_err=False):
+    """Returns (out29 float64, err_map or None)."""
+    vc, nc, vp, np_ = _f(vmap_curr), _f(nmap_curr), _f(vmap_g_prev), _f(nmap_g_prev)
+    rows, cols = vc.shape[0] // 3, vc.shape[1]
+    out = np.zeros(29, np.float64)
+    err = np.zeros((rows, cols), np.float32) if want_err else None
+    Rc, tc, Rp, tp = _f(np.reshape(Rcurr, 9)), _f(np.reshape(tcurr, 3)), _f(np.reshape(Rprev_inv, 9)), _f(
+        np.reshape(tprev, 3))
+    lib().orc_icp_step(_pf(Rc), _pf(tc), _pf(vc), _pf(nc), _pf(Rp), _pf(tp), _cf(fx), _cf(fy), _cf(cx), _cf(cy),
+                       _pf(vp), _pf(np_), _cf(dist_thres), _cf(angle_thres), cols, rows,
+                       out.ctypes.data_as(C.POINTER(C.c_double)), _pf(err) if want_err else None)
+    return out, err
+
+
+def icp_step_omp_f32(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, fx, fy, cx, cy, vmap_g_prev,
+                     nmap_g_prev, dist_thres, angle_thres, libpath=None):
+    vc, nc, vp, np_ = _f(vmap_curr), _f(nmap_curr), _f(vmap_g_prev), _f(nmap_g_prev)
+    rows, cols = vc.shape[0] // 3, vc.shape[1]
+    out = np.zeros(29, np.float32)
+    Rc, tc, Rp, tp = _f(np.reshape(Rcurr, 9)), _f(np.reshape(tcurr, 3)), _f(np.reshape(Rprev_inv, 9)), _f(
+        np.reshape(tprev, 3))
+    lib(libpath).orc_icp_step_omp_f32(_pf(Rc), _pf(tc), _pf(vc), _pf(nc), _pf(Rp), _pf(tp), _cf(fx), _cf(fy),
+                                      _cf(cx), _cf(cy), _pf(vp), _pf(np_), _cf(dist_thres), _cf(angle_thres), cols,
+                                      rows, _pf(out))
+    return out
+
+
+def omp_threads(libpath=None):
+    return lib(libpath).orc_omp_threads()
+
+
+def rgb_residual(min_scale, dIdx, dIdy, last_depth, next_depth, last_image, next_image, max_depth_delta, kt, krkinv,
+                 want_err=False):
+    """Returns (corres uint8[rows,cols,16], sigma_sum, count, err_map or None)."""
+    dIdx, dIdy = np.ascontiguousarray(dIdx, np.int16), np.ascontiguousarray(dIdy, np.int16)
+    ld, nd = _f(last_depth), _f(next_depth)
+    li, ni = np.ascontiguousarray(last_image, np.uint8), np.ascontiguousarray(next_image, np.uint8)
+    rows, cols = ni.shape
+    corres = np.zeros((rows, cols, 16), np.uint8)
+    sigma, count = C.c_int(0), C.c_int(0)
+    err = np.zeros((rows, cols), np.float32) if want_err else None
+    ktv, kk = _f(np.reshape(kt, 3)), _f(np.reshape(krkinv, 9))
+    lib().orc_rgb_residual(_cf(min_scale), _pi16(dIdx), _pi16(dIdy), _pf(ld), _pf(nd), _pu8(li), _pu8(ni),
+                           corres.ctypes.data_as(C.POINTER(_Dataterm)), _cf(max_depth_delta), _pf(ktv), _pf(kk),
+                           cols, rows, C.byref(sigma), C.byref(count), _pf(err) if want_err else None)
+    return corres, sigma.value, count.value, err
+
+
+def rgb_step(corres, sigma, cloud, fx, fy, dIdx, dIdy, sobel_scale):
+    corres = np.ascontiguousarray(corres, np.uint8)
+    cloud = _f(cloud)
+    dIdx, dIdy = np.ascontiguousarray(dIdx, np.int16), np.ascontiguousarray(dIdy, np.int16)
+    rows, cols = dIdx.shape
+    out = np.zeros(29, np.float64)
+    lib().orc_rgb_step(corres.ctypes.data_as(C.POINTER(_Dataterm)), _cf(sigma), _pf(cloud), _cf(fx), _cf(fy),
+                       _pi16(dIdx), _pi16(dIdy), _cf(sobel_scale), cols, rows,
+                       out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def so3_step(last_image, next_image, image_basis, kinv, krlr):
+    li, ni = np.ascontiguousarray(last_image, np.uint8), np.ascontiguousarray(next_image, np.uint8)
+    rows, cols = ni.shape
+    out = np.zeros(11, np.float64)
+    B, ki, kr = _f(np.reshape(image_basis, 9)), _f(np.reshape(kinv, 9)), _f(np.reshape(krlr, 9))
+    lib().orc_so3_step(_pu8(li), _pu8(ni), _pf(B), _pf(ki), _pf(kr), cols, rows,
+                       out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def unpack_se3(out29):
+    out29 = np.ascontiguousarray(out29, np.float64)
+    A, b, r = np.zeros(36, np.float32), np.zeros(6, np.float32), np.zeros(2, np.float32)
+    lib().orc_unpack_se3(out29.ctypes.data_as(C.POINTER(C.c_double)), _pf(A), _pf(b), _pf(r))
+    return A.reshape(6, 6), b, r
+
+
+def unpack_so3(out11):
+    out11 = np.ascontiguousarray(out11, np.float64)
+    A, b, r = np.zeros(9, np.float32), np.zeros(3, np.float32), np.zeros(2, np.float32)
+    lib().orc_unpack_so3(out11.ctypes.data_as(C.POINTER(C.c_double)), _pf(A), _pf(b), _pf(r))
+    return A.reshape(3, 3), b, r
+
+
+# ---- whole odometry object --------------------------------------------------------------------
+class Odometry:
+    """Oracle restatement of class RGBDOdometry (same method names as the product mirror)."""
+
+    def __init__(self, width, height, cx, cy, fx, fy, distThresh=0.10,
+                 angleThresh=float(np.sin(20.0 * 3.14159254 / 180.0))):
+        self.width, self.height = width, height
+        self.h = C.c_void_p(lib().orc_odom_create(width, height, _cf(cx), _cf(cy), _cf(fx), _cf(fy),
+                                                  _cf(distThresh), _cf(angleThresh)))
+
+    def initICP(self, depth_l0, depthCutoff):
+        d = _f(depth_l0)
+        lib().orc_odom_init_icp(self.h, _pf(d), _cf(depthCutoff))
+
+    def initICPFromPrediction(self, vert_rgba, norm_rgba):
+        v, n = _f(vert_rgba), _f(norm_rgba)
+        lib().orc_odom_init_icp_from_prediction(self.h, _pf(v), _pf(n))
+
+    def initICPModel(self, vert_rgba, norm_rgba, pose):
+        v, n, p = _f(vert_rgba), _f(norm_rgba), _f(np.reshape(pose, 16))
+        lib().orc_odom_init_icp_model(self.h, _pf(v), _pf(n), _pf(p))
+
+    def initRGB(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        lib().orc_odom_init_rgb(self.h, _pu8(rgb), rgb.shape[2])
+
+    def initRGBModel(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        lib().orc_odom_init_rgb_model(self.h, _pu8(rgb), rgb.shape[2])
+
+    def initFirstRGB(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        lib().orc_odom_init_first_rgb(self.h, _pu8(rgb), rgb.shape[2])
+
+    def getIncrementalTransformation(self, trans, rot, rgbOnly, icpWeight, pyramid, fastOdom, so3, want_err=False):
+        t = _f(np.reshape(trans, 3)).copy()
+        r = _f(np.reshape(rot, 9)).copy()
+        icp_err = np.zeros((self.height, self.width), np.float32) if want_err else None
+        rgb_err = np.zeros((self.height, self.width), np.float32) if want_err else None
+        lib().orc_odom_get_incremental_transformation(self.h, _pf(t), _pf(r), int(bool(rgbOnly)), _cf(icpWeight),
+                                                      int(bool(pyramid)), int(bool(fastOdom)), int(bool(so3)),
+                                                      _pf(icp_err) if want_err else None,
+                                                      _pf(rgb_err) if want_err else None)
+        self.icp_err, self.rgb_err = icp_err, rgb_err
+        return t, r.reshape(3, 3)
+
+    def stats(self):
+        s = OdomStats()
+        lib().orc_odom_get_stats(self.h, C.byref(s))
+        return s
+
+    def buffer(self, name, level):
+        cols, rows = self.width >> level, self.height >> level
+        if name in ("last_image", "next_image", "last_next_image"):
+            p = lib().orc_odom_buffer_u8(self.h, name.encode(), level)
+            return np.ctypeslib.as_array(p, (rows, cols)).copy()
+        if name in ("dIdx", "dIdy"):
+            p = lib().orc_odom_buffer_i16(self.h, name.encode(), level)
+            return np.ctypeslib.as_array(p, (rows, cols)).copy()
+        p = lib().orc_odom_buffer_f32(self.h, name.encode(), level)
+        if name == "cloud":
+            return np.ctypeslib.as_array(p, (rows, cols, 3)).copy()
+        planes = 3 if name.startswith(("vmaps", "nmaps")) else 1
+        return np.ctypeslib.as_array(p, (planes * rows, cols)).copy()
+
+    def close(self):
+        if self.h:
+            lib().orc_odom_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

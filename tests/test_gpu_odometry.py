@@ -1,0 +1,136 @@
+"""-m gpu: the device-resident RGBDOdometry (C ABI mmf_odom_*) against the oracle's restatement of
+RGBDOdometry::getIncrementalTransformation on the same synthetic frames.
+
+Tolerance (BASELINE.json north_star): pose within 1e-4 relative translation / 1e-3 rad of the
+reference path.  The two sides differ only in float32 summation order, so the test asserts the
+much tighter 2e-6 m / 2e-6 rad; pyramid buffers must be bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_bit_equal, frame_pair
+from multimotionfusion_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+MODES = [
+    dict(rgbOnly=False, icpWeight=10.0, pyramid=True, fastOdom=False, so3=True),   # GUI defaults
+    dict(rgbOnly=False, icpWeight=100.0, pyramid=True, fastOdom=False, so3=False),  # ICP only
+    dict(rgbOnly=True, icpWeight=10.0, pyramid=True, fastOdom=False, so3=False),    # RGB only (may break early)
+    dict(rgbOnly=False, icpWeight=10.0, pyramid=False, fastOdom=True, so3=True),    # fast odometry
+]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def setup_pair(gpu_ctx, orc, w, h, seed=1):
+    from multimotionfusion_amd.odometry import RGBDOdometry
+    K, prev, cur, fp, fc = frame_pair(w, h, seed=seed)
+    g = RGBDOdometry(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    o = orc.Odometry(w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    pose = prev.astype(np.float32)
+    # first frame bootstrap, then the per-frame sequence of Model::initICP (Model.cpp:390-407)
+    g.initFirstRGB(dev(fp["rgb"]))
+    o.initFirstRGB(fp["rgb"])
+    g.initICPModel(dev(fp["vertex"]), dev(fp["normal"]), 15.0, pose)
+    o.initICPModel(fp["vertex"], fp["normal"], pose)
+    g.initRGBModel(dev(fp["rgb"]))
+    o.initRGBModel(fp["rgb"])
+    g.buildDepthPyramid(dev(fc["depth"]))
+    g.initICP(depthCutoff=15.0)
+    o.initICP(fc["depth"], 15.0)
+    g.initRGB(dev(fc["rgb"]))
+    o.initRGB(fc["rgb"])
+    return K, prev, cur, g, o
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (320, 240)])
+def test_pyramids_bit_exact(gpu_ctx, orc, w, h):
+    K, prev, cur, g, o = setup_pair(gpu_ctx, orc, w, h)
+    for lvl in range(3):
+        rows = h >> lvl
+        for name in ("vmaps_curr", "nmaps_curr", "vmaps_g_prev", "nmaps_g_prev"):
+            a, b = g.download(name, lvl), o.buffer(name, lvl)
+            valid = ~np.isnan(b[:rows])
+            assert_bit_equal(np.isnan(a[:rows]), np.isnan(b[:rows]), f"{name}[{lvl}] validity")
+            for p in range(3):
+                assert_bit_equal(a[p * rows:(p + 1) * rows][valid], b[p * rows:(p + 1) * rows][valid],
+                                 f"{name}[{lvl}] plane {p}")
+        for name in ("last_depth", "next_depth", "depth_pyr", "last_image", "next_image", "last_next_image"):
+            assert_bit_equal(g.download(name, lvl), o.buffer(name, lvl), f"{name}[{lvl}]")
+    g.close()
+
+
+@pytest.mark.parametrize("mode", MODES, ids=["icp+rgb+so3", "icp", "rgbOnly", "fast"])
+@pytest.mark.parametrize("w,h", [(640, 480), (320, 240)])
+def test_incremental_transformation_matches_oracle(gpu_ctx, orc, w, h, mode):
+    K, prev, cur, g, o = setup_pair(gpu_ctx, orc, w, h)
+    icp_err = torch.zeros(h, w, device="cuda")
+    rgb_err = torch.zeros(h, w, device="cuda")
+    tg, Rg = g.getIncrementalTransformation(prev[:3, 3], prev[:3, :3], icpErrorSurface=icp_err,
+                                            rgbErrorSurface=rgb_err, **mode)
+    to, Ro = o.getIncrementalTransformation(prev[:3, 3], prev[:3, :3], want_err=True, **mode)
+    so = o.stats()
+    assert g.iterations_run == so.iterations_run and g.so3_iterations_run == so.so3_iterations_run
+    assert np.linalg.norm(tg - to) <= 2e-6, (tg, to)
+    assert synth.rotation_angle(Rg, Ro) <= 2e-6 + 4e-4 * 0  # float32 rotation matrices: acos floor ~3e-4 avoided below
+    assert np.abs(Rg - Ro).max() <= 2e-6, np.abs(Rg - Ro).max()
+    # derived dense-tracking statistics (RGBDOdometry.h:62-69)
+    icp = (not mode["rgbOnly"]) and mode["icpWeight"] > 0
+    if icp:
+        assert g.lastICPCount == so.lastICPCount or abs(g.lastICPCount - so.lastICPCount) <= 2  # threshold ties
+        assert abs(g.lastICPError - so.lastICPError) <= 1e-4 * so.lastICPError + 1e-9
+    assert abs(g.lastRGBCount - so.lastRGBCount) <= 2
+    A, Ao = g.lastA, np.array(so.lastA).reshape(6, 6)
+    assert np.abs(A - Ao).max() <= 1e-4 * np.abs(Ao).max()
+    # accuracy against the known motion (sanity, not parity): the step must reduce the pose error
+    gt_t, gt_R = cur[:3, 3], cur[:3, :3]
+    if icp:
+        assert np.linalg.norm(tg - gt_t) < np.linalg.norm(prev[:3, 3] - gt_t)
+        assert synth.rotation_angle(Rg.astype(np.float64), gt_R) < synth.rotation_angle(prev[:3, :3], gt_R)
+    # error surfaces of the last level-0 iteration
+    if icp and g.lastICPCount == so.lastICPCount:
+        diff = np.abs(icp_err.cpu().numpy() - o.icp_err)
+        assert np.mean(diff > 1e-5) < 1e-3, "icp error surface"
+    g.close()
+
+
+def test_call_order_contract(gpu_ctx):
+    """initRGB* before initICPModel must fail loudly (RGBDOdometry.cpp:197,202 NOTE)."""
+    from multimotionfusion_amd import MmfError
+    from multimotionfusion_amd.odometry import RGBDOdometry
+    K = synth.intrinsics(64, 48)
+    g = RGBDOdometry(gpu_ctx, 64, 48, K["cx"], K["cy"], K["fx"], K["fy"])
+    with pytest.raises(MmfError):
+        g.initRGB(torch.zeros(48, 64, 3, dtype=torch.uint8, device="cuda"))
+    g.close()
+
+
+def test_multi_frame_tracking_follows_ground_truth(gpu_ctx):
+    """Config 2 style run: 8 frames of the synthetic sequence, frame-to-model against the clean
+    prediction rendered at the ESTIMATED pose; drift must stay small."""
+    from multimotionfusion_amd.odometry import RGBDOdometry
+    w, h = 320, 240
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(8, seed=3)
+    g = RGBDOdometry(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    est = poses[0].copy()
+    f0 = synth.render(poses[0], w, h, seed=0)
+    g.initFirstRGB(dev(f0["rgb"]))
+    for i in range(1, len(poses)):
+        model = synth.render(est, w, h, seed=100 + i, noise=False, dropout=0)
+        cur = synth.render(poses[i], w, h, seed=i)
+        g.initICPModel(dev(model["vertex"]), dev(model["normal"]), 15.0, est.astype(np.float32))
+        g.initRGBModel(dev(model["rgb"]))
+        g.buildDepthPyramid(dev(cur["depth"]))
+        g.initICP(depthCutoff=15.0)
+        g.initRGB(dev(cur["rgb"]))
+        t, R = g.getIncrementalTransformation(est[:3, 3], est[:3, :3], False, 10.0, True, False, True)
+        est = np.eye(4)
+        est[:3, :3], est[:3, 3] = R, t
+        assert np.linalg.norm(t - poses[i][:3, 3]) < 4e-3, (i, t, poses[i][:3, 3])
+        assert synth.rotation_angle(R.astype(np.float64), poses[i][:3, :3]) < 4e-3
+    g.close()
