@@ -63,8 +63,10 @@ typedef struct {
 int mmf_abi_version(void);
 const char *mmf_last_error(void);
 
-/* `stream` is a hipStream_t to run on (e.g. the caller's), or NULL to create a private one. */
-int mmf_ctx_create(int device, void *stream, mmf_ctx **out);
+/* private_stream != 0: create and own a non-blocking stream (`stream` is ignored).
+ * private_stream == 0: run on the caller's hipStream_t `stream`; NULL is the device's default
+ * (null) stream, which is what the reference uses throughout. */
+int mmf_ctx_create(int device, void *stream, int private_stream, mmf_ctx **out);
 void mmf_ctx_destroy(mmf_ctx *ctx);
 int mmf_ctx_synchronize(mmf_ctx *ctx);
 void *mmf_ctx_stream(mmf_ctx *ctx);
@@ -209,8 +211,9 @@ int mmf_odom_download(mmf_odom *o, const char *name, int level, void *host_dst, 
 
 /* Timing hook for bench.py: enqueue `reps` back-to-back launches of the level-`level` ICP
  * reduction kernel on the odometry object's current maps and pose (no host work in
- * between), bracketed by HIP events on the context's stream; returns the mean time per launch. */
-int mmf_odom_time_icp_kernel(mmf_odom *o, int level, int reps, float *mean_us_out);
+ * between), bracketed by HIP events on the context's stream; returns the mean time per launch.
+ * variant: 0 = the shipped launch geometry, else PX * 10000 + BLOCK (tuning sweeps). */
+int mmf_odom_time_icp_kernel(mmf_odom *o, int level, int reps, int variant, float *mean_us_out);
 
 #ifdef __cplusplus
 }

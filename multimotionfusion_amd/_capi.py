@@ -44,7 +44,7 @@ _cam = C.POINTER(mmf_camera)
 SIGNATURES = {
     "mmf_abi_version": (_i, []),
     "mmf_last_error": (C.c_char_p, []),
-    "mmf_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "mmf_ctx_create": (_i, [_i, _vp, _i, C.POINTER(_vp)]),
     "mmf_ctx_destroy": (None, [_vp]),
     "mmf_ctx_synchronize": (_i, [_vp]),
     "mmf_ctx_stream": (_vp, [_vp]),
@@ -81,7 +81,7 @@ SIGNATURES = {
     "mmf_odom_get_covariance": (_i, [_vp, C.POINTER(C.c_double)]),
     "mmf_odom_buffer": (_i, [_vp, C.c_char_p, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "mmf_odom_download": (_i, [_vp, C.c_char_p, _i, _vp, _sz]),
-    "mmf_odom_time_icp_kernel": (_i, [_vp, _i, _i, _fp]),
+    "mmf_odom_time_icp_kernel": (_i, [_vp, _i, _i, _i, _fp]),
 }
 
 _lib = None
@@ -96,6 +96,9 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m multimotionfusion_amd.build` "
             "(hipcc, gfx950). multimotionfusion_amd has no CPU fallback.")
+    # torch bundles its own libamdhip64; it must be the FIRST HIP runtime mapped into the process
+    # (ours then binds to the same SONAME).  Two runtimes in one process do not see the device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

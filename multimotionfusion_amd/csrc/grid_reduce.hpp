@@ -2,26 +2,31 @@
 //
 // Replaces the reference's warpReduceSum / blockReduceSum / second-launch reduceSum
 // (Core/Cuda/reduce.cu:64-229, 663-720), which assume 32-wide warps and cost a second kernel
-// launch plus a device synchronise per Gauss-Newton step.  Here:
+// launch plus a device synchronise per Gauss-Newton step.  Here, in ONE launch:
 //   1. each lane keeps NV running sums in registers;
 //   2. a wave64 reduces them with DPP row shifts / row broadcasts (no LDS traffic);
 //   3. the workgroup's waves combine through LDS in wave order;
-//   4. the workgroup publishes its NV partials with write-through (sc1) stores, drains them and
-//      takes a ticket from one device-scope counter; the workgroup whose ticket is the last
-//      re-reads every partial with sc1 loads and sums them in a fixed order.
+//   4. the workgroup publishes its partial record (32 values = one 128-byte line) with 16-byte
+//      write-through (sc1) stores, drains them and takes a ticket.  Tickets are SHARDED over
+//      kShards counters (one 128-byte line each) plus a top counter, because one device-scope
+//      counter serialises at ~12 ns per arrival (a 1200-workgroup grid would spend ~14 us in
+//      its ticket alone); the last arriver of a shard arrives at the top counter;
+//   5. the workgroup that completes the top counter re-reads every record with 16-byte sc1
+//      buffer loads, ALL issued before the first use (one round trip instead of one per
+//      record), and sums them in a fixed order.
 // The summation order depends only on the launch geometry, so results are bit-reproducible
-// from run to run (float atomics would not be).  The hand-off follows the write-through form
-// of the CDNA4 guide (sc1 payload stores, every storing wave drains with s_waitcnt vmcnt(0),
-// ONE lane signals with an agent-scope atomic, the last arriver loads with sc1 loads after
-// its add has returned and the other waves after a workgroup barrier).
+// from run to run (float atomics would not be).  The hand-off is the write-through form of the
+// CDNA4 guide (sc1 payload stores, the storing wave drains with s_waitcnt vmcnt(0), ONE lane
+// signals with an agent-scope atomic, the last arriver loads with sc1 loads after its add has
+// returned and the other waves after a workgroup barrier).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace mmf {
 
-constexpr int kBlock = 256;           // threads per workgroup for every reduction kernel
-constexpr int kWaves = kBlock / 64;   // wave64
-constexpr int kPartialStride = 32;    // floats per workgroup partial record (NV <= 32)
+constexpr int kPartialStride = 32;  // values per workgroup partial record (NV <= 32), 128 bytes
+constexpr int kShards = 16;         // ticket shards; counters live 32 words (128 B) apart
+constexpr int kTicketWords = (kShards + 1) * 32;
 
 // One DPP move: lanes without a source (row edge, masked row/bank) read 0, the sum's identity.
 template <int CTRL, int ROW_MASK, int BANK_MASK, typename T>
@@ -43,81 +48,194 @@ __device__ __forceinline__ T wave_sum_to_lane63(T v) {
     return v;
 }
 
-__device__ __forceinline__ void store_sc1(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void store_sc1(int* p, int v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float load_sc1(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int load_sc1(const int* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// the exact vector type of __builtin_amdgcn_raw_buffer_{load,store}_b128 (a converted ext_vector
+// made hipcc splat element 0 -- checked in the ISA)
+typedef unsigned int v4u __attribute__((__vector_size__(4 * sizeof(unsigned int))));
 
-// LDS scratch one reduction needs.
-template <typename T>
+// LDS scratch of one reduction.
+template <typename T, int BLOCK>
 struct GridReduceLds {
-    T wave[kWaves][kPartialStride];
-    T group[8][kPartialStride];
+    T wave[BLOCK / 64][kPartialStride];
+    T group[32][kPartialStride + 4];  // +4: keeps 16-byte alignment, staggers banks between rows
     T total[kPartialStride];
     int is_last;
 };
 
-// Reduce v[0..NV) over the whole grid.  Returns true in every thread of the LAST workgroup to
-// arrive; there lds.total[0..NV) holds the grid totals (valid after the function returns).
-// partials: gridDim.x * kPartialStride elements; ticket: one zero-initialised counter, reset to
-// zero by the last workgroup so the same buffer serves the next launch on the stream.
-template <int NV, typename T>
-__device__ __forceinline__ bool grid_reduce(T (&v)[NV], T* __restrict__ partials,
-                                            unsigned* __restrict__ ticket, GridReduceLds<T>& lds) {
+// Descriptor over a partial-record array; inputs go through readfirstlane so hipcc can PROVE them
+// wave-uniform (otherwise every buffer op is wrapped in a serialising "waterfall" loop).
+template <typename T>
+__device__ __forceinline__ auto partials_rsrc(const T* partials, unsigned nrecords) {
+    const unsigned long long pbits = reinterpret_cast<unsigned long long>(partials);
+    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pbits);
+    const unsigned phi = __builtin_amdgcn_readfirstlane((unsigned)(pbits >> 32));
+    void* pbase = reinterpret_cast<void*>(((unsigned long long)phi << 32) | plo);
+    const int pbytes = __builtin_amdgcn_readfirstlane((int)(nrecords * kPartialStride * sizeof(T)));
+    return __builtin_amdgcn_make_buffer_rsrc(pbase, 0, pbytes, 0x00020000);
+}
+
+// Steps 2-4a: reduce v[] over the workgroup and store its 128-byte record (record index =
+// blockIdx.x).  WRITE_THROUGH selects sc1 stores (needed when another workgroup of the SAME launch
+// reads the record); plain stores are enough when the consumer is a later kernel on the stream.
+// Ends with a workgroup barrier; wave 0 has issued (not drained) the stores.
+template <int NV, int BLOCK, bool WRITE_THROUGH, typename T>
+__device__ __forceinline__ void block_reduce_store(T (&v)[NV], T* __restrict__ partials,
+                                                   GridReduceLds<T, BLOCK>& lds) {
     static_assert(NV <= kPartialStride, "too many values");
+    static_assert(BLOCK % 64 == 0 && BLOCK >= 256, "BLOCK must be >= 256 and a multiple of 64");
+    constexpr int kWaves = BLOCK / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-
+    // step-major DPP reduction: the NV chains advance together, so consecutive instructions are
+    // independent and the DPP read-after-write wait states are hidden (value-major order ran one
+    // 6-deep dependent chain after the other: ~2 us per workgroup in phase stamps)
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const T s = wave_sum_to_lane63(v[k]);
-        if (lane == 63) lds.wave[wave][k] = s;
+    for (int k = 0; k < NV; ++k) v[k] = v[k] + dpp_mov0<0x111, 0xf, 0xf>(v[k]);  // row_shr:1
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = v[k] + dpp_mov0<0x112, 0xf, 0xf>(v[k]);  // row_shr:2
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = v[k] + dpp_mov0<0x114, 0xf, 0xe>(v[k]);  // row_shr:4
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = v[k] + dpp_mov0<0x118, 0xf, 0xc>(v[k]);  // row_shr:8
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = v[k] + dpp_mov0<0x142, 0xa, 0xf>(v[k]);  // row_bcast:15
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = v[k] + dpp_mov0<0x143, 0xc, 0xf>(v[k]);  // row_bcast:31
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) lds.wave[wave][k] = v[k];
+        for (int k = NV; k < kPartialStride; ++k) lds.wave[wave][k] = T(0);
     }
     __syncthreads();
-
-    if (wave == 0) {
-        if (lane < NV) {
-            T s = lds.wave[0][lane];
+    if (wave == 0 && lane < 8) {  // 8 lanes x 16 bytes = the workgroup's 128-byte record
+        const auto rsrc = partials_rsrc(partials, gridDim.x);
+        T s[4];
 #pragma unroll
-            for (int w = 1; w < kWaves; ++w) s = s + lds.wave[w][lane];
-            store_sc1(&partials[blockIdx.x * kPartialStride + lane], s);
+        for (int j = 0; j < 4; ++j) {
+            s[j] = lds.wave[0][lane * 4 + j];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) s[j] = s[j] + lds.wave[w][lane * 4 + j];
         }
-        // every storing wave drains its write-through stores before the signal
+        v4u pk;
+        pk[0] = __builtin_bit_cast(unsigned, s[0]);
+        pk[1] = __builtin_bit_cast(unsigned, s[1]);
+        pk[2] = __builtin_bit_cast(unsigned, s[2]);
+        pk[3] = __builtin_bit_cast(unsigned, s[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (int)((blockIdx.x * kPartialStride + lane * 4) * sizeof(T)), 0,
+                                               WRITE_THROUGH ? 16 /* sc1 */ : 0);
+    }
+}
+
+// Step 5: fixed-order sum of `nrecords` partial records by the first 256 threads of a workgroup
+// (all BLOCK threads must call); totals land in lds.total[0..32).  All 16-byte loads of a pass are
+// issued before the first use; reads beyond the last record return zero (buffer range check).
+// SC1 selects loads that bypass this CU's L1 (records written during the SAME launch).
+template <int BLOCK, bool SC1, typename T>
+__device__ __forceinline__ void sum_partial_records(const T* __restrict__ partials, unsigned nrecords,
+                                                    GridReduceLds<T, BLOCK>& lds) {
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        const auto rsrc = partials_rsrc(partials, nrecords);
+        const int rec0 = tid >> 3, q = tid & 7;
+        T acc[4] = {T(0), T(0), T(0), T(0)};
+        constexpr int U = 8;
+        for (unsigned base = 0; base < nrecords; base += 32 * U) {
+            v4u r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                r[u] = __builtin_amdgcn_raw_buffer_load_b128(
+                    rsrc, (int)(((base + u * 32 + rec0) * kPartialStride + q * 4) * sizeof(T)), 0, SC1 ? 16 : 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[0] = acc[0] + __builtin_bit_cast(T, (unsigned)r[u][0]);
+                acc[1] = acc[1] + __builtin_bit_cast(T, (unsigned)r[u][1]);
+                acc[2] = acc[2] + __builtin_bit_cast(T, (unsigned)r[u][2]);
+                acc[3] = acc[3] + __builtin_bit_cast(T, (unsigned)r[u][3]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds.group[rec0][q * 4 + j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < kPartialStride) {
+        T s = lds.group[0][tid];
+#pragma unroll
+        for (int g = 1; g < 32; ++g) s = s + lds.group[g][tid];
+        lds.total[tid] = s;
+    }
+    __syncthreads();
+}
+
+// Workgroup-wide sum of two ints, result broadcast to every thread (the photometric pass only
+// reduces {count, sum diff^2}; a full 128-byte record per workgroup would waste the consumer's
+// bandwidth, so these travel as dense int2 records instead).
+template <int BLOCK>
+__device__ __forceinline__ void block_sum2(int& a, int& b, GridReduceLds<int, BLOCK>& lds) {
+    constexpr int kWaves = BLOCK / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    a = wave_sum_to_lane63(a);
+    b = wave_sum_to_lane63(b);
+    __syncthreads();  // protects lds.wave against a previous use
+    if (lane == 63) {
+        lds.wave[wave][0] = a;
+        lds.wave[wave][1] = b;
+    }
+    __syncthreads();
+    a = lds.wave[0][0];
+    b = lds.wave[0][1];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) {
+        a += lds.wave[w][0];
+        b += lds.wave[w][1];
+    }
+}
+
+// Sum `n` dense int2 records (written by an EARLIER launch) over the workgroup; result in every thread.
+template <int BLOCK>
+__device__ __forceinline__ void sum_int2_records(const int2* __restrict__ rec, unsigned n, int& a, int& b,
+                                                 GridReduceLds<int, BLOCK>& lds) {
+    a = 0;
+    b = 0;
+    for (unsigned i = threadIdx.x; i < n; i += BLOCK) {
+        const int2 r = rec[i];
+        a += r.x;
+        b += r.y;
+    }
+    block_sum2<BLOCK>(a, b, lds);
+}
+
+// Reduce v[0..NV) over the whole grid in one launch.  Returns true in every thread of the LAST
+// workgroup to arrive; there lds.total[0..NV) holds the grid totals.  partials: gridDim.x records;
+// tickets: kTicketWords zero-initialised words, left zeroed for the next launch.
+template <int NV, int BLOCK, typename T>
+__device__ __forceinline__ bool grid_reduce(T (&v)[NV], T* __restrict__ partials,
+                                            unsigned* __restrict__ tickets, GridReduceLds<T, BLOCK>& lds) {
+    const int tid = threadIdx.x;
+    const unsigned nblocks = gridDim.x;
+    block_reduce_store<NV, BLOCK, true>(v, partials, lds);
+    if (tid < 64) {
+        // the storing wave drains its write-through stores before the signal
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            const unsigned t =
-                __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lds.is_last = (t == gridDim.x - 1) ? 1 : 0;
+        if (tid == 0) {
+            int last = 0;
+            const unsigned shard = blockIdx.x % kShards;
+            const unsigned in_shard = (nblocks - shard + kShards - 1) / kShards;
+            const unsigned t = __hip_atomic_fetch_add(&tickets[shard * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == in_shard - 1) {
+                __hip_atomic_store(&tickets[shard * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned nshards = nblocks < (unsigned)kShards ? nblocks : (unsigned)kShards;
+                const unsigned t2 = __hip_atomic_fetch_add(&tickets[kShards * 32], 1u, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+                if (t2 == nshards - 1) {
+                    __hip_atomic_store(&tickets[kShards * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = 1;
+                }
+            }
+            lds.is_last = last;
         }
     }
     __syncthreads();
     if (!lds.is_last) return false;
-
-    // last workgroup: fixed-order sum of all partials (sc1 loads bypass this CU's L1)
-    {
-        const int c = tid & 31, g = tid >> 5;  // 8 groups of 32
-        T s = T(0);
-        if (c < NV)
-            for (unsigned b = g; b < gridDim.x; b += 8) s = s + load_sc1(&partials[b * kPartialStride + c]);
-        lds.group[g][c] = s;
-    }
-    __syncthreads();
-    if (tid < NV) {
-        T s = lds.group[0][tid];
-#pragma unroll
-        for (int g = 1; g < 8; ++g) s = s + lds.group[g][tid];
-        lds.total[tid] = s;
-    }
-    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
+    sum_partial_records<BLOCK, true>(partials, nblocks, lds);
     return true;
 }
 

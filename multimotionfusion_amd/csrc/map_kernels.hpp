@@ -142,33 +142,40 @@ __global__ __launch_bounds__(256) void resize_map_kernel(int drows, int dcols, i
     out[(size_t)(y + 2 * drows) * o_stride + x] = n.z;
 }
 
-// 5x5 binomial weights (cudafuncs.cu:517-521).  The reference cudaMallocs, uploads and frees
-// this table on every call (:523-531); here it is a compile-time constant.
-__device__ __forceinline__ float gauss5(int idx) {
-    constexpr float w[25] = {1, 4, 6, 4, 1, 4, 16, 24, 16, 4, 6, 24, 36, 24, 6, 4, 16, 24, 16, 4, 1, 4, 6, 4, 1};
-    return w[idx];
-}
+// 5x5 binomial weights (cudafuncs.cu:517-521) = outer product of {1,4,6,4,1}.  The reference
+// cudaMallocs, uploads and frees this table on every call (:523-531); here the weight is
+// computed (a table indexed per tap would live in scratch or constant memory).
+__device__ __forceinline__ float binom5(int k) { return k == 2 ? 6.f : ((k == 1 || k == 3) ? 4.f : 1.f); }
 
-// cudafuncs.cu:333-364 (pyrDownKernelGaussF), quirks kept: int `count`, clipped asymmetric window
+// cudafuncs.cu:333-364 (pyrDownKernelGaussF), quirks kept: int `count`, the window is
+// [max(0,2x-2), min(2x+3, cols-1)) and the weight index is mirrored from the clipped end (:358)
 __global__ __launch_bounds__(256) void pyrdown_gauss_f_kernel(const float* __restrict__ src, int s_stride, int scols,
                                                               int srows, float* __restrict__ dst, int d_stride,
                                                               int dcols, int drows) {
     MMF_PIXEL_XY();
     if (x >= dcols || y >= drows) return;
-    const int D = 5;
-    const int tx = min(2 * x - D / 2 + D, scols - 1);
-    const int ty = min(2 * y - D / 2 + D, srows - 1);
+    const int tx = min(2 * x + 3, scols - 1);
+    const int ty = min(2 * y + 3, srows - 1);
     float sum = 0;
     int count = 0;
-    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
-        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
-            const float s = src[(size_t)cy * s_stride + cx];
-            if (!(s != s)) {
-                const float w = gauss5((ty - cy - 1) * 5 + (tx - cx - 1));
-                sum += s * w;
-                count = (int)((float)count + w);
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+        const int cy = 2 * y - 2 + dy;
+        const bool rowok = cy >= 0 && cy < ty;
+        const float wy = binom5(ty - cy - 1);
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+            const int cx = 2 * x - 2 + dx;
+            if (rowok && cx >= 0 && cx < tx) {
+                const float s = src[(size_t)cy * s_stride + cx];
+                if (!(s != s)) {
+                    const float w = wy * binom5(tx - cx - 1);
+                    sum += s * w;
+                    count = (int)((float)count + w);
+                }
             }
         }
+    }
     dst[(size_t)y * d_stride + x] = (float)(sum / (float)count);
 }
 
@@ -178,20 +185,28 @@ __global__ __launch_bounds__(256) void pyrdown_uchar_gauss_kernel(const uint8_t*
                                                                   int d_stride, int dcols, int drows) {
     MMF_PIXEL_XY();
     if (x >= dcols || y >= drows) return;
-    const int D = 5;
-    const int tx = min(2 * x - D / 2 + D, scols - 1);
-    const int ty = min(2 * y - D / 2 + D, srows - 1);
+    const int tx = min(2 * x + 3, scols - 1);
+    const int ty = min(2 * y + 3, srows - 1);
     float sum = 0;
     int count = 0;
-    for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
-        for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
-            const uint8_t s = src[(size_t)cy * s_stride + cx];
-            if (s > 0) {
-                const float w = gauss5((ty - cy - 1) * 5 + (tx - cx - 1));
-                sum += s * w;
-                count = (int)((float)count + w);
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+        const int cy = 2 * y - 2 + dy;
+        const bool rowok = cy >= 0 && cy < ty;
+        const float wy = binom5(ty - cy - 1);
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+            const int cx = 2 * x - 2 + dx;
+            if (rowok && cx >= 0 && cx < tx) {
+                const uint8_t s = src[(size_t)cy * s_stride + cx];
+                if (s > 0) {
+                    const float w = wy * binom5(tx - cx - 1);
+                    sum += s * w;
+                    count = (int)((float)count + w);
+                }
             }
         }
+    }
     const float q = sum / (float)count;
     dst[(size_t)y * d_stride + x] = (q != q) ? (uint8_t)0 : (uint8_t)(unsigned)q;
 }

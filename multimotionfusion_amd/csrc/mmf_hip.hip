@@ -51,7 +51,9 @@ struct mmf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    float* partials_f = nullptr;  // kMaxGrid * kPartialStride
+    float* partials_f = nullptr;    // kMaxGrid records: in-launch (ticket) reductions
+    float* partials_icp = nullptr;  // kMaxGrid records: icp_kernel -> its consumer
+    int2* partials_res = nullptr;   // kMaxGrid {count, sigma} records: rgb_residual_kernel -> its consumer
     unsigned* ticket = nullptr;
     OdomState* scratch_state = nullptr;  // for the stand-alone *Step entry points
     OdomState* host_state = nullptr;     // pinned staging
@@ -59,7 +61,7 @@ struct mmf_ctx {
     char arch[64] = {0};
 };
 
-extern "C" int mmf_ctx_create(int device, void* stream, mmf_ctx** out) {
+extern "C" int mmf_ctx_create(int device, void* stream, int private_stream, mmf_ctx** out) {
     MMF_REQUIRE(out != nullptr, "mmf_ctx_create: out is null");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -77,15 +79,17 @@ extern "C" int mmf_ctx_create(int device, void* stream, mmf_ctx** out) {
         delete c;
         return fail(MMF_ERR_NO_DEVICE, m);
     }
-    if (stream) {
-        c->stream = (hipStream_t)stream;
-    } else {
+    if (private_stream) {
         MMF_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
+    } else {
+        c->stream = (hipStream_t)stream;
     }
     MMF_HIP_TRY(hipMalloc(&c->partials_f, sizeof(float) * kMaxGrid * kPartialStride));
-    MMF_HIP_TRY(hipMalloc(&c->ticket, 64));
-    MMF_HIP_TRY(hipMemsetAsync(c->ticket, 0, 64, c->stream));
+    MMF_HIP_TRY(hipMalloc(&c->partials_icp, sizeof(float) * kMaxGrid * kPartialStride));
+    MMF_HIP_TRY(hipMalloc(&c->partials_res, sizeof(int2) * kMaxGrid));
+    MMF_HIP_TRY(hipMalloc(&c->ticket, sizeof(unsigned) * kTicketWords));
+    MMF_HIP_TRY(hipMemsetAsync(c->ticket, 0, sizeof(unsigned) * kTicketWords, c->stream));
     MMF_HIP_TRY(hipMalloc(&c->scratch_state, sizeof(OdomState)));
     MMF_HIP_TRY(hipMemsetAsync(c->scratch_state, 0, sizeof(OdomState), c->stream));
     MMF_HIP_TRY(hipHostMalloc(&c->host_state, sizeof(OdomState), hipHostMallocDefault));
@@ -101,6 +105,8 @@ extern "C" void mmf_ctx_destroy(mmf_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->partials_f);
+    (void)hipFree(c->partials_icp);
+    (void)hipFree(c->partials_res);
     (void)hipFree(c->ticket);
     (void)hipFree(c->scratch_state);
     (void)hipHostFree(c->host_state);
@@ -150,20 +156,46 @@ static inline LevelIntr level_intr(float fx, float fy, float cx, float cy, int l
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// ICP reduction launch: 4 pixels per lane when the layout allows 16-byte row loads
+// ICP reduction launch.  `variant` = PX * 10000 + BLOCK picks the geometry (pixels per lane per pass,
+// threads per workgroup); 0 = the tuned default.  Vector loads need cols % PX == 0 and aligned rows,
+// otherwise the scalar PX = 1 kernel runs.
+static int g_icp_default_variant = 40256;
+
+template <int PX, int BLOCK, int MODE>
+static int launch_icp_variant(mmf_ctx* c, OdomState* st, const IcpArgs& a) {
+    const int grid = reduce_grid(a.cols * a.rows, BLOCK * PX);
+    hipLaunchKernelGGL((icp_kernel<PX, BLOCK, MODE>), dim3(grid), dim3(BLOCK), 0, c->stream, st, a, c->partials_icp);
+    return grid;
+}
+
+// launches the ICP producer; *records_out = number of partial records it writes to c->partials_icp
 template <int MODE>
-static hipError_t launch_icp(mmf_ctx* c, OdomState* st, const IcpArgs& a) {
-    const int n = a.cols * a.rows;
-    const bool vec4 = (a.cols % 4 == 0) && (a.vmap_curr.stride % 4 == 0) && (a.nmap_curr.stride % 4 == 0) &&
-                      aligned16(a.vmap_curr.base) && aligned16(a.nmap_curr.base) &&
-                      (!a.err_map || (aligned16(a.err_map) && a.err_stride % 4 == 0));
-    if (vec4) {
-        const int grid = reduce_grid(n, kBlock * 4);
-        hipLaunchKernelGGL((icp_kernel<4, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, st, a, c->partials_f, c->ticket);
-    } else {
-        const int grid = reduce_grid(n, kBlock);
-        hipLaunchKernelGGL((icp_kernel<1, MODE>), dim3(grid), dim3(kBlock), 0, c->stream, st, a, c->partials_f, c->ticket);
+static hipError_t launch_icp(mmf_ctx* c, OdomState* st, const IcpArgs& a, int variant = 0, int* records_out = nullptr) {
+    if (variant == 0) variant = g_icp_default_variant;
+    int px = variant / 10000;
+    const int block = variant % 10000;
+    auto ok = [&](int k) {
+        const uintptr_t m = (uintptr_t)k * 4 - 1;
+        return (a.cols % k == 0) && (a.vmap_curr.stride % k == 0) && (a.nmap_curr.stride % k == 0) &&
+               ((uintptr_t)a.vmap_curr.base & m) == 0 && ((uintptr_t)a.nmap_curr.base & m) == 0 &&
+               (!a.err_map || (((uintptr_t)a.err_map & m) == 0 && a.err_stride % k == 0));
+    };
+    while (px > 1 && !ok(px)) px /= 2;
+    int grid = 0;
+    switch (px * 10000 + block) {
+        case 40256: grid = launch_icp_variant<4, 256, MODE>(c, st, a); break;
+        case 20256: grid = launch_icp_variant<2, 256, MODE>(c, st, a); break;
+        case 10256: grid = launch_icp_variant<1, 256, MODE>(c, st, a); break;
+        case 20512: grid = launch_icp_variant<2, 512, MODE>(c, st, a); break;
+        case 10512: grid = launch_icp_variant<1, 512, MODE>(c, st, a); break;
+        case 11024: grid = launch_icp_variant<1, 1024, MODE>(c, st, a); break;
+        case 21024: grid = launch_icp_variant<2, 1024, MODE>(c, st, a); break;
+        default:
+            if (px == 4) grid = launch_icp_variant<4, 256, MODE>(c, st, a);
+            else if (px == 2) grid = launch_icp_variant<2, 256, MODE>(c, st, a);
+            else grid = launch_icp_variant<1, 256, MODE>(c, st, a);
     }
+    if (records_out) *records_out = grid;
     return hipGetLastError();
 }
 
@@ -213,7 +245,11 @@ extern "C" int mmf_icp_step(mmf_ctx* c, const float Rcurr[9], const float tcurr[
     a.rows = rows;
     a.err_map = err_map_dev;
     a.err_stride = stride_elems(err_map_step, cols, 4);
-    MMF_HIP_TRY(launch_icp<FINISH_RAW>(c, c->scratch_state, a));
+    int records = 0;
+    MMF_HIP_TRY(launch_icp<FINISH_RAW>(c, c->scratch_state, a, 0, &records));
+    hipLaunchKernelGGL((icp_finish_kernel<FINISH_RAW>), dim3(1), dim3(256), 0, c->stream, c->scratch_state,
+                       c->partials_icp, (unsigned)records, a.intr);
+    MMF_HIP_TRY(hipGetLastError());
     float tot[32];
     MMF_HIP_TRY(hipMemcpyAsync(tot, c->scratch_state->out_f, sizeof(float) * 32, hipMemcpyDeviceToHost, c->stream));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -278,7 +314,10 @@ extern "C" int mmf_compute_rgb_residual(mmf_ctx* c, float min_scale, const int16
                                            err_map_step);
     const int grid = reduce_grid(cols * rows, kBlock);
     hipLaunchKernelGGL((rgb_residual_kernel<FINISH_RAW>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state, a,
-                       reinterpret_cast<int*>(c->partials_f), c->ticket);
+                       c->partials_res);
+    MMF_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(residual_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->scratch_state, c->partials_res,
+                       (unsigned)grid);
     MMF_HIP_TRY(hipGetLastError());
     int tot[2];
     MMF_HIP_TRY(hipMemcpyAsync(tot, c->scratch_state->out_i, sizeof(tot), hipMemcpyDeviceToHost, c->stream));
@@ -300,6 +339,10 @@ extern "C" int mmf_rgb_step(mmf_ctx* c, const mmf_dataterm* corres_dev, float si
     MMF_HIP_TRY(hipMemcpyAsync(&c->scratch_state->sigmaVal, &c->host_state->sigmaVal, sizeof(float),
                                hipMemcpyHostToDevice, c->stream));
     RgbStepArgs a;
+    a.residual_partials = nullptr;
+    a.residual_records = 0;
+    a.icp_partials = nullptr;
+    a.icp_records = 0;
     a.corres = corres_dev;
     a.cloud = cloud_dev;
     a.fx = fx;
@@ -901,6 +944,7 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
 
         for (int j = 0; j < iterations[i]; ++j) {
             const bool last_l0 = (i == 0 && j == iterations[i] - 1);
+            int res_records = 0, icp_records = 0;
             if (rgb) {  // :363-371
                 const float min_scale = (float)(std::pow((double)o->min_grad[i], 2.0) / std::pow((double)o->sobel_scale, 2.0));
                 RgbResidualArgs a = make_residual_args(min_scale, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0,
@@ -908,17 +952,26 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
                                                        o->corres[i], o->max_depth_delta_rgb, cols, rows,
                                                        last_l0 ? rgb_err_dev : nullptr, 0);
                 a.intr = in;
-                const int grid = reduce_grid(cols * rows, kBlock);
-                hipLaunchKernelGGL((rgb_residual_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), 0, c->stream, o->state,
-                                   a, reinterpret_cast<int*>(c->partials_f), c->ticket);
+                res_records = reduce_grid(cols * rows, kBlock);
+                hipLaunchKernelGGL((rgb_residual_kernel<FINISH_GN>), dim3(res_records), dim3(kBlock), 0, c->stream,
+                                   o->state, a, c->partials_res);
                 MMF_HIP_TRY(hipGetLastError());
             }
             if (icp) {  // :403-410
                 IcpArgs a = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
-                MMF_HIP_TRY(launch_icp<FINISH_GN>(c, o->state, a));
+                MMF_HIP_TRY(launch_icp<FINISH_GN>(c, o->state, a, 0, &icp_records));
+                if (!rgb) {  // ICP-only tracking: one workgroup sums the records, solves, updates the pose
+                    hipLaunchKernelGGL((icp_finish_kernel<FINISH_GN>), dim3(1), dim3(256), 0, c->stream, o->state,
+                                       c->partials_icp, (unsigned)icp_records, in);
+                    MMF_HIP_TRY(hipGetLastError());
+                }
             }
             if (rgb) {  // :418-423, then :425-460 in the finishing workgroup
                 RgbStepArgs a;
+                a.residual_partials = c->partials_res;
+                a.residual_records = (unsigned)res_records;
+                a.icp_partials = c->partials_icp;
+                a.icp_records = (unsigned)icp_records;
                 a.corres = o->corres[i];
                 a.cloud = o->cloud[i];
                 a.fx = in.fx;
@@ -1042,16 +1095,16 @@ extern "C" int mmf_odom_download(mmf_odom* o, const char* name, int level, void*
     return MMF_OK;
 }
 
-extern "C" int mmf_odom_time_icp_kernel(mmf_odom* o, int level, int reps, float* mean_us_out) {
+extern "C" int mmf_odom_time_icp_kernel(mmf_odom* o, int level, int reps, int variant, float* mean_us_out) {
     MMF_REQUIRE(o && mean_us_out && level >= 0 && level < MMF_NUM_PYRS && reps > 0, "mmf_odom_time_icp_kernel: bad argument");
     mmf_ctx* c = o->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     IcpArgs a = odom_icp_args(o, level, nullptr);
     // the state's pose fields are whatever the last getIncrementalTransformation left (or zero);
     // FINISH_RAW only writes out_f
-    for (int w = 0; w < 3; ++w) MMF_HIP_TRY(launch_icp<FINISH_RAW>(c, o->state, a));
+    for (int w = 0; w < 3; ++w) MMF_HIP_TRY(launch_icp<FINISH_RAW>(c, o->state, a, variant));
     MMF_HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    for (int r = 0; r < reps; ++r) MMF_HIP_TRY(launch_icp<FINISH_RAW>(c, o->state, a));
+    for (int r = 0; r < reps; ++r) MMF_HIP_TRY(launch_icp<FINISH_RAW>(c, o->state, a, variant));
     MMF_HIP_TRY(hipEventRecord(c->ev1, c->stream));
     MMF_HIP_TRY(hipEventSynchronize(c->ev1));
     float ms = 0.f;

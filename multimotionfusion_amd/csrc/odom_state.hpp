@@ -189,22 +189,48 @@ __device__ inline void k_matrix(const LevelIntr& in, double* K) {  // RGBDOdomet
     K[8] = 1;
 }
 
+// NOTE on structure: everything below works on LOCAL copies (registers) and touches the state in
+// HBM exactly twice -- one batch of independent loads at entry, one batch of stores at exit.  A
+// first version read and wrote `st->...` in place; every dependent global round trip costs
+// 0.5-1 us on one lane and the finishing step took ~10 us.
+
 // SO3 kernel parameters for the next iteration (RGBDOdometry.cpp:261-272)
-__device__ inline void so3_prepare(OdomState* st, const LevelIntr& in) {
+__device__ inline void so3_prepare(const double* resultR, const LevelIntr& in, float* imageBasis, float* kinv,
+                                   float* krlr) {
     double K[9], K_inv[9], tmp[9], H[9];
     k_matrix(in, K);
     inverse3d(K, K_inv);
-    matmul<3>(K, st->resultR, tmp);
-    for (int k = 0; k < 9; ++k) st->krlr[k] = (float)tmp[k];
+    matmul<3>(K, resultR, tmp);
+    for (int k = 0; k < 9; ++k) krlr[k] = (float)tmp[k];
     matmul<3>(tmp, K_inv, H);
     for (int k = 0; k < 9; ++k) {
-        st->imageBasis[k] = (float)H[k];
-        st->kinv[k] = (float)K_inv[k];
+        imageBasis[k] = (float)H[k];
+        kinv[k] = (float)K_inv[k];
+    }
+}
+
+__device__ inline void so3_prepare_store(OdomState* st, const double* resultR, const LevelIntr& in) {
+    float B[9], ki[9], kr[9];
+    so3_prepare(resultR, in, B, ki, kr);
+    for (int k = 0; k < 9; ++k) {
+        st->imageBasis[k] = B[k];
+        st->kinv[k] = ki[k];
+        st->krlr[k] = kr[k];
     }
 }
 
 // after a so3 reduction: RGBDOdometry.cpp:281-308
 __device__ inline void so3_finish(OdomState* st, const float* tot, const LevelIntr& in) {
+    // entry loads
+    const float lastError = st->so3_lastError, lastCount = st->so3_lastCount;
+    const int it = st->st.so3_iterations_run;
+    double resultR[9], lastResultR[9];
+    float R_lr[9];
+    for (int k = 0; k < 9; ++k) {
+        resultR[k] = st->resultR[k];
+        lastResultR[k] = st->lastResultR[k];
+        R_lr[k] = st->R_lr[k];
+    }
     float jtj[9], jtr[3];
     int shift = 0;  // reduce.cu:1135-1146
     for (int i = 0; i < 3; ++i)
@@ -216,22 +242,21 @@ __device__ inline void so3_finish(OdomState* st, const float* tot, const LevelIn
                 jtj[j * 3 + i] = jtj[i * 3 + j] = value;
         }
     const float r0 = tot[9], r1 = tot[10];
-    st->st.so3_iterations_run++;
-    st->st.lastSO3Error = sqrtf(r0) / r1;
-    st->st.lastSO3Count = r1;
-    if (st->st.lastSO3Error < st->so3_lastError && fabsf(st->so3_lastError - st->st.lastSO3Count) < 0.001) {
-        st->so3_done = 1;  // "converged" (the reference compares the error with the COUNT, :285)
+    const float err = sqrtf(r0) / r1;
+    st->st.so3_iterations_run = it + 1;
+    if (err < lastError && fabsf(lastError - r1) < 0.001) {
+        // "converged" (the reference compares the error with the COUNT, :285)
+        st->st.lastSO3Error = err;
+        st->st.lastSO3Count = r1;
+        st->so3_done = 1;
         return;
-    } else if (st->st.lastSO3Error > st->so3_lastError + 0.001) {  // diverging
-        st->st.lastSO3Error = st->so3_lastError;
-        st->st.lastSO3Count = st->so3_lastCount;
-        for (int k = 0; k < 9; ++k) st->resultR[k] = st->lastResultR[k];
+    } else if (err > lastError + 0.001) {  // diverging: roll back
+        st->st.lastSO3Error = lastError;
+        st->st.lastSO3Count = lastCount;
+        for (int k = 0; k < 9; ++k) st->resultR[k] = lastResultR[k];
         st->so3_done = 1;
         return;
     }
-    st->so3_lastError = st->st.lastSO3Error;
-    st->so3_lastCount = st->st.lastSO3Count;
-    for (int k = 0; k < 9; ++k) st->lastResultR[k] = st->resultR[k];
     float delta[3];
     ldlt_solve<3, float>(jtj, jtr, delta);
     const double dd[3] = {delta[0], delta[1], delta[2]};
@@ -239,24 +264,39 @@ __device__ inline void so3_finish(OdomState* st, const float* tot, const LevelIn
     float rotUpdatef[9];
     rodrigues(dd, rotUpdate);
     for (int k = 0; k < 9; ++k) rotUpdatef[k] = (float)rotUpdate[k];
-    matmul<3, float>(rotUpdatef, st->R_lr, st->R_lr);
-    for (int k = 0; k < 9; ++k) st->resultR[k] = st->R_lr[k];
-    so3_prepare(st, in);
+    matmul<3, float>(rotUpdatef, R_lr, R_lr);
+    double newR[9];
+    for (int k = 0; k < 9; ++k) newR[k] = R_lr[k];
+    float B[9], ki[9], kr[9];
+    so3_prepare(newR, in, B, ki, kr);
+    // exit stores
+    st->st.lastSO3Error = err;
+    st->st.lastSO3Count = r1;
+    st->so3_lastError = err;
+    st->so3_lastCount = r1;
+    for (int k = 0; k < 9; ++k) {
+        st->lastResultR[k] = resultR[k];
+        st->R_lr[k] = R_lr[k];
+        st->resultR[k] = newR[k];
+        st->imageBasis[k] = B[k];
+        st->kinv[k] = ki[k];
+        st->krlr[k] = kr[k];
+    }
 }
 
 // KRK^-1 and K t of the inverse running transform (RGBDOdometry.cpp:348-358)
-__device__ inline void rgb_prepare(OdomState* st, const LevelIntr& in) {
+__device__ inline void rgb_prepare(const double* resultRt, const LevelIntr& in, float* krkinv, float* kt) {
     double K[9], K_inv[9], Rt[16], tmp[9], KRK[9];
     k_matrix(in, K);
     inverse3d(K, K_inv);
-    inverse4d(st->resultRt, Rt);
+    inverse4d(resultRt, Rt);
     const double R[9] = {Rt[0], Rt[1], Rt[2], Rt[4], Rt[5], Rt[6], Rt[8], Rt[9], Rt[10]};
     matmul<3>(K, R, tmp);
     matmul<3>(tmp, K_inv, KRK);
-    for (int k = 0; k < 9; ++k) st->krkinv[k] = (float)KRK[k];
+    for (int k = 0; k < 9; ++k) krkinv[k] = (float)KRK[k];
     const double t3[3] = {Rt[3], Rt[7], Rt[11]};
     for (int r = 0; r < 3; ++r)
-        st->kt[r] = (float)(K[r * 3 + 0] * t3[0] + K[r * 3 + 1] * t3[1] + K[r * 3 + 2] * t3[2]);
+        kt[r] = (float)(K[r * 3 + 0] * t3[0] + K[r * 3 + 1] * t3[1] + K[r * 3 + 2] * t3[2]);
 }
 
 // unpack 29 sums into the symmetric A and b (reduce.cu:458-472)
@@ -272,40 +312,35 @@ __device__ inline void unpack_se3(const float* tot, float* A, float* b) {
         }
 }
 
-// after the photometric correspondence pass: RGBDOdometry.cpp:373-385
-__device__ inline void residual_finish(OdomState* st, int count, int sigma) {
-    st->sigma = sigma;
-    st->rgbCount = count;
-    const float tmpError = (float)(sqrt((double)sigma) / count);
-    float sigmaVal = (tmpError == 0) ? 1 : (float)count;
-    if (st->rgb_only && tmpError > st->st.lastRGBError) {
-        st->level_break = 1;
-        return;
-    }
-    st->st.lastRGBError = tmpError;
-    st->st.lastRGBCount = (float)count;
-    if (st->rgb_only) sigmaVal = -1;
-    st->sigmaVal = sigmaVal;
-}
+// combine, solve, update the pose: RGBDOdometry.cpp:412-460 + OdometryProvider.h:69-89.
+// tot_rgb / tot_icp: the 29 grid totals of the photometric / ICP reduction (nullptr = term off).
+__device__ inline void solve_and_update(OdomState* st, const float* tot_rgb, const float* tot_icp,
+                                        const LevelIntr& in) {
+    // entry loads (independent)
+    const double w = st->icp_weight;
+    const int iters = st->st.iterations_run;
+    double resultRt[16];
+    float Rprev[9], tprev[3];
+    for (int k = 0; k < 16; ++k) resultRt[k] = st->resultRt[k];
+    for (int k = 0; k < 9; ++k) Rprev[k] = st->Rprev[k];
+    for (int k = 0; k < 3; ++k) tprev[k] = st->tprev[k];
 
-// combine, solve, update the pose: RGBDOdometry.cpp:425-460 + OdometryProvider.h:69-89
-__device__ inline void solve_and_update(OdomState* st, const LevelIntr& in) {
-    double* A = st->st.lastA;
-    double* b = st->st.lastb;
-    if (st->icp && st->rgb) {
-        const double w = st->icp_weight;
-        for (int k = 0; k < 36; ++k) A[k] = (double)st->A_rgb[k] + w * w * (double)st->A_icp[k];
-        for (int k = 0; k < 6; ++k) b[k] = (double)st->b_rgb[k] + w * (double)st->b_icp[k];
-    } else if (st->icp) {
-        for (int k = 0; k < 36; ++k) A[k] = st->A_icp[k];
-        for (int k = 0; k < 6; ++k) b[k] = st->b_icp[k];
+    float A_rgb[36], b_rgb[6], A_icp[36], b_icp[6];
+    double A[36], b[6];
+    if (tot_rgb) unpack_se3(tot_rgb, A_rgb, b_rgb);
+    if (tot_icp) unpack_se3(tot_icp, A_icp, b_icp);
+    if (tot_icp && tot_rgb) {  // :431-435
+        for (int k = 0; k < 36; ++k) A[k] = (double)A_rgb[k] + w * w * (double)A_icp[k];
+        for (int k = 0; k < 6; ++k) b[k] = (double)b_rgb[k] + w * (double)b_icp[k];
+    } else if (tot_icp) {
+        for (int k = 0; k < 36; ++k) A[k] = A_icp[k];
+        for (int k = 0; k < 6; ++k) b[k] = b_icp[k];
     } else {
-        for (int k = 0; k < 36; ++k) A[k] = st->A_rgb[k];
-        for (int k = 0; k < 6; ++k) b[k] = st->b_rgb[k];
+        for (int k = 0; k < 36; ++k) A[k] = A_rgb[k];
+        for (int k = 0; k < 6; ++k) b[k] = b_rgb[k];
     }
     double result[6];
     ldlt_solve<6, double>(A, b, result);
-    st->st.iterations_run++;
 
     double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rup[9];
     const double rvec[3] = {result[3], result[4], result[5]};
@@ -314,25 +349,44 @@ __device__ inline void solve_and_update(OdomState* st, const LevelIntr& in) {
         for (int c = 0; c < 3; ++c) upd[r * 4 + c] = Rup[r * 3 + c];
         upd[r * 4 + 3] = result[r];
     }
-    matmul<4>(upd, st->resultRt, st->resultRt);
+    matmul<4>(upd, resultRt, resultRt);
 
-    float Ro[9], to[3], RoT[9], ti[3];
+    float Ro[9], to[3], RoT[9], ti[3], Rcurr[9], tcurr[3];
     for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) Ro[r * 3 + c] = (float)st->resultRt[r * 4 + c];
-        to[r] = (float)st->resultRt[r * 4 + 3];
+        for (int c = 0; c < 3; ++c) Ro[r * 3 + c] = (float)resultRt[r * 4 + c];
+        to[r] = (float)resultRt[r * 4 + 3];
     }
     // currentT = [Rprev|tprev] * rgbOdom.inverse(); isometry inverse = (R^T, -R^T t)
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) RoT[r * 3 + c] = Ro[c * 3 + r];
     for (int r = 0; r < 3; ++r)
         ti[r] = -RoT[r * 3 + 0] * to[0] + -RoT[r * 3 + 1] * to[1] + -RoT[r * 3 + 2] * to[2];
-    matmul<3, float>(st->Rprev, RoT, st->Rcurr);
+    matmul<3, float>(Rprev, RoT, Rcurr);
     for (int r = 0; r < 3; ++r) {
         float s = 0;
-        for (int k = 0; k < 3; ++k) s += st->Rprev[r * 3 + k] * ti[k];
-        st->tcurr[r] = s + st->tprev[r];
+        for (int k = 0; k < 3; ++k) s += Rprev[r * 3 + k] * ti[k];
+        tcurr[r] = s + tprev[r];
     }
-    rgb_prepare(st, in);  // parameters of the next iteration's correspondence pass
+    float krkinv[9], kt[3];
+    rgb_prepare(resultRt, in, krkinv, kt);  // parameters of the next iteration's correspondence pass
+
+    // exit stores
+    st->st.iterations_run = iters + 1;
+    for (int k = 0; k < 36; ++k) st->st.lastA[k] = A[k];
+    for (int k = 0; k < 6; ++k) st->st.lastb[k] = b[k];
+    for (int k = 0; k < 16; ++k) st->resultRt[k] = resultRt[k];
+    for (int k = 0; k < 9; ++k) {
+        st->Rcurr[k] = Rcurr[k];
+        st->krkinv[k] = krkinv[k];
+    }
+    for (int k = 0; k < 3; ++k) {
+        st->tcurr[k] = tcurr[k];
+        st->kt[k] = kt[k];
+    }
+    if (tot_icp) {  // RGBDOdometry.cpp:412-413
+        st->st.lastICPError = sqrtf(tot_icp[27]) / tot_icp[28];
+        st->st.lastICPCount = tot_icp[28];
+    }
 }
 
 }  // namespace mmf

@@ -17,6 +17,22 @@ namespace mmf {
 
 enum FinishMode { FINISH_RAW = 0, FINISH_GN = 1 };
 
+// Diagnostic builds only (tools/latency_probe.hip): per-workgroup phase stamps of the 100 MHz
+// constant clock into a side buffer nothing else reads.  Compiled out of the library.
+#ifdef MMF_STAMPS
+__device__ unsigned long long* g_mmf_dbg = nullptr;
+#define MMF_STAMP(i)                                                                         \
+    do {                                                                                     \
+        if (g_mmf_dbg && threadIdx.x == 0) g_mmf_dbg[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define MMF_STAMP(i) \
+    do {             \
+    } while (0)
+#endif
+
+constexpr int kBlock = 256;  // threads per workgroup of the photometric / SO3 reductions
+
 // planar 3-plane map view: element (plane k, row y, col x) at base[(y + k*rows)*stride + x]
 struct MapView {
     const float* base;
@@ -24,17 +40,20 @@ struct MapView {
 };
 
 // accumulate the 27 upper-triangular products of a 7-vector + residual^2 + inlier flag
-// in the member order of JtJJtrSE3 (types.cuh:101-112, reduce.cu:331-365)
+// in the member order of JtJJtrSE3 (types.cuh:101-112, reduce.cu:331-365).  The Jacobian row is
+// computed without contraction (bit-exact with the oracle); only this running sum uses an
+// explicit fused multiply-add -- sums are compared within a summation-order tolerance anyway,
+// and it halves the accumulate instruction count.
 __device__ __forceinline__ void accumulate_se3(float (&sum)[29], const float (&row)[7], float found) {
     int k = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = i; j < 7; ++j) {
-            sum[k] = sum[k] + row[i] * row[j];
+            sum[k] = __builtin_fmaf(row[i], row[j], sum[k]);
             ++k;
         }
-    sum[27] = sum[27] + row[6] * row[6];
+    sum[27] = __builtin_fmaf(row[6], row[6], sum[27]);
     sum[28] = sum[28] + found;
 }
 
@@ -100,13 +119,44 @@ __device__ __forceinline__ void icp_row(const OdomState* st, const IcpArgs& a, c
     found_f = found ? 1.0f : 0.0f;
 }
 
-// PX pixels per lane per pass (PX = 4: one 16-byte load per plane; needs cols % 4 == 0 and
-// 16-byte aligned rows, else PX = 1).
-template <int PX, int MODE>
-__global__ __launch_bounds__(kBlock) void icp_kernel(OdomState* __restrict__ st, IcpArgs a,
-                                                     float* __restrict__ partials,
-                                                     unsigned* __restrict__ ticket) {
-    __shared__ GridReduceLds<float> lds;
+// PX consecutive floats of one plane row as ONE load instruction (4, 8 or 16 bytes per lane)
+template <int PX>
+__device__ __forceinline__ void load_px(const float* __restrict__ p, float (&out)[PX]) {
+    if constexpr (PX == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        out[0] = t.x, out[1] = t.y, out[2] = t.z, out[3] = t.w;
+    } else if constexpr (PX == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        out[0] = t.x, out[1] = t.y;
+    } else {
+        out[0] = *p;
+    }
+}
+template <int PX>
+__device__ __forceinline__ void store_px(float* __restrict__ p, const float (&v)[PX]) {
+    if constexpr (PX == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (PX == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+    } else {
+        *p = v[0];
+    }
+}
+
+// PX pixels per lane per pass (PX = 4 / 2: one 16 / 8-byte load per plane; needs cols % PX == 0
+// and PX*4-byte aligned rows, else PX = 1); BLOCK threads per workgroup.
+//
+// The kernel only PRODUCES one 128-byte partial record per workgroup (plain stores): the record
+// sum, the 6x6 solve and the pose update run in the consumer kernel that follows on the stream
+// (icp_finish_kernel, or the finishing workgroup of rgb_step_kernel).  A kernel boundary is
+// cheaper than an in-launch hand-off here: it needs no write-through drain, no ticket atomics
+// and no second round of loads inside this launch.
+template <int PX, int BLOCK, int MODE>
+__global__ __launch_bounds__(BLOCK) void icp_kernel(const OdomState* __restrict__ st, IcpArgs a,
+                                                    float* __restrict__ partials) {
+    constexpr int kBlock = BLOCK;
+    __shared__ GridReduceLds<float, BLOCK> lds;
+    MMF_STAMP(0);
     if (MODE == FINISH_GN && st->level_break) return;
 
     float sum[29];
@@ -120,37 +170,25 @@ __global__ __launch_bounds__(kBlock) void icp_kernel(OdomState* __restrict__ st,
         const int x = i0 - y * a.cols;
 
         float vx[PX], vy[PX], vz[PX], nx[PX], ny[PX], nz[PX];
-        if (PX == 4) {
-            const float4 t0 = *reinterpret_cast<const float4*>(a.vmap_curr.base + (size_t)y * a.vmap_curr.stride + x);
-            const float4 t1 = *reinterpret_cast<const float4*>(a.vmap_curr.base + (size_t)(y + rows) * a.vmap_curr.stride + x);
-            const float4 t2 = *reinterpret_cast<const float4*>(a.vmap_curr.base + (size_t)(y + 2 * rows) * a.vmap_curr.stride + x);
-            const float4 t3 = *reinterpret_cast<const float4*>(a.nmap_curr.base + (size_t)y * a.nmap_curr.stride + x);
-            const float4 t4 = *reinterpret_cast<const float4*>(a.nmap_curr.base + (size_t)(y + rows) * a.nmap_curr.stride + x);
-            const float4 t5 = *reinterpret_cast<const float4*>(a.nmap_curr.base + (size_t)(y + 2 * rows) * a.nmap_curr.stride + x);
-            const float av[6][4] = {{t0.x, t0.y, t0.z, t0.w}, {t1.x, t1.y, t1.z, t1.w}, {t2.x, t2.y, t2.z, t2.w},
-                                    {t3.x, t3.y, t3.z, t3.w}, {t4.x, t4.y, t4.z, t4.w}, {t5.x, t5.y, t5.z, t5.w}};
-#pragma unroll
-            for (int p = 0; p < PX; ++p) {
-                vx[p] = av[0][p];
-                vy[p] = av[1][p];
-                vz[p] = av[2][p];
-                nx[p] = av[3][p];
-                ny[p] = av[4][p];
-                nz[p] = av[5][p];
-            }
-        } else {
-            vx[0] = a.vmap_curr.base[(size_t)y * a.vmap_curr.stride + x];
-            vy[0] = a.vmap_curr.base[(size_t)(y + rows) * a.vmap_curr.stride + x];
-            vz[0] = a.vmap_curr.base[(size_t)(y + 2 * rows) * a.vmap_curr.stride + x];
-            nx[0] = a.nmap_curr.base[(size_t)y * a.nmap_curr.stride + x];
-            ny[0] = a.nmap_curr.base[(size_t)(y + rows) * a.nmap_curr.stride + x];
-            nz[0] = a.nmap_curr.base[(size_t)(y + 2 * rows) * a.nmap_curr.stride + x];
-        }
+        load_px<PX>(a.vmap_curr.base + (size_t)y * a.vmap_curr.stride + x, vx);
+        load_px<PX>(a.vmap_curr.base + (size_t)(y + rows) * a.vmap_curr.stride + x, vy);
+        load_px<PX>(a.vmap_curr.base + (size_t)(y + 2 * rows) * a.vmap_curr.stride + x, vz);
+        load_px<PX>(a.nmap_curr.base + (size_t)y * a.nmap_curr.stride + x, nx);
+        load_px<PX>(a.nmap_curr.base + (size_t)(y + rows) * a.nmap_curr.stride + x, ny);
+        load_px<PX>(a.nmap_curr.base + (size_t)(y + 2 * rows) * a.nmap_curr.stride + x, nz);
 
         IcpPixel px[PX];
         f3 vp[PX], np[PX];
+#ifdef MMF_STAMPS
+        if (vx[0] == 1234.5f) sum[0] += ny[0] + nz[0] + nx[0];  // force the loads to have landed
+        MMF_STAMP(1);
+#endif
 #pragma unroll
         for (int p = 0; p < PX; ++p) px[p] = icp_project(st, a, make_f3(vx[p], vy[p], vz[p]));
+#ifdef MMF_STAMPS
+        if (px[0].ux == -12345) sum[0] += 1.f;
+        MMF_STAMP(2);
+#endif
         // all gathers of the group issued before any is consumed; pixels that project outside
         // read element 0 (a valid address) and are masked afterwards
 #pragma unroll
@@ -163,33 +201,40 @@ __global__ __launch_bounds__(kBlock) void icp_kernel(OdomState* __restrict__ st,
             np[p] = make_f3(a.nmap_g_prev.base[on], a.nmap_g_prev.base[on + pn], a.nmap_g_prev.base[on + 2 * pn]);
         }
         float errs[PX];
+#ifdef MMF_STAMPS
+        if (vp[0].x == 1234.5f) sum[0] += np[0].x + np[0].y + np[0].z + vp[0].y + vp[0].z;
+        MMF_STAMP(3);
+#endif
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
             float row[7], found;
             icp_row(st, a, px[p], make_f3(nx[p], ny[p], nz[p]), vp[p], np[p], row, found, errs[p]);
             accumulate_se3(sum, row, found);
         }
-        if (a.err_map) {
-            if (PX == 4)
-                *reinterpret_cast<float4*>(a.err_map + (size_t)y * a.err_stride + x) =
-                    make_float4(errs[0], errs[1], errs[2], errs[3]);
-            else
-                a.err_map[(size_t)y * a.err_stride + x] = errs[0];
-        }
+#ifdef MMF_STAMPS
+        if (sum[3] == 1234.5f) sum[0] += 1.f;
+        MMF_STAMP(4);
+#endif
+        if (a.err_map) store_px<PX>(a.err_map + (size_t)y * a.err_stride + x, errs);
     }
 
-    if (!grid_reduce<29>(sum, partials, ticket, lds)) return;
+    block_reduce_store<29, BLOCK, false>(sum, partials, lds);
+    MMF_STAMP(5);
+}
+
+// One workgroup: sums the ICP partial records of the preceding launch.  MODE RAW: totals ->
+// st->out_f (stand-alone icpStep); MODE GN (ICP-only tracking): unpack, solve, update the pose.
+template <int MODE>
+__global__ __launch_bounds__(256) void icp_finish_kernel(OdomState* __restrict__ st, const float* __restrict__ partials,
+                                                         unsigned nrecords, LevelIntr intr) {
+    __shared__ GridReduceLds<float, 256> lds;
+    if (MODE == FINISH_GN && st->level_break) return;
+    sum_partial_records<256, false>(partials, nrecords, lds);
     if (threadIdx.x == 0) {
-        const float* tot = lds.total;
         if (MODE == FINISH_RAW) {
-            for (int k = 0; k < 29; ++k) st->out_f[k] = tot[k];
+            for (int k = 0; k < 29; ++k) st->out_f[k] = lds.total[k];
         } else {
-            unpack_se3(tot, st->A_icp, st->b_icp);  // reduce.cu:458-472
-            st->residual_icp[0] = tot[27];
-            st->residual_icp[1] = tot[28];
-            st->st.lastICPError = sqrtf(tot[27]) / tot[28];  // RGBDOdometry.cpp:412-413
-            st->st.lastICPCount = tot[28];
-            if (!st->rgb) solve_and_update(st, a.intr);
+            solve_and_update(st, nullptr, lds.total, intr);
         }
     }
 }
@@ -210,11 +255,12 @@ struct RgbResidualArgs {
     LevelIntr intr;
 };
 
+// Like the ICP kernel this one only produces partial records {count, sum diff^2}; they are summed
+// by residual_finish_kernel (stand-alone) or by the prologue of rgb_step_kernel.
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void rgb_residual_kernel(OdomState* __restrict__ st, RgbResidualArgs a,
-                                                              int* __restrict__ partials,
-                                                              unsigned* __restrict__ ticket) {
-    __shared__ GridReduceLds<int> lds;
+__global__ __launch_bounds__(kBlock) void rgb_residual_kernel(const OdomState* __restrict__ st, RgbResidualArgs a,
+                                                              int2* __restrict__ partials) {
+    __shared__ GridReduceLds<int, kBlock> lds;
     if (MODE == FINISH_GN && st->level_break) return;
     int sum[2] = {0, 0};
     const int N = a.cols * a.rows, cols = a.cols, rows = a.rows;
@@ -268,19 +314,42 @@ __global__ __launch_bounds__(kBlock) void rgb_residual_kernel(OdomState* __restr
         sum[1] += vy;
     }
 
-    if (!grid_reduce<2>(sum, partials, ticket, lds)) return;
+    block_sum2<kBlock>(sum[0], sum[1], lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = make_int2(sum[0], sum[1]);
+}
+
+// {count, sigma} decision of RGBDOdometry.cpp:373-385 as a pure function of the two totals
+struct ResidualDecision {
+    float tmpError, sigmaVal;
+    bool brk;
+};
+__device__ __forceinline__ ResidualDecision residual_decide(int count, int sigma, int rgb_only, float lastRGBError) {
+    ResidualDecision d;
+    d.tmpError = (float)(sqrt((double)sigma) / count);
+    d.sigmaVal = (d.tmpError == 0) ? 1 : (float)count;
+    d.brk = rgb_only && d.tmpError > lastRGBError;
+    if (rgb_only) d.sigmaVal = -1;  // signals the Jacobian pass to weight evenly
+    return d;
+}
+
+// stand-alone computeRgbResidual: one workgroup sums the records into st->out_i
+__global__ __launch_bounds__(256) void residual_finish_kernel(OdomState* __restrict__ st, const int2* __restrict__ partials,
+                                                              unsigned nrecords) {
+    __shared__ GridReduceLds<int, 256> lds;
+    int count, sigma;
+    sum_int2_records<256>(partials, nrecords, count, sigma, lds);
     if (threadIdx.x == 0) {
-        if (MODE == FINISH_RAW) {
-            st->out_i[0] = lds.total[0];
-            st->out_i[1] = lds.total[1];
-        } else {
-            residual_finish(st, lds.total[0], lds.total[1]);
-        }
+        st->out_i[0] = count;
+        st->out_i[1] = sigma;
     }
 }
 
 // ---- photometric Jacobian reduction -------------------------------------------------------
 struct RgbStepArgs {
+    const int2* residual_partials;  // GN mode: {count, sigma} records of the preceding rgb_residual_kernel
+    unsigned residual_records;
+    const float* icp_partials;     // GN mode, when the ICP term is on: records of icp_kernel
+    unsigned icp_records;
     const mmf_dataterm* corres;
     const float* cloud;  // AoS float3, dense
     float fx, fy;
@@ -295,13 +364,28 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict__ st, RgbStepArgs a,
                                                           float* __restrict__ partials,
                                                           unsigned* __restrict__ ticket) {
-    __shared__ GridReduceLds<float> lds;
-    if (MODE == FINISH_GN && st->level_break) return;
+    __shared__ GridReduceLds<float, kBlock> lds;
+    float sigma = st->sigmaVal;
+    int res_count = 0, res_sigma = 0;
+    ResidualDecision dec = {0.f, 0.f, false};
+    if (MODE == FINISH_GN) {
+        if (st->level_break) return;
+        // every workgroup sums the {count, sigma} records itself (a few KB from L2) instead of
+        // waiting for a separate finishing launch: RGBDOdometry.cpp:373-385
+        auto& ilds = reinterpret_cast<GridReduceLds<int, kBlock>&>(lds);
+        sum_int2_records<kBlock>(a.residual_partials, a.residual_records, res_count, res_sigma, ilds);
+        dec = residual_decide(res_count, res_sigma, st->rgb_only, st->st.lastRGBError);
+        __syncthreads();  // lds is reused below
+        if (dec.brk) {    // rgbOnly divergence: the reference `break`s out of this level's loop
+            if (blockIdx.x == 0 && threadIdx.x == 0) st->level_break = 1;
+            return;
+        }
+        sigma = dec.sigmaVal;
+    }
     float sum[29];
 #pragma unroll
     for (int k = 0; k < 29; ++k) sum[k] = 0.f;
     const int N = a.cols * a.rows;
-    const float sigma = st->sigmaVal;
 
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
         const int4 raw = *reinterpret_cast<const int4*>(&a.corres[i]);
@@ -334,13 +418,27 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
         accumulate_se3(sum, row, found ? 1.0f : 0.0f);
     }
 
-    if (!grid_reduce<29>(sum, partials, ticket, lds)) return;
+    if (!grid_reduce<29, kBlock>(sum, partials, ticket, lds)) return;
     if (threadIdx.x == 0) {
         if (MODE == FINISH_RAW) {
             for (int k = 0; k < 29; ++k) st->out_f[k] = lds.total[k];
-        } else {
-            unpack_se3(lds.total, st->A_rgb, st->b_rgb);
-            solve_and_update(st, a.intr);
+        }
+    }
+    if (MODE == FINISH_GN) {
+        if (threadIdx.x < kPartialStride) lds.wave[0][threadIdx.x] = lds.total[threadIdx.x];  // keep the RGB totals
+        const bool icp = st->icp != 0;  // wave-uniform
+        if (icp) {  // the ICP records of the preceding launch (kernel boundary => plain loads)
+            __syncthreads();
+            sum_partial_records<kBlock, false>(a.icp_partials, a.icp_records, lds);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            st->sigma = res_sigma;
+            st->rgbCount = res_count;
+            st->sigmaVal = dec.sigmaVal;
+            st->st.lastRGBError = dec.tmpError;
+            st->st.lastRGBCount = (float)res_count;
+            solve_and_update(st, lds.wave[0], icp ? lds.total : nullptr, a.intr);
         }
     }
 }
@@ -367,7 +465,7 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void so3_kernel(OdomState* __restrict__ st, So3Args a,
                                                      float* __restrict__ partials,
                                                      unsigned* __restrict__ ticket) {
-    __shared__ GridReduceLds<float> lds;
+    __shared__ GridReduceLds<float, kBlock> lds;
     if (MODE == FINISH_GN && st->so3_done) return;
     float sum[11];
 #pragma unroll
@@ -421,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void so3_kernel(OdomState* __restrict__ st,
         sum[10] = sum[10] + (found ? 1.0f : 0.0f);
     }
 
-    if (!grid_reduce<11>(sum, partials, ticket, lds)) return;
+    if (!grid_reduce<11, kBlock>(sum, partials, ticket, lds)) return;
     if (threadIdx.x == 0) {
         if (MODE == FINISH_RAW) {
             for (int k = 0; k < 11; ++k) st->out_f[k] = lds.total[k];
@@ -462,21 +560,31 @@ __global__ void odom_begin_kernel(OdomState* st, BeginArgs a) {
     st->level_break = 0;
     st->st.iterations_run = 0;
     st->st.so3_iterations_run = 0;
-    if (a.so3) so3_prepare(st, a.so3_intr);
+    if (a.so3) {
+        const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        so3_prepare_store(st, I3, a.so3_intr);
+    }
 }
 
 // start of a pyramid level: RGBDOdometry.cpp:320-328 (first level only), :344, :348-358
 __global__ void gn_level_begin_kernel(OdomState* st, int first_level, LevelIntr intr) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double resultRt[16];
     if (first_level) {
-        for (int k = 0; k < 16; ++k) st->resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+        for (int k = 0; k < 16; ++k) resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
         if (st->so3)
             for (int x = 0; x < 3; ++x)
-                for (int y = 0; y < 3; ++y) st->resultRt[x * 4 + y] = st->resultR[x * 3 + y];
+                for (int y = 0; y < 3; ++y) resultRt[x * 4 + y] = st->resultR[x * 3 + y];
+        for (int k = 0; k < 16; ++k) st->resultRt[k] = resultRt[k];
+    } else {
+        for (int k = 0; k < 16; ++k) resultRt[k] = st->resultRt[k];
     }
+    float krkinv[9], kt[3];
+    rgb_prepare(resultRt, intr, krkinv, kt);
     st->st.lastRGBError = FLT_MAX;
     st->level_break = 0;
-    rgb_prepare(st, intr);
+    for (int k = 0; k < 9; ++k) st->krkinv[k] = krkinv[k];
+    for (int k = 0; k < 3; ++k) st->kt[k] = kt[k];
 }
 
 // RGBDOdometry.cpp:464-467, 475-476

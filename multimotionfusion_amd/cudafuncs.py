@@ -26,8 +26,9 @@ class Context:
         torch.cuda.set_device(self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else 0
         h = C.c_void_p()
-        check(self.lib.mmf_ctx_create(self.device, C.c_void_p(stream), C.byref(h)))
+        check(self.lib.mmf_ctx_create(self.device, C.c_void_p(stream), 0 if use_torch_stream else 1, C.byref(h)))
         self.handle = h
+        self._children = []  # weakrefs of objects holding device memory of this context
 
     def synchronize(self):
         check(self.lib.mmf_ctx_synchronize(self.handle))
@@ -39,6 +40,11 @@ class Context:
 
     def close(self):
         if self.handle:
+            for ref in self._children:  # children dereference the context when destroyed
+                child = ref()
+                if child is not None:
+                    child.close()
+            self._children = []
             self.lib.mmf_ctx_destroy(self.handle)
             self.handle = None
 

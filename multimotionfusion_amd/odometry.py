@@ -6,6 +6,7 @@ matrices become numpy arrays.  All arithmetic runs in libmmf_hip.so.
 """
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -26,6 +27,7 @@ class RGBDOdometry:
         check(ctx.lib.mmf_odom_create(ctx.handle, width, height, cx, cy, fx, fy, distThresh, angleThresh,
                                       C.byref(h)))
         self.handle = h
+        ctx._children.append(weakref.ref(self))
         self._refresh_stats()
 
     # -- data preparation ---------------------------------------------------------------------
@@ -111,15 +113,15 @@ class RGBDOdometry:
         npdt = {torch.float32: np.float32, torch.uint8: np.uint8, torch.int16: np.int16}[dt]
         return host.view(npdt).reshape(planes * rows, cols)
 
-    def timeIcpKernel(self, level, reps):
+    def timeIcpKernel(self, level, reps, variant=0):
         us = C.c_float(0)
-        check(self.ctx.lib.mmf_odom_time_icp_kernel(self.handle, level, reps, C.byref(us)))
+        check(self.ctx.lib.mmf_odom_time_icp_kernel(self.handle, level, reps, variant, C.byref(us)))
         return us.value
 
     def close(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             self.ctx.lib.mmf_odom_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:

@@ -76,7 +76,8 @@ def test_incremental_transformation_matches_oracle(gpu_ctx, orc, w, h, mode):
     so = o.stats()
     assert g.iterations_run == so.iterations_run and g.so3_iterations_run == so.so3_iterations_run
     assert np.linalg.norm(tg - to) <= 2e-6, (tg, to)
-    assert synth.rotation_angle(Rg, Ro) <= 2e-6 + 4e-4 * 0  # float32 rotation matrices: acos floor ~3e-4 avoided below
+    # rotation difference bounded through the matrix entries (acos of a float32 trace has a
+    # ~3e-4 rad noise floor even for identical matrices); |dR|_max <= 2e-6 implies < 1e-5 rad
     assert np.abs(Rg - Ro).max() <= 2e-6, np.abs(Rg - Ro).max()
     # derived dense-tracking statistics (RGBDOdometry.h:62-69)
     icp = (not mode["rgbOnly"]) and mode["icpWeight"] > 0
