@@ -215,6 +215,58 @@ int mmf_odom_download(mmf_odom *o, const char *name, int level, void *host_dst, 
  * variant: 0 = the shipped launch geometry, else PX * 10000 + BLOCK (tuning sweeps). */
 int mmf_odom_time_icp_kernel(mmf_odom *o, int level, int reps, int variant, float *mean_us_out);
 
+/* ---------------------------------------------------------------------------------------
+ * Surfel model: Core/Model/Model.{h,cpp} (store, fuse, clean, initialise) and
+ * Core/Model/ModelProjection.{h,cpp} (index map, splat prediction), without OpenGL.
+ * The surfel store is a structure of float4 arrays in HBM; "textures" are dense device images.
+ * All images are cols x rows, dense; rgb is interleaved u8 x 3 as uploaded from FrameData.rgb,
+ * depth is float32 metres (0 = invalid), mask is u8.
+ * ------------------------------------------------------------------------------------- */
+typedef struct mmf_model mmf_model; /* replaces class Model + its ModelProjection */
+
+/* Model::Model (Model.h:120-130): id doubles as the mask value of the model's pixels;
+ * conf_threshold = confGlobalInit (10) / confObjectInit (0.01); max_surfels 0 = 1024*1024
+ * (Model::MAX_VERTICES, Model.cpp:119-126). */
+int mmf_model_create(mmf_ctx *ctx, int width, int height, float cx, float cy, float fx, float fy,
+                     unsigned char id, float conf_threshold, int max_surfels, mmf_model **out);
+void mmf_model_destroy(mmf_model *m);
+/* Model::overridePose / getPose (Model.h:196-205): row-major camera-to-world 4x4 */
+int mmf_model_set_pose(mmf_model *m, const float pose[16]);
+int mmf_model_get_pose(mmf_model *m, float pose[16]);
+/* Model::lastCount (Model.h:227) */
+int mmf_model_count(mmf_model *m, unsigned *count);
+
+/* MultiMotionFusion::filterDepth (MultiMotionFusion.cpp:897-904, depth_bilateral_metric.frag) */
+int mmf_filter_depth(mmf_ctx *ctx, const float *depth, int cols, int rows, float max_depth, float *out);
+
+/* computeFeedbackBuffers + Model::initialise (MultiMotionFusion.cpp:197-205, Model.cpp:267-312) */
+int mmf_model_initialise(mmf_model *m, const uint8_t *rgb, const float *depth_raw,
+                         const float *depth_filtered, int time, float max_depth);
+/* Model::predictIndices -> ModelProjection::predictIndices (ModelProjection.cpp:94-143) */
+int mmf_model_predict_indices(mmf_model *m, int time, float depth_cutoff, int time_delta);
+/* Model::combinedPredict(ACTIVE) -> ModelProjection::combinedPredict (ModelProjection.cpp:187-269) */
+int mmf_model_combined_predict(mmf_model *m, float depth_cutoff, int time, int max_time, int time_delta);
+/* Model::fuse (Model.cpp:893-1048); weighting = Model::computeFusionWeight(weightMultiplier) */
+int mmf_model_fuse(mmf_model *m, int time, const uint8_t *rgb, const uint8_t *mask, const float *depth_raw,
+                   const float *depth_filtered, float depth_cutoff, float weighting);
+/* Model::clean (Model.cpp:1050-1182); outlier_coeff = GPUSetup::outlierCoefficient (GUI default 3) */
+int mmf_model_clean(mmf_model *m, int time, int time_delta, float depth_cutoff, const float *depth_filtered,
+                    const uint8_t *mask, float outlier_coeff);
+/* Model::performFillIn (Model.cpp:1607-1616) and MultiMotionFusion::requiresFillIn (:877-895) */
+int mmf_model_perform_fill_in(mmf_model *m, const uint8_t *rgb, const float *depth_filtered,
+                              int frame_to_frame_rgb, int lost);
+int mmf_model_requires_fill_in(mmf_model *m, float ratio, int *result);
+/* Model::downloadMap (Model.cpp:1353-1384): count_out surfels of 12 floats
+ * {x y z conf | colour24 unused initTime timestamp | nx ny nz radius} (Vertex::SIZE = 48) */
+int mmf_model_download_map(mmf_model *m, float *host_aos, unsigned max_surfels, unsigned *count_out);
+/* inverse of download (tests, -restore) */
+int mmf_model_upload_map(mmf_model *m, const float *host_aos, unsigned count);
+/* device image behind a GPUTexture getter (ModelProjection.h:52-77, Model.h:232-244).
+ * names: index(u32) vertConf colorTime normRad (float4) -- sparse index map;
+ *        image(rgba8) vertexConf normalRadius (float4) time(u16) -- splat prediction;
+ *        fillVertex fillNormal (float4) fillImage (rgba8) -- fill-in */
+int mmf_model_texture(mmf_model *m, const char *name, void **dev_ptr, size_t *bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,22 @@ SIGNATURES = {
     "mmf_odom_buffer": (_i, [_vp, C.c_char_p, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "mmf_odom_download": (_i, [_vp, C.c_char_p, _i, _vp, _sz]),
     "mmf_odom_time_icp_kernel": (_i, [_vp, _i, _i, _i, _fp]),
+    "mmf_model_create": (_i, [_vp, _i, _i, _f, _f, _f, _f, C.c_ubyte, _f, _i, C.POINTER(_vp)]),
+    "mmf_model_destroy": (None, [_vp]),
+    "mmf_model_set_pose": (_i, [_vp, _fp]),
+    "mmf_model_get_pose": (_i, [_vp, _fp]),
+    "mmf_model_count": (_i, [_vp, C.POINTER(C.c_uint)]),
+    "mmf_filter_depth": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "mmf_model_initialise": (_i, [_vp, _vp, _vp, _vp, _i, _f]),
+    "mmf_model_predict_indices": (_i, [_vp, _i, _f, _i]),
+    "mmf_model_combined_predict": (_i, [_vp, _f, _i, _i, _i]),
+    "mmf_model_fuse": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _f, _f]),
+    "mmf_model_clean": (_i, [_vp, _i, _i, _f, _vp, _vp, _f]),
+    "mmf_model_perform_fill_in": (_i, [_vp, _vp, _vp, _i, _i]),
+    "mmf_model_requires_fill_in": (_i, [_vp, _f, _ip]),
+    "mmf_model_download_map": (_i, [_vp, _fp, C.c_uint, C.POINTER(C.c_uint)]),
+    "mmf_model_upload_map": (_i, [_vp, _fp, C.c_uint]),
+    "mmf_model_texture": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_sz)]),
 }
 
 _lib = None

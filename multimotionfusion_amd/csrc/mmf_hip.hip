@@ -1112,3 +1112,434 @@ extern "C" int mmf_odom_time_icp_kernel(mmf_odom* o, int level, int reps, int va
     *mean_us_out = ms * 1000.0f / reps;
     return MMF_OK;
 }
+
+// =============================================================================================
+// Surfel model (Core/Model/Model.{h,cpp} + Core/Model/ModelProjection.{h,cpp}), pure HIP
+// =============================================================================================
+#include "surfel_kernels.hpp"
+
+struct mmf_model {
+    mmf_ctx* ctx = nullptr;
+    int width = 0, height = 0;
+    float cx = 0, cy = 0, fx = 0, fy = 0;
+    unsigned char id = 0;
+    float conf_threshold = 10.f;
+    int capacity = 0;
+    float pose[16];
+    unsigned count = 0;  // host copy of the number of surfels in set[cur]
+
+    void* slab = nullptr;
+    size_t slab_bytes = 0;
+    SurfelSoA set[2];  // ping-pong surfel stores (Model.cpp:174-188: two VBOs)
+    int cur = 0;
+    SurfelSoA meas;    // per-pixel measurement of the data pass (the "update map" + newUnstableBuffer)
+    SurfelSoA cand2;   // second per-pixel candidate set (first frame: filtered-depth pass)
+    unsigned* flags_a = nullptr;   // count + npix
+    unsigned* flags_b = nullptr;   // npix
+    unsigned* prefix_a = nullptr;  // count + npix
+    unsigned* prefix_b = nullptr;  // npix
+    unsigned* block_sums = nullptr;
+    unsigned* totals = nullptr;    // [0] scan total a, [1] scan total b, [2] thumbnail count
+    unsigned* winner = nullptr;    // capacity
+    float2* conf_time = nullptr;   // capacity + npix
+    unsigned long long* keys = nullptr;  // npix
+    // sparse index map (ModelProjection.cpp:28-41)
+    unsigned* index = nullptr;
+    float4 *vertConf = nullptr, *colorTime = nullptr, *normRad = nullptr;
+    // splat prediction (ModelProjection.cpp:47-55)
+    uchar4* image = nullptr;
+    float4 *vertexConf = nullptr, *normalRadius = nullptr;
+    unsigned short* time_tex = nullptr;
+    // fill-in (Shaders/FillIn.cpp)
+    float4 *fill_vertex = nullptr, *fill_normal = nullptr;
+    uchar4* fill_image = nullptr;
+    unsigned* host_totals = nullptr;  // pinned
+};
+
+static Cam make_cam(const mmf_model* m, bool double_reciprocal) {
+    Cam c;
+    c.cx = m->cx, c.cy = m->cy, c.fx = m->fx, c.fy = m->fy;
+    if (double_reciprocal) {  // Model.cpp:920-921: 1.0 / fx in double, then to float
+        c.ifx = (float)(1.0 / m->fx), c.ify = (float)(1.0 / m->fy);
+    } else {  // FeedbackBuffer.cpp:86-87, FillIn.cpp:93-94: 1.0f / fx
+        c.ifx = 1.0f / m->fx, c.ify = 1.0f / m->fy;
+    }
+    return c;
+}
+
+static void inverse4f_host(const float* m, float* inv) {  // Eigen `pose.inverse()` (ModelProjection.cpp:108)
+    const float s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2];
+    const float s2 = m[0] * m[7] - m[4] * m[3], s3 = m[1] * m[6] - m[5] * m[2];
+    const float s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+    const float c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11];
+    const float c3 = m[9] * m[14] - m[13] * m[10], c2 = m[8] * m[15] - m[12] * m[11];
+    const float c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    const float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    const float id = 1.0f / det;
+    inv[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
+    inv[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
+    inv[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
+    inv[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
+    inv[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
+    inv[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
+    inv[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
+    inv[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
+    inv[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
+    inv[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
+    inv[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
+    inv[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
+    inv[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
+    inv[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
+    inv[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
+    inv[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
+}
+
+static inline dim3 grid1d(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+// exclusive scan of n flags -> prefix, grand total -> *total_dev
+static int device_scan(mmf_ctx* c, const unsigned* flags, unsigned n, unsigned* prefix, unsigned* block_sums,
+                       unsigned* total_dev) {
+    const unsigned nblocks = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nblocks), dim3(kScanBlock), 0, c->stream, flags, n, block_sums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, block_sums, nblocks, total_dev);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(kScanBlock), 0, c->stream, flags, n, block_sums, prefix);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, float cy, float fx, float fy,
+                                unsigned char id, float conf_threshold, int max_surfels, mmf_model** out) {
+    MMF_REQUIRE(c && out, "mmf_model_create: null argument");
+    MMF_REQUIRE(width >= 32 && height >= 32 && width % 4 == 0 && height % 4 == 0, "mmf_model_create: bad size");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    mmf_model* m = new (std::nothrow) mmf_model();
+    MMF_REQUIRE(m != nullptr, "mmf_model_create: out of host memory");
+    m->ctx = c;
+    m->width = width, m->height = height;
+    m->cx = cx, m->cy = cy, m->fx = fx, m->fy = fy;
+    m->id = id;
+    m->conf_threshold = conf_threshold;
+    m->capacity = max_surfels > 0 ? max_surfels : 1024 * 1024;  // Model::MAX_VERTICES (Model.cpp:119-126)
+    for (int i = 0; i < 16; ++i) m->pose[i] = (i % 5 == 0) ? 1.f : 0.f;
+    const size_t npix = (size_t)width * height, cap = (size_t)m->capacity;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    size_t o_set[2][3], o_meas[3], o_cand[3];
+    for (int s = 0; s < 2; ++s)
+        for (int k = 0; k < 3; ++k) o_set[s][k] = carve(cap * 16);
+    for (int k = 0; k < 3; ++k) o_meas[k] = carve(npix * 16);
+    for (int k = 0; k < 3; ++k) o_cand[k] = carve(npix * 16);
+    const size_t o_fa = carve((cap + npix) * 4), o_fb = carve(npix * 4), o_pa = carve((cap + npix) * 4),
+                 o_pb = carve(npix * 4), o_bs = carve(((cap + npix) / kScanTile + 2) * 4), o_tot = carve(64),
+                 o_win = carve(cap * 4), o_ct = carve((cap + npix) * 8), o_keys = carve(npix * 8),
+                 o_idx = carve(npix * 4), o_vc = carve(npix * 16), o_ctm = carve(npix * 16), o_nr = carve(npix * 16),
+                 o_img = carve(npix * 4), o_vxc = carve(npix * 16), o_nrr = carve(npix * 16), o_tt = carve(npix * 2),
+                 o_fv = carve(npix * 16), o_fn = carve(npix * 16), o_fi = carve(npix * 4);
+    m->slab_bytes = off;
+    hipError_t e = hipMalloc(&m->slab, m->slab_bytes);
+    if (e != hipSuccess) {
+        delete m;
+        return fail(MMF_ERR_HIP, std::string("mmf_model_create: hipMalloc: ") + hipGetErrorString(e));
+    }
+    MMF_HIP_TRY(hipMemsetAsync(m->slab, 0, m->slab_bytes, c->stream));
+    char* b = static_cast<char*>(m->slab);
+    for (int s = 0; s < 2; ++s)
+        m->set[s] = SurfelSoA{(float4*)(b + o_set[s][0]), (float4*)(b + o_set[s][1]), (float4*)(b + o_set[s][2])};
+    m->meas = SurfelSoA{(float4*)(b + o_meas[0]), (float4*)(b + o_meas[1]), (float4*)(b + o_meas[2])};
+    m->cand2 = SurfelSoA{(float4*)(b + o_cand[0]), (float4*)(b + o_cand[1]), (float4*)(b + o_cand[2])};
+    m->flags_a = (unsigned*)(b + o_fa), m->flags_b = (unsigned*)(b + o_fb);
+    m->prefix_a = (unsigned*)(b + o_pa), m->prefix_b = (unsigned*)(b + o_pb);
+    m->block_sums = (unsigned*)(b + o_bs), m->totals = (unsigned*)(b + o_tot);
+    m->winner = (unsigned*)(b + o_win), m->conf_time = (float2*)(b + o_ct);
+    m->keys = (unsigned long long*)(b + o_keys);
+    m->index = (unsigned*)(b + o_idx);
+    m->vertConf = (float4*)(b + o_vc), m->colorTime = (float4*)(b + o_ctm), m->normRad = (float4*)(b + o_nr);
+    m->image = (uchar4*)(b + o_img), m->vertexConf = (float4*)(b + o_vxc), m->normalRadius = (float4*)(b + o_nrr);
+    m->time_tex = (unsigned short*)(b + o_tt);
+    m->fill_vertex = (float4*)(b + o_fv), m->fill_normal = (float4*)(b + o_fn), m->fill_image = (uchar4*)(b + o_fi);
+    hipLaunchKernelGGL(fill_u32_kernel, grid1d(cap), dim3(256), 0, c->stream, m->winner, cap, kNoWinner);
+    MMF_HIP_TRY(hipGetLastError());
+    MMF_HIP_TRY(hipHostMalloc(&m->host_totals, 64, hipHostMallocDefault));
+    MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = m;
+    return MMF_OK;
+}
+
+extern "C" void mmf_model_destroy(mmf_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipFree(m->slab);
+    (void)hipHostFree(m->host_totals);
+    delete m;
+}
+
+extern "C" int mmf_model_set_pose(mmf_model* m, const float pose[16]) {
+    MMF_REQUIRE(m && pose, "mmf_model_set_pose: null argument");
+    std::memcpy(m->pose, pose, sizeof(m->pose));
+    return MMF_OK;
+}
+extern "C" int mmf_model_get_pose(mmf_model* m, float pose[16]) {
+    MMF_REQUIRE(m && pose, "mmf_model_get_pose: null argument");
+    std::memcpy(pose, m->pose, sizeof(m->pose));
+    return MMF_OK;
+}
+extern "C" int mmf_model_count(mmf_model* m, unsigned* count) {
+    MMF_REQUIRE(m && count, "mmf_model_count: null argument");
+    *count = m->count;
+    return MMF_OK;
+}
+
+// MultiMotionFusion::filterDepth (MultiMotionFusion.cpp:897-904)
+extern "C" int mmf_filter_depth(mmf_ctx* c, const float* depth, int cols, int rows, float max_depth, float* out) {
+    MMF_REQUIRE(c && depth && out && cols > 0 && rows > 0, "mmf_filter_depth: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(bilateral_filter_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, depth, cols, rows,
+                       max_depth, out);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+static int model_read_totals(mmf_model* m) {
+    mmf_ctx* c = m->ctx;
+    MMF_HIP_TRY(hipMemcpyAsync(m->host_totals, m->totals, 16, hipMemcpyDeviceToHost, c->stream));
+    MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    return MMF_OK;
+}
+
+// Model::initialise (Model.cpp:267-312) with the two FeedbackBuffer::compute passes it consumes
+extern "C" int mmf_model_initialise(mmf_model* m, const uint8_t* rgb, const float* depth_raw,
+                                    const float* depth_filtered, int time, float max_depth) {
+    MMF_REQUIRE(m && rgb && depth_raw && depth_filtered, "mmf_model_initialise: null argument");
+    mmf_ctx* c = m->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const int npix = m->width * m->height;
+    const Cam cam = make_cam(m, false);
+    hipLaunchKernelGGL(feedback_kernel, grid1d(npix), dim3(256), 0, c->stream, rgb, depth_raw, m->width, m->height, cam,
+                       time, max_depth, m->meas, m->flags_a);
+    hipLaunchKernelGGL(feedback_kernel, grid1d(npix), dim3(256), 0, c->stream, rgb, depth_filtered, m->width, m->height,
+                       cam, time, max_depth, m->cand2, m->flags_b);
+    MMF_HIP_TRY(hipGetLastError());
+    int rc = device_scan(c, m->flags_a, npix, m->prefix_a, m->block_sums, &m->totals[0]);
+    if (rc) return rc;
+    rc = device_scan(c, m->flags_b, npix, m->prefix_b, m->block_sums, &m->totals[1]);
+    if (rc) return rc;
+    hipLaunchKernelGGL(init_scatter_kernel, grid1d(npix), dim3(256), 0, c->stream, npix, m->meas, m->flags_a,
+                       m->prefix_a, m->cand2, m->flags_b, m->prefix_b, m->set[m->cur]);
+    MMF_HIP_TRY(hipGetLastError());
+    rc = model_read_totals(m);
+    if (rc) return rc;
+    m->count = m->host_totals[0];  // "both raw and filtered have the same amount of vertices" (Model.cpp:292)
+    return MMF_OK;
+}
+
+static IndexArgs model_index_args(mmf_model* m, int time, float depth_cutoff, int time_delta) {
+    IndexArgs a;
+    inverse4f_host(m->pose, a.t_inv.m);
+    a.c = make_cam(m, false);
+    a.cols = m->width, a.rows = m->height;
+    a.maxDepth = depth_cutoff;
+    a.time = time, a.timeDelta = time_delta;
+    return a;
+}
+
+// ModelProjection::predictIndices (ModelProjection.cpp:94-143)
+extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cutoff, int time_delta) {
+    MMF_REQUIRE(m != nullptr, "mmf_model_predict_indices: null model");
+    mmf_ctx* c = m->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const size_t npix = (size_t)m->width * m->height;
+    const IndexArgs a = model_index_args(m, time, depth_cutoff, time_delta);
+    hipLaunchKernelGGL(fill_u64_kernel, grid1d(npix), dim3(256), 0, c->stream, m->keys, npix, kEmptyKey);
+    if (m->count)
+        hipLaunchKernelGGL(index_map_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
+                           m->keys);
+    hipLaunchKernelGGL(index_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->index,
+                       m->vertConf, m->colorTime, m->normRad);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+// ModelProjection::combinedPredict(ACTIVE) (ModelProjection.cpp:187-269); Model.h:210-214
+extern "C" int mmf_model_combined_predict(mmf_model* m, float depth_cutoff, int time, int max_time, int time_delta) {
+    MMF_REQUIRE(m != nullptr, "mmf_model_combined_predict: null model");
+    mmf_ctx* c = m->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const size_t npix = (size_t)m->width * m->height;
+    SplatArgs a;
+    inverse4f_host(m->pose, a.t_inv.m);
+    a.c = make_cam(m, false);
+    a.cols = m->width, a.rows = m->height;
+    a.maxDepth = depth_cutoff;
+    a.confThreshold = m->conf_threshold;
+    a.time = time, a.maxTime = max_time, a.timeDelta = time_delta;
+    hipLaunchKernelGGL(fill_u64_kernel, grid1d(npix), dim3(256), 0, c->stream, m->keys, npix, kEmptyKey);
+    if (m->count)
+        hipLaunchKernelGGL(splat_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
+                           m->keys);
+    hipLaunchKernelGGL(splat_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->image,
+                       m->vertexConf, m->normalRadius, m->time_tex);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+// Model::fuse (Model.cpp:893-1048): data association + update; `weighting` = computeFusionWeight()
+extern "C" int mmf_model_fuse(mmf_model* m, int time, const uint8_t* rgb, const uint8_t* mask, const float* depth_raw,
+                              const float* depth_filtered, float depth_cutoff, float weighting) {
+    MMF_REQUIRE(m && rgb && mask && depth_raw && depth_filtered, "mmf_model_fuse: null argument");
+    mmf_ctx* c = m->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const int npix = m->width * m->height;
+    FuseArgs a;
+    std::memcpy(a.pose.m, m->pose, sizeof(m->pose));
+    a.c = make_cam(m, true);
+    a.cols = m->width, a.rows = m->height;
+    a.time = time;
+    a.weighting = weighting;
+    a.maskID = m->id;
+    a.maxDepth = depth_cutoff;  // std::min(depthCutoff, maxDepth) with maxDepth = FLT_MAX by default (Model.h:129)
+    a.count = (int)m->count;
+    hipLaunchKernelGGL(fuse_data_kernel, grid1d(npix), dim3(256), 0, c->stream, rgb, depth_raw, depth_filtered, mask,
+                       m->index, m->vertConf, m->normRad, a, m->meas, m->flags_b, m->winner);
+    if (m->count)
+        hipLaunchKernelGGL(fuse_update_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count,
+                           m->meas, time, m->winner);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+// Model::clean (Model.cpp:1050-1182); must follow mmf_model_fuse + mmf_model_predict_indices of the same frame
+extern "C" int mmf_model_clean(mmf_model* m, int time, int time_delta, float depth_cutoff, const float* depth_filtered,
+                               const uint8_t* mask, float outlier_coeff) {
+    (void)depth_cutoff;  // only consumed by the deformation part, which never runs (nodes == 0)
+    MMF_REQUIRE(m && depth_filtered && mask, "mmf_model_clean: null argument");
+    mmf_ctx* c = m->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const int npix = m->width * m->height;
+    CleanArgs a;
+    inverse4f_host(m->pose, a.t_inv.m);
+    a.c = make_cam(m, false);
+    a.cols = m->width, a.rows = m->height;
+    a.time = time, a.timeDelta = time_delta;
+    a.confThreshold = m->conf_threshold;
+    a.outlierCoeff = outlier_coeff;
+    a.maskID = m->id;
+    a.count = (int)m->count;
+    a.npix = npix;
+    const unsigned n = m->count + npix;
+    hipLaunchKernelGGL(clean_flag_kernel, grid1d(n), dim3(256), 0, c->stream, m->set[m->cur], m->meas, m->flags_b, a,
+                       m->index, m->vertConf, m->colorTime, depth_filtered, mask, m->flags_a, m->conf_time);
+    MMF_HIP_TRY(hipGetLastError());
+    int rc = device_scan(c, m->flags_a, n, m->prefix_a, m->block_sums, &m->totals[0]);
+    if (rc) return rc;
+    hipLaunchKernelGGL(clean_scatter_kernel, grid1d(n), dim3(256), 0, c->stream, m->set[m->cur], m->meas, (int)m->count,
+                       npix, m->flags_a, m->prefix_a, m->conf_time, m->set[1 - m->cur], m->capacity);
+    MMF_HIP_TRY(hipGetLastError());
+    rc = model_read_totals(m);  // glGetQueryObjectuiv(countQuery) in the reference (Model.cpp:1166)
+    if (rc) return rc;
+    m->count = m->host_totals[0] < (unsigned)m->capacity ? m->host_totals[0] : (unsigned)m->capacity;
+    m->cur = 1 - m->cur;
+    return MMF_OK;
+}
+
+// Model::performFillIn (Model.cpp:1607-1616)
+extern "C" int mmf_model_perform_fill_in(mmf_model* m, const uint8_t* rgb, const float* depth_filtered,
+                                         int frame_to_frame_rgb, int lost) {
+    MMF_REQUIRE(m && rgb && depth_filtered, "mmf_model_perform_fill_in: null argument");
+    mmf_ctx* c = m->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const int npix = m->width * m->height;
+    hipLaunchKernelGGL(fill_in_kernel, grid1d(npix), dim3(256), 0, c->stream, m->vertexConf, m->normalRadius, m->image,
+                       depth_filtered, rgb, m->width, m->height, make_cam(m, false), lost ? 1 : 0,
+                       (lost || frame_to_frame_rgb) ? 1 : 0, m->fill_vertex, m->fill_normal, m->fill_image);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+// MultiMotionFusion::requiresFillIn (MultiMotionFusion.cpp:877-895)
+extern "C" int mmf_model_requires_fill_in(mmf_model* m, float ratio, int* result) {
+    MMF_REQUIRE(m && result, "mmf_model_requires_fill_in: null argument");
+    mmf_ctx* c = m->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const int dc = m->width / 20, dr = m->height / 20;
+    MMF_HIP_TRY(hipMemsetAsync(&m->totals[2], 0, 4, c->stream));
+    hipLaunchKernelGGL(thumbnail_count_kernel, grid1d(dc * dr), dim3(256), 0, c->stream, m->image, m->width, m->height,
+                       &m->totals[2]);
+    MMF_HIP_TRY(hipGetLastError());
+    int rc = model_read_totals(m);
+    if (rc) return rc;
+    *result = ((float)m->host_totals[2] / (float)(dr * dc) < ratio) ? 1 : 0;
+    return MMF_OK;
+}
+
+// Model::downloadMap (Model.cpp:1353-1384): 48-byte AoS surfels {pos+conf, colour/time, normal+radius}
+extern "C" int mmf_model_download_map(mmf_model* m, float* host_aos, unsigned max_surfels, unsigned* count_out) {
+    MMF_REQUIRE(m && host_aos && count_out, "mmf_model_download_map: null argument");
+    mmf_ctx* c = m->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const unsigned n = m->count < max_surfels ? m->count : max_surfels;
+    *count_out = n;
+    if (!n) return MMF_OK;
+    // stage through the (free) other surfel set as an AoS image
+    float4* aos = m->set[1 - m->cur].pos;  // 3 * 16 B * capacity contiguous? no: use its three arrays in turn
+    (void)aos;
+    float4* stage = nullptr;
+    MMF_HIP_TRY(hipMalloc(&stage, (size_t)n * 48));
+    hipLaunchKernelGGL(soa_to_aos_kernel, grid1d(n), dim3(256), 0, c->stream, m->set[m->cur], (int)n, stage);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host_aos, stage, (size_t)n * 48, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(stage);
+    if (e != hipSuccess) return fail(MMF_ERR_HIP, std::string("mmf_model_download_map: ") + hipGetErrorString(e));
+    return MMF_OK;
+}
+
+// test / restore hook: replace the store's content with host AoS surfels
+extern "C" int mmf_model_upload_map(mmf_model* m, const float* host_aos, unsigned count) {
+    MMF_REQUIRE(m && (host_aos || count == 0) && count <= (unsigned)m->capacity, "mmf_model_upload_map: bad argument");
+    mmf_ctx* c = m->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    m->count = count;
+    if (!count) return MMF_OK;
+    float4* stage = nullptr;
+    MMF_HIP_TRY(hipMalloc(&stage, (size_t)count * 48));
+    hipError_t e = hipMemcpyAsync(stage, host_aos, (size_t)count * 48, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(aos_to_soa_kernel, grid1d(count), dim3(256), 0, c->stream, stage, (int)count, m->set[m->cur]);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(stage);
+    if (e != hipSuccess) return fail(MMF_ERR_HIP, std::string("mmf_model_upload_map: ") + hipGetErrorString(e));
+    return MMF_OK;
+}
+
+// device images of the projections (the reference's GPUTexture getters, ModelProjection.h:52-77,
+// Model.h:232-244).  names: index vertConf colorTime normRad | image vertexConf normalRadius time |
+// fillVertex fillNormal fillImage
+extern "C" int mmf_model_texture(mmf_model* m, const char* name, void** dev_ptr, size_t* bytes) {
+    MMF_REQUIRE(m && name && dev_ptr && bytes, "mmf_model_texture: null argument");
+    const size_t npix = (size_t)m->width * m->height;
+    const std::string s(name);
+    void* p = nullptr;
+    size_t b = 0;
+    if (s == "index") p = m->index, b = npix * 4;
+    else if (s == "vertConf") p = m->vertConf, b = npix * 16;
+    else if (s == "colorTime") p = m->colorTime, b = npix * 16;
+    else if (s == "normRad") p = m->normRad, b = npix * 16;
+    else if (s == "image") p = m->image, b = npix * 4;
+    else if (s == "vertexConf") p = m->vertexConf, b = npix * 16;
+    else if (s == "normalRadius") p = m->normalRadius, b = npix * 16;
+    else if (s == "time") p = m->time_tex, b = npix * 2;
+    else if (s == "fillVertex") p = m->fill_vertex, b = npix * 16;
+    else if (s == "fillNormal") p = m->fill_normal, b = npix * 16;
+    else if (s == "fillImage") p = m->fill_image, b = npix * 4;
+    else return fail(MMF_ERR_INVALID, "mmf_model_texture: unknown name '" + s + "'");
+    *dev_ptr = p;
+    *bytes = b;
+    return MMF_OK;
+}

@@ -1,0 +1,734 @@
+// surfel_kernels.hpp -- pure-HIP compute replacement of the reference's OpenGL surfel passes
+// (no GL interop):
+//   index_map_kernel + index_resolve_kernel   <- index_map.vert/.frag   (ModelProjection.cpp:94-143)
+//   splat_kernel + splat_resolve_kernel       <- splat.vert + combo_splat.frag (ModelProjection.cpp:187-269)
+//   fuse_data_kernel + fuse_update_kernel     <- data.vert/.geom/.frag + update.vert (Model.cpp:893-1048)
+//   clean_flag_kernel + clean_scatter_kernel  <- copy_unstable.vert/.geom (Model.cpp:1050-1182)
+//   feedback_kernel + init_scatter_kernel     <- vertex_feedback.vert/.geom + init_unstable.vert (Model.cpp:267-312)
+//   bilateral_filter_kernel                   <- depth_bilateral_metric.frag (MultiMotionFusion.cpp:897-904)
+//   fill_in_kernel, thumbnail_count_kernel    <- fill_*.frag, resize.frag + requiresFillIn
+//
+// Data layout: the surfel store is a structure of three float4 arrays (position+confidence,
+// colour/time, normal+radius), so a wave64 reads 1 KiB contiguous per attribute (16 B per lane);
+// the reference's 48-byte AoS vertex (Vertex::SIZE) only exists at the download boundary.
+// GL's depth-tested rasterisation becomes a 64-bit atomicMin of (24-bit depth << 32 | vertexId)
+// per pixel followed by a per-pixel resolve pass that re-derives the winner's attributes; GL's
+// transform-feedback compaction becomes flag -> exclusive scan -> scatter, which keeps the
+// reference's draw order (surfel order, then column-major pixel order for new points).
+// The arithmetic follows oracle/mmf_oracle_surfel.c statement by statement (assumptions A1-A5
+// about the fixed-function GL state are listed there); built without FMA contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mmf_math.h"
+
+namespace mmf {
+
+struct v3 {
+    float x, y, z;
+};
+__device__ __forceinline__ v3 V3(float x, float y, float z) { return v3{x, y, z}; }
+__device__ __forceinline__ v3 v3add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 v3sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 v3scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float v3dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ v3 v3cross(v3 a, v3 b) {
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ v3 v3normalize(v3 a) { return v3scale(a, 1.0f / sqrtf(v3dot(a, a))); }
+__device__ __forceinline__ float v3length(v3 a) { return sqrtf(v3dot(a, a)); }
+
+struct Mat4 {  // row major, passed by value as a kernel argument
+    float m[16];
+};
+__device__ __forceinline__ v3 m4point(const Mat4& M, v3 p) {
+    const float* m = M.m;
+    return V3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+__device__ __forceinline__ v3 m4dir(const Mat4& M, v3 n) {
+    const float* m = M.m;
+    return V3(m[0] * n.x + m[1] * n.y + m[2] * n.z, m[4] * n.x + m[5] * n.y + m[6] * n.z,
+              m[8] * n.x + m[9] * n.y + m[10] * n.z);
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int texel(float coord, int size) { return clampi((int)floorf(coord * (float)size), 0, size - 1); }
+
+struct Cam {  // cx, cy, fx, fy and the reciprocals the shaders receive as uniforms
+    float cx, cy, fx, fy, ifx, ify;
+};
+
+__device__ __forceinline__ float encode_color(float r, float g, float b) {  // color_encoding.glsl
+    int rgb = (int)roundf(r * 255.0f);
+    rgb = (rgb << 8) + (int)roundf(g * 255.0f);
+    rgb = (rgb << 8) + (int)roundf(b * 255.0f);
+    return (float)rgb;
+}
+__device__ __forceinline__ v3 decode_color(float c) {
+    const int ci = (int)c;
+    return V3((float)(ci >> 16 & 0xFF) / 255.0f, (float)(ci >> 8 & 0xFF) / 255.0f, (float)(ci & 0xFF) / 255.0f);
+}
+__device__ __forceinline__ float get_radius(float depth, float norm_z, float ifx, float ify) {  // surfels.glsl:19-34
+    const float meanFocal = ((1.0f / fabsf(ifx)) + (1.0f / fabsf(ify))) / 2.0f;
+    const float sqrt2 = 1.41421356237f;
+    const float radius = (depth / meanFocal) * sqrt2;
+    float radius_n = radius;
+    radius_n = radius_n / fabsf(norm_z);
+    radius_n = fminf(2.0f * radius, radius_n);
+    return radius_n;
+}
+__device__ __forceinline__ float confidence(float x, float y, float cx, float cy, float weighting) {  // surfels.glsl:36-46
+    const float maxRadDist = 400, twoSigmaSquared = 0.72f;
+    const float px = x - cx, py = y - cy;
+    const float radialDist = sqrtf(px * px + py * py) / maxRadDist;
+    return mmf_expf((-(radialDist * radialDist) / twoSigmaSquared)) * weighting;
+}
+__device__ __forceinline__ uint32_t depth24(float zw) {
+    if (!(zw >= 0.f)) zw = 0.f;
+    if (zw > 1.f) zw = 1.f;
+    return (uint32_t)(zw * 16777215.0f + 0.5f);
+}
+// texture coordinate of pixel centre i as the reference's host code builds it (Model.cpp:206-210)
+__device__ __forceinline__ float uv_coord(int i, int n) {
+    return (float)((double)((float)i / (float)n) + 1.0 / (2 * (double)(float)n));
+}
+__device__ __forceinline__ v3 get_vertex(const float* __restrict__ depth, int cols, int rows, float tx, float ty,
+                                         float x, float y, const Cam& c) {  // geometry.glsl:22-26
+    const float z = depth[texel(ty, rows) * cols + texel(tx, cols)];
+    return V3((x - c.cx) * z * c.ifx, (y - c.cy) * z * c.ify, z);
+}
+__device__ __forceinline__ v3 get_normal(const float* __restrict__ depth, int cols, int rows, v3 p, float tx,
+                                         float ty, float x, float y, const Cam& c) {  // geometry.glsl:28-40
+    const v3 xf = get_vertex(depth, cols, rows, tx + (1.0f / cols), ty, x + 1, y, c);
+    const v3 xb = get_vertex(depth, cols, rows, tx - (1.0f / cols), ty, x - 1, y, c);
+    const v3 yf = get_vertex(depth, cols, rows, tx, ty + (1.0f / rows), x, y + 1, c);
+    const v3 yb = get_vertex(depth, cols, rows, tx, ty - (1.0f / rows), x, y - 1, c);
+    const v3 del_x = v3sub(v3scale(v3add(xb, p), 0.5f), v3scale(v3add(xf, p), 0.5f));
+    const v3 del_y = v3sub(v3scale(v3add(yb, p), 0.5f), v3scale(v3add(yf, p), 0.5f));
+    return v3normalize(v3cross(del_x, del_y));
+}
+
+// the surfel store (one of the two ping-pong sets)
+struct SurfelSoA {
+    float4* pos;  // xyz + confidence
+    float4* col;  // colour24-as-float, unused, initTime, timestamp
+    float4* nrm;  // normal xyz + radius
+};
+
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+// ---- depth bilateral filter ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bilateral_filter_kernel(const float* __restrict__ depth, int cols, int rows,
+                                                               float maxD, float* __restrict__ out) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cols || y >= rows) return;
+    const float sigma_space2_inv_half = 0.024691358f, sigma_color2_inv_half = 555.556f;
+    const int R = 6, D = R * 2 + 1;
+    const float value = depth[y * cols + x];
+    if (value > maxD || value < 0.3f) {
+        out[y * cols + x] = 0;
+        return;
+    }
+    const int tx = min(x - D / 2 + D, cols), ty = min(y - D / 2 + D, rows);
+    float sum1 = 0, sum2 = 0;
+    for (int cy = max(y - D / 2, 0); cy < ty; ++cy)
+        for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
+            const float tmp = depth[cy * cols + cx];
+            const float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) + ((float)y - (float)cy) * ((float)y - (float)cy);
+            const float color2 = (value - tmp) * (value - tmp);
+            const float weight = mmf_expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+            sum1 += tmp * weight;
+            sum2 += weight;
+        }
+    out[y * cols + x] = sum1 / sum2;
+}
+
+// ---- exclusive scan of uint32 flags (3 launches; 1024 elements per workgroup) -------------------
+constexpr int kScanBlock = 256, kScanPer = 4, kScanTile = kScanBlock * kScanPer;
+
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* lds, unsigned& total) {
+    // inclusive scan over the 256 threads through LDS (Hillis-Steele), returns the exclusive value
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        const unsigned add = t >= off ? lds[t - off] : 0u;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    total = lds[kScanBlock - 1];
+    const unsigned incl = lds[t];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_block_sums_kernel(const unsigned* __restrict__ flags, unsigned n,
+                                                                     unsigned* __restrict__ block_sums) {
+    __shared__ unsigned lds[kScanBlock];
+    const unsigned base = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k)
+        if (base + k < n) s += flags[base + k];
+    unsigned total;
+    block_exclusive_scan(s, lds, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// one workgroup: exclusive scan of up to 4096 block sums in place; writes the grand total
+__global__ __launch_bounds__(kScanBlock) void scan_top_kernel(unsigned* __restrict__ block_sums, unsigned nblocks,
+                                                              unsigned* __restrict__ total_out) {
+    __shared__ unsigned lds[kScanBlock];
+    unsigned carry = 0;
+    for (unsigned base = 0; base < nblocks; base += kScanBlock) {
+        const unsigned i = base + threadIdx.x;
+        const unsigned v = i < nblocks ? block_sums[i] : 0u;
+        unsigned total;
+        const unsigned ex = block_exclusive_scan(v, lds, total);
+        if (i < nblocks) block_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const unsigned* __restrict__ flags, unsigned n,
+                                                                const unsigned* __restrict__ block_offsets,
+                                                                unsigned* __restrict__ prefix) {
+    __shared__ unsigned lds[kScanBlock];
+    const unsigned base = blockIdx.x * kScanTile + threadIdx.x * kScanPer;
+    unsigned f[kScanPer], s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) {
+        f[k] = base + k < n ? flags[base + k] : 0u;
+        s += f[k];
+    }
+    unsigned total;
+    unsigned ex = block_exclusive_scan(s, lds, total) + block_offsets[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) {
+        if (base + k < n) prefix[base + k] = ex;
+        ex += f[k];
+    }
+}
+
+// ---- first frame: vertex_feedback.vert/.geom for one depth image -------------------------------
+// draw index d = i * rows + j (column-major pixel order, FeedbackBuffer.cpp:41-49).  Writes the
+// candidate surfel of every pixel into per-draw-index arrays plus its zVal > 0 flag.
+__global__ __launch_bounds__(256) void feedback_kernel(const uint8_t* __restrict__ rgb, const float* __restrict__ depth,
+                                                       int cols, int rows, Cam c, int time, float maxDepth,
+                                                       SurfelSoA cand, unsigned* __restrict__ flags) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= cols * rows) return;
+    const int i = d / rows, j = d - i * rows;
+    const float tx = uv_coord(i, cols), ty = uv_coord(j, rows);
+    const float x = tx * cols, y = ty * rows;
+    const v3 p = get_vertex(depth, cols, rows, tx, ty, x, y, c);
+    const v3 nl = get_normal(depth, cols, rows, p, tx, ty, x, y, c);
+    const bool ok = !(p.z <= 0 || p.z > maxDepth);
+    flags[d] = ok ? 1u : 0u;
+    if (!ok) return;
+    const uint8_t* px = rgb + (size_t)(texel(ty, rows) * cols + texel(tx, cols)) * 3;
+    cand.pos[d] = make_float4(p.x, p.y, p.z, confidence(x, y, c.cx, c.cy, 1.0f));
+    cand.col[d] = make_float4(encode_color(px[0] / 255.0f, px[1] / 255.0f, px[2] / 255.0f), 0.f, 1.0f, (float)time);
+    cand.nrm[d] = make_float4(nl.x, nl.y, nl.z, get_radius(p.z, nl.z, c.ifx, c.ify));
+}
+
+// Model::initialise + init_unstable.vert: position/colour from the k-th valid RAW pixel, normal +
+// radius from the k-th valid FILTERED pixel (the reference zips the two compacted buffers).
+__global__ __launch_bounds__(256) void init_scatter_kernel(int n, SurfelSoA raw, const unsigned* __restrict__ raw_flags,
+                                                           const unsigned* __restrict__ raw_prefix, SurfelSoA fil,
+                                                           const unsigned* __restrict__ fil_flags,
+                                                           const unsigned* __restrict__ fil_prefix, SurfelSoA dst) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= n) return;
+    if (raw_flags[d]) {
+        const unsigned k = raw_prefix[d];
+        dst.pos[k] = raw.pos[d];
+        float4 col = raw.col[d];
+        col.y = 0;
+        col.z = 1;
+        dst.col[k] = col;
+    }
+    if (fil_flags[d]) dst.nrm[fil_prefix[d]] = fil.nrm[d];
+}
+
+// ---- index map --------------------------------------------------------------------------------
+struct IndexArgs {
+    Mat4 t_inv;
+    Cam c;
+    int cols, rows;
+    float maxDepth;
+    int time, timeDelta;
+};
+
+__global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, IndexArgs a,
+                                                        unsigned long long* __restrict__ keys) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= count) return;
+    const float4 p = s.pos[id];
+    const float ts = s.col[id].w;
+    const v3 h = m4point(a.t_inv, V3(p.x, p.y, p.z));
+    if (h.z > a.maxDepth || h.z < 0 || (float)a.time - ts > (float)a.timeDelta) return;
+    const float xn = ((((a.c.fx * h.x) / h.z) + a.c.cx) - (a.cols * 0.5f)) / (a.cols * 0.5f);
+    const float yn = ((((a.c.fy * h.y) / h.z) + a.c.cy) - (a.rows * 0.5f)) / (a.rows * 0.5f);
+    const float zn = h.z / a.maxDepth;
+    if (!(xn >= -1 && xn <= 1 && yn >= -1 && yn <= 1 && zn >= -1 && zn <= 1)) return;
+    const float xw = (xn + 1.0f) * (a.cols * 0.5f), yw = (yn + 1.0f) * (a.rows * 0.5f);
+    const int px = (int)floorf(xw), py = (int)floorf(yw);
+    if (px < 0 || py < 0 || px >= a.cols || py >= a.rows) return;
+    const unsigned long long k = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | (unsigned)id;
+    atomicMin(&keys[py * a.cols + px], k);
+}
+
+__global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexArgs a,
+                                                            const unsigned long long* __restrict__ keys,
+                                                            unsigned* __restrict__ index, float4* __restrict__ vertConf,
+                                                            float4* __restrict__ colorTime, float4* __restrict__ normRad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.cols * a.rows) return;
+    const unsigned long long k = keys[i];
+    if (k == kEmptyKey) {
+        index[i] = 0;
+        vertConf[i] = colorTime[i] = normRad[i] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const unsigned id = (unsigned)k;
+    const float4 p = s.pos[id], n = s.nrm[id];
+    const v3 h = m4point(a.t_inv, V3(p.x, p.y, p.z));
+    const v3 nn = v3normalize(m4dir(a.t_inv, V3(n.x, n.y, n.z)));
+    index[i] = id;
+    vertConf[i] = make_float4(h.x, h.y, h.z, p.w);
+    colorTime[i] = s.col[id];
+    normRad[i] = make_float4(nn.x, nn.y, nn.z, n.w);
+}
+
+// ---- splat prediction ----------------------------------------------------------------------------
+struct SplatArgs {
+    Mat4 t_inv;
+    Cam c;
+    int cols, rows;
+    float maxDepth, confThreshold;
+    int time, maxTime, timeDelta;
+};
+
+struct SplatFrag {  // per-surfel quantities shared by the rasterising and the resolving pass
+    v3 h, nrm;
+    float rad;
+    int x0, x1, y0, y1;
+    bool ok;
+};
+
+__device__ __forceinline__ SplatFrag splat_setup(const float4 p, const float4 col, const float4 n, const SplatArgs& a) {
+    SplatFrag f;
+    f.ok = false;
+    f.h = m4point(a.t_inv, V3(p.x, p.y, p.z));
+    const v3 h = f.h;
+    if (h.z > a.maxDepth || h.z < 0 || p.w < a.confThreshold || (float)a.time - col.w > (float)a.timeDelta ||
+        col.w > (float)a.maxTime)
+        return f;
+    const float fx = a.c.fx, fy = a.c.fy, cx = a.c.cx, cy = a.c.cy;
+    const float xn = ((((fx * h.x) / h.z) + cx) - (a.cols * 0.5f)) / (a.cols * 0.5f);
+    const float yn = ((((fy * h.y) / h.z) + cy) - (a.rows * 0.5f)) / (a.rows * 0.5f);
+    const float zn = h.z / a.maxDepth;
+    if (!(xn >= -1 && xn <= 1 && yn >= -1 && yn <= 1 && zn >= -1 && zn <= 1)) return f;
+    f.nrm = v3normalize(m4dir(a.t_inv, V3(n.x, n.y, n.z)));
+    f.rad = n.w;
+    const v3 nrm = f.nrm;
+    const v3 x1 = v3scale(v3scale(v3normalize(V3((nrm.y - nrm.z), -nrm.x, nrm.x)), f.rad), 1.41421356f);
+    const v3 y1 = v3cross(nrm, x1);
+    const v3 q1 = v3add(h, x1), q2 = v3add(h, y1), q3 = v3sub(h, y1), q4 = v3sub(h, x1);
+    const float p1x = ((fx * q1.x) / q1.z) + cx, p2x = ((fx * q2.x) / q2.z) + cx;
+    const float p3x = ((fx * q3.x) / q3.z) + cx, p4x = ((fx * q4.x) / q4.z) + cx;
+    const float p1y = ((fy * q1.y) / q1.z) + cy, p2y = ((fy * q2.y) / q2.z) + cy;
+    const float p3y = ((fy * q3.y) / q3.z) + cy, p4y = ((fy * q4.y) / q4.z) + cy;
+    const float xmin = fminf(p1x, fminf(p2x, fminf(p3x, p4x))), xmax = fmaxf(p1x, fmaxf(p2x, fmaxf(p3x, p4x)));
+    const float ymin = fminf(p1y, fminf(p2y, fminf(p3y, p4y))), ymax = fmaxf(p1y, fmaxf(p2y, fmaxf(p3y, p4y)));
+    float size = fmaxf(0.f, fmaxf(fabsf(xmax - xmin), fabsf(ymax - ymin)));
+    if (!(size >= 1.0f)) size = 1.0f;
+    const float xw = (xn + 1.0f) * (a.cols * 0.5f), yw = (yn + 1.0f) * (a.rows * 0.5f), hs = size * 0.5f;
+    int x0 = (int)ceilf(xw - hs - 0.5f), x1i = (int)ceilf(xw + hs - 0.5f) - 1;
+    int y0 = (int)ceilf(yw - hs - 0.5f), y1i = (int)ceilf(yw + hs - 0.5f) - 1;
+    f.x0 = x0 < 0 ? 0 : x0, f.y0 = y0 < 0 ? 0 : y0;
+    f.x1 = x1i > a.cols - 1 ? a.cols - 1 : x1i, f.y1 = y1i > a.rows - 1 ? a.rows - 1 : y1i;
+    f.ok = true;
+    return f;
+}
+
+// one fragment of combo_splat.frag: returns false when discarded; `z` = corrected_pos.z
+__device__ __forceinline__ bool splat_fragment(const SplatFrag& f, const SplatArgs& a, int px, int py, float& z,
+                                               unsigned& d24) {
+    const float fcx = px + 0.5f, fcy = py + 0.5f;
+    const v3 l = v3normalize(V3((fcx - a.c.cx) / a.c.fx, (fcy - a.c.cy) / a.c.fy, 1.0f));
+    const v3 corrected = v3scale(l, v3dot(f.h, f.nrm) / v3dot(l, f.nrm));
+    const v3 diff = v3sub(corrected, f.h);
+    if (v3dot(diff, diff) > f.rad * f.rad) return false;
+    z = corrected.z;
+    d24 = depth24((corrected.z / (2 * a.maxDepth)) + 0.5f);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, SplatArgs a,
+                                                    unsigned long long* __restrict__ keys) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= count) return;
+    const SplatFrag f = splat_setup(s.pos[id], s.col[id], s.nrm[id], a);
+    if (!f.ok) return;
+    for (int py = f.y0; py <= f.y1; ++py)
+        for (int px = f.x0; px <= f.x1; ++px) {
+            float z;
+            unsigned d24;
+            if (!splat_fragment(f, a, px, py, z, d24)) continue;
+            atomicMin(&keys[(size_t)py * a.cols + px], ((unsigned long long)d24 << 32) | (unsigned)id);
+        }
+}
+
+__global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatArgs a,
+                                                            const unsigned long long* __restrict__ keys,
+                                                            uchar4* __restrict__ image, float4* __restrict__ vertexConf,
+                                                            float4* __restrict__ normalRadius,
+                                                            unsigned short* __restrict__ time_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.cols * a.rows) return;
+    const unsigned long long k = keys[i];
+    if (k == kEmptyKey) {
+        image[i] = make_uchar4(0, 0, 0, 0);
+        vertexConf[i] = normalRadius[i] = make_float4(0, 0, 0, 0);
+        time_out[i] = 0;
+        return;
+    }
+    const unsigned id = (unsigned)k;
+    const int py = i / a.cols, px = i - py * a.cols;
+    const float4 p = s.pos[id], col = s.col[id];
+    const SplatFrag f = splat_setup(p, col, s.nrm[id], a);
+    float z;
+    unsigned d24;
+    splat_fragment(f, a, px, py, z, d24);  // the winner's own fragment: same arithmetic as in splat_kernel
+    const v3 rgb = decode_color(col.x);
+    image[i] = make_uchar4((unsigned char)(int)roundf(rgb.x * 255.0f), (unsigned char)(int)roundf(rgb.y * 255.0f),
+                           (unsigned char)(int)roundf(rgb.z * 255.0f), 255);
+    const float fcx = px + 0.5f, fcy = py + 0.5f;
+    vertexConf[i] = make_float4((fcx - a.c.cx) * z * (1.f / a.c.fx), (fcy - a.c.cy) * z * (1.f / a.c.fy), z, p.w);
+    normalRadius[i] = make_float4(f.nrm.x, f.nrm.y, f.nrm.z, f.rad);
+    time_out[i] = (unsigned short)(unsigned)col.z;
+}
+
+// ---- fusion: data association (data.vert) ----------------------------------------------------------
+struct FuseArgs {
+    Mat4 pose;
+    Cam c;  // ifx, ify = (float)(1.0 / fx) computed in double on the host (Model.cpp:920-921)
+    int cols, rows;
+    int time;
+    float weighting;
+    unsigned char maskID;
+    float maxDepth;
+    int count;  // surfels in the store
+};
+
+constexpr unsigned kNoWinner = 0xFFFFFFFFu;
+
+// Per pixel in draw order d = i*rows + j: the new measurement goes to meas.{pos,col,nrm}[d];
+// op[d] = 0 (nothing), 1 (merge; target in best[d]), 2 (new unstable).  For merges the first
+// pixel in draw order owns the target surfel: atomicMin(winner[best], d).
+__global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restrict__ rgb, const float* __restrict__ depth_raw,
+                                                        const float* __restrict__ depth_fil, const uint8_t* __restrict__ mask,
+                                                        const unsigned* __restrict__ index, const float4* __restrict__ vertConf,
+                                                        const float4* __restrict__ normRad, FuseArgs a, SurfelSoA meas,
+                                                        unsigned* __restrict__ new_flags, unsigned* __restrict__ winner) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int cols = a.cols, rows = a.rows;
+    if (d >= cols * rows) return;
+    const int i = d / rows, j = d - i * rows;
+    const Cam& c = a.c;
+    const float tx = uv_coord(i, cols), ty = uv_coord(j, rows);
+    const float x = tx * cols, y = ty * rows;
+    const v3 vPosLocal = get_vertex(depth_raw, cols, rows, tx, ty, x, y, c);
+    new_flags[d] = 0u;
+    const int tm = ((int)(float)a.time) % 2;
+    const int pxi = texel(tx, cols), pyi = texel(ty, rows);
+    const float zl = depth_raw[pyi * cols + texel(tx - (1.0f / cols), cols)];
+    const float zu = depth_raw[texel(ty - (1.0f / rows), rows) * cols + pxi];
+    const float zr = depth_raw[pyi * cols + texel(tx + (1.0f / cols), cols)];
+    const float zd = depth_raw[texel(ty + (1.0f / rows), rows) * cols + pxi];
+    const bool neighbours = !(zl == 0) && !(zu == 0) && !(zr == 0) && !(zd == 0);
+    if (!(((int)x) % 2 == tm && ((int)y) % 2 == tm && mask[pyi * cols + pxi] == a.maskID && neighbours &&
+          vPosLocal.z > 0 && vPosLocal.z <= a.maxDepth))
+        return;
+
+    const v3 vPos = m4point(a.pose, vPosLocal);
+    const v3 vPos_f = get_vertex(depth_fil, cols, rows, tx, ty, x, y, c);
+    const uint8_t* px = rgb + (size_t)(pyi * cols + pxi) * 3;
+    const v3 nl = get_normal(depth_fil, cols, rows, vPos_f, tx, ty, x, y, c);
+    const v3 ng = m4dir(a.pose, nl);
+
+    int operation = 0;
+    unsigned best = 0;
+    const float scale = 1.0f;
+    const float indexXStep = (1.0f / (cols * scale)) * 0.5f, indexYStep = (1.0f / (rows * scale)) * 0.5f;
+    float bestDist = 1000;
+    const float windowMultiplier = 2;
+    const float xl = (x - c.cx) * c.ifx, yl = (y - c.cy) * c.ify;
+    const float lambda = sqrtf(xl * xl + yl * yl + 1);
+    const v3 ray = V3(xl, yl, 1);
+    for (float ii = tx - (scale * indexXStep * windowMultiplier); ii < tx + (scale * indexXStep * windowMultiplier);
+         ii += indexXStep)
+        for (float jj = ty - (scale * indexYStep * windowMultiplier); jj < ty + (scale * indexYStep * windowMultiplier);
+             jj += indexYStep) {
+            const size_t t = (size_t)texel(jj, rows) * cols + texel(ii, cols);
+            const unsigned current = index[t];
+            if (current > 0U) {
+                const float4 vc = vertConf[t];
+                const float zdiff = (vc.z - vPosLocal.z);
+                if (fabsf(zdiff * lambda) < 0.05f) {
+                    const float dist = v3length(v3cross(ray, V3(vc.x, vc.y, vc.z)));
+                    const float4 nr = normRad[t];
+                    const v3 nrv = V3(nr.x, nr.y, nr.z);
+                    const float cosang = v3dot(nrv, nl) / (v3length(nrv) * v3length(nl));
+                    if (dist < bestDist && (fabsf(nr.z) < 0.75f || (cosang > 0.87758255f && cosang <= 1.0f))) {
+                        operation = 1;
+                        bestDist = dist;
+                        best = current;
+                    }
+                }
+            }
+        }
+    const float conf = confidence(x, y, c.cx, c.cy, a.weighting);
+    meas.pos[d] = make_float4(vPos.x, vPos.y, vPos.z, conf);
+    meas.col[d] = make_float4(encode_color(px[0] / 255.0f, px[1] / 255.0f, px[2] / 255.0f), 0.f, (float)a.time,
+                              operation == 1 ? -1.f : -2.f);
+    meas.nrm[d] = make_float4(ng.x, ng.y, ng.z, get_radius(vPos_f.z, nl.z, c.ifx, c.ify));
+    if (operation == 1) {
+        if (best < (unsigned)a.count) atomicMin(&winner[best], (unsigned)d);
+    } else {
+        new_flags[d] = 1u;
+    }
+}
+
+// update.vert:38-111, in place (each surfel only touches itself); resets winner[] for the next frame
+__global__ __launch_bounds__(256) void fuse_update_kernel(SurfelSoA s, int count, SurfelSoA meas, int time,
+                                                          unsigned* __restrict__ winner) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const unsigned w = winner[k];
+    if (w == kNoWinner) return;
+    winner[k] = kNoWinner;
+    const float4 np = meas.pos[w], nc = meas.col[w], nn = meas.nrm[w];
+    float4 op = s.pos[k], oc = s.col[k], on = s.nrm[k];
+    const float c_k = op.w, av = np.w;
+    if (nn.w < (1.0f + 0.5f) * on.w) {
+        op.x = ((c_k * op.x) + (av * np.x)) / (c_k + av);
+        op.y = ((c_k * op.y) + (av * np.y)) / (c_k + av);
+        op.z = ((c_k * op.z) + (av * np.z)) / (c_k + av);
+        const v3 oldCol = decode_color(oc.x), newCol = decode_color(nc.x);
+        const float ar = ((c_k * oldCol.x) + (av * newCol.x)) / (c_k + av);
+        const float ag = ((c_k * oldCol.y) + (av * newCol.y)) / (c_k + av);
+        const float ab = ((c_k * oldCol.z) + (av * newCol.z)) / (c_k + av);
+        oc.x = encode_color(ar, ag, ab);
+        oc.w = (float)time;
+        const float n0 = ((c_k * on.x) + (av * nn.x)) / (c_k + av), n1 = ((c_k * on.y) + (av * nn.y)) / (c_k + av);
+        const float n2 = ((c_k * on.z) + (av * nn.z)) / (c_k + av), n3 = ((c_k * on.w) + (av * nn.w)) / (c_k + av);
+        const v3 nz = v3normalize(V3(n0, n1, n2));
+        on = make_float4(nz.x, nz.y, nz.z, n3);
+        op.w = c_k + av;
+        s.pos[k] = op;
+        s.col[k] = oc;
+        s.nrm[k] = on;
+    } else {
+        op.w = c_k + av;
+        oc.w = (float)time;
+        s.pos[k] = op;
+        s.col[k] = oc;
+    }
+}
+
+// ---- clean: copy_unstable.vert:53-150 ---------------------------------------------------------------
+struct CleanArgs {
+    Mat4 t_inv;
+    Cam c;
+    int cols, rows;
+    int time, timeDelta;
+    float confThreshold, outlierCoeff;
+    unsigned char maskID;
+    int count;   // existing surfels
+    int npix;    // cols*rows candidates follow (new unstable where new_flags is set)
+};
+
+// candidate e in [0, count + npix): existing surfel e, or pixel draw-index e - count.
+// Writes keep[e] and the two fields the shader modifies (confidence, timestamp).
+__global__ __launch_bounds__(256) void clean_flag_kernel(SurfelSoA s, SurfelSoA meas, const unsigned* __restrict__ new_flags,
+                                                         CleanArgs a, const unsigned* __restrict__ index,
+                                                         const float4* __restrict__ vertConf,
+                                                         const float4* __restrict__ colorTime,
+                                                         const float* __restrict__ depth_in, const uint8_t* __restrict__ mask,
+                                                         unsigned* __restrict__ keep, float2* __restrict__ conf_time) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.count + a.npix) return;
+    float4 vpos, vcol, vnrm;
+    if (e < a.count) {
+        vpos = s.pos[e], vcol = s.col[e], vnrm = s.nrm[e];
+    } else {
+        const int d = e - a.count;
+        if (!new_flags[d]) {
+            keep[e] = 0u;
+            return;
+        }
+        vpos = meas.pos[d], vcol = meas.col[d], vnrm = meas.nrm[d];
+    }
+    const int cols = a.cols, rows = a.rows;
+    int test = 1;
+    const float scale = 1.0f;
+    const v3 localPos = m4point(a.t_inv, V3(vpos.x, vpos.y, vpos.z));
+    const float x = ((a.c.fx * localPos.x) / localPos.z) + a.c.cx, y = ((a.c.fy * localPos.y) / localPos.z) + a.c.cy;
+    const v3 localNorm = v3normalize(m4dir(a.t_inv, V3(vnrm.x, vnrm.y, vnrm.z)));
+    const float x_n = x / cols, y_n = y / rows;
+    const float stepX = 1.0f / cols, stepY = 1.0f / rows;
+    const float indexXStep = stepX * 0.5f / scale, indexYStep = stepY * 0.5f / scale;
+    const float windowMultiplier = 2;
+    int count = 0, zCount = 0, violationCount = 0;
+    float avgViolation = 0;
+    if ((float)a.time - vcol.w < (float)a.timeDelta && localPos.z > 0 && x > 0 && y > 0 && x < cols && y < rows) {
+        for (float i = x_n - (scale * indexXStep * windowMultiplier); i < x_n + (scale * indexXStep * windowMultiplier);
+             i += indexXStep)
+            for (float j = y_n - (scale * indexYStep * windowMultiplier); j < y_n + (scale * indexYStep * windowMultiplier);
+                 j += indexYStep) {
+                const size_t t = (size_t)texel(j, rows) * cols + texel(i, cols);
+                const unsigned current = index[t];
+                if (current > 0U) {
+                    const float4 vc = vertConf[t], ct = colorTime[t];
+                    const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
+                    if (ct.z < vcol.z && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
+                        sqrtf(dx * dx + dy * dy) < vnrm.w * 1.4f)
+                        count++;
+                    if (ct.w == (float)a.time && vc.w > a.confThreshold && vc.z > localPos.z &&
+                        vc.z - localPos.z > 0.01f && fabsf(localNorm.z) > 0.85f)
+                        zCount++;
+                }
+            }
+        for (float i = x_n - stepX; i <= x_n + stepX; i += stepX)
+            for (float j = y_n - stepY; j <= y_n + stepY; j += stepY) {
+                const float dd = depth_in[texel(j, rows) * cols + texel(i, cols)] - localPos.z;
+                if (dd > 0.03f) {
+                    violationCount++;
+                    avgViolation += dd;
+                }
+            }
+    }
+    if (count > 8 || zCount > 4) test = 0;
+    if (vcol.w == -2) vcol.w = (float)a.time;
+    if ((vcol.w == -1 || (((float)a.time - vcol.w) > 20 && vpos.w < a.confThreshold))) test = 0;
+    if (vcol.w > 0 && (float)a.time - vcol.w > (float)a.timeDelta) test = 1;
+    if (violationCount > 0) {
+        avgViolation /= violationCount;
+        vpos.w *= 1.0f / (1 + a.outlierCoeff * avgViolation);
+        const size_t t = (size_t)texel(y_n, rows) * cols + texel(x_n, cols);
+        const float wDepth = depth_in[t];
+        if (mask[t] != a.maskID && (wDepth > localPos.z - 0.05f && wDepth < localPos.z + 0.05f))
+            vpos.w *= (0.5f + 0.5f * (1 - a.outlierCoeff / 10.0f));
+    }
+    keep[e] = test ? 1u : 0u;
+    conf_time[e] = make_float2(vpos.w, vcol.w);
+}
+
+// ordered compaction into the other surfel set (transform feedback of copy_unstable.geom)
+__global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelSoA meas, int count, int npix,
+                                                            const unsigned* __restrict__ keep,
+                                                            const unsigned* __restrict__ prefix,
+                                                            const float2* __restrict__ conf_time, SurfelSoA dst,
+                                                            int capacity) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= count + npix || !keep[e]) return;
+    const unsigned k = prefix[e];
+    if (k >= (unsigned)capacity) return;  // the reference's VBO is full: further primitives are dropped
+    float4 p, c, n;
+    if (e < count) {
+        p = s.pos[e], c = s.col[e], n = s.nrm[e];
+    } else {
+        const int d = e - count;
+        p = meas.pos[d], c = meas.col[d], n = meas.nrm[d];
+    }
+    const float2 ct = conf_time[e];
+    p.w = ct.x;
+    c.w = ct.y;
+    dst.pos[k] = p;
+    dst.col[k] = c;
+    dst.nrm[k] = n;
+}
+
+// ---- fill-in (fill_vertex.frag, fill_normal.frag, fill_rgb.frag) + thumbnail count ------------------
+__global__ __launch_bounds__(256) void fill_in_kernel(const float4* __restrict__ vertex_pred, const float4* __restrict__ normal_pred,
+                                                      const uchar4* __restrict__ image_pred, const float* __restrict__ depth_fil,
+                                                      const uint8_t* __restrict__ rgb, int cols, int rows, Cam c,
+                                                      int passthrough_geom, int passthrough_rgb, float4* __restrict__ vertex_out,
+                                                      float4* __restrict__ normal_out, uchar4* __restrict__ image_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cols * rows) return;
+    const int py = i / cols, px = i - py * cols;
+    const float tx = (px + 0.5f) / cols, ty = (py + 0.5f) / rows;
+    const int ix = (int)(tx * cols), iy = (int)(ty * rows);
+    const float4 vp = vertex_pred[i];
+    if (vp.z == 0 || passthrough_geom == 1) {
+        const float z = depth_fil[texel(ty, rows) * cols + texel(tx, cols)];
+        vertex_out[i] = make_float4((ix - c.cx) * z * c.ifx, (iy - c.cy) * z * c.ify, z, 1.f);
+    } else {
+        vertex_out[i] = vp;
+    }
+    const float4 np = normal_pred[i];
+    if (np.z == 0 || passthrough_geom == 1) {
+        const v3 p = get_vertex(depth_fil, cols, rows, tx, ty, (float)ix, (float)iy, c);
+        const v3 vx = get_vertex(depth_fil, cols, rows, tx + (1.0f / cols), ty, (float)(ix + 1), (float)iy, c);
+        const v3 vy = get_vertex(depth_fil, cols, rows, tx, ty + (1.0f / rows), (float)ix, (float)(iy + 1), c);
+        const v3 nn = v3normalize(v3cross(v3sub(vx, p), v3sub(vy, p)));
+        normal_out[i] = make_float4(nn.x, nn.y, nn.z, 1.f);
+    } else {
+        normal_out[i] = np;
+    }
+    const uchar4 e = image_pred[i];
+    if (e.x / 255.0f + e.y / 255.0f + e.z / 255.0f == 0 || passthrough_rgb == 1)
+        image_out[i] = make_uchar4(rgb[3 * i + 0], rgb[3 * i + 1], rgb[3 * i + 2], 255);
+    else
+        image_out[i] = e;
+}
+
+// requiresFillIn: number of (cols/20 x rows/20) thumbnail samples with all three channels > 0
+__global__ __launch_bounds__(256) void thumbnail_count_kernel(const uchar4* __restrict__ image_pred, int cols, int rows,
+                                                              unsigned* __restrict__ out) {
+    const int dc = cols / 20, dr = rows / 20;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    unsigned hit = 0;
+    if (t < dc * dr) {
+        const int j = t / dc, i = t - j * dc;
+        const float tx = (i + 0.5f) / dc, ty = (j + 0.5f) / dr;
+        const uchar4 p = image_pred[(size_t)texel(ty, rows) * cols + texel(tx, cols)];
+        hit = (p.x > 0 && p.y > 0 && p.z > 0) ? 1u : 0u;
+    }
+    const unsigned long long b = __ballot(hit != 0);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned)__popcll(b));
+}
+
+__global__ void fill_u64_kernel(unsigned long long* p, size_t n, unsigned long long v) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// AoS <-> SoA at the download / upload boundary (Model::downloadMap, Model.cpp:1353-1384)
+__global__ void soa_to_aos_kernel(SurfelSoA s, int count, float4* __restrict__ aos) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    aos[3 * k + 0] = s.pos[k];
+    aos[3 * k + 1] = s.col[k];
+    aos[3 * k + 2] = s.nrm[k];
+}
+__global__ void aos_to_soa_kernel(const float4* __restrict__ aos, int count, SurfelSoA s) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    s.pos[k] = aos[3 * k + 0];
+    s.col[k] = aos[3 * k + 1];
+    s.nrm[k] = aos[3 * k + 2];
+}
+
+}  // namespace mmf

@@ -132,6 +132,40 @@ const float *orc_odom_buffer_f32(const orc_odometry *o, const char *name, int le
 const uint8_t *orc_odom_buffer_u8(const orc_odometry *o, const char *name, int level);
 const int16_t *orc_odom_buffer_i16(const orc_odometry *o, const char *name, int level);
 
+/* ---- surfel path (mmf_oracle_surfel.c): index map, splat, fuse, clean, init, filter ------ */
+/* Vertex::SIZE = 48 bytes (Core/Shaders/Vertex.cpp:21-43, Model.h:247-264):
+ * pos = xyz + confidence; col = {colour24-as-float, unused, initTime, timestamp}; nrm = xyz + radius */
+typedef struct {
+    float pos[4], col[4], nrm[4];
+} orc_surfel;
+
+void orc_inverse4f(const float m[16], float inv[16]);
+void orc_bilateral_filter(const float *depth, int cols, int rows, float maxD, float *out);
+int orc_surfel_initialise(const uint8_t *rgb, const float *depth_raw, const float *depth_filtered, int cols,
+                          int rows, float cx, float cy, float fx, float fy, int time, float maxDepth,
+                          orc_surfel *out);
+void orc_predict_indices(const orc_surfel *s, int count, const float pose[16], float cx, float cy, float fx,
+                         float fy, int cols, int rows, float maxDepth, int time, int timeDelta,
+                         uint32_t *index, float *vertConf, float *colorTime, float *normRad);
+void orc_combined_predict(const orc_surfel *s, int count, const float pose[16], float cx, float cy, float fx,
+                          float fy, int cols, int rows, float maxDepth, float confThreshold, int time,
+                          int maxTime, int timeDelta, uint8_t *image_rgba, float *vertexConf,
+                          float *normalRadius, uint16_t *time_out);
+int orc_fuse(orc_surfel *s, int count, const uint8_t *rgb, const float *depth_raw, const float *depth_filtered,
+             const uint8_t *mask, const uint32_t *index, const float *vertConf, const float *normRad,
+             const float pose[16], float cx, float cy, float fx, float fy, int cols, int rows, int time,
+             float weighting, uint8_t maskID, float maxDepth, orc_surfel *new_out);
+int orc_clean(const orc_surfel *s, int count, const orc_surfel *new_unstable, int nnew, const float pose[16],
+              float cx, float cy, float fx, float fy, int cols, int rows, int time, int timeDelta,
+              float confThreshold, float outlierCoeff, uint8_t maskID, const uint32_t *index,
+              const float *vertConf, const float *colorTime, const float *depth_filtered, const uint8_t *mask,
+              orc_surfel *out);
+void orc_fill_in(const float *vertex_pred, const float *normal_pred, const uint8_t *image_pred_rgba,
+                 const float *depth_filtered, const uint8_t *rgb, int cols, int rows, float cx, float cy,
+                 float fx, float fy, int passthrough_geom, int passthrough_rgb, float *vertex_out,
+                 float *normal_out, uint8_t *image_out_rgba);
+int orc_requires_fill_in(const uint8_t *image_pred_rgba, int cols, int rows, float ratio);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,8 @@ def build(force=False, march=None, out=None):
     """make the oracle library (gcc).  `march`/`out` let bench.py build a -march=native copy."""
     target = out or "liboracle.so"
     path = os.path.join(_DIR, target)
-    src_m = max(os.path.getmtime(os.path.join(_DIR, f)) for f in ("mmf_oracle.c", "mmf_oracle.h", "Makefile"))
+    src_m = max(os.path.getmtime(os.path.join(_DIR, f))
+                for f in ("mmf_oracle.c", "mmf_oracle_surfel.c", "mmf_oracle.h", "Makefile"))
     if not force and os.path.exists(path) and os.path.getmtime(path) >= src_m:
         return path
     cmd = ["make", "-C", _DIR, f"OUT={target}", "-B"]
@@ -331,3 +332,115 @@ class Odometry:
             self.close()
         except Exception:
             pass
+
+
+# ---- surfel path (mmf_oracle_surfel.c) ------------------------------------------------------------------
+def _pu32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _surf(a):
+    return np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1, 12))
+
+
+def inverse4f(m):
+    m = _f(np.reshape(m, 16))
+    out = np.zeros(16, np.float32)
+    lib().orc_inverse4f(_pf(m), _pf(out))
+    return out.reshape(4, 4)
+
+
+def bilateral_filter(depth, maxD):
+    depth = _f(depth)
+    rows, cols = depth.shape
+    out = np.zeros_like(depth)
+    lib().orc_bilateral_filter(_pf(depth), cols, rows, _cf(maxD), _pf(out))
+    return out
+
+
+def surfel_initialise(rgb, depth_raw, depth_filtered, K, time, maxDepth):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    dr, df = _f(depth_raw), _f(depth_filtered)
+    rows, cols = dr.shape
+    out = np.zeros((rows * cols, 12), np.float32)
+    lib().orc_surfel_initialise.restype = C.c_int
+    n = lib().orc_surfel_initialise(_pu8(rgb), _pf(dr), _pf(df), cols, rows, _cf(K["cx"]), _cf(K["cy"]), _cf(K["fx"]),
+                                    _cf(K["fy"]), int(time), _cf(maxDepth), _pf(out))
+    return out[:n].copy()
+
+
+def predict_indices(surfels, pose, K, cols, rows, maxDepth, time, timeDelta):
+    s = _surf(surfels)
+    pose = _f(np.reshape(pose, 16))
+    index = np.zeros((rows, cols), np.uint32)
+    vc, ct, nr = (np.zeros((rows, cols, 4), np.float32) for _ in range(3))
+    lib().orc_predict_indices(_pf(s), s.shape[0], _pf(pose), _cf(K["cx"]), _cf(K["cy"]), _cf(K["fx"]), _cf(K["fy"]),
+                              cols, rows, _cf(maxDepth), int(time), int(timeDelta), _pu32(index), _pf(vc), _pf(ct),
+                              _pf(nr))
+    return index, vc, ct, nr
+
+
+def combined_predict(surfels, pose, K, cols, rows, maxDepth, confThreshold, time, maxTime, timeDelta):
+    s = _surf(surfels)
+    pose = _f(np.reshape(pose, 16))
+    image = np.zeros((rows, cols, 4), np.uint8)
+    vc, nr = np.zeros((rows, cols, 4), np.float32), np.zeros((rows, cols, 4), np.float32)
+    tm = np.zeros((rows, cols), np.uint16)
+    lib().orc_combined_predict(_pf(s), s.shape[0], _pf(pose), _cf(K["cx"]), _cf(K["cy"]), _cf(K["fx"]), _cf(K["fy"]),
+                               cols, rows, _cf(maxDepth), _cf(confThreshold), int(time), int(maxTime), int(timeDelta),
+                               _pu8(image), _pf(vc), _pf(nr), tm.ctypes.data_as(C.POINTER(C.c_uint16)))
+    return image, vc, nr, tm
+
+
+def fuse(surfels, rgb, depth_raw, depth_filtered, mask, index, vertConf, normRad, pose, K, time, weighting, maskID,
+         maxDepth):
+    """Returns (updated surfels, new unstable surfels in draw order)."""
+    s = _surf(surfels).copy()
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    dr, df = _f(depth_raw), _f(depth_filtered)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    index = np.ascontiguousarray(index, np.uint32)
+    vc, nr = _f(vertConf), _f(normRad)
+    pose = _f(np.reshape(pose, 16))
+    rows, cols = dr.shape
+    new = np.zeros((rows * cols, 12), np.float32)
+    lib().orc_fuse.restype = C.c_int
+    n = lib().orc_fuse(_pf(s), s.shape[0], _pu8(rgb), _pf(dr), _pf(df), _pu8(mask), _pu32(index), _pf(vc), _pf(nr),
+                       _pf(pose), _cf(K["cx"]), _cf(K["cy"]), _cf(K["fx"]), _cf(K["fy"]), cols, rows, int(time),
+                       _cf(weighting), C.c_uint8(maskID), _cf(maxDepth), _pf(new))
+    return s, new[:n].copy()
+
+
+def clean(surfels, new_unstable, pose, K, cols, rows, time, timeDelta, confThreshold, outlierCoeff, maskID, index,
+          vertConf, colorTime, depth_filtered, mask):
+    s, nu = _surf(surfels), _surf(new_unstable)
+    pose = _f(np.reshape(pose, 16))
+    index = np.ascontiguousarray(index, np.uint32)
+    vc, ct, df = _f(vertConf), _f(colorTime), _f(depth_filtered)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros((s.shape[0] + nu.shape[0] + 1, 12), np.float32)
+    lib().orc_clean.restype = C.c_int
+    n = lib().orc_clean(_pf(s), s.shape[0], _pf(nu), nu.shape[0], _pf(pose), _cf(K["cx"]), _cf(K["cy"]), _cf(K["fx"]),
+                        _cf(K["fy"]), cols, rows, int(time), int(timeDelta), _cf(confThreshold), _cf(outlierCoeff),
+                        C.c_uint8(maskID), _pu32(index), _pf(vc), _pf(ct), _pf(df), _pu8(mask), _pf(out))
+    return out[:n].copy()
+
+
+def fill_in(vertex_pred, normal_pred, image_pred, depth_filtered, rgb, K, passthrough_geom, passthrough_rgb):
+    vp, npd = _f(vertex_pred), _f(normal_pred)
+    ip = np.ascontiguousarray(image_pred, np.uint8)
+    df = _f(depth_filtered)
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    rows, cols = df.shape
+    vo, no, io = np.zeros_like(vp), np.zeros_like(npd), np.zeros_like(ip)
+    lib().orc_fill_in(_pf(vp), _pf(npd), _pu8(ip), _pf(df), _pu8(rgb), cols, rows, _cf(K["cx"]), _cf(K["cy"]),
+                      _cf(K["fx"]), _cf(K["fy"]), int(passthrough_geom), int(passthrough_rgb), _pf(vo), _pf(no),
+                      _pu8(io))
+    return vo, no, io
+
+
+def requires_fill_in(image_pred, ratio=0.75):
+    ip = np.ascontiguousarray(image_pred, np.uint8)
+    rows, cols = ip.shape[:2]
+    lib().orc_requires_fill_in.restype = C.c_int
+    return bool(lib().orc_requires_fill_in(_pu8(ip), cols, rows, _cf(ratio)))

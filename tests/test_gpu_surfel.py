@@ -1,0 +1,122 @@
+"""-m gpu: the pure-HIP surfel path (mmf_model_*, mmf_filter_depth) against the oracle's restatement
+of the reference's GL passes.  Everything on this path is per-element work with integer decisions,
+so every output must be BIT-EXACT: filtered depth, surfel arrays after initialise / fuse / clean
+(including their order), the index map's pixel assignments and attributes, the splat prediction."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_bit_equal
+from multimotionfusion_amd import synth
+
+pytestmark = pytest.mark.gpu
+MAXD = 20.0      # maxDepthProcessed
+CUTOFF = 15.0    # depthCutoff of the bilateral filter (GUI default)
+TIME_DELTA = 200
+CONF = 10.0      # confGlobalInit
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def make_model(gpu_ctx, w, h, conf=CONF):
+    from multimotionfusion_amd.model import Model
+    K = synth.intrinsics(w, h)
+    return K, Model(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], 0, conf)
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (160, 120)])
+def test_filter_depth_bit_exact(gpu_ctx, orc, w, h):
+    from multimotionfusion_amd.model import filterDepth
+    f = synth.render(np.eye(4), w, h, seed=3, depth_noise=1e-3)
+    out = filterDepth(gpu_ctx, dev(f["depth"]), CUTOFF)
+    assert_bit_equal(out.cpu().numpy(), orc.bilateral_filter(f["depth"], CUTOFF), "bilateral filter")
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (160, 120)])
+def test_surfel_cycle_bit_exact(gpu_ctx, orc, w, h):
+    """initialise -> (predictIndices, fuse, predictIndices, clean, combinedPredict, fill-in) x 3 frames."""
+    from multimotionfusion_amd.model import filterDepth
+    K, m = make_model(gpu_ctx, w, h)
+    poses = synth.trajectory(4, seed=5)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    mask = np.zeros((h, w), np.uint8)
+    d_mask = dev(mask)
+
+    f0 = frames[0]
+    fil0 = orc.bilateral_filter(f0["depth"], CUTOFF)
+    d_fil0 = filterDepth(gpu_ctx, dev(f0["depth"]), CUTOFF)
+    m.overridePose(poses[0])
+    m.initialise(dev(f0["rgb"]), dev(f0["depth"]), d_fil0, 1, MAXD)
+    s = orc.surfel_initialise(f0["rgb"], f0["depth"], fil0, K, 1, MAXD)
+    assert m.lastCount() == s.shape[0] > 0.8 * w * h
+    assert_bit_equal(m.downloadMap(), s, "initialise")
+
+    for t in range(1, 4):
+        tick = t + 1
+        f = frames[t]
+        pose = poses[t].astype(np.float32)  # ground-truth pose stands in for the tracker here
+        fil = orc.bilateral_filter(f["depth"], CUTOFF)
+        d_rgb, d_raw = dev(f["rgb"]), dev(f["depth"])
+        d_fil = filterDepth(gpu_ctx, d_raw, CUTOFF)
+        m.overridePose(pose)
+
+        m.predictIndices(tick, MAXD, TIME_DELTA)
+        index, vc, ct, nr = orc.predict_indices(s, pose, K, w, h, MAXD, tick, TIME_DELTA)
+        assert_bit_equal(m.texture("index").cpu().numpy().view(np.uint32), index, f"index map t={t}")
+        assert_bit_equal(m.texture("vertConf").cpu().numpy(), vc, f"vertConf t={t}")
+        assert_bit_equal(m.texture("colorTime").cpu().numpy(), ct, f"colorTime t={t}")
+        assert_bit_equal(m.texture("normRad").cpu().numpy(), nr, f"normRad t={t}")
+
+        m.fuse(tick, d_rgb, d_mask, d_raw, d_fil, MAXD, 1.0)
+        s_upd, new = orc.fuse(s, f["rgb"], f["depth"], fil, mask, index, vc, nr, pose, K, tick, 1.0, 0, MAXD)
+        assert_bit_equal(m.downloadMap(), s_upd, f"fused surfels t={t}")
+
+        m.predictIndices(tick, MAXD, TIME_DELTA)
+        index, vc, ct, nr = orc.predict_indices(s_upd, pose, K, w, h, MAXD, tick, TIME_DELTA)
+        assert_bit_equal(m.texture("index").cpu().numpy().view(np.uint32), index, f"index map after fuse t={t}")
+
+        m.clean(tick, TIME_DELTA, MAXD, d_fil, d_mask, 3.0)
+        s = orc.clean(s_upd, new, pose, K, w, h, tick, TIME_DELTA, CONF, 3.0, 0, index, vc, ct, fil, mask)
+        assert m.lastCount() == s.shape[0]
+        assert_bit_equal(m.downloadMap(), s, f"cleaned surfels t={t}")
+
+        m.combinedPredict(MAXD, tick, tick, TIME_DELTA)
+        image, vcp, nrp, tm = orc.combined_predict(s, pose, K, w, h, MAXD, CONF, tick, tick, TIME_DELTA)
+        assert_bit_equal(m.texture("image").cpu().numpy(), image, f"splat image t={t}")
+        assert_bit_equal(m.texture("vertexConf").cpu().numpy(), vcp, f"splat vertexConf t={t}")
+        assert_bit_equal(m.texture("normalRadius").cpu().numpy(), nrp, f"splat normalRadius t={t}")
+        assert_bit_equal(m.texture("time").cpu().numpy().view(np.uint16), tm, f"splat time t={t}")
+
+        m.performFillIn(d_rgb, d_fil, False, False)
+        vo, no, io = orc.fill_in(vcp, nrp, image, fil, f["rgb"], K, 0, 0)
+        assert_bit_equal(m.texture("fillVertex").cpu().numpy(), vo, f"fill vertex t={t}")
+        assert_bit_equal(m.texture("fillNormal").cpu().numpy(), no, f"fill normal t={t}")
+        assert_bit_equal(m.texture("fillImage").cpu().numpy(), io, f"fill image t={t}")
+        assert m.requiresFillIn(0.75) == orc.requires_fill_in(image, 0.75)
+    m.close()
+
+
+def test_index_map_edge_cases(gpu_ctx, orc):
+    w, h = 160, 120
+    K, m = make_model(gpu_ctx, w, h)
+
+    def surf(x, y, z, t=1.0, conf=20.0):
+        return [x, y, z, conf, 255.0, 0, 1, t, 0, 0, -1, 0.02]
+    s = np.array([surf(0, 0, 3.0), surf(0, 0, 2.0), surf(0, 0, 2.0), surf(0, 0, 30.0), surf(0.5, 0, 1.0, t=-500.0),
+                  surf(100.0, 0, 1.0), surf(0, 0, -1.0), surf(0.1, 0.1, 0.0), surf(-0.3, 0.2, 1.5)], np.float32)
+    m.uploadMap(s)
+    m.overridePose(np.eye(4))
+    m.predictIndices(10, MAXD, TIME_DELTA)
+    index, vc, ct, nr = orc.predict_indices(s, np.eye(4), K, w, h, MAXD, 10, TIME_DELTA)
+    assert_bit_equal(m.texture("index").cpu().numpy().view(np.uint32), index, "index edge cases")
+    assert_bit_equal(m.texture("vertConf").cpu().numpy(), vc, "vertConf edge cases")
+    m.combinedPredict(MAXD, 10, 10, TIME_DELTA)
+    image, vcp, nrp, tm = orc.combined_predict(s, np.eye(4), K, w, h, MAXD, CONF, 10, 10, TIME_DELTA)
+    assert_bit_equal(m.texture("vertexConf").cpu().numpy(), vcp, "splat edge cases")
+    # empty store
+    m.uploadMap(np.zeros((0, 12), np.float32))
+    m.predictIndices(10, MAXD, TIME_DELTA)
+    assert not m.texture("index").any()
+    m.close()
