@@ -267,6 +267,43 @@ int mmf_model_upload_map(mmf_model *m, const float *host_aos, unsigned count);
  *        fillVertex fillNormal (float4) fillImage (rgba8) -- fill-in */
 int mmf_model_texture(mmf_model *m, const char *name, void **dev_ptr, size_t *bytes);
 
+/* ---------------------------------------------------------------------------------------
+ * Orchestrator: MultiMotionFusion::processFrame / predict (Core/MultiMotionFusion.h:78-86,
+ * .cpp:207-854, 863-875) for the static-scene configuration (one global model, all-zero mask:
+ * enableMultipleModels == false, :268-275).  Segmentation, model spawning, relocalisation and
+ * loop closure stay in the reference's front-end.
+ * ------------------------------------------------------------------------------------- */
+typedef struct mmf_fusion mmf_fusion;
+
+typedef struct {
+    int time_delta;            /* MultiMotionFusion ctor timeDelta (GUI default 200) */
+    float conf_global_init;    /* confGlobalInit, GUI default 10 */
+    float icp_weight;          /* GUI default 10 */
+    float depth_cutoff;        /* bilateral filter maxD, GUI default */
+    float max_depth_processed; /* 20 (MultiMotionFusion.cpp:53) */
+    int rgb_only, pyramid, fast_odom, so3, frame_to_frame_rgb;
+    float outlier_coeff;       /* GPUSetup::outlierCoefficient, GUI default 3 */
+    int fill_in;               /* global model is created with fill-in enabled */
+    int max_surfels;           /* 0 = Model::MAX_VERTICES */
+} mmf_fusion_config;
+
+int mmf_fusion_default_config(mmf_fusion_config *cfg);
+int mmf_fusion_create(mmf_ctx *ctx, int width, int height, float cx, float cy, float fx, float fy,
+                      const mmf_fusion_config *cfg, mmf_fusion **out);
+void mmf_fusion_destroy(mmf_fusion *f);
+/* processFrame(frame, inPose, weightMultiplier, gt_pose, bootstrap): rgb = u8 x 3 interleaved and
+ * depth = float32 metres, both already in HBM (the reference uploads FrameData to GL textures
+ * here, :221,261); in_pose may be NULL.  Returns MMF_ERR_INVALID with "invalid image data" where
+ * the reference returns false (:209-212). */
+int mmf_fusion_process_frame(mmf_fusion *f, const uint8_t *rgb, const float *depth, long long timestamp,
+                             const float *in_pose, float weight_multiplier, int bootstrap);
+/* getCurrPose / getTick / getBackgroundModel (MultiMotionFusion.h:130-160) */
+int mmf_fusion_get_pose(mmf_fusion *f, float pose[16]);
+int mmf_fusion_tick(mmf_fusion *f);
+mmf_model *mmf_fusion_model(mmf_fusion *f);
+mmf_odom *mmf_fusion_odometry(mmf_fusion *f);
+const float *mmf_fusion_depth_filtered(mmf_fusion *f);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,13 @@ class mmf_odom_stats(C.Structure):
                 ("so3_iterations_run", C.c_int)]
 
 
+class mmf_fusion_config(C.Structure):
+    _fields_ = [("time_delta", C.c_int), ("conf_global_init", C.c_float), ("icp_weight", C.c_float),
+                ("depth_cutoff", C.c_float), ("max_depth_processed", C.c_float), ("rgb_only", C.c_int),
+                ("pyramid", C.c_int), ("fast_odom", C.c_int), ("so3", C.c_int), ("frame_to_frame_rgb", C.c_int),
+                ("outlier_coeff", C.c_float), ("fill_in", C.c_int), ("max_surfels", C.c_int)]
+
+
 _vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
@@ -98,6 +105,15 @@ SIGNATURES = {
     "mmf_model_download_map": (_i, [_vp, _fp, C.c_uint, C.POINTER(C.c_uint)]),
     "mmf_model_upload_map": (_i, [_vp, _fp, C.c_uint]),
     "mmf_model_texture": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_sz)]),
+    "mmf_fusion_default_config": (_i, [C.POINTER(mmf_fusion_config)]),
+    "mmf_fusion_create": (_i, [_vp, _i, _i, _f, _f, _f, _f, C.POINTER(mmf_fusion_config), C.POINTER(_vp)]),
+    "mmf_fusion_destroy": (None, [_vp]),
+    "mmf_fusion_process_frame": (_i, [_vp, _vp, _vp, C.c_longlong, _fp, _f, _i]),
+    "mmf_fusion_get_pose": (_i, [_vp, _fp]),
+    "mmf_fusion_tick": (_i, [_vp]),
+    "mmf_fusion_model": (_vp, [_vp]),
+    "mmf_fusion_odometry": (_vp, [_vp]),
+    "mmf_fusion_depth_filtered": (_vp, [_vp]),
 }
 
 _lib = None

@@ -1543,3 +1543,212 @@ extern "C" int mmf_model_texture(mmf_model* m, const char* name, void** dev_ptr,
     *bytes = b;
     return MMF_OK;
 }
+
+// =============================================================================================
+// Orchestrator: MultiMotionFusion::processFrame / predict (Core/MultiMotionFusion.cpp:207-854,
+// 863-875) for one rigid-body model per object (the static-scene configuration,
+// enableMultipleModels == false; segmentation, model spawning and loop closure are out of scope).
+// =============================================================================================
+struct mmf_fusion {
+    mmf_ctx* ctx = nullptr;
+    mmf_fusion_config cfg;
+    int width = 0, height = 0;
+    mmf_model* model = nullptr;   // globalModel
+    mmf_odom* odom = nullptr;     // its frameToModel
+    float* depth_filtered = nullptr;
+    uint8_t* mask = nullptr;      // all zeros: static scene (MultiMotionFusion.cpp:268-275)
+    int tick = 1;                 // MultiMotionFusion.cpp:36
+    float last_pose[16];
+    int tracking_ok = 1;
+};
+
+extern "C" int mmf_fusion_default_config(mmf_fusion_config* cfg) {
+    MMF_REQUIRE(cfg != nullptr, "mmf_fusion_default_config: null argument");
+    cfg->time_delta = 200;          // GUI/MainController.cpp:333 (timeDelta flag default)
+    cfg->conf_global_init = 10.0f;  // GUI default confGlobalInit
+    cfg->icp_weight = 10.0f;        // GUI default icpWeight
+    cfg->depth_cutoff = 15.0f;      // GUI default depthCutoff (bilateral filter maxD)
+    cfg->max_depth_processed = 20.0f;  // MultiMotionFusion.cpp:53
+    cfg->rgb_only = 0;
+    cfg->pyramid = 1;
+    cfg->fast_odom = 0;
+    cfg->so3 = 1;
+    cfg->frame_to_frame_rgb = 0;
+    cfg->outlier_coeff = 3.0f;      // GPUSetup::outlierCoefficient GUI default
+    cfg->fill_in = 1;               // the global model is created with fill-in enabled
+    cfg->max_surfels = 0;
+    return MMF_OK;
+}
+
+extern "C" int mmf_fusion_create(mmf_ctx* c, int width, int height, float cx, float cy, float fx, float fy,
+                                 const mmf_fusion_config* cfg, mmf_fusion** out) {
+    MMF_REQUIRE(c && out, "mmf_fusion_create: null argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    mmf_fusion* f = new (std::nothrow) mmf_fusion();
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_create: out of host memory");
+    f->ctx = c;
+    if (cfg)
+        f->cfg = *cfg;
+    else
+        mmf_fusion_default_config(&f->cfg);
+    f->width = width, f->height = height;
+    int rc = mmf_model_create(c, width, height, cx, cy, fx, fy, 0, f->cfg.conf_global_init, f->cfg.max_surfels, &f->model);
+    if (rc == MMF_OK)
+        rc = mmf_odom_create(c, width, height, cx, cy, fx, fy, 0.10f, std::sin(20.f * 3.14159254f / 180.f), &f->odom);
+    if (rc != MMF_OK) {
+        mmf_model_destroy(f->model);
+        mmf_odom_destroy(f->odom);
+        delete f;
+        return rc;
+    }
+    const size_t npix = (size_t)width * height;
+    MMF_HIP_TRY(hipMalloc(&f->depth_filtered, npix * 4));
+    MMF_HIP_TRY(hipMalloc(&f->mask, npix));
+    MMF_HIP_TRY(hipMemsetAsync(f->mask, 0, npix, c->stream));
+    for (int i = 0; i < 16; ++i) f->last_pose[i] = (i % 5 == 0) ? 1.f : 0.f;
+    *out = f;
+    return MMF_OK;
+}
+
+extern "C" void mmf_fusion_destroy(mmf_fusion* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->ctx->device);
+    (void)hipStreamSynchronize(f->ctx->stream);
+    mmf_model_destroy(f->model);
+    mmf_odom_destroy(f->odom);
+    (void)hipFree(f->depth_filtered);
+    (void)hipFree(f->mask);
+    delete f;
+}
+
+extern "C" mmf_model* mmf_fusion_model(mmf_fusion* f) { return f ? f->model : nullptr; }
+extern "C" mmf_odom* mmf_fusion_odometry(mmf_fusion* f) { return f ? f->odom : nullptr; }
+extern "C" int mmf_fusion_tick(mmf_fusion* f) { return f ? f->tick : -1; }
+extern "C" const float* mmf_fusion_depth_filtered(mmf_fusion* f) { return f ? f->depth_filtered : nullptr; }
+
+// MultiMotionFusion::predict (MultiMotionFusion.cpp:863-875)
+static int fusion_predict(mmf_fusion* f, const uint8_t* rgb) {
+    int rc = mmf_model_combined_predict(f->model, f->cfg.max_depth_processed, f->tick, f->tick, f->cfg.time_delta);
+    if (rc) return rc;
+    if (f->cfg.fill_in)
+        rc = mmf_model_perform_fill_in(f->model, rgb, f->depth_filtered, f->cfg.frame_to_frame_rgb, /*lost*/ 0);
+    return rc;
+}
+
+// Model::computeFusionWeight (Model.cpp:876-891): the norm of rodrigues2(R) is the rotation angle
+static float fusion_weight(const float* pose, const float* last_pose, float multiplier) {
+    float inv[16], d[16];
+    inverse4f_host(pose, inv);  // getLastTransform() = getPose().inverse() * lastPose (Model.h:305)
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            float s = 0;
+            for (int k = 0; k < 4; ++k) s += inv[r * 4 + k] * last_pose[k * 4 + c];
+            d[r * 4 + c] = s;
+        }
+    const float tn = std::sqrt(d[3] * d[3] + d[7] * d[7] + d[11] * d[11]);
+    const double rx = d[9] - d[6], ry = d[2] - d[8], rz = d[4] - d[1];
+    const double s = std::sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double cth = ((double)(d[0] + d[5] + d[10]) - 1) * 0.5;
+    cth = cth > 1. ? 1. : cth < -1. ? -1. : cth;
+    const double theta = std::acos(cth);
+    const float rn = (s < 1e-5) ? (cth > 0 ? 0.f : (float)theta) : (float)theta;
+    float weighting = tn > rn ? tn : rn;
+    const float largest = 0.01f, minWeight = 0.5f;
+    if (weighting > largest) weighting = largest;
+    const float w = 1.0f - (weighting / largest);
+    return (w > minWeight ? w : minWeight) * multiplier;
+}
+
+extern "C" int mmf_fusion_process_frame(mmf_fusion* f, const uint8_t* rgb, const float* depth, long long timestamp,
+                                        const float* in_pose, float weight_multiplier, int bootstrap) {
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_process_frame: null fusion object");
+    if (!rgb || !depth || timestamp < 0)  // MultiMotionFusion.cpp:209-212
+        return fail(MMF_ERR_INVALID, "invalid image data");
+    mmf_ctx* c = f->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const mmf_fusion_config& g = f->cfg;
+    int rc = mmf_filter_depth(c, depth, f->width, f->height, g.depth_cutoff, f->depth_filtered);  // :262
+    if (rc) return rc;
+
+    if (f->tick == 1) {  // :290-296
+        rc = mmf_model_initialise(f->model, rgb, depth, f->depth_filtered, f->tick, g.max_depth_processed);
+        if (rc) return rc;
+        rc = mmf_odom_init_first_rgb(f->odom, rgb, 0, 3);
+        if (rc) return rc;
+    } else {
+        f->tracking_ok = 1;
+        if (bootstrap || !in_pose) {
+            // Model::performTracking (Model.cpp:409-433) with Model::initICP (:390-407)
+            int do_fill_in = 0;
+            if (g.fill_in) {
+                rc = mmf_model_requires_fill_in(f->model, 0.75f, &do_fill_in);  // :380, :877-895
+                if (rc) return rc;
+            }
+            float pose[16];
+            mmf_model_get_pose(f->model, pose);
+            std::memcpy(f->last_pose, pose, sizeof(pose));  // lastPose = pose (Model.cpp:412)
+            rc = mmf_odom_build_depth_pyramid(f->odom, f->depth_filtered, 0);  // generateCUDATextures (:302)
+            if (rc) return rc;
+            const mmf_model* m = f->model;
+            if (do_fill_in) {
+                rc = mmf_odom_init_icp_model(f->odom, (const float*)m->fill_vertex, (const float*)m->fill_normal,
+                                             g.max_depth_processed, pose);
+                if (rc) return rc;
+                rc = mmf_odom_init_rgb_model(f->odom, (const uint8_t*)m->fill_image, 0, 4);
+            } else {
+                rc = mmf_odom_init_icp_model(f->odom, (const float*)m->vertexConf, (const float*)m->normalRadius,
+                                             g.max_depth_processed, pose);
+                if (rc) return rc;
+                rc = mmf_odom_init_rgb_model(
+                    f->odom, (const uint8_t*)((g.frame_to_frame_rgb && g.fill_in) ? m->fill_image : m->image), 0, 4);
+            }
+            if (rc) return rc;
+            rc = mmf_odom_init_icp(f->odom, nullptr, nullptr, g.max_depth_processed);
+            if (rc) return rc;
+            rc = mmf_odom_init_rgb(f->odom, rgb, 0, 3);
+            if (rc) return rc;
+            float trans[3] = {pose[3], pose[7], pose[11]};
+            float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+            rc = mmf_odom_get_incremental_transformation(f->odom, trans, rot, g.rgb_only, g.icp_weight, g.pyramid,
+                                                         g.fast_odom, g.so3, nullptr, nullptr);
+            if (rc) return rc;
+            for (int r = 0; r < 3; ++r) {
+                for (int k = 0; k < 3; ++k) pose[r * 4 + k] = rot[r * 3 + k];
+                pose[r * 4 + 3] = trans[r];
+            }
+            mmf_model_set_pose(f->model, pose);
+        } else {
+            float pose[16];
+            mmf_model_get_pose(f->model, pose);
+            std::memcpy(f->last_pose, pose, sizeof(pose));
+            mmf_model_set_pose(f->model, in_pose);  // globalModel->overridePose(*inPose) (:670)
+        }
+
+        rc = fusion_predict(f, rgb);  // :675
+        if (rc) return rc;
+
+        if (!g.rgb_only && f->tracking_ok) {  // :791-817
+            float pose[16];
+            mmf_model_get_pose(f->model, pose);
+            rc = mmf_model_predict_indices(f->model, f->tick, g.max_depth_processed, g.time_delta);
+            if (rc) return rc;
+            rc = mmf_model_fuse(f->model, f->tick, rgb, f->mask, depth, f->depth_filtered, g.max_depth_processed,
+                                fusion_weight(pose, f->last_pose, weight_multiplier));
+            if (rc) return rc;
+            rc = mmf_model_predict_indices(f->model, f->tick, g.max_depth_processed, g.time_delta);
+            if (rc) return rc;
+            rc = mmf_model_clean(f->model, f->tick, g.time_delta, g.max_depth_processed, f->depth_filtered, f->mask,
+                                 g.outlier_coeff);
+            if (rc) return rc;
+        }
+    }
+    rc = fusion_predict(f, rgb);  // :821
+    if (rc) return rc;
+    f->tick++;  // :825
+    return MMF_OK;
+}
+
+extern "C" int mmf_fusion_get_pose(mmf_fusion* f, float pose[16]) {
+    MMF_REQUIRE(f && pose, "mmf_fusion_get_pose: null argument");
+    return mmf_model_get_pose(f->model, pose);
+}

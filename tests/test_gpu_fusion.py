@@ -1,0 +1,59 @@
+"""-m gpu: MultiMotionFusion::processFrame (native orchestrator mmf_fusion_*) against the same
+sequence restated on the oracle (helpers.OracleFusion), plus ground-truth accuracy.
+
+Tracking differs from the oracle only in float32 summation order (~1e-7 in the pose), so the
+surfel maps are compared statistically (count, centroid) and poses within 1e-5 m / 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import OracleFusion
+from multimotionfusion_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("w,h,nframes", [(320, 240, 6), (640, 480, 4)])
+def test_process_frame_sequence(gpu_ctx, orc, w, h, nframes):
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(nframes, seed=7)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    o = OracleFusion(orc, w, h, K)
+    for i, f in enumerate(frames):
+        g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=i)
+        o.process_frame(f["rgb"], f["depth"])
+        assert g.getTick() == o.tick == i + 2
+        pg = g.getCurrPose()
+        assert np.abs(pg[:3, 3] - o.pose[:3, 3]).max() <= 1e-5, (i, pg[:3, 3], o.pose[:3, 3])
+        assert np.abs(pg[:3, :3] - o.pose[:3, :3]).max() <= 1e-5
+        ng, no = g.getBackgroundModel().lastCount(), o.surfels.shape[0]
+        assert abs(ng - no) <= max(8, 0.002 * no), (i, ng, no)
+        if i == 0:  # nothing tracked yet: the first frame is bit-exact
+            assert np.array_equal(g.getBackgroundModel().downloadMap(), o.surfels)
+        # accuracy against the known trajectory (relative to the first camera)
+        gt = np.linalg.inv(poses[0]) @ poses[i]
+        assert np.linalg.norm(pg[:3, 3] - gt[:3, 3]) < 0.01, (i, pg[:3, 3], gt[:3, 3])
+        assert synth.rotation_angle(pg[:3, :3].astype(np.float64), gt[:3, :3]) < 0.01
+    sg, so = g.getBackgroundModel().downloadMap(), o.surfels
+    assert np.allclose(sg[:, :3].mean(0), so[:, :3].mean(0), atol=1e-3)
+    assert abs(sg[:, 3].mean() - so[:, 3].mean()) < 1e-2
+    od = g.getFrameOdometry()
+    assert od.iterations_run == 19 and od.lastICPCount > 0.5 * w * h
+    g.close()
+
+
+def test_process_frame_rejects_bad_input(gpu_ctx):
+    from multimotionfusion_amd import MmfError
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    K = synth.intrinsics(64, 48)
+    g = MultiMotionFusion(gpu_ctx, 64, 48, K["cx"], K["cy"], K["fx"], K["fy"])
+    with pytest.raises(MmfError, match="invalid image data"):
+        g.processFrame(torch.zeros(48, 64, 3, dtype=torch.uint8, device="cuda"),
+                       torch.zeros(48, 64, device="cuda"), timestamp=-1)
+    g.close()
