@@ -5,10 +5,10 @@ JtJ-reduce roofline figure and a CPU baseline (BASELINE.json metric).
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one frame through the path for one rigid-body model: model-side pyramids
-(initICPModel + initRGBModel), frame-side pyramids (depth pyramid + initICP + initRGB) and
-RGBDOdometry::getIncrementalTransformation (SO3 pre-alignment + 4/5/10 ICP+RGB Gauss-Newton
-iterations), all inputs already resident in HBM.  With N GPUs every rank tracks its own model
+A "step" is one MultiMotionFusion::processFrame for one rigid-body model (static scene):
+bilateral depth filter, dense tracking (pyramids, SO3 pre-alignment, 4/5/10 ICP+RGB Gauss-Newton
+iterations against the splat prediction), splat, index map, fuse, index map, clean, splat and
+fill-in -- all inputs already resident in HBM.  With N GPUs every rank tracks its own model
 on the same broadcast frame (per-object shard, weak scaling); value = model-frames/s over all
 ranks.  Prints ONE JSON line on rank 0.
 """
@@ -27,7 +27,7 @@ if REPO not in sys.path:
 W, H = 640, 480
 ICP_WEIGHT = 10.0  # GUI default (GUI/MainController.cpp:333-345)
 DEPTH_CUTOFF = 15.0
-N_FRAMES = 8  # distinct synthetic frames cycled through
+N_FRAMES = 30  # frames of the synthetic sequence; the map is reset when the sequence wraps
 
 
 def icp_step_bytes(n_px):
@@ -107,11 +107,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     K = synth.intrinsics(W, H)
     # every rank tracks one rigid-body model against the SAME sensor frames (broadcast by rank 0)
-    poses = synth.trajectory(N_FRAMES + 1, seed=1)
+    poses = synth.trajectory(N_FRAMES, seed=1)
     frames = [synth.render(p, W, H, seed=i) for i, p in enumerate(poses)]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    d_vertex = [up(f["vertex"]) for f in frames]
-    d_normal = [up(f["normal"]) for f in frames]
     d_rgb = [up(f["rgb"]) for f in frames]
     d_depth = [up(f["depth"]) for f in frames]
     rgb_in = torch.empty_like(d_rgb[0])
@@ -119,26 +117,26 @@ def main():
     mask_in = torch.zeros(H, W, dtype=torch.uint8, device=dev)
 
     ctx = Context(local_rank)
-    odom = RGBDOdometry(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"])
-    odom.initFirstRGB(d_rgb[0])
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    mmf = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], icp_weight=ICP_WEIGHT)
+    odom = mmf.getFrameOdometry()
+    state = {"frame": 0}
 
     def step(i):
-        k = i % N_FRAMES
-        prev = poses[k].astype(np.float32)
-        # frame replication (rank 0 owns the sensor); no-op on one GPU
-        rgb_in.copy_(d_rgb[k + 1])
-        depth_in.copy_(d_depth[k + 1])
-        shard.broadcast_frame(rgb_in, depth_in, mask_in, src=0)
-        odom.initICPModel(d_vertex[k], d_normal[k], DEPTH_CUTOFF, prev)
-        odom.initRGBModel(d_rgb[k])
-        odom.buildDepthPyramid(depth_in)
-        odom.initICP(depthCutoff=DEPTH_CUTOFF)
-        odom.initRGB(rgb_in)
-        t, R = odom.getIncrementalTransformation(prev[:3, 3], prev[:3, :3], False, ICP_WEIGHT, True, False, True)
-        pose = np.eye(4, dtype=np.float32)
-        pose[:3, :3], pose[:3, 3] = R, t
+        """One processFrame: bilateral filter, tracking (SO3 + 4/5/10 ICP+RGB GN iterations against
+        the splat prediction), splat, index map, fuse, index map, clean, splat + fill-in."""
+        k = state["frame"] % len(frames)
+        if state["frame"] and k == 0:  # sequence wrapped: start a fresh map (the trajectory jumps back)
+            mmf.reset()
+        state["frame"] += 1
+        rgb_in.copy_(d_rgb[k])
+        depth_in.copy_(d_depth[k])
+        shard.broadcast_frame(rgb_in, depth_in, mask_in, src=0)  # no-op on one GPU
+        mmf.processFrame(rgb_in, depth_in, timestamp=i)
+        pose = mmf.getCurrPose()
         if world > 1:
-            shard.gather_poses(pose, odom.lastICPError, odom.lastICPCount, dev)
+            od = mmf.getFrameOdometry()
+            shard.gather_poses(pose, od.lastICPError, od.lastICPCount, dev)
         return pose
 
     def fence():
@@ -160,10 +158,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # accuracy sanity of the last tracked frame against the known motion
-    k = (args.steps - 1) % N_FRAMES
-    gt = poses[k + 1]
+    # accuracy sanity of the last tracked frame against the known trajectory (relative to frame 0)
+    k = (state["frame"] - 1) % len(frames)
+    gt = np.linalg.inv(poses[0]) @ poses[k]
     t_err = float(np.linalg.norm(last_pose[:3, 3] - gt[:3, 3]))
+    odom = mmf.getFrameOdometry()
+    n_surfels = mmf.getBackgroundModel().lastCount()
 
     result = None
     if rank == 0:
@@ -189,21 +189,23 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "640x480 synthetic RGB-D sequence, camera-only dense ICP+RGB odometry per frame "
-                                   "(model+frame pyramids, SO3 pre-alignment, 4/5/10 Gauss-Newton iterations, "
-                                   "icpWeight 10), one rigid-body model per GPU; no surfel fusion yet",
+            "config": {"workload": "640x480 synthetic RGB-D sequence through MultiMotionFusion::processFrame, static "
+                                   "scene (no segmentation): bilateral filter, dense ICP+RGB odometry (SO3 + 4/5/10 "
+                                   "Gauss-Newton iterations, icpWeight 10) against the surfel splat, index map, fuse, "
+                                   "clean, splat + fill-in; one rigid-body model per GPU",
                        "width": W, "height": H, "models_per_gpu": 1, "parallelism": f"model-shard x{world}"},
             "roofline": roofline,
             "device": ctx.device_name(),
             "last_frame_translation_error_m": t_err,
             "icp_inliers_last": odom.lastICPCount,
+            "surfels": n_surfels,
         }
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(frames, K, poses)
     fence()
     if rank == 0:
         print(json.dumps(result), flush=True)
-    odom.close()
+    mmf.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -298,6 +298,7 @@ void mmf_fusion_destroy(mmf_fusion *f);
 int mmf_fusion_process_frame(mmf_fusion *f, const uint8_t *rgb, const float *depth, long long timestamp,
                              const float *in_pose, float weight_multiplier, int bootstrap);
 /* getCurrPose / getTick / getBackgroundModel (MultiMotionFusion.h:130-160) */
+int mmf_fusion_reset(mmf_fusion *f); /* empty map, identity pose, tick = 1 (a freshly constructed object) */
 int mmf_fusion_get_pose(mmf_fusion *f, float pose[16]);
 int mmf_fusion_tick(mmf_fusion *f);
 mmf_model *mmf_fusion_model(mmf_fusion *f);

@@ -1752,3 +1752,14 @@ extern "C" int mmf_fusion_get_pose(mmf_fusion* f, float pose[16]) {
     MMF_REQUIRE(f && pose, "mmf_fusion_get_pose: null argument");
     return mmf_model_get_pose(f->model, pose);
 }
+
+// start a new map: empty surfel store, identity pose, tick = 1 (what constructing a fresh
+// MultiMotionFusion does, MultiMotionFusion.cpp:21-97)
+extern "C" int mmf_fusion_reset(mmf_fusion* f) {
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_reset: null fusion object");
+    f->tick = 1;
+    f->model->count = 0;
+    for (int i = 0; i < 16; ++i) f->model->pose[i] = f->last_pose[i] = (i % 5 == 0) ? 1.f : 0.f;
+    f->odom->have_tmp = false;
+    return MMF_OK;
+}

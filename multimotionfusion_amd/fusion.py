@@ -45,6 +45,9 @@ class MultiMotionFusion:
                                                     fptr(pose) if pose is not None else None,
                                                     float(weightMultiplier), int(bool(bootstrap))))
 
+    def reset(self):
+        check(self.ctx.lib.mmf_fusion_reset(self.handle))
+
     def getCurrPose(self):
         p = np.zeros(16, np.float32)
         check(self.ctx.lib.mmf_fusion_get_pose(self.handle, fptr(p)))
