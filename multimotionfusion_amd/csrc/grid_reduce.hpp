@@ -79,7 +79,8 @@ __device__ __forceinline__ auto partials_rsrc(const T* partials, unsigned nrecor
 // Ends with a workgroup barrier; wave 0 has issued (not drained) the stores.
 template <int NV, int BLOCK, bool WRITE_THROUGH, typename T>
 __device__ __forceinline__ void block_reduce_store(T (&v)[NV], T* __restrict__ partials,
-                                                   GridReduceLds<T, BLOCK>& lds) {
+                                                   GridReduceLds<T, BLOCK>& lds, unsigned record,
+                                                   unsigned nrecords) {
     static_assert(NV <= kPartialStride, "too many values");
     static_assert(BLOCK % 64 == 0 && BLOCK >= 256, "BLOCK must be >= 256 and a multiple of 64");
     constexpr int kWaves = BLOCK / 64;
@@ -107,7 +108,7 @@ __device__ __forceinline__ void block_reduce_store(T (&v)[NV], T* __restrict__ p
     }
     __syncthreads();
     if (wave == 0 && lane < 8) {  // 8 lanes x 16 bytes = the workgroup's 128-byte record
-        const auto rsrc = partials_rsrc(partials, gridDim.x);
+        const auto rsrc = partials_rsrc(partials, nrecords);
         T s[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -120,7 +121,7 @@ __device__ __forceinline__ void block_reduce_store(T (&v)[NV], T* __restrict__ p
         pk[1] = __builtin_bit_cast(unsigned, s[1]);
         pk[2] = __builtin_bit_cast(unsigned, s[2]);
         pk[3] = __builtin_bit_cast(unsigned, s[3]);
-        __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (int)((blockIdx.x * kPartialStride + lane * 4) * sizeof(T)), 0,
+        __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (int)((record * kPartialStride + lane * 4) * sizeof(T)), 0,
                                                WRITE_THROUGH ? 16 /* sc1 */ : 0);
     }
 }
@@ -211,7 +212,7 @@ __device__ __forceinline__ bool grid_reduce(T (&v)[NV], T* __restrict__ partials
                                             unsigned* __restrict__ tickets, GridReduceLds<T, BLOCK>& lds) {
     const int tid = threadIdx.x;
     const unsigned nblocks = gridDim.x;
-    block_reduce_store<NV, BLOCK, true>(v, partials, lds);
+    block_reduce_store<NV, BLOCK, true>(v, partials, lds, blockIdx.x, nblocks);
     if (tid < 64) {
         // the storing wave drains its write-through stores before the signal
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -945,25 +945,37 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
         for (int j = 0; j < iterations[i]; ++j) {
             const bool last_l0 = (i == 0 && j == iterations[i] - 1);
             int res_records = 0, icp_records = 0;
+            RgbResidualArgs ra;
             if (rgb) {  // :363-371
                 const float min_scale = (float)(std::pow((double)o->min_grad[i], 2.0) / std::pow((double)o->sobel_scale, 2.0));
-                RgbResidualArgs a = make_residual_args(min_scale, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0,
-                                                       o->next_depth[i], 0, o->last_image[i], 0, o->next_image[i], 0,
-                                                       o->corres[i], o->max_depth_delta_rgb, cols, rows,
-                                                       last_l0 ? rgb_err_dev : nullptr, 0);
-                a.intr = in;
+                ra = make_residual_args(min_scale, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0, o->next_depth[i], 0,
+                                        o->last_image[i], 0, o->next_image[i], 0, o->corres[i], o->max_depth_delta_rgb,
+                                        cols, rows, last_l0 ? rgb_err_dev : nullptr, 0);
+                ra.intr = in;
                 res_records = reduce_grid(cols * rows, kBlock);
-                hipLaunchKernelGGL((rgb_residual_kernel<FINISH_GN>), dim3(res_records), dim3(kBlock), 0, c->stream,
-                                   o->state, a, c->partials_res);
-                MMF_HIP_TRY(hipGetLastError());
             }
-            if (icp) {  // :403-410
-                IcpArgs a = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
-                MMF_HIP_TRY(launch_icp<FINISH_GN>(c, o->state, a, 0, &icp_records));
-                if (!rgb) {  // ICP-only tracking: one workgroup sums the records, solves, updates the pose
-                    hipLaunchKernelGGL((icp_finish_kernel<FINISH_GN>), dim3(1), dim3(256), 0, c->stream, o->state,
-                                       c->partials_icp, (unsigned)icp_records, in);
+            const bool fuse_producers = rgb && icp && (cols % 4 == 0) &&
+                                        (!icp_err_dev || !last_l0 || ((uintptr_t)icp_err_dev & 15u) == 0);
+            if (fuse_producers) {  // ICP reduction + correspondence pass side by side in one launch
+                IcpArgs ia = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
+                icp_records = reduce_grid(cols * rows, kBlock * 4);
+                hipLaunchKernelGGL((track_producer_kernel<4>), dim3(icp_records + res_records), dim3(kBlock), 0,
+                                   c->stream, o->state, ia, (unsigned)icp_records, ra, c->partials_icp, c->partials_res);
+                MMF_HIP_TRY(hipGetLastError());
+            } else {
+                if (rgb) {
+                    hipLaunchKernelGGL((rgb_residual_kernel<FINISH_GN>), dim3(res_records), dim3(kBlock), 0, c->stream,
+                                       o->state, ra, c->partials_res);
                     MMF_HIP_TRY(hipGetLastError());
+                }
+                if (icp) {  // :403-410
+                    IcpArgs a = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
+                    MMF_HIP_TRY(launch_icp<FINISH_GN>(c, o->state, a, 0, &icp_records));
+                    if (!rgb) {  // ICP-only tracking: one workgroup sums the records, solves, updates the pose
+                        hipLaunchKernelGGL((icp_finish_kernel<FINISH_GN>), dim3(1), dim3(256), 0, c->stream, o->state,
+                                           c->partials_icp, (unsigned)icp_records, in);
+                        MMF_HIP_TRY(hipGetLastError());
+                    }
                 }
             }
             if (rgb) {  // :418-423, then :425-460 in the finishing workgroup

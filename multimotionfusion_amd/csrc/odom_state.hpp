@@ -176,6 +176,35 @@ __device__ inline void ldlt_solve(const T* A, const T* b, T* x) {
     }
 }
 
+// Same LDL^T solve with ONE reciprocal per pivot instead of a division per element (21 -> 6
+// double divisions on the critical path; each result changes by at most an ulp or two).
+template <int N>
+__device__ inline void ldlt_solve_recip(const double* A, const double* b, double* x) {
+    double L[N * N], D[N], iD[N], y[N];
+    for (int j = 0; j < N; ++j) {
+        double d = A[j * N + j];
+        for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k] * D[k];
+        D[j] = d;
+        iD[j] = 1.0 / d;
+        for (int i = j + 1; i < N; ++i) {
+            double s = A[i * N + j];
+            for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k] * D[k];
+            L[i * N + j] = s * iD[j];
+        }
+    }
+    for (int i = 0; i < N; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i * N + k] * y[k];
+        y[i] = s;
+    }
+    for (int i = 0; i < N; ++i) y[i] *= iD[i];
+    for (int i = N - 1; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k];
+        x[i] = s;
+    }
+}
+
 struct LevelIntr {  // CameraModel::operator()(level), types.cuh:94-98 (computed on the host)
     float fx, fy, cx, cy;
 };
@@ -285,18 +314,40 @@ __device__ inline void so3_finish(OdomState* st, const float* tot, const LevelIn
 }
 
 // KRK^-1 and K t of the inverse running transform (RGBDOdometry.cpp:348-358)
+//
+// The reference evaluates this with a general 4x4 inverse and two dense 3x3 products in double,
+// then casts to float.  This runs on ONE lane on the critical path of every Gauss-Newton
+// iteration (double-precision issue is ~8 cycles per op there), so the same quantities are
+// formed from the structure of the operands: resultRt is a product of rigid transforms
+// (inverse = [R^T | -R^T t], exact to ~1e-16) and K = [fx 0 cx; 0 fy cy; 0 0 1].  The results
+// differ from the literal formulas by O(1e-16) relative before the cast to float -- far inside
+// the parity tolerance, and ~8x fewer double operations.
 __device__ inline void rgb_prepare(const double* resultRt, const LevelIntr& in, float* krkinv, float* kt) {
-    double K[9], K_inv[9], Rt[16], tmp[9], KRK[9];
-    k_matrix(in, K);
-    inverse3d(K, K_inv);
-    inverse4d(resultRt, Rt);
-    const double R[9] = {Rt[0], Rt[1], Rt[2], Rt[4], Rt[5], Rt[6], Rt[8], Rt[9], Rt[10]};
-    matmul<3>(K, R, tmp);
-    matmul<3>(tmp, K_inv, KRK);
-    for (int k = 0; k < 9; ++k) krkinv[k] = (float)KRK[k];
-    const double t3[3] = {Rt[3], Rt[7], Rt[11]};
-    for (int r = 0; r < 3; ++r)
-        kt[r] = (float)(K[r * 3 + 0] * t3[0] + K[r * 3 + 1] * t3[1] + K[r * 3 + 2] * t3[2]);
+    const double fx = in.fx, fy = in.fy, cx = in.cx, cy = in.cy;
+    // Rt = resultRt^-1
+    const double R[9] = {resultRt[0], resultRt[4], resultRt[8], resultRt[1], resultRt[5],
+                         resultRt[9], resultRt[2], resultRt[6], resultRt[10]};
+    const double tx = resultRt[3], ty = resultRt[7], tz = resultRt[11];
+    const double t3[3] = {-(R[0] * tx + R[1] * ty + R[2] * tz), -(R[3] * tx + R[4] * ty + R[5] * tz),
+                          -(R[6] * tx + R[7] * ty + R[8] * tz)};
+    // KR = K * R
+    double KR[9];
+    for (int c = 0; c < 3; ++c) {
+        KR[c] = fx * R[c] + cx * R[6 + c];
+        KR[3 + c] = fy * R[3 + c] + cy * R[6 + c];
+        KR[6 + c] = R[6 + c];
+    }
+    // (K R) K^-1 with K^-1 = [1/fx 0 -cx/fx; 0 1/fy -cy/fy; 0 0 1]
+    const double ifx = 1.0 / fx, ify = 1.0 / fy;
+    for (int r = 0; r < 3; ++r) {
+        const double a = KR[r * 3 + 0] * ifx, b = KR[r * 3 + 1] * ify;
+        krkinv[r * 3 + 0] = (float)a;
+        krkinv[r * 3 + 1] = (float)b;
+        krkinv[r * 3 + 2] = (float)(KR[r * 3 + 2] - a * cx - b * cy);
+    }
+    kt[0] = (float)(fx * t3[0] + cx * t3[2]);
+    kt[1] = (float)(fy * t3[1] + cy * t3[2]);
+    kt[2] = (float)t3[2];
 }
 
 // unpack 29 sums into the symmetric A and b (reduce.cu:458-472)
@@ -340,16 +391,22 @@ __device__ inline void solve_and_update(OdomState* st, const float* tot_rgb, con
         for (int k = 0; k < 6; ++k) b[k] = b_rgb[k];
     }
     double result[6];
-    ldlt_solve<6, double>(A, b, result);
+    ldlt_solve_recip<6>(A, b, result);
 
-    double upd[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Rup[9];
+    double Rup[9];
     const double rvec[3] = {result[3], result[4], result[5]};
     rodrigues(rvec, Rup);
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) upd[r * 4 + c] = Rup[r * 3 + c];
-        upd[r * 4 + 3] = result[r];
+    // resultRt <- [Rup | result(0..2); 0 0 0 1] * resultRt, both with a (0 0 0 1) last row
+    {
+        double nr[12];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) {
+                double s = Rup[r * 3 + 0] * resultRt[c] + Rup[r * 3 + 1] * resultRt[4 + c] + Rup[r * 3 + 2] * resultRt[8 + c];
+                if (c == 3) s += result[r];
+                nr[r * 4 + c] = s;
+            }
+        for (int k = 0; k < 12; ++k) resultRt[k] = nr[k];
     }
-    matmul<4>(upd, resultRt, resultRt);
 
     float Ro[9], to[3], RoT[9], ti[3], Rcurr[9], tcurr[3];
     for (int r = 0; r < 3; ++r) {

@@ -151,13 +151,12 @@ __device__ __forceinline__ void store_px(float* __restrict__ p, const float (&v)
 // (icp_finish_kernel, or the finishing workgroup of rgb_step_kernel).  A kernel boundary is
 // cheaper than an in-launch hand-off here: it needs no write-through drain, no ticket atomics
 // and no second round of loads inside this launch.
-template <int PX, int BLOCK, int MODE>
-__global__ __launch_bounds__(BLOCK) void icp_kernel(const OdomState* __restrict__ st, IcpArgs a,
-                                                    float* __restrict__ partials) {
+template <int PX, int BLOCK>
+__device__ __forceinline__ void icp_block(const OdomState* __restrict__ st, const IcpArgs& a,
+                                          float* __restrict__ partials, GridReduceLds<float, BLOCK>& lds,
+                                          unsigned bid, unsigned nblocks) {
     constexpr int kBlock = BLOCK;
-    __shared__ GridReduceLds<float, BLOCK> lds;
     MMF_STAMP(0);
-    if (MODE == FINISH_GN && st->level_break) return;
 
     float sum[29];
 #pragma unroll
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(const OdomState* __restrict_
 
     const int N = a.cols * a.rows;
     const int rows = a.rows;
-    for (int i0 = (blockIdx.x * kBlock + threadIdx.x) * PX; i0 < N; i0 += gridDim.x * kBlock * PX) {
+    for (int i0 = (bid * kBlock + threadIdx.x) * PX; i0 < N; i0 += nblocks * kBlock * PX) {
         const int y = i0 / a.cols;
         const int x = i0 - y * a.cols;
 
@@ -218,8 +217,16 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(const OdomState* __restrict_
         if (a.err_map) store_px<PX>(a.err_map + (size_t)y * a.err_stride + x, errs);
     }
 
-    block_reduce_store<29, BLOCK, false>(sum, partials, lds);
+    block_reduce_store<29, BLOCK, false>(sum, partials, lds, bid, nblocks);
     MMF_STAMP(5);
+}
+
+template <int PX, int BLOCK, int MODE>
+__global__ __launch_bounds__(BLOCK) void icp_kernel(const OdomState* __restrict__ st, IcpArgs a,
+                                                    float* __restrict__ partials) {
+    __shared__ GridReduceLds<float, BLOCK> lds;
+    if (MODE == FINISH_GN && st->level_break) return;
+    icp_block<PX, BLOCK>(st, a, partials, lds, blockIdx.x, gridDim.x);
 }
 
 // One workgroup: sums the ICP partial records of the preceding launch.  MODE RAW: totals ->
@@ -257,17 +264,15 @@ struct RgbResidualArgs {
 
 // Like the ICP kernel this one only produces partial records {count, sum diff^2}; they are summed
 // by residual_finish_kernel (stand-alone) or by the prologue of rgb_step_kernel.
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void rgb_residual_kernel(const OdomState* __restrict__ st, RgbResidualArgs a,
-                                                              int2* __restrict__ partials) {
-    __shared__ GridReduceLds<int, kBlock> lds;
-    if (MODE == FINISH_GN && st->level_break) return;
+__device__ __forceinline__ void residual_block(const OdomState* __restrict__ st, const RgbResidualArgs& a,
+                                               int2* __restrict__ partials, GridReduceLds<int, kBlock>& lds,
+                                               unsigned bid, unsigned nblocks) {
     int sum[2] = {0, 0};
     const int N = a.cols * a.rows, cols = a.cols, rows = a.rows;
     const float* K = st->krkinv;
     const float ktx = st->kt[0], kty = st->kt[1], ktz = st->kt[2];
 
-    for (int k = blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
+    for (int k = bid * kBlock + threadIdx.x; k < N; k += nblocks * kBlock) {
         const int i = k / cols, j0 = k - i * cols;
         mmf_dataterm c;
         c.zero_x = c.zero_y = c.one_x = c.one_y = 0;
@@ -315,7 +320,33 @@ __global__ __launch_bounds__(kBlock) void rgb_residual_kernel(const OdomState* _
     }
 
     block_sum2<kBlock>(sum[0], sum[1], lds);
-    if (threadIdx.x == 0) partials[blockIdx.x] = make_int2(sum[0], sum[1]);
+    if (threadIdx.x == 0) partials[bid] = make_int2(sum[0], sum[1]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void rgb_residual_kernel(const OdomState* __restrict__ st, RgbResidualArgs a,
+                                                              int2* __restrict__ partials) {
+    __shared__ GridReduceLds<int, kBlock> lds;
+    if (MODE == FINISH_GN && st->level_break) return;
+    residual_block(st, a, partials, lds, blockIdx.x, gridDim.x);
+}
+
+// Both producers of one Gauss-Newton iteration in ONE launch: workgroups [0, icp_blocks) run the
+// ICP reduction, the rest the photometric correspondence pass.  The two passes are independent
+// (RGBDOdometry.cpp:363-410), so running them side by side removes a launch boundary and lets
+// their latency chains overlap.
+template <int PX>
+__global__ __launch_bounds__(kBlock) void track_producer_kernel(const OdomState* __restrict__ st, IcpArgs ia,
+                                                                unsigned icp_blocks, RgbResidualArgs ra,
+                                                                float* __restrict__ icp_partials,
+                                                                int2* __restrict__ res_partials) {
+    __shared__ GridReduceLds<float, kBlock> lds;
+    if (st->level_break) return;
+    if (blockIdx.x < icp_blocks)
+        icp_block<PX, kBlock>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
+    else
+        residual_block(st, ra, res_partials, reinterpret_cast<GridReduceLds<int, kBlock>&>(lds), blockIdx.x - icp_blocks,
+                       gridDim.x - icp_blocks);
 }
 
 // {count, sigma} decision of RGBDOdometry.cpp:373-385 as a pure function of the two totals
