@@ -289,6 +289,14 @@ static RgbResidualArgs make_residual_args(float min_scale, const int16_t* dIdx, 
     return a;
 }
 
+// 4 pixels per lane needs whole 4-pixel groups per row and 16-byte aligned rows of every image
+static bool residual_vec4_ok(const RgbResidualArgs& a) {
+    auto al = [](const void* p, uintptr_t n) { return ((uintptr_t)p & (n - 1)) == 0; };
+    return a.cols % 4 == 0 && a.ni_stride % 4 == 0 && a.d_stride % 4 == 0 && a.nd_stride % 4 == 0 &&
+           al(a.next_image, 4) && al(a.dIdx, 8) && al(a.dIdy, 8) && al(a.next_depth, 16) &&
+           (!a.err_map || (al(a.err_map, 16) && a.err_stride % 4 == 0));
+}
+
 extern "C" int mmf_compute_rgb_residual(mmf_ctx* c, float min_scale, const int16_t* dIdx, size_t dIdx_step,
                                         const int16_t* dIdy, size_t dIdy_step, const float* last_depth,
                                         size_t last_depth_step, const float* next_depth, size_t next_depth_step,
@@ -312,9 +320,14 @@ extern "C" int mmf_compute_rgb_residual(mmf_ctx* c, float min_scale, const int16
                                            next_depth, next_depth_step, last_image, last_image_step, next_image,
                                            next_image_step, corres_dev, max_depth_delta, cols, rows, err_map_dev,
                                            err_map_step);
-    const int grid = reduce_grid(cols * rows, kBlock);
-    hipLaunchKernelGGL((rgb_residual_kernel<FINISH_RAW>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state, a,
-                       c->partials_res);
+    const bool vec4 = residual_vec4_ok(a);
+    const int grid = reduce_grid(cols * rows, vec4 ? kBlock * 4 : kBlock);
+    if (vec4)
+        hipLaunchKernelGGL((rgb_residual_kernel<FINISH_RAW, 4>), dim3(grid), dim3(kBlock), 0, c->stream,
+                           c->scratch_state, a, c->partials_res);
+    else
+        hipLaunchKernelGGL((rgb_residual_kernel<FINISH_RAW, 1>), dim3(grid), dim3(kBlock), 0, c->stream,
+                           c->scratch_state, a, c->partials_res);
     MMF_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(residual_finish_kernel, dim3(1), dim3(256), 0, c->stream, c->scratch_state, c->partials_res,
                        (unsigned)grid);
@@ -354,9 +367,15 @@ extern "C" int mmf_rgb_step(mmf_ctx* c, const mmf_dataterm* corres_dev, float si
     a.cols = cols;
     a.rows = rows;
     a.intr = LevelIntr{0, 0, 0, 0};
-    const int grid = reduce_grid(cols * rows, kBlock);
-    hipLaunchKernelGGL((rgb_step_kernel<FINISH_RAW>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state, a,
-                       c->partials_f, c->ticket);
+    if ((cols * rows) % 4 == 0) {
+        const int grid = reduce_grid(cols * rows, kBlock * 4);
+        hipLaunchKernelGGL((rgb_step_kernel<FINISH_RAW, 4>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state,
+                           a, c->partials_f, c->ticket);
+    } else {
+        const int grid = reduce_grid(cols * rows, kBlock);
+        hipLaunchKernelGGL((rgb_step_kernel<FINISH_RAW, 1>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state,
+                           a, c->partials_f, c->ticket);
+    }
     MMF_HIP_TRY(hipGetLastError());
     float tot[32];
     MMF_HIP_TRY(hipMemcpyAsync(tot, c->scratch_state->out_f, sizeof(float) * 32, hipMemcpyDeviceToHost, c->stream));
@@ -946,15 +965,17 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
             const bool last_l0 = (i == 0 && j == iterations[i] - 1);
             int res_records = 0, icp_records = 0;
             RgbResidualArgs ra;
+            bool res_vec4 = false;
             if (rgb) {  // :363-371
                 const float min_scale = (float)(std::pow((double)o->min_grad[i], 2.0) / std::pow((double)o->sobel_scale, 2.0));
                 ra = make_residual_args(min_scale, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0, o->next_depth[i], 0,
                                         o->last_image[i], 0, o->next_image[i], 0, o->corres[i], o->max_depth_delta_rgb,
                                         cols, rows, last_l0 ? rgb_err_dev : nullptr, 0);
                 ra.intr = in;
-                res_records = reduce_grid(cols * rows, kBlock);
+                res_vec4 = residual_vec4_ok(ra);
+                res_records = reduce_grid(cols * rows, res_vec4 ? kBlock * 4 : kBlock);
             }
-            const bool fuse_producers = rgb && icp && (cols % 4 == 0) &&
+            const bool fuse_producers = rgb && icp && res_vec4 && (cols % 4 == 0) &&
                                         (!icp_err_dev || !last_l0 || ((uintptr_t)icp_err_dev & 15u) == 0);
             if (fuse_producers) {  // ICP reduction + correspondence pass side by side in one launch
                 IcpArgs ia = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
@@ -964,8 +985,12 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
                 MMF_HIP_TRY(hipGetLastError());
             } else {
                 if (rgb) {
-                    hipLaunchKernelGGL((rgb_residual_kernel<FINISH_GN>), dim3(res_records), dim3(kBlock), 0, c->stream,
-                                       o->state, ra, c->partials_res);
+                    if (res_vec4)
+                        hipLaunchKernelGGL((rgb_residual_kernel<FINISH_GN, 4>), dim3(res_records), dim3(kBlock), 0,
+                                           c->stream, o->state, ra, c->partials_res);
+                    else
+                        hipLaunchKernelGGL((rgb_residual_kernel<FINISH_GN, 1>), dim3(res_records), dim3(kBlock), 0,
+                                           c->stream, o->state, ra, c->partials_res);
                     MMF_HIP_TRY(hipGetLastError());
                 }
                 if (icp) {  // :403-410
@@ -995,8 +1020,8 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
                 a.cols = cols;
                 a.rows = rows;
                 a.intr = in;
-                const int grid = reduce_grid(cols * rows, kBlock);
-                hipLaunchKernelGGL((rgb_step_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), 0, c->stream, o->state, a,
+                const int grid = reduce_grid(cols * rows, kBlock * 4);  // width, height are multiples of 4
+                hipLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4>), dim3(grid), dim3(kBlock), 0, c->stream, o->state, a,
                                    c->partials_f, c->ticket);
                 MMF_HIP_TRY(hipGetLastError());
             }

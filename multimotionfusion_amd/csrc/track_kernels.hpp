@@ -323,12 +323,105 @@ __device__ __forceinline__ void residual_block(const OdomState* __restrict__ st,
     if (threadIdx.x == 0) partials[bid] = make_int2(sum[0], sum[1]);
 }
 
-template <int MODE>
+// Four consecutive pixels of a row per lane: one 4-byte load of the intensities, one 8-byte load of
+// each gradient image, one 16-byte load of the depth, four 16-byte stores of the records; the
+// 4x4 "all neighbours > 0" windows of the four pixels are evaluated from three aligned 32-bit
+// words per image row (12 loads instead of 64).  Needs cols % 4 == 0 and 16-byte aligned rows.
+__device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st, const RgbResidualArgs& a,
+                                                int2* __restrict__ partials, GridReduceLds<int, kBlock>& lds,
+                                                unsigned bid, unsigned nblocks) {
+    int sum[2] = {0, 0};
+    const int cols = a.cols, rows = a.rows, N4 = (cols * rows) / 4;
+    const float* K = st->krkinv;
+    const float ktx = st->kt[0], kty = st->kt[1], ktz = st->kt[2];
+
+    for (int g = bid * kBlock + threadIdx.x; g < N4; g += nblocks * kBlock) {
+        const int k0 = g * 4;
+        const int i = k0 / cols, j0 = k0 - i * cols;
+        // nonzero masks of columns j0-4 .. j0+7 (bit b <-> column j0-4+b) for rows i-2 .. i+1;
+        // columns / rows outside the image are skipped by the reference's loops => treated as set
+        unsigned ok = 0xFFFu;
+#pragma unroll
+        for (int dr = -2; dr <= 1; ++dr) {
+            const int u = i + dr;
+            if (u < 0 || u >= rows) continue;
+            const uint8_t* rowp = a.next_image + (size_t)u * a.ni_stride + j0;
+            unsigned m = 0;
+            const unsigned w1 = *reinterpret_cast<const unsigned*>(rowp);
+            const unsigned w0 = j0 >= 4 ? *reinterpret_cast<const unsigned*>(rowp - 4) : 0xFFFFFFFFu;
+            const unsigned w2 = j0 + 4 < cols ? *reinterpret_cast<const unsigned*>(rowp + 4) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                m |= ((w0 >> (8 * b)) & 0xFFu) ? (1u << b) : 0u;
+                m |= ((w1 >> (8 * b)) & 0xFFu) ? (1u << (4 + b)) : 0u;
+                m |= ((w2 >> (8 * b)) & 0xFFu) ? (1u << (8 + b)) : 0u;
+            }
+            ok &= m;
+        }
+        const unsigned own = *reinterpret_cast<const unsigned*>(a.next_image + (size_t)i * a.ni_stride + j0);
+        const short4 gx = *reinterpret_cast<const short4*>(a.dIdx + (size_t)i * a.d_stride + j0);
+        const short4 gy = *reinterpret_cast<const short4*>(a.dIdy + (size_t)i * a.d_stride + j0);
+        const float4 dv = *reinterpret_cast<const float4*>(a.next_depth + (size_t)i * a.nd_stride + j0);
+        const int valxs[4] = {gx.x, gx.y, gx.z, gx.w}, valys[4] = {gy.x, gy.y, gy.z, gy.w};
+        const float d1s[4] = {dv.x, dv.y, dv.z, dv.w};
+        float errs[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int x = j0 + p, y = i;
+            mmf_dataterm c;
+            c.zero_x = c.zero_y = c.one_x = c.one_y = 0;
+            c.diff = 0.f;
+            c.valid = 0;
+            c.pad_[0] = c.pad_[1] = c.pad_[2] = 0;
+            int vx = 0, vy = 0;
+            // window of pixel x: columns x-2 .. x+1 = bits p+2 .. p+5
+            const bool valid = x < cols - 5 && y < rows - 1 && ((ok >> (p + 2)) & 0xFu) == 0xFu;
+            if (valid) {
+                const int valx = valxs[p], valy = valys[p];
+                const float mTwo = (float)((valx * valx) + (valy * valy));
+                const float d1 = d1s[p];
+                if (mTwo >= a.min_scale && !(d1 != d1)) {
+                    const float td1 = (float)(d1 * (K[6] * x + K[7] * y + K[8]) + ktz);
+                    const int u0 = float2int_rn((d1 * (K[0] * x + K[1] * y + K[2]) + ktx) / td1);
+                    const int v0 = float2int_rn((d1 * (K[3] * x + K[4] * y + K[5]) + kty) / td1);
+                    if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+                        const float d0 = a.last_depth[(size_t)v0 * a.ld_stride + u0];
+                        const uint8_t li = a.last_image[(size_t)v0 * a.li_stride + u0];
+                        if (d0 > 0 && fabsf(td1 - d0) <= a.max_depth_delta && li != 0) {
+                            c.zero_x = (int16_t)u0;
+                            c.zero_y = (int16_t)v0;
+                            c.one_x = (int16_t)x;
+                            c.one_y = (int16_t)y;
+                            c.diff = (float)((own >> (8 * p)) & 0xFFu) - (float)li;
+                            c.valid = 1;
+                            vx = 1;
+                            vy = (int)(c.diff * c.diff);
+                        }
+                    }
+                }
+            }
+            errs[p] = c.valid ? 0.001f * vy : 0.0f;
+            *reinterpret_cast<int4*>(&a.corres[k0 + p]) = *reinterpret_cast<const int4*>(&c);
+            sum[0] += vx;
+            sum[1] += vy;
+        }
+        if (a.err_map)
+            *reinterpret_cast<float4*>(a.err_map + (size_t)i * a.err_stride + j0) = make_float4(errs[0], errs[1], errs[2], errs[3]);
+    }
+
+    block_sum2<kBlock>(sum[0], sum[1], lds);
+    if (threadIdx.x == 0) partials[bid] = make_int2(sum[0], sum[1]);
+}
+
+template <int MODE, int PX>
 __global__ __launch_bounds__(kBlock) void rgb_residual_kernel(const OdomState* __restrict__ st, RgbResidualArgs a,
                                                               int2* __restrict__ partials) {
     __shared__ GridReduceLds<int, kBlock> lds;
     if (MODE == FINISH_GN && st->level_break) return;
-    residual_block(st, a, partials, lds, blockIdx.x, gridDim.x);
+    if (PX == 4)
+        residual_block4(st, a, partials, lds, blockIdx.x, gridDim.x);
+    else
+        residual_block(st, a, partials, lds, blockIdx.x, gridDim.x);
 }
 
 // Both producers of one Gauss-Newton iteration in ONE launch: workgroups [0, icp_blocks) run the
@@ -345,8 +438,8 @@ __global__ __launch_bounds__(kBlock) void track_producer_kernel(const OdomState*
     if (blockIdx.x < icp_blocks)
         icp_block<PX, kBlock>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
     else
-        residual_block(st, ra, res_partials, reinterpret_cast<GridReduceLds<int, kBlock>&>(lds), blockIdx.x - icp_blocks,
-                       gridDim.x - icp_blocks);
+        residual_block4(st, ra, res_partials, reinterpret_cast<GridReduceLds<int, kBlock>&>(lds), blockIdx.x - icp_blocks,
+                        gridDim.x - icp_blocks);
 }
 
 // {count, sigma} decision of RGBDOdometry.cpp:373-385 as a pure function of the two totals
@@ -391,7 +484,9 @@ struct RgbStepArgs {
     LevelIntr intr;
 };
 
-template <int MODE>
+// PX = 4: a lane takes four consecutive records (64 contiguous bytes), so the grid -- and with it
+// the number of partial records the finishing workgroup has to re-read -- shrinks 4x.
+template <int MODE, int PX>
 __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict__ st, RgbStepArgs a,
                                                           float* __restrict__ partials,
                                                           unsigned* __restrict__ ticket) {
@@ -418,35 +513,40 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     for (int k = 0; k < 29; ++k) sum[k] = 0.f;
     const int N = a.cols * a.rows;
 
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-        const int4 raw = *reinterpret_cast<const int4*>(&a.corres[i]);
-        mmf_dataterm c;
-        *reinterpret_cast<int4*>(&c) = raw;
-        float row[7];
+    for (int i0 = (blockIdx.x * kBlock + threadIdx.x) * PX; i0 < N; i0 += gridDim.x * kBlock * PX) {
+        int4 raws[PX];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) row[k] = 0.f;
-        const bool found = c.valid != 0;
-        if (found) {  // reduce.cu:504-535
-            float w = sigma + fabsf(c.diff);
-            w = w > FLT_EPSILON ? 1.0f / w : 1.0f;
-            if (sigma == -1) w = 1;
-            row[6] = -w * c.diff;
-            const float* cp = a.cloud + (size_t)(c.zero_y * a.cols + c.zero_x) * 3;
-            const float X = cp[0], Y = cp[1], Z = cp[2];
-            const float invz = 1.0f / Z;  // (float)(1.0 / Z): double rounding is innocuous for division
-            const float dI_dx = w * a.sobel_scale * a.dIdx[(size_t)c.one_y * a.d_stride + c.one_x];
-            const float dI_dy = w * a.sobel_scale * a.dIdy[(size_t)c.one_y * a.d_stride + c.one_x];
-            const float v0 = dI_dx * a.fx * invz;
-            const float v1 = dI_dy * a.fy * invz;
-            const float v2 = -(v0 * X + v1 * Y) * invz;
-            row[0] = v0;
-            row[1] = v1;
-            row[2] = v2;
-            row[3] = -Z * v1 + Y * v2;
-            row[4] = Z * v0 - X * v2;
-            row[5] = -Y * v0 + X * v1;
+        for (int p = 0; p < PX; ++p) raws[p] = *reinterpret_cast<const int4*>(&a.corres[i0 + p]);
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            mmf_dataterm c;
+            *reinterpret_cast<int4*>(&c) = raws[p];
+            float row[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) row[k] = 0.f;
+            const bool found = c.valid != 0;
+            if (found) {  // reduce.cu:504-535
+                float w = sigma + fabsf(c.diff);
+                w = w > FLT_EPSILON ? 1.0f / w : 1.0f;
+                if (sigma == -1) w = 1;
+                row[6] = -w * c.diff;
+                const float* cp = a.cloud + (size_t)(c.zero_y * a.cols + c.zero_x) * 3;
+                const float X = cp[0], Y = cp[1], Z = cp[2];
+                const float invz = 1.0f / Z;  // (float)(1.0 / Z): double rounding is innocuous for division
+                const float dI_dx = w * a.sobel_scale * a.dIdx[(size_t)c.one_y * a.d_stride + c.one_x];
+                const float dI_dy = w * a.sobel_scale * a.dIdy[(size_t)c.one_y * a.d_stride + c.one_x];
+                const float v0 = dI_dx * a.fx * invz;
+                const float v1 = dI_dy * a.fy * invz;
+                const float v2 = -(v0 * X + v1 * Y) * invz;
+                row[0] = v0;
+                row[1] = v1;
+                row[2] = v2;
+                row[3] = -Z * v1 + Y * v2;
+                row[4] = Z * v0 - X * v2;
+                row[5] = -Y * v0 + X * v1;
+            }
+            accumulate_se3(sum, row, found ? 1.0f : 0.0f);
         }
-        accumulate_se3(sum, row, found ? 1.0f : 0.0f);
     }
 
     if (!grid_reduce<29, kBlock>(sum, partials, ticket, lds)) return;
