@@ -588,31 +588,95 @@ __global__ __launch_bounds__(256) void clean_flag_kernel(SurfelSoA s, SurfelSoA 
     int count = 0, zCount = 0, violationCount = 0;
     float avgViolation = 0;
     if ((float)a.time - vcol.w < (float)a.timeDelta && localPos.z > 0 && x > 0 && y > 0 && x < cols && y < rows) {
-        for (float i = x_n - (scale * indexXStep * windowMultiplier); i < x_n + (scale * indexXStep * windowMultiplier);
-             i += indexXStep)
-            for (float j = y_n - (scale * indexYStep * windowMultiplier); j < y_n + (scale * indexYStep * windowMultiplier);
-                 j += indexYStep) {
-                const size_t t = (size_t)texel(j, rows) * cols + texel(i, cols);
-                const unsigned current = index[t];
-                if (current > 0U) {
-                    const float4 vc = vertConf[t], ct = colorTime[t];
+        // The shader walks both windows with float loop counters (copy_unstable.vert:86-128).  The
+        // counters are reproduced exactly (same sequence of float additions), but sampling is
+        // decoupled from them: the 4-5 half-pixel steps of the index window only ever touch the
+        // texels c0, c0+1, c0+2 per axis, so the window is read as <= 3x3 distinct texels with
+        // multiplicities (all loads independent, one round trip) instead of 16 dependent samples.
+        int cx0, mx[3] = {0, 0, 0}, cy0, my[3] = {0, 0, 0};
+        {
+            const float endx = x_n + (scale * indexXStep * windowMultiplier);
+            float i = x_n - (scale * indexXStep * windowMultiplier);
+            cx0 = texel(i, cols);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (i < endx) {
+                    const int t = texel(i, cols) - cx0;
+                    mx[0] += t == 0, mx[1] += t == 1, mx[2] += t == 2;
+                }
+                i += indexXStep;
+            }
+            const float endy = y_n + (scale * indexYStep * windowMultiplier);
+            float j = y_n - (scale * indexYStep * windowMultiplier);
+            cy0 = texel(j, rows);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (j < endy) {
+                    const int t = texel(j, rows) - cy0;
+                    my[0] += t == 0, my[1] += t == 1, my[2] += t == 2;
+                }
+                j += indexYStep;
+            }
+        }
+        unsigned cur[9];
+        float4 vcs[9], cts[9];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int e2 = 0; e2 < 3; ++e2) {
+                const size_t t = (size_t)min(cy0 + e2, rows - 1) * cols + min(cx0 + d, cols - 1);
+                cur[d * 3 + e2] = index[t];
+                vcs[d * 3 + e2] = vertConf[t];
+                cts[d * 3 + e2] = colorTime[t];
+            }
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int e2 = 0; e2 < 3; ++e2) {
+                const int mult = mx[d] * my[e2];
+                if (mult > 0 && cur[d * 3 + e2] > 0U) {
+                    const float4 vc = vcs[d * 3 + e2], ct = cts[d * 3 + e2];
                     const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
                     if (ct.z < vcol.z && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
                         sqrtf(dx * dx + dy * dy) < vnrm.w * 1.4f)
-                        count++;
+                        count += mult;
                     if (ct.w == (float)a.time && vc.w > a.confThreshold && vc.z > localPos.z &&
                         vc.z - localPos.z > 0.01f && fabsf(localNorm.z) > 0.85f)
-                        zCount++;
+                        zCount += mult;
                 }
             }
-        for (float i = x_n - stepX; i <= x_n + stepX; i += stepX)
-            for (float j = y_n - stepY; j <= y_n + stepY; j += stepY) {
-                const float dd = depth_in[texel(j, rows) * cols + texel(i, cols)] - localPos.z;
-                if (dd > 0.03f) {
+        // see-through test (:117-125): <= 3 samples per axis, accumulated in the shader's order
+        int txs[3], tys[3];
+        bool vxs[3], vys[3];
+        {
+            float i = x_n - stepX;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                vxs[k] = i <= x_n + stepX;
+                txs[k] = texel(i, cols);
+                i += stepX;
+            }
+            float j = y_n - stepY;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                vys[k] = j <= y_n + stepY;
+                tys[k] = texel(j, rows);
+                j += stepY;
+            }
+        }
+        float dd[9];
+#pragma unroll
+        for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+            for (int kj = 0; kj < 3; ++kj) dd[ki * 3 + kj] = depth_in[tys[kj] * cols + txs[ki]] - localPos.z;
+#pragma unroll
+        for (int ki = 0; ki < 3; ++ki)
+#pragma unroll
+            for (int kj = 0; kj < 3; ++kj)
+                if (vxs[ki] && vys[kj] && dd[ki * 3 + kj] > 0.03f) {
                     violationCount++;
-                    avgViolation += dd;
+                    avgViolation += dd[ki * 3 + kj];
                 }
-            }
     }
     if (count > 8 || zCount > 4) test = 0;
     if (vcol.w == -2) vcol.w = (float)a.time;
