@@ -166,13 +166,13 @@ __global__ __launch_bounds__(256) void pyrdown_gauss_f_kernel(const float* __res
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx) {
             const int cx = 2 * x - 2 + dx;
-            if (rowok && cx >= 0 && cx < tx) {
-                const float s = src[(size_t)cy * s_stride + cx];
-                if (!(s != s)) {
-                    const float w = wy * binom5(tx - cx - 1);
-                    sum += s * w;
-                    count = (int)((float)count + w);
-                }
+            // unconditional load from a clamped address, then select: a load under a divergent
+            // branch cannot be hoisted, and 25 dependent round trips made this kernel ~9 us
+            const float s = src[(size_t)min(max(cy, 0), srows - 1) * s_stride + min(max(cx, 0), scols - 1)];
+            if (rowok && cx >= 0 && cx < tx && !(s != s)) {
+                const float w = wy * binom5(tx - cx - 1);
+                sum += s * w;
+                count = (int)((float)count + w);
             }
         }
     }
@@ -197,13 +197,11 @@ __global__ __launch_bounds__(256) void pyrdown_uchar_gauss_kernel(const uint8_t*
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx) {
             const int cx = 2 * x - 2 + dx;
-            if (rowok && cx >= 0 && cx < tx) {
-                const uint8_t s = src[(size_t)cy * s_stride + cx];
-                if (s > 0) {
-                    const float w = wy * binom5(tx - cx - 1);
-                    sum += s * w;
-                    count = (int)((float)count + w);
-                }
+            const uint8_t s = src[(size_t)min(max(cy, 0), srows - 1) * s_stride + min(max(cx, 0), scols - 1)];
+            if (rowok && cx >= 0 && cx < tx && s > 0) {
+                const float w = wy * binom5(tx - cx - 1);
+                sum += s * w;
+                count = (int)((float)count + w);
             }
         }
     }
@@ -239,14 +237,27 @@ __global__ __launch_bounds__(256) void derivative_kernel(const uint8_t* __restri
     if (x >= cols || y >= rows) return;
     constexpr float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
     constexpr float gy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+    // the 9 taps are loaded unconditionally (clamped), then the reference's running kernel index
+    // (it only advances over the taps actually visited, cudafuncs.cu:681-690) is replayed
+    float v[9];
+#pragma unroll
+    for (int dj = -1; dj <= 1; ++dj)
+#pragma unroll
+        for (int di = -1; di <= 1; ++di)
+            v[(dj + 1) * 3 + di + 1] = (float)src[(size_t)min(max(y + dj, 0), rows - 1) * s_stride + min(max(x + di, 0), cols - 1)];
     float dxv = 0, dyv = 0;
     int k = 8;
-    for (int j = max(y - 1, 0); j <= min(y + 1, rows - 1); ++j)
-        for (int i = max(x - 1, 0); i <= min(x + 1, cols - 1); ++i) {
-            const float s = (float)src[(size_t)j * s_stride + i];
-            dxv += s * gx[k];
-            dyv += s * gy[k];
-            --k;
+#pragma unroll
+    for (int dj = -1; dj <= 1; ++dj)
+#pragma unroll
+        for (int di = -1; di <= 1; ++di) {
+            const int j = y + dj, i = x + di;
+            if (j >= 0 && j <= rows - 1 && i >= 0 && i <= cols - 1) {
+                const float gxk = gx[k], gyk = gy[k];
+                dxv += v[(dj + 1) * 3 + di + 1] * gxk;
+                dyv += v[(dj + 1) * 3 + di + 1] * gyk;
+                --k;
+            }
         }
     dx[(size_t)y * dx_stride + x] = (int16_t)dxv;
     dy[(size_t)y * dy_stride + x] = (int16_t)dyv;
