@@ -130,17 +130,32 @@ __global__ __launch_bounds__(256) void bilateral_filter_kernel(const float* __re
         out[y * cols + x] = 0;
         return;
     }
-    const int tx = min(x - D / 2 + D, cols), ty = min(y - D / 2 + D, rows);
+    // 13 x 13 taps in the shader's order (rows ascending, columns ascending; taps outside the image
+    // are skipped).  The inner row is fully unrolled with compile-time spatial terms and loads from
+    // clamped addresses, so the 13 loads of a row issue together and nothing depends on a branch;
+    // space2 = dx^2 + dy^2 is a small integer, exact in float like the shader's float arithmetic.
     float sum1 = 0, sum2 = 0;
-    for (int cy = max(y - D / 2, 0); cy < ty; ++cy)
-        for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
-            const float tmp = depth[cy * cols + cx];
-            const float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) + ((float)y - (float)cy) * ((float)y - (float)cy);
+    for (int dy = -R; dy <= R; ++dy) {
+        const int cy = y + dy;
+        if (cy < 0 || cy >= rows) continue;  // wave-uniform except at the image border rows
+        const float dy2 = (float)(dy * dy);
+        const float* rowp = depth + (size_t)cy * cols;
+        float taps[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) taps[k] = rowp[min(max(x + k - R, 0), cols - 1)];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int cx = x + k - R;
+            const float tmp = taps[k];
+            const float space2 = (float)((k - R) * (k - R)) + dy2;
             const float color2 = (value - tmp) * (value - tmp);
             const float weight = mmf_expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
-            sum1 += tmp * weight;
-            sum2 += weight;
+            if (cx >= 0 && cx < cols) {
+                sum1 += tmp * weight;
+                sum2 += weight;
+            }
         }
+    }
     out[y * cols + x] = sum1 / sum2;
 }
 

@@ -569,7 +569,9 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
             st->sigmaVal = dec.sigmaVal;
             st->st.lastRGBError = dec.tmpError;
             st->st.lastRGBCount = (float)res_count;
+#ifndef MMF_SKIP_SOLVE
             solve_and_update(st, lds.wave[0], icp ? lds.total : nullptr, a.intr);
+#endif
         }
     }
 }
