@@ -177,7 +177,7 @@ def main():
         # bound) + WRITE_SIZE 37.5 KiB.  Algorithmic bytes are 14.75 MB: no wasted re-reads.
         traffic = (2 * 7877.25 + 37.5) * 1024
         roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": traffic, "kernel": "icp_kernel<4,256> level 0 (640x480)", "us_per_launch": us,
+                    "traffic": traffic, "kernel": "icp_kernel<2,256> level 0 (640x480)", "us_per_launch": us,
                     "bytes_per_launch": icp_step_bytes(n0),
                     "us_per_launch_l1": odom.timeIcpKernel(1, args.roofline_reps),
                     "us_per_launch_l2": odom.timeIcpKernel(2, args.roofline_reps)}

@@ -159,7 +159,9 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // ICP reduction launch.  `variant` = PX * 10000 + BLOCK picks the geometry (pixels per lane per pass,
 // threads per workgroup); 0 = the tuned default.  Vector loads need cols % PX == 0 and aligned rows,
 // otherwise the scalar PX = 1 kernel runs.
-static int g_icp_default_variant = 40256;
+// Default geometry from tools/sweep_icp.py on MI355X: the kernel is bound by its latency chain, not
+// by bandwidth, so small levels want MORE workgroups (1 px/lane), the 640x480 level 2 px/lane.
+static int icp_default_variant(int npix) { return npix >= 150000 ? 20256 : 10256; }
 
 template <int PX, int BLOCK, int MODE>
 static int launch_icp_variant(mmf_ctx* c, OdomState* st, const IcpArgs& a) {
@@ -171,7 +173,7 @@ static int launch_icp_variant(mmf_ctx* c, OdomState* st, const IcpArgs& a) {
 // launches the ICP producer; *records_out = number of partial records it writes to c->partials_icp
 template <int MODE>
 static hipError_t launch_icp(mmf_ctx* c, OdomState* st, const IcpArgs& a, int variant = 0, int* records_out = nullptr) {
-    if (variant == 0) variant = g_icp_default_variant;
+    if (variant == 0) variant = icp_default_variant(a.cols * a.rows);
     int px = variant / 10000;
     const int block = variant % 10000;
     auto ok = [&](int k) {
@@ -979,9 +981,16 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
                                         (!icp_err_dev || !last_l0 || ((uintptr_t)icp_err_dev & 15u) == 0);
             if (fuse_producers) {  // ICP reduction + correspondence pass side by side in one launch
                 IcpArgs ia = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
-                icp_records = reduce_grid(cols * rows, kBlock * 4);
-                hipLaunchKernelGGL((track_producer_kernel<4>), dim3(icp_records + res_records), dim3(kBlock), 0,
-                                   c->stream, o->state, ia, (unsigned)icp_records, ra, c->partials_icp, c->partials_res);
+                const int ipx = icp_default_variant(cols * rows) / 10000;
+                icp_records = reduce_grid(cols * rows, kBlock * ipx);
+                if (ipx == 2)
+                    hipLaunchKernelGGL((track_producer_kernel<2>), dim3(icp_records + res_records), dim3(kBlock), 0,
+                                       c->stream, o->state, ia, (unsigned)icp_records, ra, c->partials_icp,
+                                       c->partials_res);
+                else
+                    hipLaunchKernelGGL((track_producer_kernel<1>), dim3(icp_records + res_records), dim3(kBlock), 0,
+                                       c->stream, o->state, ia, (unsigned)icp_records, ra, c->partials_icp,
+                                       c->partials_res);
                 MMF_HIP_TRY(hipGetLastError());
             } else {
                 if (rgb) {
