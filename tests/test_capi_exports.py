@@ -54,3 +54,18 @@ def test_product_never_imports_the_oracle():
                         assert "from oracle" not in code and "import oracle" not in code, (f, line)
                     elif line.lstrip().startswith("#include"):
                         assert "oracle" not in line, (f, line)  # comments may cite the oracle, code may not use it
+
+
+def test_cpp_shims_compile_and_link(tmp_path):
+    """The C++ classes with the reference's names (RGBDOdometry, Model, MultiMotionFusion) build
+    with plain g++ against the C ABI (no Eigen / OpenCV / GL needed)."""
+    import subprocess
+    from multimotionfusion_amd import build
+    build.build(verbose=False)
+    pkg = os.path.join(REPO, "multimotionfusion_amd")
+    exe = tmp_path / "shim_link_check"
+    cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", os.path.join(REPO, "tests", "cpp", "shim_link_check.cpp"),
+           "-o", str(exe), f"-L{pkg}", "-lmmf_hip", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.strip() == "abi 1"
