@@ -4,9 +4,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -45,7 +47,8 @@ extern "C" const char* mmf_last_error(void) { return g_last_error.c_str(); }
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxGrid = 2048;  // workgroups per reduction launch (grid-stride beyond)
+constexpr int kMaxGrid = 2048;
+constexpr int kMaxIcpGrid = 8192;  // the single-pass ICP producer needs one workgroup per BLOCK * PX pixels  // workgroups per reduction launch (grid-stride beyond)
 
 struct mmf_ctx {
     int device = 0;
@@ -86,7 +89,7 @@ extern "C" int mmf_ctx_create(int device, void* stream, int private_stream, mmf_
         c->stream = (hipStream_t)stream;
     }
     MMF_HIP_TRY(hipMalloc(&c->partials_f, sizeof(float) * kMaxGrid * kPartialStride));
-    MMF_HIP_TRY(hipMalloc(&c->partials_icp, sizeof(float) * kMaxGrid * kPartialStride));
+    MMF_HIP_TRY(hipMalloc(&c->partials_icp, sizeof(float) * kMaxIcpGrid * kPartialStride));
     MMF_HIP_TRY(hipMalloc(&c->partials_res, sizeof(int2) * kMaxGrid));
     MMF_HIP_TRY(hipMalloc(&c->ticket, sizeof(unsigned) * kTicketWords));
     MMF_HIP_TRY(hipMemsetAsync(c->ticket, 0, sizeof(unsigned) * kTicketWords, c->stream));
@@ -156,26 +159,51 @@ static inline LevelIntr level_intr(float fx, float fy, float cx, float cy, int l
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// ICP reduction launch.  `variant` = PX * 10000 + BLOCK picks the geometry (pixels per lane per pass,
-// threads per workgroup); 0 = the tuned default.  Vector loads need cols % PX == 0 and aligned rows,
-// otherwise the scalar PX = 1 kernel runs.
-// Default geometry from tools/sweep_icp.py on MI355X: the kernel is bound by its latency chain, not
-// by bandwidth, so small levels want MORE workgroups (1 px/lane), the 640x480 level 2 px/lane.
-static int icp_default_variant(int npix) { return npix >= 150000 ? 20256 : 10256; }
+// ICP reduction launch.  `variant` = GEN * 1000000 + PX * 10000 + BLOCK picks the kernel (0 = the
+// tuned default): GEN 2 = icp_kernel2 gathering from a.prev_packed when it is set, GEN 1 = icp_kernel2
+// with planar gathers, PX pixels per lane (1, 2 or 4; the vector forms need cols % PX == 0 and
+// aligned rows), BLOCK threads per workgroup.  tools/sweep_icp.py on MI355X: every geometry of
+// icp_kernel2 lands within 0.2 us at 640x480 (the launch is bound by its two memory round trips
+// and the dispatch floor, no longer by instruction issue), so one default serves all levels.
+static int icp_default_variant(int /*npix*/) {
+    static const int forced = [] {  // tuning aid: MMF_ICP_VARIANT=<GEN*1000000 + PX*10000 + BLOCK>
+        const char* e = std::getenv("MMF_ICP_VARIANT");
+        return e ? std::atoi(e) : 0;
+    }();
+    return forced ? forced : 2020256;
+}
 
-template <int PX, int BLOCK, int MODE>
-static int launch_icp_variant(mmf_ctx* c, OdomState* st, const IcpArgs& a) {
-    const int grid = reduce_grid(a.cols * a.rows, BLOCK * PX);
-    hipLaunchKernelGGL((icp_kernel<PX, BLOCK, MODE>), dim3(grid), dim3(BLOCK), 0, c->stream, st, a, c->partials_icp);
+template <int W, int NV, int BLOCK, bool PACKED, int MODE>
+static int launch_icp2_variant(mmf_ctx* c, OdomState* st, const IcpArgs& a) {
+    const int grid = (a.cols * a.rows + BLOCK * W * NV - 1) / (BLOCK * W * NV);  // <= kMaxIcpGrid, checked by the caller
+    hipLaunchKernelGGL((icp_kernel2<W, NV, BLOCK, PACKED, MODE>), dim3(grid), dim3(BLOCK), 0, c->stream, st, a,
+                       c->partials_icp);
     return grid;
 }
 
-// launches the ICP producer; *records_out = number of partial records it writes to c->partials_icp
-template <int MODE>
-static hipError_t launch_icp(mmf_ctx* c, OdomState* st, const IcpArgs& a, int variant = 0, int* records_out = nullptr) {
-    if (variant == 0) variant = icp_default_variant(a.cols * a.rows);
-    int px = variant / 10000;
-    const int block = variant % 10000;
+// largest float x with sqrtf(x) <= t, and smallest x with sqrtf(x) >= t: sqrtf is monotonic and
+// correctly rounded, so comparing squares against these is EXACTLY the reference's comparison of
+// the norms (reduce.cu:301-306) -- see icp_rows_v
+static float sq_max_le(float t) {
+    float x = t * t;
+    while (std::sqrt(std::nextafter(x, INFINITY)) <= t) x = std::nextafter(x, INFINITY);
+    while (std::sqrt(x) > t) x = std::nextafter(x, -INFINITY);
+    return x;
+}
+static float sq_min_ge(float t) {
+    float x = t * t;
+    while (std::sqrt(std::nextafter(x, -INFINITY)) >= t) x = std::nextafter(x, -INFINITY);
+    while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
+    return x;
+}
+static void icp_args_derive(IcpArgs& a) {
+    a.dist_sq_max = sq_max_le(a.dist_thres);
+    a.sine_sq_min = sq_min_ge(a.angle_thres);
+    a.cols_magic = (unsigned)((1ull << 32) / (unsigned)a.cols) + 1u;
+}
+
+// pixels per lane the vector loads allow for these maps (4, 2 or 1)
+static int icp_max_px(const IcpArgs& a, int px) {
     auto ok = [&](int k) {
         const uintptr_t m = (uintptr_t)k * 4 - 1;
         return (a.cols % k == 0) && (a.vmap_curr.stride % k == 0) && (a.nmap_curr.stride % k == 0) &&
@@ -183,19 +211,42 @@ static hipError_t launch_icp(mmf_ctx* c, OdomState* st, const IcpArgs& a, int va
                (!a.err_map || (((uintptr_t)a.err_map & m) == 0 && a.err_stride % k == 0));
     };
     while (px > 1 && !ok(px)) px /= 2;
+    return px;
+}
+// icp_kernel2 is single pass (its grid must cover the image) and divides by multiply-high
+static bool icp2_fits(const IcpArgs& a, int block, int px) {
+    const long long n = (long long)a.cols * a.rows;
+    return n * a.cols < (1ll << 32) && (long long)kMaxIcpGrid * block * px >= n;
+}
+
+// launches the ICP producer; *records_out = number of partial records it writes to c->partials_icp
+template <int MODE>
+static hipError_t launch_icp(mmf_ctx* c, OdomState* st, IcpArgs a, int variant = 0, int* records_out = nullptr) {
+    if (variant == 0) variant = icp_default_variant(a.cols * a.rows);
+    icp_args_derive(a);
+    const int gen = variant / 1000000;
+    const int px = icp_max_px(a, (variant / 10000) % 100);
+    int block = variant % 10000;
+    if (block != 64 && block != 128) block = 256;
     int grid = 0;
-    switch (px * 10000 + block) {
-        case 40256: grid = launch_icp_variant<4, 256, MODE>(c, st, a); break;
-        case 20256: grid = launch_icp_variant<2, 256, MODE>(c, st, a); break;
-        case 10256: grid = launch_icp_variant<1, 256, MODE>(c, st, a); break;
-        case 20512: grid = launch_icp_variant<2, 512, MODE>(c, st, a); break;
-        case 10512: grid = launch_icp_variant<1, 512, MODE>(c, st, a); break;
-        case 11024: grid = launch_icp_variant<1, 1024, MODE>(c, st, a); break;
-        case 21024: grid = launch_icp_variant<2, 1024, MODE>(c, st, a); break;
-        default:
-            if (px == 4) grid = launch_icp_variant<4, 256, MODE>(c, st, a);
-            else if (px == 2) grid = launch_icp_variant<2, 256, MODE>(c, st, a);
-            else grid = launch_icp_variant<1, 256, MODE>(c, st, a);
+    if (icp2_fits(a, block, px)) {
+        const bool packed = gen != 1 && a.prev_packed != nullptr;
+#define MMF_ICP2(W, NV, B)                                                                 \
+    grid = packed ? launch_icp2_variant<W, NV, B, true, MODE>(c, st, a) : launch_icp2_variant<W, NV, B, false, MODE>(c, st, a)
+        switch (px * 10000 + block) {
+            case 40256: MMF_ICP2(2, 2, 256); break;
+            case 40128: MMF_ICP2(2, 2, 128); break;
+            case 20128: MMF_ICP2(2, 1, 128); break;
+            case 20064: MMF_ICP2(2, 1, 64); break;
+            case 10128: MMF_ICP2(1, 1, 128); break;
+            case 10064: MMF_ICP2(1, 1, 64); break;
+            case 10256: MMF_ICP2(1, 1, 256); break;
+            default: MMF_ICP2(2, 1, 256);
+        }
+#undef MMF_ICP2
+    } else {  // very large images: the grid-stride first-generation kernel
+        grid = reduce_grid(a.cols * a.rows, 256);
+        hipLaunchKernelGGL((icp_kernel<1, 256, MODE>), dim3(grid), dim3(256), 0, c->stream, st, a, c->partials_icp);
     }
     if (records_out) *records_out = grid;
     return hipGetLastError();
@@ -245,6 +296,7 @@ extern "C" int mmf_icp_step(mmf_ctx* c, const float Rcurr[9], const float tcurr[
     a.angle_thres = angle_thres;
     a.cols = cols;
     a.rows = rows;
+    a.prev_packed = nullptr;
     a.err_map = err_map_dev;
     a.err_stride = stride_elems(err_map_step, cols, 4);
     int records = 0;
@@ -651,6 +703,7 @@ struct mmf_odom {
     int16_t *dIdx[MMF_NUM_PYRS], *dIdy[MMF_NUM_PYRS];
     float* cloud[MMF_NUM_PYRS];
     mmf_dataterm* corres[MMF_NUM_PYRS];
+    float4* prev_packed[MMF_NUM_PYRS];  // model vertex + normal, pixel interleaved (the ICP gather side)
     OdomState* state = nullptr;  // device
     OdomState* host_result = nullptr;  // pinned
     bool have_tmp = false;  // vmaps_tmp filled by an initICP* call (ordering contract)
@@ -689,7 +742,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     const size_t n0 = (size_t)width * height;
     size_t o_vt = carve(4 * n0 * 4), o_nt = carve(4 * n0 * 4);
     size_t o_vgp[3], o_ngp[3], o_vc[3], o_nc[3], o_ld[3], o_nd[3], o_dp[3], o_li[3], o_ni[3], o_lni[3], o_dx[3],
-        o_dy[3], o_cl[3], o_co[3];
+        o_dy[3], o_cl[3], o_co[3], o_pp[3];
     for (int i = 0; i < MMF_NUM_PYRS; ++i) {
         const size_t n = (size_t)(width >> i) * (height >> i);
         o_vgp[i] = carve(3 * n * 4);
@@ -706,6 +759,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
         o_dy[i] = carve(n * 2);
         o_cl[i] = carve(3 * n * 4);
         o_co[i] = carve(n * sizeof(mmf_dataterm));
+        o_pp[i] = carve(n * 2 * sizeof(float4));
     }
     size_t o_state = carve(sizeof(OdomState));
     o->slab_bytes = off;
@@ -733,6 +787,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
         o->dIdy[i] = (int16_t*)(base + o_dy[i]);
         o->cloud[i] = (float*)(base + o_cl[i]);
         o->corres[i] = (mmf_dataterm*)(base + o_co[i]);
+        o->prev_packed[i] = (float4*)(base + o_pp[i]);
     }
     o->state = (OdomState*)(base + o_state);
     MMF_HIP_TRY(hipHostMalloc(&o->host_result, sizeof(OdomState), hipHostMallocDefault));
@@ -828,6 +883,10 @@ extern "C" int mmf_odom_init_icp_model(mmf_odom* o, const float* vert_rgba, cons
         rc = launch_transform(o->ctx, o->vmaps_g_prev[i], o->nmaps_g_prev[i], cols, cols, rows, R, t,
                               o->vmaps_g_prev[i], o->nmaps_g_prev[i], cols);
         if (rc) return rc;
+        const int n = cols * rows;
+        hipLaunchKernelGGL(pack_prev_kernel, dim3((n + 255) / 256), dim3(256), 0, o->ctx->stream, o->vmaps_g_prev[i],
+                           o->nmaps_g_prev[i], n, o->prev_packed[i]);
+        MMF_HIP_TRY(hipGetLastError());
     }
     return MMF_OK;
 }
@@ -896,8 +955,10 @@ static IcpArgs odom_icp_args(mmf_odom* o, int level, float* err_map) {
     a.angle_thres = o->angle_thres;
     a.cols = cols;
     a.rows = rows;
+    a.prev_packed = o->prev_packed[level];
     a.err_map = err_map;
     a.err_stride = cols;
+    icp_args_derive(a);
     return a;
 }
 
@@ -977,18 +1038,22 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
                 res_vec4 = residual_vec4_ok(ra);
                 res_records = reduce_grid(cols * rows, res_vec4 ? kBlock * 4 : kBlock);
             }
-            const bool fuse_producers = rgb && icp && res_vec4 && (cols % 4 == 0) &&
-                                        (!icp_err_dev || !last_l0 || ((uintptr_t)icp_err_dev & 15u) == 0);
+            IcpArgs ia;
+            int ipx = 1;
+            if (icp) {
+                ia = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
+                ipx = std::min(2, icp_max_px(ia, 2));
+            }
+            const bool fuse_producers = rgb && icp && res_vec4 && icp2_fits(ia, kBlock, ipx) &&
+                                        icp_default_variant(cols * rows) / 1000000 != 1;
             if (fuse_producers) {  // ICP reduction + correspondence pass side by side in one launch
-                IcpArgs ia = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
-                const int ipx = icp_default_variant(cols * rows) / 10000;
-                icp_records = reduce_grid(cols * rows, kBlock * ipx);
+                icp_records = (cols * rows + kBlock * ipx - 1) / (kBlock * ipx);
                 if (ipx == 2)
-                    hipLaunchKernelGGL((track_producer_kernel<2>), dim3(icp_records + res_records), dim3(kBlock), 0,
+                    hipLaunchKernelGGL((track_producer_kernel<2, true>), dim3(icp_records + res_records), dim3(kBlock), 0,
                                        c->stream, o->state, ia, (unsigned)icp_records, ra, c->partials_icp,
                                        c->partials_res);
                 else
-                    hipLaunchKernelGGL((track_producer_kernel<1>), dim3(icp_records + res_records), dim3(kBlock), 0,
+                    hipLaunchKernelGGL((track_producer_kernel<1, true>), dim3(icp_records + res_records), dim3(kBlock), 0,
                                        c->stream, o->state, ia, (unsigned)icp_records, ra, c->partials_icp,
                                        c->partials_res);
                 MMF_HIP_TRY(hipGetLastError());
@@ -1003,8 +1068,7 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
                     MMF_HIP_TRY(hipGetLastError());
                 }
                 if (icp) {  // :403-410
-                    IcpArgs a = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
-                    MMF_HIP_TRY(launch_icp<FINISH_GN>(c, o->state, a, 0, &icp_records));
+                    MMF_HIP_TRY(launch_icp<FINISH_GN>(c, o->state, ia, 0, &icp_records));
                     if (!rgb) {  // ICP-only tracking: one workgroup sums the records, solves, updates the pose
                         hipLaunchKernelGGL((icp_finish_kernel<FINISH_GN>), dim3(1), dim3(256), 0, c->stream, o->state,
                                            c->partials_icp, (unsigned)icp_records, in);

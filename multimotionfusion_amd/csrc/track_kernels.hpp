@@ -11,6 +11,7 @@
 #pragma once
 #include "device_math.hpp"
 #include "grid_reduce.hpp"
+#include "icp_kernels.hpp"
 #include "odom_state.hpp"
 
 namespace mmf {
@@ -33,12 +34,6 @@ __device__ unsigned long long* g_mmf_dbg = nullptr;
 
 constexpr int kBlock = 256;  // threads per workgroup of the photometric / SO3 reductions
 
-// planar 3-plane map view: element (plane k, row y, col x) at base[(y + k*rows)*stride + x]
-struct MapView {
-    const float* base;
-    int stride;  // in floats
-};
-
 // accumulate the 27 upper-triangular products of a 7-vector + residual^2 + inlier flag
 // in the member order of JtJJtrSE3 (types.cuh:101-112, reduce.cu:331-365).  The Jacobian row is
 // computed without contraction (bit-exact with the oracle); only this running sum uses an
@@ -56,15 +51,6 @@ __device__ __forceinline__ void accumulate_se3(float (&sum)[29], const float (&r
     sum[27] = __builtin_fmaf(row[6], row[6], sum[27]);
     sum[28] = sum[28] + found;
 }
-
-struct IcpArgs {
-    MapView vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev;
-    LevelIntr intr;
-    float dist_thres, angle_thres;
-    int cols, rows;
-    float* err_map;  // optional
-    int err_stride;
-};
 
 // One pixel of ICPReduction::search + getProducts (reduce.cu:257-368), given its current
 // vertex / normal.  Branch-free up to the gather so a lane's four pixels issue their gathers
@@ -117,30 +103,6 @@ __device__ __forceinline__ void icp_row(const OdomState* st, const IcpArgs& a, c
         row[6] = dot(n_cp, s_cp - d_cp);
     }
     found_f = found ? 1.0f : 0.0f;
-}
-
-// PX consecutive floats of one plane row as ONE load instruction (4, 8 or 16 bytes per lane)
-template <int PX>
-__device__ __forceinline__ void load_px(const float* __restrict__ p, float (&out)[PX]) {
-    if constexpr (PX == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        out[0] = t.x, out[1] = t.y, out[2] = t.z, out[3] = t.w;
-    } else if constexpr (PX == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(p);
-        out[0] = t.x, out[1] = t.y;
-    } else {
-        out[0] = *p;
-    }
-}
-template <int PX>
-__device__ __forceinline__ void store_px(float* __restrict__ p, const float (&v)[PX]) {
-    if constexpr (PX == 4) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    } else if constexpr (PX == 2) {
-        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
-    } else {
-        *p = v[0];
-    }
 }
 
 // PX pixels per lane per pass (PX = 4 / 2: one 16 / 8-byte load per plane; needs cols % PX == 0
@@ -227,6 +189,19 @@ __global__ __launch_bounds__(BLOCK) void icp_kernel(const OdomState* __restrict_
     __shared__ GridReduceLds<float, BLOCK> lds;
     if (MODE == FINISH_GN && st->level_break) return;
     icp_block<PX, BLOCK>(st, a, partials, lds, blockIdx.x, gridDim.x);
+}
+
+// second-generation ICP producer (icp_kernels.hpp): W pixels per lane vector x NV vectors per lane
+template <int W, int NV, int BLOCK, bool PACKED, int MODE>
+__global__ __launch_bounds__(BLOCK) void icp_kernel2(const OdomState* __restrict__ st, IcpArgs a,
+                                                     float* __restrict__ partials) {
+    __shared__ GridReduceLds<float, BLOCK> lds;
+    if (MODE == FINISH_GN && st->level_break) return;
+    using T = typename std::conditional<W == 2, v2f, float>::type;
+    if (a.err_map)
+        icp_block2<T, NV, BLOCK, PACKED, true>(st, a, partials, lds, blockIdx.x, gridDim.x);
+    else
+        icp_block2<T, NV, BLOCK, PACKED, false>(st, a, partials, lds, blockIdx.x, gridDim.x);
 }
 
 // One workgroup: sums the ICP partial records of the preceding launch.  MODE RAW: totals ->
@@ -428,18 +403,23 @@ __global__ __launch_bounds__(kBlock) void rgb_residual_kernel(const OdomState* _
 // ICP reduction, the rest the photometric correspondence pass.  The two passes are independent
 // (RGBDOdometry.cpp:363-410), so running them side by side removes a launch boundary and lets
 // their latency chains overlap.
-template <int PX>
+template <int W, bool PACKED>
 __global__ __launch_bounds__(kBlock) void track_producer_kernel(const OdomState* __restrict__ st, IcpArgs ia,
                                                                 unsigned icp_blocks, RgbResidualArgs ra,
                                                                 float* __restrict__ icp_partials,
                                                                 int2* __restrict__ res_partials) {
     __shared__ GridReduceLds<float, kBlock> lds;
     if (st->level_break) return;
-    if (blockIdx.x < icp_blocks)
-        icp_block<PX, kBlock>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
-    else
+    using T = typename std::conditional<W == 2, v2f, float>::type;
+    if (blockIdx.x < icp_blocks) {
+        if (ia.err_map)
+            icp_block2<T, 1, kBlock, PACKED, true>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
+        else
+            icp_block2<T, 1, kBlock, PACKED, false>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
+    } else {
         residual_block4(st, ra, res_partials, reinterpret_cast<GridReduceLds<int, kBlock>&>(lds), blockIdx.x - icp_blocks,
                         gridDim.x - icp_blocks);
+    }
 }
 
 // {count, sigma} decision of RGBDOdometry.cpp:373-385 as a pure function of the two totals

@@ -23,10 +23,10 @@ g.initICP(depthCutoff=15.0)
 g.initRGB(dev(fc["rgb"]))
 g.getIncrementalTransformation(pose[:3, 3], pose[:3, :3], False, 10.0, True, False, True)
 print("inliers", g.lastICPCount)
-for variant in (40256, 20256, 10256, 20512, 10512, 11024, 21024):
+for variant in (20256, 10256, 1020256, 2020256, 1040256, 2040256, 2040128, 2020128, 2020064, 1010256, 2010256, 2010128, 2010064):
     row = []
     for lvl in range(3):
         us = min(g.timeIcpKernel(lvl, 300, variant) for _ in range(3))
         n = (W >> lvl) * (H >> lvl)
         row.append(f"L{lvl} {us:7.2f} us {(48*n+116)/us/1e3:7.1f} GB/s")
-    print(f"PX={variant//10000} BLOCK={variant%10000:4d}: " + " | ".join(row), flush=True)
+    print(f"V={variant//1000000} PX={(variant//10000)%100} BLOCK={variant%10000:4d}: " + " | ".join(row), flush=True)
