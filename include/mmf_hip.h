@@ -246,6 +246,11 @@ int mmf_model_initialise(mmf_model *m, const uint8_t *rgb, const float *depth_ra
 int mmf_model_predict_indices(mmf_model *m, int time, float depth_cutoff, int time_delta);
 /* Model::combinedPredict(ACTIVE) -> ModelProjection::combinedPredict (ModelProjection.cpp:187-269) */
 int mmf_model_combined_predict(mmf_model *m, float depth_cutoff, int time, int max_time, int time_delta);
+/* ModelProjection::synthesizeDepth (ModelProjection.cpp:275-335, depth_splat.frag): the splat's depth
+ * only, into the model's "depth" image (float32 metres, 0 where no surfel lands); conf_threshold is
+ * an argument here as in the reference (MultiMotionFusion.cpp:809-810 passes initConfThresGlobal) */
+int mmf_model_synthesize_depth(mmf_model *m, float depth_cutoff, float conf_threshold, int time, int max_time,
+                               int time_delta);
 /* Model::fuse (Model.cpp:893-1048); weighting = Model::computeFusionWeight(weightMultiplier) */
 int mmf_model_fuse(mmf_model *m, int time, const uint8_t *rgb, const uint8_t *mask, const float *depth_raw,
                    const float *depth_filtered, float depth_cutoff, float weighting);

@@ -49,6 +49,11 @@ class Model {
     void combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta) {
         mmf::check(mmf_model_combined_predict(m_, depthCutoff, time, maxTime, timeDelta), "mmf_model_combined_predict");
     }
+    // ModelProjection::synthesizeDepth (ModelProjection.h:49-50); result: texture("depth")
+    void synthesizeDepth(float depthCutoff, float confThreshold, int time, int maxTime, int timeDelta) {
+        mmf::check(mmf_model_synthesize_depth(m_, depthCutoff, confThreshold, time, maxTime, timeDelta),
+                   "mmf_model_synthesize_depth");
+    }
     void fuse(const int& time, const uint8_t* rgb, const uint8_t* mask, const float* depthRaw,
               const float* depthFiltered, const float depthCutoff, const float weighting) {
         mmf::check(mmf_model_fuse(m_, time, rgb, mask, depthRaw, depthFiltered, depthCutoff, weighting), "mmf_model_fuse");

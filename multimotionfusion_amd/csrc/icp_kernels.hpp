@@ -95,76 +95,6 @@ struct IcpArgs {
     int err_stride;
 };
 
-// ---- transposed wave reduction ----------------------------------------------------------------
-// v_permlane{32,16}_swap through inline asm: the builtin of this compiler drops the second result.
-// Eight independent swaps per asm statement so the leading wait state is paid once.
-#define MMF_SWAP8(op, v, i, h)                                                                               \
-    asm volatile("s_nop 1\n\t" op " %0, %8\n\t" op " %1, %9\n\t" op " %2, %10\n\t" op " %3, %11\n\t" op      \
-                 " %4, %12\n\t" op " %5, %13\n\t" op " %6, %14\n\t" op " %7, %15"                            \
-                 : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), \
-                   "+v"(v[i + 6]), "+v"(v[i + 7]), "+v"(v[i + h]), "+v"(v[i + h + 1]), "+v"(v[i + h + 2]),     \
-                   "+v"(v[i + h + 3]), "+v"(v[i + h + 4]), "+v"(v[i + h + 5]), "+v"(v[i + h + 6]), "+v"(v[i + h + 7]))
-// r = a + a[partner] on the lanes of the banks in `bank` (4-lane groups of a row); other lanes keep r
-#define MMF_ADD_DPP(r, a, ctrl, bank) \
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:" bank : "+v"(r) : "v"(a))
-
-// Sums v[0..32) over the 64 lanes; lane L returns the total of value L >> 1.  Each stage pairs
-// lanes across one lane-index bit and HALVES the values a lane carries: the lane with the bit clear
-// keeps the lower half, its partner the upper half.  All 64 lanes must be active.
-__device__ __forceinline__ float wave_sum_transposed(float (&v)[32]) {
-    MMF_SWAP8("v_permlane32_swap_b32", v, 0, 16);  // lane bit 5
-    MMF_SWAP8("v_permlane32_swap_b32", v, 8, 16);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = v[i] + v[i + 16];
-    MMF_SWAP8("v_permlane16_swap_b32", v, 0, 8);  // lane bit 4
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = v[i] + v[i + 8];
-    float r[4], q[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // lane bit 3: partner = lane ^ 8 = rotate the 16-lane row by 8
-        MMF_ADD_DPP(r[i], v[i], "row_ror:8", "0x3");
-        MMF_ADD_DPP(r[i], v[i + 4], "row_ror:8", "0xc");
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {  // lane bit 2: partner = lane + 4 (banks 0, 2) or lane - 4 (banks 1, 3)
-        MMF_ADD_DPP(q[i], r[i], "row_shl:4", "0x5");
-        MMF_ADD_DPP(q[i], r[i + 2], "row_shr:4", "0xa");
-    }
-    // lane bit 1 (inside a quad, where bank masks cannot select): selects + quad_perm [2,3,0,1]
-    const bool hi = (threadIdx.x & 2) != 0;
-    const float keep = hi ? q[1] : q[0], send = hi ? q[0] : q[1];
-    float t = keep + dpp_mov0<0x4E, 0xf, 0xf>(send);
-    t = t + dpp_mov0<0xB1, 0xf, 0xf>(t);  // lane bit 0: quad_perm [1,0,3,2], both lanes keep the sum
-    return t;
-}
-
-// Workgroup sum of v[0..32) -> its 128-byte partial record (record index `record`); plain stores
-// (the consumer is a later kernel on the stream).
-template <int BLOCK>
-__device__ __forceinline__ void block_sum_store_transposed(float (&v)[32], float* __restrict__ partials,
-                                                           GridReduceLds<float, BLOCK>& lds, unsigned record,
-                                                           unsigned nrecords) {
-    constexpr int kWaves = BLOCK / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float t = wave_sum_transposed(v);
-    if ((lane & 1) == 0) lds.wave[wave][lane >> 1] = t;
-    __syncthreads();
-    if (wave == 0 && lane < 8) {
-        const auto rsrc = partials_rsrc(partials, nrecords);
-        float s[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] = lds.wave[0][lane * 4 + j];
-#pragma unroll
-            for (int w = 1; w < kWaves; ++w) s[j] = s[j] + lds.wave[w][lane * 4 + j];
-        }
-        v4u pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pk[j] = __builtin_bit_cast(unsigned, s[j]);
-        __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (int)((record * kPartialStride + lane * 4) * sizeof(float)), 0, 0);
-    }
-}
-
 // PX consecutive floats of one plane row as ONE load instruction (4, 8 or 16 bytes per lane)
 template <int PX>
 __device__ __forceinline__ void load_px(const float* __restrict__ p, float (&out)[PX]) {
@@ -405,7 +335,7 @@ __device__ __forceinline__ void icp_block2(const OdomState* __restrict__ st, con
 #pragma unroll
     for (int k = 0; k < 29; ++k) s32[k] = L::hsum(sum[k]);
     s32[29] = s32[30] = s32[31] = 0.f;
-    block_sum_store_transposed<BLOCK>(s32, partials, lds, bid, nblocks);
+    block_reduce_store<32, BLOCK, false>(s32, partials, lds, bid, nblocks);
 }
 
 // dense planar model maps -> the pixel-interleaved copy the packed gather reads

@@ -1260,6 +1260,7 @@ struct mmf_model {
     uchar4* image = nullptr;
     float4 *vertexConf = nullptr, *normalRadius = nullptr;
     unsigned short* time_tex = nullptr;
+    float* synth_depth = nullptr;  // ModelProjection::synthesizeDepth target (depthTexture, R32F)
     // fill-in (Shaders/FillIn.cpp)
     float4 *fill_vertex = nullptr, *fill_normal = nullptr;
     uchar4* fill_image = nullptr;
@@ -1347,7 +1348,7 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
                  o_pb = carve(npix * 4), o_bs = carve(((cap + npix) / kScanTile + 2) * 4), o_tot = carve(64),
                  o_win = carve(cap * 4), o_ct = carve((cap + npix) * 8), o_keys = carve(npix * 8),
                  o_idx = carve(npix * 4), o_vc = carve(npix * 16), o_ctm = carve(npix * 16), o_nr = carve(npix * 16),
-                 o_img = carve(npix * 4), o_vxc = carve(npix * 16), o_nrr = carve(npix * 16), o_tt = carve(npix * 2),
+                 o_img = carve(npix * 4), o_vxc = carve(npix * 16), o_nrr = carve(npix * 16), o_tt = carve(npix * 2), o_sd = carve(npix * 4),
                  o_fv = carve(npix * 16), o_fn = carve(npix * 16), o_fi = carve(npix * 4);
     m->slab_bytes = off;
     hipError_t e = hipMalloc(&m->slab, m->slab_bytes);
@@ -1370,6 +1371,7 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     m->vertConf = (float4*)(b + o_vc), m->colorTime = (float4*)(b + o_ctm), m->normRad = (float4*)(b + o_nr);
     m->image = (uchar4*)(b + o_img), m->vertexConf = (float4*)(b + o_vxc), m->normalRadius = (float4*)(b + o_nrr);
     m->time_tex = (unsigned short*)(b + o_tt);
+    m->synth_depth = (float*)(b + o_sd);
     m->fill_vertex = (float4*)(b + o_fv), m->fill_normal = (float4*)(b + o_fn), m->fill_image = (uchar4*)(b + o_fi);
     hipLaunchKernelGGL(fill_u32_kernel, grid1d(cap), dim3(256), 0, c->stream, m->winner, cap, kNoWinner);
     MMF_HIP_TRY(hipGetLastError());
@@ -1493,6 +1495,31 @@ extern "C" int mmf_model_combined_predict(mmf_model* m, float depth_cutoff, int 
                            m->keys);
     hipLaunchKernelGGL(splat_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->image,
                        m->vertexConf, m->normalRadius, m->time_tex);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+// ModelProjection::synthesizeDepth (ModelProjection.cpp:275-335): same sprites and depth test as
+// combinedPredict, only corrected_pos.z is kept
+extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, float conf_threshold, int time, int max_time,
+                                          int time_delta) {
+    MMF_REQUIRE(m != nullptr, "mmf_model_synthesize_depth: null model");
+    mmf_ctx* c = m->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const size_t npix = (size_t)m->width * m->height;
+    SplatArgs a;
+    inverse4f_host(m->pose, a.t_inv.m);
+    a.c = make_cam(m, false);
+    a.cols = m->width, a.rows = m->height;
+    a.maxDepth = depth_cutoff;
+    a.confThreshold = conf_threshold;
+    a.time = time, a.maxTime = max_time, a.timeDelta = time_delta;
+    hipLaunchKernelGGL(fill_u64_kernel, grid1d(npix), dim3(256), 0, c->stream, m->keys, npix, kEmptyKey);
+    if (m->count)
+        hipLaunchKernelGGL(splat_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
+                           m->keys);
+    hipLaunchKernelGGL(splat_depth_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys,
+                       m->synth_depth);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }
@@ -1630,7 +1657,7 @@ extern "C" int mmf_model_upload_map(mmf_model* m, const float* host_aos, unsigne
 
 // device images of the projections (the reference's GPUTexture getters, ModelProjection.h:52-77,
 // Model.h:232-244).  names: index vertConf colorTime normRad | image vertexConf normalRadius time |
-// fillVertex fillNormal fillImage
+// depth (synthesizeDepth) | fillVertex fillNormal fillImage
 extern "C" int mmf_model_texture(mmf_model* m, const char* name, void** dev_ptr, size_t* bytes) {
     MMF_REQUIRE(m && name && dev_ptr && bytes, "mmf_model_texture: null argument");
     const size_t npix = (size_t)m->width * m->height;
@@ -1645,6 +1672,7 @@ extern "C" int mmf_model_texture(mmf_model* m, const char* name, void** dev_ptr,
     else if (s == "vertexConf") p = m->vertexConf, b = npix * 16;
     else if (s == "normalRadius") p = m->normalRadius, b = npix * 16;
     else if (s == "time") p = m->time_tex, b = npix * 2;
+    else if (s == "depth") p = m->synth_depth, b = npix * 4;
     else if (s == "fillVertex") p = m->fill_vertex, b = npix * 16;
     else if (s == "fillNormal") p = m->fill_normal, b = npix * 16;
     else if (s == "fillImage") p = m->fill_image, b = npix * 4;

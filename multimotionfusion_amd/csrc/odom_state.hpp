@@ -54,7 +54,12 @@ struct OdomState {
     // outputs
     float trans_out[3], rot_out[9];
     OdomStats st;
+    // {count, sum diff^2} of the photometric correspondence pass of the current Gauss-Newton step,
+    // accumulated with integer atomics (exact, order independent) over kResShards address pairs;
+    // zeroed by gn_level_begin_kernel and by the finishing lane of every step
+    unsigned res_acc[16];
 };
+constexpr int kResShards = 8;
 
 // ---- small dense algebra (double unless suffixed f) -----------------------------------------
 

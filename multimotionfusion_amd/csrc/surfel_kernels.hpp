@@ -429,6 +429,24 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatAr
     time_out[i] = (unsigned short)(unsigned)col.z;
 }
 
+// depth_splat.frag (ModelProjection::synthesizeDepth): the winner's corrected_pos.z, 0 where cleared
+__global__ __launch_bounds__(256) void splat_depth_resolve_kernel(SurfelSoA s, SplatArgs a,
+                                                                  const unsigned long long* __restrict__ keys,
+                                                                  float* __restrict__ depth) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.cols * a.rows) return;
+    const unsigned long long k = keys[i];
+    float z = 0.f;
+    if (k != kEmptyKey) {
+        const unsigned id = (unsigned)k;
+        const int py = i / a.cols, px = i - py * a.cols;
+        const SplatFrag f = splat_setup(s.pos[id], s.col[id], s.nrm[id], a);
+        unsigned d24;
+        splat_fragment(f, a, px, py, z, d24);
+    }
+    depth[i] = z;
+}
+
 // ---- fusion: data association (data.vert) ----------------------------------------------------------
 struct FuseArgs {
     Mat4 pose;

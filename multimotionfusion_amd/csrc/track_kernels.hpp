@@ -239,6 +239,22 @@ struct RgbResidualArgs {
 
 // Like the ICP kernel this one only produces partial records {count, sum diff^2}; they are summed
 // by residual_finish_kernel (stand-alone) or by the prologue of rgb_step_kernel.
+// publishes a workgroup's {count, sum diff^2}: a dense int2 record (stand-alone computeRgbResidual, summed
+// by residual_finish_kernel) or, inside the Gauss-Newton loop, two integer atomics into the device state
+template <bool ACC>
+__device__ __forceinline__ void residual_publish(const OdomState* st, int2* __restrict__ partials, unsigned bid, int count,
+                                                 int sigma) {
+    if (threadIdx.x != 0) return;
+    if (ACC) {
+        unsigned* acc = const_cast<unsigned*>(st->res_acc) + 2 * (bid % kResShards);
+        __hip_atomic_fetch_add(acc, (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(acc + 1, (unsigned)sigma, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        partials[bid] = make_int2(count, sigma);
+    }
+}
+
+template <bool ACC>
 __device__ __forceinline__ void residual_block(const OdomState* __restrict__ st, const RgbResidualArgs& a,
                                                int2* __restrict__ partials, GridReduceLds<int, kBlock>& lds,
                                                unsigned bid, unsigned nblocks) {
@@ -295,13 +311,14 @@ __device__ __forceinline__ void residual_block(const OdomState* __restrict__ st,
     }
 
     block_sum2<kBlock>(sum[0], sum[1], lds);
-    if (threadIdx.x == 0) partials[bid] = make_int2(sum[0], sum[1]);
+    residual_publish<ACC>(st, partials, bid, sum[0], sum[1]);
 }
 
 // Four consecutive pixels of a row per lane: one 4-byte load of the intensities, one 8-byte load of
 // each gradient image, one 16-byte load of the depth, four 16-byte stores of the records; the
 // 4x4 "all neighbours > 0" windows of the four pixels are evaluated from three aligned 32-bit
 // words per image row (12 loads instead of 64).  Needs cols % 4 == 0 and 16-byte aligned rows.
+template <bool ACC>
 __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st, const RgbResidualArgs& a,
                                                 int2* __restrict__ partials, GridReduceLds<int, kBlock>& lds,
                                                 unsigned bid, unsigned nblocks) {
@@ -385,7 +402,7 @@ __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st
     }
 
     block_sum2<kBlock>(sum[0], sum[1], lds);
-    if (threadIdx.x == 0) partials[bid] = make_int2(sum[0], sum[1]);
+    residual_publish<ACC>(st, partials, bid, sum[0], sum[1]);
 }
 
 template <int MODE, int PX>
@@ -394,9 +411,9 @@ __global__ __launch_bounds__(kBlock) void rgb_residual_kernel(const OdomState* _
     __shared__ GridReduceLds<int, kBlock> lds;
     if (MODE == FINISH_GN && st->level_break) return;
     if (PX == 4)
-        residual_block4(st, a, partials, lds, blockIdx.x, gridDim.x);
+        residual_block4<MODE == FINISH_GN>(st, a, partials, lds, blockIdx.x, gridDim.x);
     else
-        residual_block(st, a, partials, lds, blockIdx.x, gridDim.x);
+        residual_block<MODE == FINISH_GN>(st, a, partials, lds, blockIdx.x, gridDim.x);
 }
 
 // Both producers of one Gauss-Newton iteration in ONE launch: workgroups [0, icp_blocks) run the
@@ -417,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void track_producer_kernel(const OdomState*
         else
             icp_block2<T, 1, kBlock, PACKED, false>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
     } else {
-        residual_block4(st, ra, res_partials, reinterpret_cast<GridReduceLds<int, kBlock>&>(lds), blockIdx.x - icp_blocks,
+        residual_block4<true>(st, ra, res_partials, reinterpret_cast<GridReduceLds<int, kBlock>&>(lds), blockIdx.x - icp_blocks,
                         gridDim.x - icp_blocks);
     }
 }
@@ -476,12 +493,14 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     ResidualDecision dec = {0.f, 0.f, false};
     if (MODE == FINISH_GN) {
         if (st->level_break) return;
-        // every workgroup sums the {count, sigma} records itself (a few KB from L2) instead of
-        // waiting for a separate finishing launch: RGBDOdometry.cpp:373-385
-        auto& ilds = reinterpret_cast<GridReduceLds<int, kBlock>&>(lds);
-        sum_int2_records<kBlock>(a.residual_partials, a.residual_records, res_count, res_sigma, ilds);
+        // {count, sigma} of the preceding correspondence pass (integer atomics, see res_acc):
+        // RGBDOdometry.cpp:373-385
+        unsigned cnt = 0, sg = 0;
+#pragma unroll
+        for (int k = 0; k < kResShards; ++k) cnt += st->res_acc[2 * k], sg += st->res_acc[2 * k + 1];
+        res_count = (int)cnt;
+        res_sigma = (int)sg;
         dec = residual_decide(res_count, res_sigma, st->rgb_only, st->st.lastRGBError);
-        __syncthreads();  // lds is reused below
         if (dec.brk) {    // rgbOnly divergence: the reference `break`s out of this level's loop
             if (blockIdx.x == 0 && threadIdx.x == 0) st->level_break = 1;
             return;
@@ -529,28 +548,27 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
         }
     }
 
-    if (!grid_reduce<29, kBlock>(sum, partials, ticket, lds)) return;
-    if (threadIdx.x == 0) {
-        if (MODE == FINISH_RAW) {
+    if (!grid_arrive<29, kBlock>(sum, partials, ticket, lds)) return;
+    if (MODE == FINISH_RAW) {
+        sum_partial_records<kBlock, true>(partials, gridDim.x, lds);
+        if (threadIdx.x == 0)
             for (int k = 0; k < 29; ++k) st->out_f[k] = lds.total[k];
-        }
     }
     if (MODE == FINISH_GN) {
-        if (threadIdx.x < kPartialStride) lds.wave[0][threadIdx.x] = lds.total[threadIdx.x];  // keep the RGB totals
         const bool icp = st->icp != 0;  // wave-uniform
-        if (icp) {  // the ICP records of the preceding launch (kernel boundary => plain loads)
-            __syncthreads();
-            sum_partial_records<kBlock, false>(a.icp_partials, a.icp_records, lds);
-        }
-        __syncthreads();
+        // the photometric records of this launch and the ICP records of the preceding one (kernel
+        // boundary => plain loads), all loads in flight together
+        sum_partial_records2<kBlock>(partials, gridDim.x, a.icp_partials, icp ? a.icp_records : 0u, lds);
         if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 2 * kResShards; ++k) st->res_acc[k] = 0u;
             st->sigma = res_sigma;
             st->rgbCount = res_count;
             st->sigmaVal = dec.sigmaVal;
             st->st.lastRGBError = dec.tmpError;
             st->st.lastRGBCount = (float)res_count;
 #ifndef MMF_SKIP_SOLVE
-            solve_and_update(st, lds.wave[0], icp ? lds.total : nullptr, a.intr);
+            solve_and_update(st, lds.total, icp ? lds.total2 : nullptr, a.intr);
 #endif
         }
     }
@@ -696,6 +714,7 @@ __global__ void gn_level_begin_kernel(OdomState* st, int first_level, LevelIntr 
     rgb_prepare(resultRt, intr, krkinv, kt);
     st->st.lastRGBError = FLT_MAX;
     st->level_break = 0;
+    for (int k = 0; k < 2 * kResShards; ++k) st->res_acc[k] = 0u;
     for (int k = 0; k < 9; ++k) st->krkinv[k] = krkinv[k];
     for (int k = 0; k < 3; ++k) st->kt[k] = kt[k];
 }

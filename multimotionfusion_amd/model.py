@@ -17,7 +17,7 @@ _TEX = {  # name -> (torch dtype, trailing shape)
     "index": (torch.int32, ()), "vertConf": (torch.float32, (4,)), "colorTime": (torch.float32, (4,)),
     "normRad": (torch.float32, (4,)), "image": (torch.uint8, (4,)), "vertexConf": (torch.float32, (4,)),
     "normalRadius": (torch.float32, (4,)), "time": (torch.int16, ()), "fillVertex": (torch.float32, (4,)),
-    "fillNormal": (torch.float32, (4,)), "fillImage": (torch.uint8, (4,)),
+    "fillNormal": (torch.float32, (4,)), "fillImage": (torch.uint8, (4,)), "depth": (torch.float32, ()),
 }
 
 
@@ -65,6 +65,11 @@ class Model:
     def combinedPredict(self, depthCutoff, time, maxTime, timeDelta):
         check(self.ctx.lib.mmf_model_combined_predict(self.handle, float(depthCutoff), int(time), int(maxTime),
                                                       int(timeDelta)))
+
+    def synthesizeDepth(self, depthCutoff, confThreshold, time, maxTime, timeDelta):
+        """ModelProjection::synthesizeDepth (ModelProjection.cpp:275-335); result in texture("depth")."""
+        check(self.ctx.lib.mmf_model_synthesize_depth(self.handle, float(depthCutoff), float(confThreshold), int(time),
+                                                      int(maxTime), int(timeDelta)))
 
     def fuse(self, time, rgb, mask, depthRaw, depthFiltered, depthCutoff, weighting):
         check(self.ctx.lib.mmf_model_fuse(self.handle, int(time), _p(rgb), _p(mask), _p(depthRaw), _p(depthFiltered),

@@ -151,6 +151,9 @@ void orc_combined_predict(const orc_surfel *s, int count, const float pose[16], 
                           float fy, int cols, int rows, float maxDepth, float confThreshold, int time,
                           int maxTime, int timeDelta, uint8_t *image_rgba, float *vertexConf,
                           float *normalRadius, uint16_t *time_out);
+void orc_synthesize_depth(const orc_surfel *s, int count, const float pose[16], float cx, float cy, float fx,
+                          float fy, int cols, int rows, float maxDepth, float confThreshold, int time,
+                          int maxTime, int timeDelta, float *depth_out);
 int orc_fuse(orc_surfel *s, int count, const uint8_t *rgb, const float *depth_raw, const float *depth_filtered,
              const uint8_t *mask, const uint32_t *index, const float *vertConf, const float *normRad,
              const float pose[16], float cx, float cy, float fx, float fy, int cols, int rows, int time,

@@ -270,10 +270,12 @@ static inline v3 project_image(v3 p, float cx, float cy, float fx, float fy) {
     return V3(((fx * p.x) / p.z) + cx, ((fy * p.y) / p.z) + cy, p.z);
 }
 
-void orc_combined_predict(const orc_surfel *s, int count, const float pose[16], float cx, float cy, float fx, float fy,
-                          int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime,
-                          int timeDelta, uint8_t *image_rgba, float *vertexConf, float *normalRadius,
-                          uint16_t *time_out) {
+/* The splat.vert point sprite + one of the two fragment shaders that share it: combo_splat.frag
+ * (image_rgba / vertexConf / normalRadius / time_out) or depth_splat.frag (depth_out). */
+static void splat_render(const orc_surfel *s, int count, const float pose[16], float cx, float cy, float fx, float fy,
+                         int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime, int timeDelta,
+                         uint8_t *image_rgba, float *vertexConf, float *normalRadius, uint16_t *time_out,
+                         float *depth_out) {
     float t_inv[16];
     orc_inverse4f(pose, t_inv);
     const size_t n = (size_t)cols * rows;
@@ -316,6 +318,8 @@ void orc_combined_predict(const orc_surfel *s, int count, const float pose[16], 
                     const size_t pi = (size_t)py * cols + px;
                     if (pass == 0) {
                         if (k < key[pi]) key[pi] = k;
+                    } else if (k == key[pi] && depth_out) { /* depth_splat.frag:39 */
+                        depth_out[pi] = corrected.z;
                     } else if (k == key[pi]) {
                         const v3 col = decode_color(s[id].col[0]);
                         image_rgba[4 * pi + 0] = (uint8_t)(int)roundf(col.x * 255.0f);
@@ -334,13 +338,34 @@ void orc_combined_predict(const orc_surfel *s, int count, const float pose[16], 
                 }
         }
         if (pass == 0) { /* cleared targets */
-            memset(image_rgba, 0, 4 * n);
-            memset(vertexConf, 0, 16 * n);
-            memset(normalRadius, 0, 16 * n);
-            memset(time_out, 0, 2 * n);
+            if (depth_out) {
+                memset(depth_out, 0, 4 * n);
+            } else {
+                memset(image_rgba, 0, 4 * n);
+                memset(vertexConf, 0, 16 * n);
+                memset(normalRadius, 0, 16 * n);
+                memset(time_out, 0, 2 * n);
+            }
         }
     }
     free(key);
+}
+
+void orc_combined_predict(const orc_surfel *s, int count, const float pose[16], float cx, float cy, float fx, float fy,
+                          int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime,
+                          int timeDelta, uint8_t *image_rgba, float *vertexConf, float *normalRadius,
+                          uint16_t *time_out) {
+    splat_render(s, count, pose, cx, cy, fx, fy, cols, rows, maxDepth, confThreshold, time, maxTime, timeDelta,
+                 image_rgba, vertexConf, normalRadius, time_out, NULL);
+}
+
+/* ModelProjection::synthesizeDepth (ModelProjection.cpp:275-335) + splat.vert + depth_splat.frag:
+ * the same sprites and depth test, the R32F target receives corrected_pos.z (0 where nothing lands) */
+void orc_synthesize_depth(const orc_surfel *s, int count, const float pose[16], float cx, float cy, float fx, float fy,
+                          int cols, int rows, float maxDepth, float confThreshold, int time, int maxTime,
+                          int timeDelta, float *depth_out) {
+    splat_render(s, count, pose, cx, cy, fx, fy, cols, rows, maxDepth, confThreshold, time, maxTime, timeDelta, NULL,
+                 NULL, NULL, NULL, depth_out);
 }
 
 /* ------------------------------------------------------------------------------------- */

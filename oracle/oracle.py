@@ -392,6 +392,16 @@ def combined_predict(surfels, pose, K, cols, rows, maxDepth, confThreshold, time
     return image, vc, nr, tm
 
 
+def synthesize_depth(surfels, pose, K, cols, rows, maxDepth, confThreshold, time, maxTime, timeDelta):
+    s = _surf(surfels)
+    pose = _f(np.reshape(pose, 16))
+    depth = np.zeros((rows, cols), np.float32)
+    lib().orc_synthesize_depth(_pf(s), s.shape[0], _pf(pose), _cf(K["cx"]), _cf(K["cy"]), _cf(K["fx"]), _cf(K["fy"]),
+                               cols, rows, _cf(maxDepth), _cf(confThreshold), int(time), int(maxTime), int(timeDelta),
+                               _pf(depth))
+    return depth
+
+
 def fuse(surfels, rgb, depth_raw, depth_filtered, mask, index, vertConf, normRad, pose, K, time, weighting, maskID,
          maxDepth):
     """Returns (updated surfels, new unstable surfels in draw order)."""

@@ -88,6 +88,11 @@ def test_surfel_cycle_bit_exact(gpu_ctx, orc, w, h):
         assert_bit_equal(m.texture("vertexConf").cpu().numpy(), vcp, f"splat vertexConf t={t}")
         assert_bit_equal(m.texture("normalRadius").cpu().numpy(), nrp, f"splat normalRadius t={t}")
         assert_bit_equal(m.texture("time").cpu().numpy().view(np.uint16), tm, f"splat time t={t}")
+        # ModelProjection::synthesizeDepth: the same sprites, depth only, explicit confidence threshold
+        for conf in (CONF, 0.5):
+            m.synthesizeDepth(MAXD, conf, tick, tick, TIME_DELTA)
+            sd = orc.synthesize_depth(s, pose, K, w, h, MAXD, conf, tick, tick, TIME_DELTA)
+            assert_bit_equal(m.texture("depth").cpu().numpy(), sd, f"synthesized depth t={t} conf={conf}")
 
         m.performFillIn(d_rgb, d_fil, False, False)
         vo, no, io = orc.fill_in(vcp, nrp, image, fil, f["rgb"], K, 0, 0)

@@ -105,6 +105,9 @@ def test_splat_prediction_reproduces_the_surface(orc):
     # vertex x,y are the ray through the pixel centre scaled by z
     ys, xs = np.nonzero(cov)
     assert np.allclose(vc[ys, xs, 0], (xs + 0.5 - K["cx"]) * vc[ys, xs, 2] / K["fx"], atol=1e-5)
+    # synthesizeDepth is the same splat keeping corrected_pos.z only
+    sd = orc.synthesize_depth(s, np.eye(4), K, W, H, MAXD, 10.0, 1, 1, 200)
+    assert np.array_equal(sd.view(np.uint32), np.ascontiguousarray(vc[..., 2]).view(np.uint32))
     # low-confidence surfels are not splatted
     s[:, 3] = 1.0
     image2, vc2, *_ = orc.combined_predict(s, np.eye(4), K, W, H, MAXD, 10.0, 1, 1, 200)
