@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libmmf_hip.so")
+# MMF_HIP_LIB: an instrumented build of the same library (tools/rgb_step_probe.py), never a fallback
+LIB_PATH = os.environ.get("MMF_HIP_LIB") or os.path.join(_PKG_DIR, "libmmf_hip.so")
 
 MMF_NUM_PYRS = 3
 

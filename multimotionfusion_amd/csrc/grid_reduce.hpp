@@ -263,23 +263,27 @@ __device__ __forceinline__ void sum_partial_records2(const T* __restrict__ pa, u
         const auto ra = partials_rsrc(pa, na), rb = partials_rsrc(pb, nb);
         const int rec0 = tid >> 3, q = tid & 7;
         T acc_a[4] = {T(0), T(0), T(0), T(0)}, acc_b[4] = {T(0), T(0), T(0), T(0)};
-        constexpr int U = 8;
-        const unsigned nmax = na > nb ? na : nb;
-        for (unsigned base = 0; base < nmax; base += 32 * U) {
-            v4u xa[U], xb[U];
+        // UA + UB loads per thread per pass = 320 + 640 records: the 300 + 600 records of a 640x480
+        // step arrive in ONE round trip (three dependent passes cost 2.6 us in the phase stamps)
+        constexpr int UA = 10, UB = 20;
+        for (unsigned ba = 0, bb = 0; ba < na || bb < nb; ba += 32 * UA, bb += 32 * UB) {
+            v4u xa[UA], xb[UB];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int off = (int)(((base + u * 32 + rec0) * kPartialStride + q * 4) * sizeof(T));
-                xa[u] = __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 16 /* sc1 */);
-                xb[u] = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0);
-            }
+            for (int u = 0; u < UA; ++u)
+                xa[u] = __builtin_amdgcn_raw_buffer_load_b128(
+                    ra, (int)(((ba + u * 32 + rec0) * kPartialStride + q * 4) * sizeof(T)), 0, 16 /* sc1 */);
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < UB; ++u)
+                xb[u] = __builtin_amdgcn_raw_buffer_load_b128(
+                    rb, (int)(((bb + u * 32 + rec0) * kPartialStride + q * 4) * sizeof(T)), 0, 0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc_a[j] = acc_a[j] + __builtin_bit_cast(T, (unsigned)xa[u][j]);
-                    acc_b[j] = acc_b[j] + __builtin_bit_cast(T, (unsigned)xb[u][j]);
-                }
+            for (int u = 0; u < UA; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc_a[j] = acc_a[j] + __builtin_bit_cast(T, (unsigned)xa[u][j]);
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc_b[j] = acc_b[j] + __builtin_bit_cast(T, (unsigned)xb[u][j]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

@@ -214,13 +214,17 @@ __device__ __forceinline__ void icp_rows_v(const IcpPose& P, const IcpArgs& a, c
 
 // T = lane vector (float: 1 px, v2f: 2 px); NV lane vectors per lane per pass, loaded as ONE
 // 4*W*NV-byte load per plane.  PACKED: gather from a.prev_packed.
-template <typename T, int NV, int BLOCK, bool PACKED, bool ERR>
+// CHECK_BREAK: return when st->level_break is set -- tested only after the current-frame loads have been
+// issued: the state was written by the previous kernel's finishing lane and reading it is a cold
+// ~1 us round trip that should overlap those loads, not precede them.
+template <typename T, int NV, int BLOCK, bool PACKED, bool ERR, bool CHECK_BREAK = false>
 __device__ __forceinline__ void icp_block2(const OdomState* __restrict__ st, const IcpArgs& a,
                                            float* __restrict__ partials, GridReduceLds<float, BLOCK>& lds,
                                            unsigned bid, unsigned nblocks) {
     using L = lanevec<T>;
     constexpr int W = L::W, PX = W * NV;
     const IcpPose P = load_icp_pose(st);
+    const int level_break = CHECK_BREAK ? st->level_break : 0;
 
     T sum[29];
     const unsigned N = (unsigned)(a.cols * a.rows);
@@ -247,6 +251,7 @@ __device__ __forceinline__ void icp_block2(const OdomState* __restrict__ st, con
             load_px<PX>(pn + 2 * sn, cur[5]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (level_break) return;  // wave-uniform
 
         IcpProj<T> pr[NV];
 #pragma unroll

@@ -1682,6 +1682,15 @@ extern "C" int mmf_model_texture(mmf_model* m, const char* name, void** dev_ptr,
     return MMF_OK;
 }
 
+#ifdef MMF_STAMPS
+// diagnostic builds only (tools/rgb_step_probe.py): phase-stamp buffer of the instrumented kernels
+extern "C" int mmf_debug_set_stamps(void* dev_buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(dev_buf);
+    MMF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_mmf_dbg), &p, sizeof(p)));
+    return MMF_OK;
+}
+#endif
+
 // =============================================================================================
 // Orchestrator: MultiMotionFusion::processFrame / predict (Core/MultiMotionFusion.cpp:207-854,
 // 863-875) for one rigid-body model per object (the static-scene configuration,

@@ -370,16 +370,33 @@ __device__ inline void unpack_se3(const float* tot, float* A, float* b) {
 
 // combine, solve, update the pose: RGBDOdometry.cpp:412-460 + OdometryProvider.h:69-89.
 // tot_rgb / tot_icp: the 29 grid totals of the photometric / ICP reduction (nullptr = term off).
-__device__ inline void solve_and_update(OdomState* st, const float* tot_rgb, const float* tot_icp,
-                                        const LevelIntr& in) {
-    // entry loads (independent)
-    const double w = st->icp_weight;
-    const int iters = st->st.iterations_run;
+// The state the solve reads.  A reduction kernel loads it at its START (wave-uniform scalar loads that
+// cost nothing there), so the finishing lane does not begin its serial tail with a global round trip.
+struct SolveIn {
+    double w;
+    int iters;
     double resultRt[16];
     float Rprev[9], tprev[3];
-    for (int k = 0; k < 16; ++k) resultRt[k] = st->resultRt[k];
-    for (int k = 0; k < 9; ++k) Rprev[k] = st->Rprev[k];
-    for (int k = 0; k < 3; ++k) tprev[k] = st->tprev[k];
+};
+__device__ inline SolveIn load_solve_in(const OdomState* st) {
+    SolveIn s;
+    s.w = st->icp_weight;
+    s.iters = st->st.iterations_run;
+    for (int k = 0; k < 16; ++k) s.resultRt[k] = st->resultRt[k];
+    for (int k = 0; k < 9; ++k) s.Rprev[k] = st->Rprev[k];
+    for (int k = 0; k < 3; ++k) s.tprev[k] = st->tprev[k];
+    return s;
+}
+
+__device__ inline void solve_and_update(OdomState* st, const SolveIn& si, const float* tot_rgb, const float* tot_icp,
+                                        const LevelIntr& in) {
+    const double w = si.w;
+    const int iters = si.iters;
+    double resultRt[16];
+    float Rprev[9], tprev[3];
+    for (int k = 0; k < 16; ++k) resultRt[k] = si.resultRt[k];
+    for (int k = 0; k < 9; ++k) Rprev[k] = si.Rprev[k];
+    for (int k = 0; k < 3; ++k) tprev[k] = si.tprev[k];
 
     float A_rgb[36], b_rgb[6], A_icp[36], b_icp[6];
     double A[36], b[6];
@@ -449,6 +466,12 @@ __device__ inline void solve_and_update(OdomState* st, const float* tot_rgb, con
         st->st.lastICPError = sqrtf(tot_icp[27]) / tot_icp[28];
         st->st.lastICPCount = tot_icp[28];
     }
+}
+
+__device__ inline void solve_and_update(OdomState* st, const float* tot_rgb, const float* tot_icp,
+                                        const LevelIntr& in) {
+    const SolveIn si = load_solve_in(st);
+    solve_and_update(st, si, tot_rgb, tot_icp, in);
 }
 
 }  // namespace mmf

@@ -18,13 +18,13 @@ namespace mmf {
 
 enum FinishMode { FINISH_RAW = 0, FINISH_GN = 1 };
 
-// Diagnostic builds only (tools/latency_probe.hip): per-workgroup phase stamps of the 100 MHz
+// Diagnostic builds only (tools/rgb_step_probe.py): per-workgroup phase stamps of the 100 MHz
 // constant clock into a side buffer nothing else reads.  Compiled out of the library.
 #ifdef MMF_STAMPS
 __device__ unsigned long long* g_mmf_dbg = nullptr;
-#define MMF_STAMP(i)                                                                         \
-    do {                                                                                     \
-        if (g_mmf_dbg && threadIdx.x == 0) g_mmf_dbg[blockIdx.x * 8 + (i)] = wall_clock64(); \
+#define MMF_STAMP(i)                                                                          \
+    do {                                                                                      \
+        if (g_mmf_dbg && threadIdx.x == 0) g_mmf_dbg[blockIdx.x * 16 + (i)] = wall_clock64(); \
     } while (0)
 #else
 #define MMF_STAMP(i) \
@@ -118,8 +118,6 @@ __device__ __forceinline__ void icp_block(const OdomState* __restrict__ st, cons
                                           float* __restrict__ partials, GridReduceLds<float, BLOCK>& lds,
                                           unsigned bid, unsigned nblocks) {
     constexpr int kBlock = BLOCK;
-    MMF_STAMP(0);
-
     float sum[29];
 #pragma unroll
     for (int k = 0; k < 29; ++k) sum[k] = 0.f;
@@ -140,16 +138,8 @@ __device__ __forceinline__ void icp_block(const OdomState* __restrict__ st, cons
 
         IcpPixel px[PX];
         f3 vp[PX], np[PX];
-#ifdef MMF_STAMPS
-        if (vx[0] == 1234.5f) sum[0] += ny[0] + nz[0] + nx[0];  // force the loads to have landed
-        MMF_STAMP(1);
-#endif
 #pragma unroll
         for (int p = 0; p < PX; ++p) px[p] = icp_project(st, a, make_f3(vx[p], vy[p], vz[p]));
-#ifdef MMF_STAMPS
-        if (px[0].ux == -12345) sum[0] += 1.f;
-        MMF_STAMP(2);
-#endif
         // all gathers of the group issued before any is consumed; pixels that project outside
         // read element 0 (a valid address) and are masked afterwards
 #pragma unroll
@@ -162,25 +152,16 @@ __device__ __forceinline__ void icp_block(const OdomState* __restrict__ st, cons
             np[p] = make_f3(a.nmap_g_prev.base[on], a.nmap_g_prev.base[on + pn], a.nmap_g_prev.base[on + 2 * pn]);
         }
         float errs[PX];
-#ifdef MMF_STAMPS
-        if (vp[0].x == 1234.5f) sum[0] += np[0].x + np[0].y + np[0].z + vp[0].y + vp[0].z;
-        MMF_STAMP(3);
-#endif
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
             float row[7], found;
             icp_row(st, a, px[p], make_f3(nx[p], ny[p], nz[p]), vp[p], np[p], row, found, errs[p]);
             accumulate_se3(sum, row, found);
         }
-#ifdef MMF_STAMPS
-        if (sum[3] == 1234.5f) sum[0] += 1.f;
-        MMF_STAMP(4);
-#endif
         if (a.err_map) store_px<PX>(a.err_map + (size_t)y * a.err_stride + x, errs);
     }
 
     block_reduce_store<29, BLOCK, false>(sum, partials, lds, bid, nblocks);
-    MMF_STAMP(5);
 }
 
 template <int PX, int BLOCK, int MODE>
@@ -196,12 +177,11 @@ template <int W, int NV, int BLOCK, bool PACKED, int MODE>
 __global__ __launch_bounds__(BLOCK) void icp_kernel2(const OdomState* __restrict__ st, IcpArgs a,
                                                      float* __restrict__ partials) {
     __shared__ GridReduceLds<float, BLOCK> lds;
-    if (MODE == FINISH_GN && st->level_break) return;
     using T = typename std::conditional<W == 2, v2f, float>::type;
     if (a.err_map)
-        icp_block2<T, NV, BLOCK, PACKED, true>(st, a, partials, lds, blockIdx.x, gridDim.x);
+        icp_block2<T, NV, BLOCK, PACKED, true, MODE == FINISH_GN>(st, a, partials, lds, blockIdx.x, gridDim.x);
     else
-        icp_block2<T, NV, BLOCK, PACKED, false>(st, a, partials, lds, blockIdx.x, gridDim.x);
+        icp_block2<T, NV, BLOCK, PACKED, false, MODE == FINISH_GN>(st, a, partials, lds, blockIdx.x, gridDim.x);
 }
 
 // One workgroup: sums the ICP partial records of the preceding launch.  MODE RAW: totals ->
@@ -326,6 +306,7 @@ __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st
     const int cols = a.cols, rows = a.rows, N4 = (cols * rows) / 4;
     const float* K = st->krkinv;
     const float ktx = st->kt[0], kty = st->kt[1], ktz = st->kt[2];
+    const int level_break = ACC ? st->level_break : 0;  // consumed after the image loads are in flight
 
     for (int g = bid * kBlock + threadIdx.x; g < N4; g += nblocks * kBlock) {
         const int k0 = g * 4;
@@ -354,6 +335,8 @@ __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st
         const short4 gx = *reinterpret_cast<const short4*>(a.dIdx + (size_t)i * a.d_stride + j0);
         const short4 gy = *reinterpret_cast<const short4*>(a.dIdy + (size_t)i * a.d_stride + j0);
         const float4 dv = *reinterpret_cast<const float4*>(a.next_depth + (size_t)i * a.nd_stride + j0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (level_break) return;  // wave-uniform; the state read overlapped the loads above
         const int valxs[4] = {gx.x, gx.y, gx.z, gx.w}, valys[4] = {gy.x, gy.y, gy.z, gy.w};
         const float d1s[4] = {dv.x, dv.y, dv.z, dv.w};
         float errs[4];
@@ -409,7 +392,7 @@ template <int MODE, int PX>
 __global__ __launch_bounds__(kBlock) void rgb_residual_kernel(const OdomState* __restrict__ st, RgbResidualArgs a,
                                                               int2* __restrict__ partials) {
     __shared__ GridReduceLds<int, kBlock> lds;
-    if (MODE == FINISH_GN && st->level_break) return;
+    if (MODE == FINISH_GN && PX != 4 && st->level_break) return;
     if (PX == 4)
         residual_block4<MODE == FINISH_GN>(st, a, partials, lds, blockIdx.x, gridDim.x);
     else
@@ -426,13 +409,13 @@ __global__ __launch_bounds__(kBlock) void track_producer_kernel(const OdomState*
                                                                 float* __restrict__ icp_partials,
                                                                 int2* __restrict__ res_partials) {
     __shared__ GridReduceLds<float, kBlock> lds;
-    if (st->level_break) return;
+    // st->level_break is checked inside the blocks, after their state-independent loads are in flight
     using T = typename std::conditional<W == 2, v2f, float>::type;
     if (blockIdx.x < icp_blocks) {
         if (ia.err_map)
-            icp_block2<T, 1, kBlock, PACKED, true>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
+            icp_block2<T, 1, kBlock, PACKED, true, true>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
         else
-            icp_block2<T, 1, kBlock, PACKED, false>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
+            icp_block2<T, 1, kBlock, PACKED, false, true>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
     } else {
         residual_block4<true>(st, ra, res_partials, reinterpret_cast<GridReduceLds<int, kBlock>&>(lds), blockIdx.x - icp_blocks,
                         gridDim.x - icp_blocks);
@@ -481,27 +464,97 @@ struct RgbStepArgs {
     LevelIntr intr;
 };
 
+// The two halves of one pass of rgbKernel (reduce.cu:504-535) over the PX records of a lane.
+// rgb_gather: every gather issued before any is consumed.  Records without a correspondence carry
+// zero coordinates, i.e. a valid address, and are masked afterwards (a per-record `if (valid)` made
+// the PX gathers PX dependent round trips).
+template <int PX>
+struct RgbLane {
+    mmf_dataterm c[PX];
+    float X[PX], Y[PX], Z[PX];
+    int gx[PX], gy[PX];
+};
+template <int PX>
+__device__ __forceinline__ void rgb_gather(const RgbStepArgs& a, const int4 (&raws)[PX], RgbLane<PX>& l) {
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        *reinterpret_cast<int4*>(&l.c[p]) = raws[p];
+        const float* cp = a.cloud + (size_t)(l.c[p].zero_y * a.cols + l.c[p].zero_x) * 3;
+        l.X[p] = cp[0], l.Y[p] = cp[1], l.Z[p] = cp[2];
+        l.gx[p] = a.dIdx[(size_t)l.c[p].one_y * a.d_stride + l.c[p].one_x];
+        l.gy[p] = a.dIdy[(size_t)l.c[p].one_y * a.d_stride + l.c[p].one_x];
+    }
+}
+template <int PX>
+__device__ __forceinline__ void rgb_rows(const RgbStepArgs& a, float sigma, bool live, const RgbLane<PX>& l,
+                                         float (&sum)[29]) {
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {  // branch free
+        const bool found = live && l.c[p].valid != 0;
+        float w = sigma + fabsf(l.c[p].diff);
+        w = w > FLT_EPSILON ? 1.0f / w : 1.0f;
+        if (sigma == -1) w = 1;
+        const float X = l.X[p], Y = l.Y[p], Z = l.Z[p];
+        const float invz = 1.0f / Z;  // (float)(1.0 / Z): double rounding is innocuous for division
+        const float dI_dx = w * a.sobel_scale * l.gx[p];
+        const float dI_dy = w * a.sobel_scale * l.gy[p];
+        const float v0 = dI_dx * a.fx * invz;
+        const float v1 = dI_dy * a.fy * invz;
+        const float v2 = -(v0 * X + v1 * Y) * invz;
+        float row[7] = {v0, v1, v2, -Z * v1 + Y * v2, Z * v0 - X * v2, -Y * v0 + X * v1, -w * l.c[p].diff};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) row[k] = found ? row[k] : 0.f;
+        accumulate_se3(sum, row, found ? 1.0f : 0.0f);
+    }
+}
+
 // PX = 4: a lane takes four consecutive records (64 contiguous bytes), so the grid -- and with it
 // the number of partial records the finishing workgroup has to re-read -- shrinks 4x.
+//
+// Order of the first pass (phase stamps, tools/rgb_step_probe.py): the device state was written by
+// the previous kernel's finishing lane, so reading it is a cold ~1 us round trip -- as long as the
+// record loads.  Neither the records nor the gathers depend on the state, so the kernel issues the
+// record loads, then the (scalar) state loads, then the gathers, and only then consumes the state
+// (break flags, sigma): three round trips overlap instead of queueing.
 template <int MODE, int PX>
 __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict__ st, RgbStepArgs a,
                                                           float* __restrict__ partials,
                                                           unsigned* __restrict__ ticket) {
     __shared__ GridReduceLds<float, kBlock> lds;
+    MMF_STAMP(0);
+    const int N = a.cols * a.rows;
+    int i0 = (blockIdx.x * kBlock + threadIdx.x) * PX;
+    const bool live = i0 < N;
+    int4 raws[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) raws[p] = *reinterpret_cast<const int4*>(&a.corres[(live ? i0 : 0) + p]);
+    __builtin_amdgcn_sched_barrier(0);
+    // state reads (wave-uniform scalar loads), not consumed before the gathers are in flight
     float sigma = st->sigmaVal;
+    const int level_break = st->level_break, rgb_only = st->rgb_only;
+    const float lastRGBError = st->st.lastRGBError;
+    SolveIn si;
+    unsigned cnt = 0, sg = 0;
+    if (MODE == FINISH_GN) {
+        si = load_solve_in(st);
+#pragma unroll
+        for (int k = 0; k < kResShards; ++k) cnt += st->res_acc[2 * k], sg += st->res_acc[2 * k + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    RgbLane<PX> lane;
+    rgb_gather<PX>(a, raws, lane);
+    __builtin_amdgcn_sched_barrier(0);
+
     int res_count = 0, res_sigma = 0;
     ResidualDecision dec = {0.f, 0.f, false};
     if (MODE == FINISH_GN) {
-        if (st->level_break) return;
+        if (level_break) return;
         // {count, sigma} of the preceding correspondence pass (integer atomics, see res_acc):
         // RGBDOdometry.cpp:373-385
-        unsigned cnt = 0, sg = 0;
-#pragma unroll
-        for (int k = 0; k < kResShards; ++k) cnt += st->res_acc[2 * k], sg += st->res_acc[2 * k + 1];
         res_count = (int)cnt;
         res_sigma = (int)sg;
-        dec = residual_decide(res_count, res_sigma, st->rgb_only, st->st.lastRGBError);
-        if (dec.brk) {    // rgbOnly divergence: the reference `break`s out of this level's loop
+        dec = residual_decide(res_count, res_sigma, rgb_only, lastRGBError);
+        if (dec.brk) {  // rgbOnly divergence: the reference `break`s out of this level's loop
             if (blockIdx.x == 0 && threadIdx.x == 0) st->level_break = 1;
             return;
         }
@@ -510,45 +563,26 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     float sum[29];
 #pragma unroll
     for (int k = 0; k < 29; ++k) sum[k] = 0.f;
-    const int N = a.cols * a.rows;
-
-    for (int i0 = (blockIdx.x * kBlock + threadIdx.x) * PX; i0 < N; i0 += gridDim.x * kBlock * PX) {
-        int4 raws[PX];
+#ifdef MMF_STAMPS
+    if (sigma == 1234.5f && lane.X[0] == 1234.5f && lane.gx[0] == 77 && lane.gy[PX - 1] == 78) sum[0] = lane.Z[PX - 1];
+    MMF_STAMP(3);
+#endif
+    rgb_rows<PX>(a, sigma, live, lane, sum);
+    // images beyond the grid's single pass
+    for (i0 += gridDim.x * kBlock * PX; i0 < N; i0 += gridDim.x * kBlock * PX) {
 #pragma unroll
         for (int p = 0; p < PX; ++p) raws[p] = *reinterpret_cast<const int4*>(&a.corres[i0 + p]);
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            mmf_dataterm c;
-            *reinterpret_cast<int4*>(&c) = raws[p];
-            float row[7];
-#pragma unroll
-            for (int k = 0; k < 7; ++k) row[k] = 0.f;
-            const bool found = c.valid != 0;
-            if (found) {  // reduce.cu:504-535
-                float w = sigma + fabsf(c.diff);
-                w = w > FLT_EPSILON ? 1.0f / w : 1.0f;
-                if (sigma == -1) w = 1;
-                row[6] = -w * c.diff;
-                const float* cp = a.cloud + (size_t)(c.zero_y * a.cols + c.zero_x) * 3;
-                const float X = cp[0], Y = cp[1], Z = cp[2];
-                const float invz = 1.0f / Z;  // (float)(1.0 / Z): double rounding is innocuous for division
-                const float dI_dx = w * a.sobel_scale * a.dIdx[(size_t)c.one_y * a.d_stride + c.one_x];
-                const float dI_dy = w * a.sobel_scale * a.dIdy[(size_t)c.one_y * a.d_stride + c.one_x];
-                const float v0 = dI_dx * a.fx * invz;
-                const float v1 = dI_dy * a.fy * invz;
-                const float v2 = -(v0 * X + v1 * Y) * invz;
-                row[0] = v0;
-                row[1] = v1;
-                row[2] = v2;
-                row[3] = -Z * v1 + Y * v2;
-                row[4] = Z * v0 - X * v2;
-                row[5] = -Y * v0 + X * v1;
-            }
-            accumulate_se3(sum, row, found ? 1.0f : 0.0f);
-        }
+        rgb_gather<PX>(a, raws, lane);
+        rgb_rows<PX>(a, sigma, true, lane, sum);
     }
 
-    if (!grid_arrive<29, kBlock>(sum, partials, ticket, lds)) return;
+#ifdef MMF_STAMPS
+    if (sum[5] == 1234.5f) sum[0] += 1.f;
+    MMF_STAMP(4);
+#endif
+    const bool is_last_wg = grid_arrive<29, kBlock>(sum, partials, ticket, lds);
+    MMF_STAMP(5);
+    if (!is_last_wg) return;
     if (MODE == FINISH_RAW) {
         sum_partial_records<kBlock, true>(partials, gridDim.x, lds);
         if (threadIdx.x == 0)
@@ -559,6 +593,7 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
         // the photometric records of this launch and the ICP records of the preceding one (kernel
         // boundary => plain loads), all loads in flight together
         sum_partial_records2<kBlock>(partials, gridDim.x, a.icp_partials, icp ? a.icp_records : 0u, lds);
+        MMF_STAMP(6);
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < 2 * kResShards; ++k) st->res_acc[k] = 0u;
@@ -568,7 +603,10 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
             st->st.lastRGBError = dec.tmpError;
             st->st.lastRGBCount = (float)res_count;
 #ifndef MMF_SKIP_SOLVE
-            solve_and_update(st, lds.total, icp ? lds.total2 : nullptr, a.intr);
+            solve_and_update(st, si, lds.total, icp ? lds.total2 : nullptr, a.intr);
+#endif
+#ifdef MMF_STAMPS
+            if (g_mmf_dbg) g_mmf_dbg[blockIdx.x * 16 + 7] = wall_clock64() + (st->Rcurr[0] == 1234.5f ? 1 : 0);
 #endif
         }
     }
