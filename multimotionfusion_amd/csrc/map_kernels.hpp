@@ -156,6 +156,16 @@ __global__ __launch_bounds__(256) void pyrdown_gauss_f_kernel(const float* __res
     if (x >= dcols || y >= drows) return;
     const int tx = min(2 * x + 3, scols - 1);
     const int ty = min(2 * y + 3, srows - 1);
+    // All 25 taps are loaded from clamped addresses BEFORE any is consumed, and the accumulation is
+    // branch free: with the loads next to their data-dependent `if`, hipcc emitted 25 load / wait /
+    // branch sequences -- 25 dependent round trips, 8-10 us for a 320x240 output.
+    float tap[5][5];
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx)
+            tap[dy][dx] = src[(size_t)min(max(2 * y - 2 + dy, 0), srows - 1) * s_stride + min(max(2 * x - 2 + dx, 0), scols - 1)];
+    __builtin_amdgcn_sched_barrier(0);
     float sum = 0;
     int count = 0;
 #pragma unroll
@@ -166,14 +176,11 @@ __global__ __launch_bounds__(256) void pyrdown_gauss_f_kernel(const float* __res
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx) {
             const int cx = 2 * x - 2 + dx;
-            // unconditional load from a clamped address, then select: a load under a divergent
-            // branch cannot be hoisted, and 25 dependent round trips made this kernel ~9 us
-            const float s = src[(size_t)min(max(cy, 0), srows - 1) * s_stride + min(max(cx, 0), scols - 1)];
-            if (rowok && cx >= 0 && cx < tx && !(s != s)) {
-                const float w = wy * binom5(tx - cx - 1);
-                sum += s * w;
-                count = (int)((float)count + w);
-            }
+            const float s = tap[dy][dx];
+            const bool use = rowok && cx >= 0 && cx < tx && !(s != s);
+            const float w = wy * binom5(tx - cx - 1);
+            sum = use ? sum + s * w : sum;
+            count = use ? (int)((float)count + w) : count;
         }
     }
     dst[(size_t)y * d_stride + x] = (float)(sum / (float)count);
@@ -187,6 +194,13 @@ __global__ __launch_bounds__(256) void pyrdown_uchar_gauss_kernel(const uint8_t*
     if (x >= dcols || y >= drows) return;
     const int tx = min(2 * x + 3, scols - 1);
     const int ty = min(2 * y + 3, srows - 1);
+    uint8_t tap[5][5];  // all taps in flight before the first use, see pyrdown_gauss_f_kernel
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx)
+            tap[dy][dx] = src[(size_t)min(max(2 * y - 2 + dy, 0), srows - 1) * s_stride + min(max(2 * x - 2 + dx, 0), scols - 1)];
+    __builtin_amdgcn_sched_barrier(0);
     float sum = 0;
     int count = 0;
 #pragma unroll
@@ -197,12 +211,11 @@ __global__ __launch_bounds__(256) void pyrdown_uchar_gauss_kernel(const uint8_t*
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx) {
             const int cx = 2 * x - 2 + dx;
-            const uint8_t s = src[(size_t)min(max(cy, 0), srows - 1) * s_stride + min(max(cx, 0), scols - 1)];
-            if (rowok && cx >= 0 && cx < tx && s > 0) {
-                const float w = wy * binom5(tx - cx - 1);
-                sum += s * w;
-                count = (int)((float)count + w);
-            }
+            const uint8_t s = tap[dy][dx];
+            const bool use = rowok && cx >= 0 && cx < tx && s > 0;
+            const float w = wy * binom5(tx - cx - 1);
+            sum = use ? sum + s * w : sum;
+            count = use ? (int)((float)count + w) : count;
         }
     }
     const float q = sum / (float)count;

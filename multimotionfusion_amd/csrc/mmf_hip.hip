@@ -337,6 +337,7 @@ static RgbResidualArgs make_residual_args(float min_scale, const int16_t* dIdx, 
     a.corres = corres;
     a.cols = cols;
     a.rows = rows;
+    a.cols_magic = (unsigned)((1ull << 32) / (unsigned)cols) + 1u;
     a.err_map = err_map;
     a.err_stride = stride_elems(err_step, cols, 4);
     a.intr = LevelIntr{0, 0, 0, 0};
@@ -348,7 +349,8 @@ static bool residual_vec4_ok(const RgbResidualArgs& a) {
     auto al = [](const void* p, uintptr_t n) { return ((uintptr_t)p & (n - 1)) == 0; };
     return a.cols % 4 == 0 && a.ni_stride % 4 == 0 && a.d_stride % 4 == 0 && a.nd_stride % 4 == 0 &&
            al(a.next_image, 4) && al(a.dIdx, 8) && al(a.dIdy, 8) && al(a.next_depth, 16) &&
-           (!a.err_map || (al(a.err_map, 16) && a.err_stride % 4 == 0));
+           (!a.err_map || (al(a.err_map, 16) && a.err_stride % 4 == 0)) && al(a.corres, 16) &&
+           (long long)a.cols * a.rows * a.cols < (1ll << 32);  // index / cols by multiply-high
 }
 
 extern "C" int mmf_compute_rgb_residual(mmf_ctx* c, float min_scale, const int16_t* dIdx, size_t dIdx_step,
@@ -1092,10 +1094,15 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
                 a.sobel_scale = o->sobel_scale;
                 a.cols = cols;
                 a.rows = rows;
+                a.cols_magic = ra.cols_magic;
                 a.intr = in;
                 const int grid = reduce_grid(cols * rows, kBlock * 4);  // width, height are multiples of 4
-                hipLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4>), dim3(grid), dim3(kBlock), 0, c->stream, o->state, a,
-                                   c->partials_f, c->ticket);
+                if (res_vec4)  // the 4-pixel correspondence pass wrote compact records
+                    hipLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, true>), dim3(grid), dim3(kBlock), 0, c->stream,
+                                       o->state, a, c->partials_f, c->ticket);
+                else
+                    hipLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, false>), dim3(grid), dim3(kBlock), 0, c->stream,
+                                       o->state, a, c->partials_f, c->ticket);
                 MMF_HIP_TRY(hipGetLastError());
             }
         }

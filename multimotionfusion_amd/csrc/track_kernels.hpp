@@ -210,8 +210,9 @@ struct RgbResidualArgs {
     int ld_stride, nd_stride;
     const uint8_t *last_image, *next_image;
     int li_stride, ni_stride;
-    mmf_dataterm* corres;  // dense
+    mmf_dataterm* corres;  // dense; holds CorresPk records inside the Gauss-Newton loop
     int cols, rows;
+    unsigned cols_magic;  // floor(2^32 / cols) + 1 (see IcpArgs)
     float* err_map;
     int err_stride;
     LevelIntr intr;
@@ -227,8 +228,8 @@ __device__ __forceinline__ void residual_publish(const OdomState* st, int2* __re
     if (threadIdx.x != 0) return;
     if (ACC) {
         unsigned* acc = const_cast<unsigned*>(st->res_acc) + 2 * (bid % kResShards);
-        __hip_atomic_fetch_add(acc, (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(acc + 1, (unsigned)sigma, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_add(acc, (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_add(acc + 1, (unsigned)sigma, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         partials[bid] = make_int2(count, sigma);
     }
@@ -294,42 +295,51 @@ __device__ __forceinline__ void residual_block(const OdomState* __restrict__ st,
     residual_publish<ACC>(st, partials, bid, sum[0], sum[1]);
 }
 
+// Compact correspondence record of the Gauss-Newton loop (8 bytes instead of the 16-byte DataTerm of
+// the stand-alone computeRgbResidual): `one` is the pixel's own position (implicit in the record index)
+// and diff is an integer in [-255, 255].  Halves the write traffic of this pass and the read traffic of
+// rgb_step_kernel.
+struct CorresPk {
+    int16_t zero_x, zero_y, diff, valid;
+};
+
+// bit 7 of every byte of the result is set iff that byte of w is non-zero
+__device__ __forceinline__ unsigned nonzero_bytes(unsigned w) {
+    return (((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u;
+}
+// the four byte flags (bit 7 of each byte) as bits 0..3
+__device__ __forceinline__ unsigned byte_flags_to_bits(unsigned m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
+
 // Four consecutive pixels of a row per lane: one 4-byte load of the intensities, one 8-byte load of
-// each gradient image, one 16-byte load of the depth, four 16-byte stores of the records; the
-// 4x4 "all neighbours > 0" windows of the four pixels are evaluated from three aligned 32-bit
-// words per image row (12 loads instead of 64).  Needs cols % 4 == 0 and 16-byte aligned rows.
-template <bool ACC>
+// each gradient image, one 16-byte load of the depth, 16-byte stores of the records; the 4x4 "all
+// neighbours > 0" windows of the four pixels are evaluated from three aligned 32-bit words per image
+// row (12 loads instead of 64) with byte-parallel bit arithmetic.  Needs cols % 4 == 0 and 16-byte
+// aligned rows.  GN: inside the Gauss-Newton loop (compact records, atomic totals, break flag).
+template <bool GN>
 __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st, const RgbResidualArgs& a,
                                                 int2* __restrict__ partials, GridReduceLds<int, kBlock>& lds,
                                                 unsigned bid, unsigned nblocks) {
     int sum[2] = {0, 0};
+    MMF_STAMP(8);
     const int cols = a.cols, rows = a.rows, N4 = (cols * rows) / 4;
     const float* K = st->krkinv;
     const float ktx = st->kt[0], kty = st->kt[1], ktz = st->kt[2];
-    const int level_break = ACC ? st->level_break : 0;  // consumed after the image loads are in flight
+    const int level_break = GN ? st->level_break : 0;  // consumed after the image loads are in flight
 
     for (int g = bid * kBlock + threadIdx.x; g < N4; g += nblocks * kBlock) {
         const int k0 = g * 4;
-        const int i = k0 / cols, j0 = k0 - i * cols;
-        // nonzero masks of columns j0-4 .. j0+7 (bit b <-> column j0-4+b) for rows i-2 .. i+1;
-        // columns / rows outside the image are skipped by the reference's loops => treated as set
-        unsigned ok = 0xFFFu;
+        const int i = (int)__umulhi((unsigned)k0, a.cols_magic), j0 = k0 - i * cols;
+        // twelve unconditional word loads from clamped addresses (conditions applied afterwards), so
+        // they and the four loads below are one round trip
+        unsigned ww[4][3];
+        const bool has_l = j0 >= 4, has_r = j0 + 4 < cols;
 #pragma unroll
         for (int dr = -2; dr <= 1; ++dr) {
-            const int u = i + dr;
-            if (u < 0 || u >= rows) continue;
+            const int u = min(max(i + dr, 0), rows - 1);
             const uint8_t* rowp = a.next_image + (size_t)u * a.ni_stride + j0;
-            unsigned m = 0;
-            const unsigned w1 = *reinterpret_cast<const unsigned*>(rowp);
-            const unsigned w0 = j0 >= 4 ? *reinterpret_cast<const unsigned*>(rowp - 4) : 0xFFFFFFFFu;
-            const unsigned w2 = j0 + 4 < cols ? *reinterpret_cast<const unsigned*>(rowp + 4) : 0xFFFFFFFFu;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                m |= ((w0 >> (8 * b)) & 0xFFu) ? (1u << b) : 0u;
-                m |= ((w1 >> (8 * b)) & 0xFFu) ? (1u << (4 + b)) : 0u;
-                m |= ((w2 >> (8 * b)) & 0xFFu) ? (1u << (8 + b)) : 0u;
-            }
-            ok &= m;
+            ww[dr + 2][1] = *reinterpret_cast<const unsigned*>(rowp);
+            ww[dr + 2][0] = *reinterpret_cast<const unsigned*>(rowp - (has_l ? 4 : 0));
+            ww[dr + 2][2] = *reinterpret_cast<const unsigned*>(rowp + (has_r ? 4 : 0));
         }
         const unsigned own = *reinterpret_cast<const unsigned*>(a.next_image + (size_t)i * a.ni_stride + j0);
         const short4 gx = *reinterpret_cast<const short4*>(a.dIdx + (size_t)i * a.d_stride + j0);
@@ -337,55 +347,108 @@ __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st
         const float4 dv = *reinterpret_cast<const float4*>(a.next_depth + (size_t)i * a.nd_stride + j0);
         __builtin_amdgcn_sched_barrier(0);
         if (level_break) return;  // wave-uniform; the state read overlapped the loads above
+        // nonzero masks of columns j0-4 .. j0+7 (bit b <-> column j0-4+b) ANDed over rows i-2 .. i+1;
+        // columns / rows outside the image are skipped by the reference's loops => treated as set
+        unsigned nz[3] = {0x80808080u, 0x80808080u, 0x80808080u};
+#pragma unroll
+        for (int dr = -2; dr <= 1; ++dr) {
+            const bool rowin = (i + dr) >= 0 && (i + dr) < rows;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) nz[k] &= rowin ? nonzero_bytes(ww[dr + 2][k]) : 0x80808080u;
+        }
+        const unsigned ok = (has_l ? byte_flags_to_bits(nz[0]) : 0xFu) | (byte_flags_to_bits(nz[1]) << 4) |
+                            ((has_r ? byte_flags_to_bits(nz[2]) : 0xFu) << 8);
+#ifdef MMF_STAMPS
+        if (dv.x == 1234.5f && gx.x == 77 && gy.y == 78 && own == 0x1234567u && ok == 77u) sum[0] += 1;
+        MMF_STAMP(9);
+#endif
         const int valxs[4] = {gx.x, gx.y, gx.z, gx.w}, valys[4] = {gy.x, gy.y, gy.z, gy.w};
         const float d1s[4] = {dv.x, dv.y, dv.z, dv.w};
-        float errs[4];
+        // The warps of the four pixels are evaluated first (under their `if`: only ~30 % of the pixels
+        // pass the gradient test, in clusters, so whole waves skip the divisions), with NO load inside
+        // the branches; then the eight gathers from the last frame are issued TOGETHER from clamped
+        // addresses and masked afterwards.  Nested `if`s around the gathers made them four dependent
+        // round trips -- the long pole of the producer launch at the coarse levels.
+        bool inb[4];
+        int u0s[4], v0s[4];
+        float td1s[4], d0s[4];
+        uint8_t lis[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int x = j0 + p, y = i;
-            mmf_dataterm c;
-            c.zero_x = c.zero_y = c.one_x = c.one_y = 0;
-            c.diff = 0.f;
-            c.valid = 0;
-            c.pad_[0] = c.pad_[1] = c.pad_[2] = 0;
-            int vx = 0, vy = 0;
             // window of pixel x: columns x-2 .. x+1 = bits p+2 .. p+5
             const bool valid = x < cols - 5 && y < rows - 1 && ((ok >> (p + 2)) & 0xFu) == 0xFu;
-            if (valid) {
-                const int valx = valxs[p], valy = valys[p];
-                const float mTwo = (float)((valx * valx) + (valy * valy));
-                const float d1 = d1s[p];
-                if (mTwo >= a.min_scale && !(d1 != d1)) {
-                    const float td1 = (float)(d1 * (K[6] * x + K[7] * y + K[8]) + ktz);
-                    const int u0 = float2int_rn((d1 * (K[0] * x + K[1] * y + K[2]) + ktx) / td1);
-                    const int v0 = float2int_rn((d1 * (K[3] * x + K[4] * y + K[5]) + kty) / td1);
-                    if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
-                        const float d0 = a.last_depth[(size_t)v0 * a.ld_stride + u0];
-                        const uint8_t li = a.last_image[(size_t)v0 * a.li_stride + u0];
-                        if (d0 > 0 && fabsf(td1 - d0) <= a.max_depth_delta && li != 0) {
-                            c.zero_x = (int16_t)u0;
-                            c.zero_y = (int16_t)v0;
-                            c.one_x = (int16_t)x;
-                            c.one_y = (int16_t)y;
-                            c.diff = (float)((own >> (8 * p)) & 0xFFu) - (float)li;
-                            c.valid = 1;
-                            vx = 1;
-                            vy = (int)(c.diff * c.diff);
-                        }
-                    }
-                }
+            const int valx = valxs[p], valy = valys[p];
+            const float mTwo = (float)((valx * valx) + (valy * valy));
+            const float d1 = d1s[p];
+            inb[p] = false;
+            u0s[p] = v0s[p] = 0;
+            td1s[p] = 0.f;
+            if (valid && mTwo >= a.min_scale && !(d1 != d1)) {
+                td1s[p] = (float)(d1 * (K[6] * x + K[7] * y + K[8]) + ktz);
+                u0s[p] = float2int_rn((d1 * (K[0] * x + K[1] * y + K[2]) + ktx) / td1s[p]);
+                v0s[p] = float2int_rn((d1 * (K[3] * x + K[4] * y + K[5]) + kty) / td1s[p]);
+                inb[p] = u0s[p] >= 0 && v0s[p] >= 0 && u0s[p] < cols && v0s[p] < rows;
             }
-            errs[p] = c.valid ? 0.001f * vy : 0.0f;
-            *reinterpret_cast<int4*>(&a.corres[k0 + p]) = *reinterpret_cast<const int4*>(&c);
-            sum[0] += vx;
+        }
+#ifdef MMF_STAMPS
+        if (u0s[0] == -12345 && v0s[3] == -4) sum[0] += 1;
+        MMF_STAMP(10);
+#endif
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int gu = inb[p] ? u0s[p] : 0, gv = inb[p] ? v0s[p] : 0;
+            d0s[p] = a.last_depth[(size_t)gv * a.ld_stride + gu];
+            lis[p] = a.last_image[(size_t)gv * a.li_stride + gu];
+        }
+#ifdef MMF_STAMPS
+        if (d0s[0] == 1234.5f && lis[3] == 7 && d0s[3] == 3.f && lis[0] == 9) sum[0] += 1;
+        MMF_STAMP(11);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        float errs[4];
+        CorresPk pk[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int x = j0 + p, y = i;
+            const float d0 = d0s[p];
+            const uint8_t li = lis[p];
+            const bool hit = inb[p] && d0 > 0 && fabsf(td1s[p] - d0) <= a.max_depth_delta && li != 0;
+            const int idiff = (int)((own >> (8 * p)) & 0xFFu) - (int)li;  // == (float)next - (float)last, exactly
+            const int vy = hit ? idiff * idiff : 0;                        // == (int)(diff * diff)
+            errs[p] = hit ? 0.001f * vy : 0.0f;
+            sum[0] += hit ? 1 : 0;
             sum[1] += vy;
+            if (GN) {
+                pk[p].zero_x = hit ? (int16_t)u0s[p] : (int16_t)0;
+                pk[p].zero_y = hit ? (int16_t)v0s[p] : (int16_t)0;
+                pk[p].diff = hit ? (int16_t)idiff : (int16_t)0;
+                pk[p].valid = hit ? (int16_t)1 : (int16_t)0;
+            } else {
+                mmf_dataterm c;
+                c.zero_x = hit ? (int16_t)u0s[p] : (int16_t)0;
+                c.zero_y = hit ? (int16_t)v0s[p] : (int16_t)0;
+                c.one_x = hit ? (int16_t)x : (int16_t)0;
+                c.one_y = hit ? (int16_t)y : (int16_t)0;
+                c.diff = hit ? (float)idiff : 0.f;
+                c.valid = hit ? 1 : 0;
+                c.pad_[0] = c.pad_[1] = c.pad_[2] = 0;
+                *reinterpret_cast<int4*>(&a.corres[k0 + p]) = *reinterpret_cast<const int4*>(&c);
+            }
+        }
+        if (GN) {  // 4 x 8 bytes = two 16-byte stores
+            int4* dst = reinterpret_cast<int4*>(reinterpret_cast<CorresPk*>(a.corres) + k0);
+            dst[0] = *reinterpret_cast<const int4*>(&pk[0]);
+            dst[1] = *reinterpret_cast<const int4*>(&pk[2]);
         }
         if (a.err_map)
             *reinterpret_cast<float4*>(a.err_map + (size_t)i * a.err_stride + j0) = make_float4(errs[0], errs[1], errs[2], errs[3]);
     }
 
+    MMF_STAMP(12);
     block_sum2<kBlock>(sum[0], sum[1], lds);
-    residual_publish<ACC>(st, partials, bid, sum[0], sum[1]);
+    residual_publish<GN>(st, partials, bid, sum[0], sum[1]);
+    MMF_STAMP(13);
 }
 
 template <int MODE, int PX>
@@ -461,6 +524,7 @@ struct RgbStepArgs {
     int d_stride;
     float sobel_scale;
     int cols, rows;
+    unsigned cols_magic;  // floor(2^32 / cols) + 1
     LevelIntr intr;
 };
 
@@ -474,11 +538,26 @@ struct RgbLane {
     float X[PX], Y[PX], Z[PX];
     int gx[PX], gy[PX];
 };
-template <int PX>
-__device__ __forceinline__ void rgb_gather(const RgbStepArgs& a, const int4 (&raws)[PX], RgbLane<PX>& l) {
+// COMPACT: the lane's PX records are CorresPk (8 bytes, PX / 2 loads); i0 = index of its first record
+template <int PX, bool COMPACT>
+__device__ __forceinline__ void rgb_gather(const RgbStepArgs& a, const int4 (&raws)[COMPACT ? PX / 2 : PX], int i0,
+                                           RgbLane<PX>& l) {
+    int y0 = 0, x0 = 0;
+    if (COMPACT) {
+        y0 = (int)__umulhi((unsigned)i0, a.cols_magic);
+        x0 = i0 - y0 * a.cols;
+    }
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
-        *reinterpret_cast<int4*>(&l.c[p]) = raws[p];
+        if (COMPACT) {
+            const CorresPk pk = reinterpret_cast<const CorresPk*>(raws)[p];
+            l.c[p].zero_x = pk.zero_x, l.c[p].zero_y = pk.zero_y;
+            l.c[p].one_x = (int16_t)(pk.valid ? x0 + p : 0), l.c[p].one_y = (int16_t)(pk.valid ? y0 : 0);
+            l.c[p].diff = (float)pk.diff;
+            l.c[p].valid = (unsigned char)pk.valid;
+        } else {
+            *reinterpret_cast<int4*>(&l.c[p]) = raws[p];
+        }
         const float* cp = a.cloud + (size_t)(l.c[p].zero_y * a.cols + l.c[p].zero_x) * 3;
         l.X[p] = cp[0], l.Y[p] = cp[1], l.Z[p] = cp[2];
         l.gx[p] = a.dIdx[(size_t)l.c[p].one_y * a.d_stride + l.c[p].one_x];
@@ -516,7 +595,7 @@ __device__ __forceinline__ void rgb_rows(const RgbStepArgs& a, float sigma, bool
 // record loads.  Neither the records nor the gathers depend on the state, so the kernel issues the
 // record loads, then the (scalar) state loads, then the gathers, and only then consumes the state
 // (break flags, sigma): three round trips overlap instead of queueing.
-template <int MODE, int PX>
+template <int MODE, int PX, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict__ st, RgbStepArgs a,
                                                           float* __restrict__ partials,
                                                           unsigned* __restrict__ ticket) {
@@ -525,9 +604,13 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     const int N = a.cols * a.rows;
     int i0 = (blockIdx.x * kBlock + threadIdx.x) * PX;
     const bool live = i0 < N;
-    int4 raws[PX];
+    static_assert(!COMPACT || PX % 2 == 0, "compact records are loaded in pairs");
+    constexpr int NQ = COMPACT ? PX / 2 : PX;          // 16-byte loads per lane
+    constexpr int REC = COMPACT ? (int)sizeof(CorresPk) : (int)sizeof(mmf_dataterm);
+    const char* recs = reinterpret_cast<const char*>(a.corres);
+    int4 raws[NQ];
 #pragma unroll
-    for (int p = 0; p < PX; ++p) raws[p] = *reinterpret_cast<const int4*>(&a.corres[(live ? i0 : 0) + p]);
+    for (int q = 0; q < NQ; ++q) raws[q] = reinterpret_cast<const int4*>(recs + (size_t)(live ? i0 : 0) * REC)[q];
     __builtin_amdgcn_sched_barrier(0);
     // state reads (wave-uniform scalar loads), not consumed before the gathers are in flight
     float sigma = st->sigmaVal;
@@ -542,7 +625,7 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     }
     __builtin_amdgcn_sched_barrier(0);
     RgbLane<PX> lane;
-    rgb_gather<PX>(a, raws, lane);
+    rgb_gather<PX, COMPACT>(a, raws, live ? i0 : 0, lane);
     __builtin_amdgcn_sched_barrier(0);
 
     int res_count = 0, res_sigma = 0;
@@ -571,8 +654,8 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     // images beyond the grid's single pass
     for (i0 += gridDim.x * kBlock * PX; i0 < N; i0 += gridDim.x * kBlock * PX) {
 #pragma unroll
-        for (int p = 0; p < PX; ++p) raws[p] = *reinterpret_cast<const int4*>(&a.corres[i0 + p]);
-        rgb_gather<PX>(a, raws, lane);
+        for (int q = 0; q < NQ; ++q) raws[q] = reinterpret_cast<const int4*>(recs + (size_t)i0 * REC)[q];
+        rgb_gather<PX, COMPACT>(a, raws, i0, lane);
         rgb_rows<PX>(a, sigma, true, lane, sum);
     }
 
