@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "map_kernels.hpp"
 #include "track_kernels.hpp"
@@ -1268,6 +1269,7 @@ struct mmf_model {
     float4 *vertexConf = nullptr, *normalRadius = nullptr;
     unsigned short* time_tex = nullptr;
     float* synth_depth = nullptr;  // ModelProjection::synthesizeDepth target (depthTexture, R32F)
+    void* export_rm = nullptr;     // row-major copies of the (transposed) index-map images for mmf_model_texture
     // fill-in (Shaders/FillIn.cpp)
     float4 *fill_vertex = nullptr, *fill_normal = nullptr;
     uchar4* fill_image = nullptr;
@@ -1355,7 +1357,7 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
                  o_pb = carve(npix * 4), o_bs = carve(((cap + npix) / kScanTile + 2) * 4), o_tot = carve(64),
                  o_win = carve(cap * 4), o_ct = carve((cap + npix) * 8), o_keys = carve(npix * 8),
                  o_idx = carve(npix * 4), o_vc = carve(npix * 16), o_ctm = carve(npix * 16), o_nr = carve(npix * 16),
-                 o_img = carve(npix * 4), o_vxc = carve(npix * 16), o_nrr = carve(npix * 16), o_tt = carve(npix * 2), o_sd = carve(npix * 4),
+                 o_img = carve(npix * 4), o_vxc = carve(npix * 16), o_nrr = carve(npix * 16), o_tt = carve(npix * 2), o_sd = carve(npix * 4), o_ex = carve(npix * 52),
                  o_fv = carve(npix * 16), o_fn = carve(npix * 16), o_fi = carve(npix * 4);
     m->slab_bytes = off;
     hipError_t e = hipMalloc(&m->slab, m->slab_bytes);
@@ -1379,6 +1381,7 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     m->image = (uchar4*)(b + o_img), m->vertexConf = (float4*)(b + o_vxc), m->normalRadius = (float4*)(b + o_nrr);
     m->time_tex = (unsigned short*)(b + o_tt);
     m->synth_depth = (float*)(b + o_sd);
+    m->export_rm = (void*)(b + o_ex);
     m->fill_vertex = (float4*)(b + o_fv), m->fill_normal = (float4*)(b + o_fn), m->fill_image = (uchar4*)(b + o_fi);
     hipLaunchKernelGGL(fill_u32_kernel, grid1d(cap), dim3(256), 0, c->stream, m->winner, cap, kNoWinner);
     MMF_HIP_TRY(hipGetLastError());
@@ -1671,10 +1674,18 @@ extern "C" int mmf_model_texture(mmf_model* m, const char* name, void** dev_ptr,
     const std::string s(name);
     void* p = nullptr;
     size_t b = 0;
-    if (s == "index") p = m->index, b = npix * 4;
-    else if (s == "vertConf") p = m->vertConf, b = npix * 16;
-    else if (s == "colorTime") p = m->colorTime, b = npix * 16;
-    else if (s == "normRad") p = m->normRad, b = npix * 16;
+    // the index map lives transposed in HBM (index_map_kernel); the getters hand out a row-major copy
+    // made on the model's stream
+    auto exported = [&](auto* src, size_t off) {
+        using T = typename std::remove_pointer<decltype(src)>::type;
+        T* dst = reinterpret_cast<T*>(reinterpret_cast<char*>(m->export_rm) + off);
+        hipLaunchKernelGGL((untranspose_kernel<T>), grid1d(npix), dim3(256), 0, m->ctx->stream, src, m->width, m->height, dst);
+        return (void*)dst;
+    };
+    if (s == "index") p = exported(m->index, 0), b = npix * 4;
+    else if (s == "vertConf") p = exported(m->vertConf, npix * 4), b = npix * 16;
+    else if (s == "colorTime") p = exported(m->colorTime, npix * 20), b = npix * 16;
+    else if (s == "normRad") p = exported(m->normRad, npix * 36), b = npix * 16;
     else if (s == "image") p = m->image, b = npix * 4;
     else if (s == "vertexConf") p = m->vertexConf, b = npix * 16;
     else if (s == "normalRadius") p = m->normalRadius, b = npix * 16;

@@ -294,9 +294,15 @@ __global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, 
     const int px = (int)floorf(xw), py = (int)floorf(yw);
     if (px < 0 || py < 0 || px >= a.cols || py >= a.rows) return;
     const unsigned long long k = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | (unsigned)id;
-    atomicMin(&keys[py * a.cols + px], k);
+    // the index map and its key image are stored TRANSPOSED (pixel (x, y) at x * rows + y): surfels are
+    // kept in the reference's draw order, which is column-major over the image, so neighbouring lanes
+    // hit neighbouring addresses here, in index_resolve_kernel's surfel gathers, and in the window
+    // look-ups of fuse_data_kernel / clean_flag_kernel (row-major storage made each of those a
+    // one-cache-line-per-lane access: 47 us for clean_flag_kernel at 640x480)
+    atomicMin(&keys[px * a.rows + py], k);
 }
 
+// linear over the transposed images (it never needs a pixel's coordinates)
 __global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexArgs a,
                                                             const unsigned long long* __restrict__ keys,
                                                             unsigned* __restrict__ index, float4* __restrict__ vertConf,
@@ -317,6 +323,15 @@ __global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexAr
     vertConf[i] = make_float4(h.x, h.y, h.z, p.w);
     colorTime[i] = s.col[id];
     normRad[i] = make_float4(nn.x, nn.y, nn.z, n.w);
+}
+
+// transposed (x * rows + y) -> row-major copy of an index-map image, for the texture getters
+template <typename T>
+__global__ __launch_bounds__(256) void untranspose_kernel(const T* __restrict__ src, int cols, int rows, T* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cols * rows) return;
+    const int y = i / cols, x = i - y * cols;
+    dst[i] = src[(size_t)x * rows + y];
 }
 
 // ---- splat prediction ----------------------------------------------------------------------------
@@ -476,9 +491,11 @@ __global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restric
     const Cam& c = a.c;
     const float tx = uv_coord(i, cols), ty = uv_coord(j, rows);
     const float x = tx * cols, y = ty * rows;
-    const v3 vPosLocal = get_vertex(depth_raw, cols, rows, tx, ty, x, y, c);
     new_flags[d] = 0u;
     const int tm = ((int)(float)a.time) % 2;
+    // the quarter-rate test of data.vert:116 first: it needs no memory, and three of four threads leave here
+    if (!(((int)x) % 2 == tm && ((int)y) % 2 == tm)) return;
+    const v3 vPosLocal = get_vertex(depth_raw, cols, rows, tx, ty, x, y, c);
     const int pxi = texel(tx, cols), pyi = texel(ty, rows);
     const float zl = depth_raw[pyi * cols + texel(tx - (1.0f / cols), cols)];
     const float zu = depth_raw[texel(ty - (1.0f / rows), rows) * cols + pxi];
@@ -504,18 +521,59 @@ __global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restric
     const float xl = (x - c.cx) * c.ifx, yl = (y - c.cy) * c.ify;
     const float lambda = sqrtf(xl * xl + yl * yl + 1);
     const v3 ray = V3(xl, yl, 1);
-    for (float ii = tx - (scale * indexXStep * windowMultiplier); ii < tx + (scale * indexXStep * windowMultiplier);
-         ii += indexXStep)
-        for (float jj = ty - (scale * indexYStep * windowMultiplier); jj < ty + (scale * indexYStep * windowMultiplier);
-             jj += indexYStep) {
-            const size_t t = (size_t)texel(jj, rows) * cols + texel(ii, cols);
-            const unsigned current = index[t];
-            if (current > 0U) {
-                const float4 vc = vertConf[t];
+    // The shader walks the window with float loop counters (data.vert:138-163).  The counters are
+    // reproduced exactly (same sequence of float additions) but only to find WHICH texels they visit:
+    // the 4-5 half-pixel steps per axis touch the texels c0, c0+1, c0+2, so the window is read as <= 3x3
+    // distinct texels -- all loads independent, one round trip -- and evaluated in the order of first
+    // visit (x outer, y inner).  Revisiting a texel never changes the result (`dist < bestDist` is strict).
+    int cx0, cy0;
+    bool hitx[3] = {false, false, false}, hity[3] = {false, false, false};
+    {
+        const float endx = tx + (scale * indexXStep * windowMultiplier);
+        float ii = tx - (scale * indexXStep * windowMultiplier);
+        cx0 = texel(ii, cols);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (ii < endx) {
+                const int t = texel(ii, cols) - cx0;
+                hitx[0] |= t == 0, hitx[1] |= t == 1, hitx[2] |= t == 2;
+            }
+            ii += indexXStep;
+        }
+        const float endy = ty + (scale * indexYStep * windowMultiplier);
+        float jj = ty - (scale * indexYStep * windowMultiplier);
+        cy0 = texel(jj, rows);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (jj < endy) {
+                const int t = texel(jj, rows) - cy0;
+                hity[0] |= t == 0, hity[1] |= t == 1, hity[2] |= t == 2;
+            }
+            jj += indexYStep;
+        }
+    }
+    unsigned cur[9];
+    float4 vcs[9], nrs[9];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const size_t t = (size_t)min(cx0 + dx, cols - 1) * rows + min(cy0 + dy, rows - 1);  // transposed index map
+            cur[dx * 3 + dy] = index[t];
+            vcs[dx * 3 + dy] = vertConf[t];
+            nrs[dx * 3 + dy] = normRad[t];
+        }
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const unsigned current = cur[dx * 3 + dy];
+            if (hitx[dx] && hity[dy] && current > 0U) {
+                const float4 vc = vcs[dx * 3 + dy];
                 const float zdiff = (vc.z - vPosLocal.z);
                 if (fabsf(zdiff * lambda) < 0.05f) {
                     const float dist = v3length(v3cross(ray, V3(vc.x, vc.y, vc.z)));
-                    const float4 nr = normRad[t];
+                    const float4 nr = nrs[dx * 3 + dy];
                     const v3 nrv = V3(nr.x, nr.y, nr.z);
                     const float cosang = v3dot(nrv, nl) / (v3length(nrv) * v3length(nl));
                     if (dist < bestDist && (fabsf(nr.z) < 0.75f || (cosang > 0.87758255f && cosang <= 1.0f))) {
@@ -657,7 +715,7 @@ __global__ __launch_bounds__(256) void clean_flag_kernel(SurfelSoA s, SurfelSoA 
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int e2 = 0; e2 < 3; ++e2) {
-                const size_t t = (size_t)min(cy0 + e2, rows - 1) * cols + min(cx0 + d, cols - 1);
+                const size_t t = (size_t)min(cx0 + d, cols - 1) * rows + min(cy0 + e2, rows - 1);  // transposed
                 cur[d * 3 + e2] = index[t];
                 vcs[d * 3 + e2] = vertConf[t];
                 cts[d * 3 + e2] = colorTime[t];
