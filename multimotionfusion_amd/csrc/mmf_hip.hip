@@ -710,6 +710,13 @@ struct mmf_odom {
     OdomState* state = nullptr;  // device
     OdomState* host_result = nullptr;  // pinned
     bool have_tmp = false;  // vmaps_tmp filled by an initICP* call (ordering contract)
+    // The reference COPIES its inputs at each init* call (RGBDOdometry.cpp:125,130; Model.cpp:359-388).
+    // An owner that guarantees the images stay untouched until getIncrementalTransformation returns
+    // (the native orchestrator: they live in its model / frame slabs) sets alias_inputs, and the three
+    // device-to-device copies per frame (2 x 4.9 MB + 1.2 MB at 640x480) become pointer assignments.
+    bool alias_inputs = false;
+    const float *vtmp = nullptr, *ntmp = nullptr;  // what populateRGBDData / copyMaps read: own copy or alias
+    const float* depth_l0 = nullptr;               // level 0 of the depth pyramid: own copy or alias
     mmf_odom_stats stats;
 };
 
@@ -813,10 +820,15 @@ extern "C" int mmf_odom_build_depth_pyramid(mmf_odom* o, const float* depth_l0, 
     mmf_ctx* c = o->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     const size_t s = step ? step : (size_t)o->width * 4;
-    MMF_HIP_TRY(hipMemcpy2DAsync(o->depth_pyr[0], (size_t)o->width * 4, depth_l0, s, (size_t)o->width * 4, o->height,
-                                 hipMemcpyDeviceToDevice, c->stream));
+    if (o->alias_inputs && s == (size_t)o->width * 4) {
+        o->depth_l0 = depth_l0;
+    } else {
+        MMF_HIP_TRY(hipMemcpy2DAsync(o->depth_pyr[0], (size_t)o->width * 4, depth_l0, s, (size_t)o->width * 4, o->height,
+                                     hipMemcpyDeviceToDevice, c->stream));
+        o->depth_l0 = o->depth_pyr[0];
+    }
     for (int i = 1; i < MMF_NUM_PYRS; ++i) {  // Model.cpp:378-382
-        int rc = launch_pyrdown_f(c, o->depth_pyr[i - 1], o->width >> (i - 1), o->width >> (i - 1),
+        int rc = launch_pyrdown_f(c, i == 1 ? o->depth_l0 : o->depth_pyr[i - 1], o->width >> (i - 1), o->width >> (i - 1),
                                   o->height >> (i - 1), o->depth_pyr[i], o->width >> i);
         if (rc) return rc;
     }
@@ -830,7 +842,7 @@ extern "C" int mmf_odom_init_icp(mmf_odom* o, const float* const depth_pyr[MMF_N
     MMF_HIP_TRY(hipSetDevice(c->device));
     for (int i = 0; i < MMF_NUM_PYRS; ++i) {  // RGBDOdometry.cpp:112-115
         const int cols = o->width >> i, rows = o->height >> i;
-        const float* d = depth_pyr ? depth_pyr[i] : o->depth_pyr[i];
+        const float* d = depth_pyr ? depth_pyr[i] : (i == 0 && o->depth_l0 ? o->depth_l0 : o->depth_pyr[i]);
         MMF_REQUIRE(d != nullptr, "mmf_odom_init_icp: null pyramid level");
         const int ds = (depth_pyr && steps && steps[i]) ? (int)(steps[i] / 4) : cols;
         int rc = launch_create_vmap(c, level_intr(o->fx, o->fy, o->cx, o->cy, i), d, ds, cols, rows, o->vmaps_curr[i],
@@ -848,10 +860,15 @@ static int odom_take_prediction(mmf_odom* o, const float* vert_rgba, const float
     const size_t bytes = (size_t)4 * o->width * o->height * sizeof(float);
     // the reference copies both textures into vmaps_tmp / nmaps_tmp (RGBDOdometry.cpp:125,130);
     // vmaps_tmp is read again by initRGB*/populateRGBDData (:179)
-    MMF_HIP_TRY(hipMemcpyAsync(o->vmaps_tmp, vert_rgba, bytes, hipMemcpyDeviceToDevice, c->stream));
-    MMF_HIP_TRY(hipMemcpyAsync(o->nmaps_tmp, norm_rgba, bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (o->alias_inputs) {
+        o->vtmp = vert_rgba, o->ntmp = norm_rgba;
+    } else {
+        MMF_HIP_TRY(hipMemcpyAsync(o->vmaps_tmp, vert_rgba, bytes, hipMemcpyDeviceToDevice, c->stream));
+        MMF_HIP_TRY(hipMemcpyAsync(o->nmaps_tmp, norm_rgba, bytes, hipMemcpyDeviceToDevice, c->stream));
+        o->vtmp = o->vmaps_tmp, o->ntmp = o->nmaps_tmp;
+    }
     o->have_tmp = true;
-    int rc = launch_copy_maps(c, o->vmaps_tmp, o->nmaps_tmp, o->width, o->height, vdst[0], ndst[0], o->width);
+    int rc = launch_copy_maps(c, o->vtmp, o->ntmp, o->width, o->height, vdst[0], ndst[0], o->width);
     if (rc) return rc;
     for (int i = 1; i < MMF_NUM_PYRS; ++i) {
         rc = launch_resize<false>(c, vdst[i - 1], o->width >> (i - 1), o->width >> (i - 1), o->height >> (i - 1),
@@ -901,7 +918,7 @@ static int odom_populate_rgbd(mmf_odom* o, const uint8_t* rgb, size_t step, int 
     if (!o->have_tmp)
         return fail(MMF_ERR_STATE, "initRGB*/initRGBModel needs a preceding initICPModel / initICP(prediction): "
                                    "it reads vmaps_tmp (RGBDOdometry.cpp:197,202)");
-    int rc = launch_vertices_to_depth(c, o->vmaps_tmp, o->width, o->height, o->max_depth_rgb, depths[0], o->width);
+    int rc = launch_vertices_to_depth(c, o->vtmp, o->width, o->height, o->max_depth_rgb, depths[0], o->width);
     if (rc) return rc;
     for (int i = 0; i + 1 < MMF_NUM_PYRS; ++i) {
         rc = launch_pyrdown_f(c, depths[i], o->width >> i, o->width >> i, o->height >> i, depths[i + 1],
@@ -1420,8 +1437,12 @@ extern "C" int mmf_model_count(mmf_model* m, unsigned* count) {
 extern "C" int mmf_filter_depth(mmf_ctx* c, const float* depth, int cols, int rows, float max_depth, float* out) {
     MMF_REQUIRE(c && depth && out && cols > 0 && rows > 0, "mmf_filter_depth: bad argument");
     MMF_HIP_TRY(hipSetDevice(c->device));
-    hipLaunchKernelGGL(bilateral_filter_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, depth, cols, rows,
-                       max_depth, out);
+    if (cols % 2 == 0 && ((uintptr_t)depth & 7u) == 0 && ((uintptr_t)out & 7u) == 0)  // two pixels per lane
+        hipLaunchKernelGGL(bilateral_filter2_kernel, tile_grid(cols / 2, rows), tile_block(), 0, c->stream, depth, cols,
+                           rows, max_depth, out);
+    else
+        hipLaunchKernelGGL(bilateral_filter_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, depth, cols, rows,
+                           max_depth, out);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }
@@ -1766,6 +1787,9 @@ extern "C" int mmf_fusion_create(mmf_ctx* c, int width, int height, float cx, fl
         delete f;
         return rc;
     }
+    // the prediction images (model slab) and the filtered depth (this object's buffer) are not written
+    // between the init* calls of a frame and the end of its tracking
+    f->odom->alias_inputs = true;
     const size_t npix = (size_t)width * height;
     MMF_HIP_TRY(hipMalloc(&f->depth_filtered, npix * 4));
     MMF_HIP_TRY(hipMalloc(&f->mask, npix));

@@ -159,6 +159,122 @@ __global__ __launch_bounds__(256) void bilateral_filter_kernel(const float* __re
     out[y * cols + x] = sum1 / sum2;
 }
 
+// Two horizontally adjacent pixels per lane in packed registers (v_pk_mul_f32 / v_pk_add_f32 work on a
+// float pair at full rate): the filter is pure instruction issue -- 169 taps x ~50 instructions per
+// pixel, 64 us at 640x480 -- so packing the exponential's polynomial halves it.  Bit-identical to the
+// kernel above: the same float operations in the same order per pixel, with two exact rewrites of
+// mmf_expf for its argument range here (x <= 0 or NaN):
+//   * the `x > 88.7` overflow test can never fire;
+//   * (p * 2^(n/2)) * 2^(n - n/2) == ldexpf(p, n): the first product is exact (p in [0.5, 2],
+//     n/2 >= -75), so both forms round the exact value p * 2^n once, also into the subnormals.
+// Waves whose 13-column windows lie inside the image (all but the first / last workgroup of a row)
+// take the INTERIOR instantiation without the per-tap column tests.
+typedef float v2fs __attribute__((ext_vector_type(2)));
+
+// NT independent arguments at once, written stage by stage: the polynomial is one long dependent chain
+// per argument, and with ~2 waves per SIMD a chain-by-chain order leaves the VALU waiting on its own
+// results; stage-major order puts NT independent instructions between dependent ones.
+template <int NT>
+__device__ __forceinline__ void expf_nonpositive2(const v2fs (&x)[NT], v2fs (&e)[NT]) {
+    v2fs n[NT], r[NT], p[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) n[k] = x[k] * 1.44269504088896341f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) n[k] = v2fs{rintf(n[k].x), rintf(n[k].y)};
+#pragma unroll
+    for (int k = 0; k < NT; ++k) r[k] = x[k] - n[k] * 0.693359375f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) r[k] = r[k] - n[k] * -2.12194440e-4f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) p[k] = v2fs{1.9875691500e-4f, 1.9875691500e-4f} * r[k] + 1.3981999507e-3f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) p[k] = p[k] * r[k] + 8.3334519073e-3f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) p[k] = p[k] * r[k] + 4.1665795894e-2f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) p[k] = p[k] * r[k] + 1.6666665459e-1f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) p[k] = p[k] * r[k] + 5.0000001201e-1f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) p[k] = p[k] * (r[k] * r[k]) + r[k] + 1.0f;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        e[k] = v2fs{ldexpf(p[k].x, (int)n[k].x), ldexpf(p[k].y, (int)n[k].y)};
+        e[k].x = x[k].x < -103.0f ? 0.0f : e[k].x;
+        e[k].y = x[k].y < -103.0f ? 0.0f : e[k].y;
+    }  // a NaN argument has propagated through the arithmetic to a NaN result, as in mmf_expf
+}
+
+template <bool INTERIOR>
+__device__ __forceinline__ void bilateral_filter2_body(const float* __restrict__ depth, int cols, int rows, float maxD,
+                                                       float* __restrict__ out, int x0, int y) {
+    const float sigma_space2_inv_half = 0.024691358f, sigma_color2_inv_half = 555.556f;
+    const int R = 6, D = R * 2 + 1;
+    const float2 vv = *reinterpret_cast<const float2*>(depth + (size_t)y * cols + x0);
+    const v2fs value = v2fs{vv.x, vv.y};
+    const bool skip0 = vv.x > maxD || vv.x < 0.3f, skip1 = vv.y > maxD || vv.y < 0.3f;
+    if (skip0 && skip1) {
+        *reinterpret_cast<float2*>(out + (size_t)y * cols + x0) = make_float2(0.f, 0.f);
+        return;
+    }
+    v2fs sum1 = v2fs{0.f, 0.f}, sum2 = v2fs{0.f, 0.f};
+    // software pipelined over the 13 rows: the taps of row dy + 1 are loaded (from a clamped row, so
+    // unconditionally) before the ~600 instructions of row dy, whose latency they then hide behind
+    float taps[D + 1], next[D + 1];  // columns x0 - R .. x0 + R + 1
+    {
+        const float* rowp = depth + (size_t)min(max(y - R, 0), rows - 1) * cols;
+#pragma unroll
+        for (int k = 0; k < D + 1; ++k) next[k] = rowp[INTERIOR ? x0 + k - R : min(max(x0 + k - R, 0), cols - 1)];
+    }
+    for (int dy = -R; dy <= R; ++dy) {
+        const int cy = y + dy;
+#pragma unroll
+        for (int k = 0; k < D + 1; ++k) taps[k] = next[k];
+        if (dy < R) {
+            const float* rowp = depth + (size_t)min(max(cy + 1, 0), rows - 1) * cols;
+#pragma unroll
+            for (int k = 0; k < D + 1; ++k) next[k] = rowp[INTERIOR ? x0 + k - R : min(max(x0 + k - R, 0), cols - 1)];
+        }
+        if (cy < 0 || cy >= rows) continue;  // wave-uniform except at the image border rows
+        const float dy2 = (float)(dy * dy);
+        v2fs arg[D], wgt[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const v2fs tmp = v2fs{taps[k], taps[k + 1]};
+            const float space2 = (float)((k - R) * (k - R)) + dy2;
+            const v2fs dv = value - tmp;
+            const v2fs color2 = dv * dv;
+            arg[k] = -(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half);
+        }
+        expf_nonpositive2<D>(arg, wgt);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {  // the sums keep the shader's tap order
+            const int cx = x0 + k - R;  // tap column of the first pixel; the second pixel's is cx + 1
+            const v2fs tmp = v2fs{taps[k], taps[k + 1]};
+            const v2fs weight = wgt[k];
+            const v2fs tw = tmp * weight;
+            const bool in0 = INTERIOR || (cx >= 0 && cx < cols), in1 = INTERIOR || (cx + 1 >= 0 && cx + 1 < cols);
+            sum1.x = in0 ? sum1.x + tw.x : sum1.x;
+            sum2.x = in0 ? sum2.x + weight.x : sum2.x;
+            sum1.y = in1 ? sum1.y + tw.y : sum1.y;
+            sum2.y = in1 ? sum2.y + weight.y : sum2.y;
+        }
+    }
+    *reinterpret_cast<float2*>(out + (size_t)y * cols + x0) =
+        make_float2(skip0 ? 0.f : sum1.x / sum2.x, skip1 ? 0.f : sum1.y / sum2.y);
+}
+
+__global__ __launch_bounds__(256) void bilateral_filter2_kernel(const float* __restrict__ depth, int cols, int rows,
+                                                                float maxD, float* __restrict__ out) {
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 2, y = blockIdx.y * 4 + threadIdx.y;  // cols is even
+    if (x0 >= cols || y >= rows) return;
+    const int bx0 = blockIdx.x * 128;  // the workgroup's column range decides, so the choice is wave uniform
+    if (bx0 - 6 >= 0 && bx0 + 127 + 7 < cols)
+        bilateral_filter2_body<true>(depth, cols, rows, maxD, out, x0, y);
+    else
+        bilateral_filter2_body<false>(depth, cols, rows, maxD, out, x0, y);
+}
+
 // ---- exclusive scan of uint32 flags (3 launches; 1024 elements per workgroup) -------------------
 constexpr int kScanBlock = 256, kScanPer = 4, kScanTile = kScanBlock * kScanPer;
 
