@@ -172,12 +172,14 @@ def main():
         us = odom.timeIcpKernel(0, args.roofline_reps)
         achieved = icp_step_bytes(n0) / (us * 1e-6) / 1e9
         # traffic: memory-side bytes per level-0 launch from the separate rocprofv3 --pmc passes kept in
-        # profiles/r01_pmc_icp_{fetch,write}_size.csv: FETCH_SIZE 7877.25 KiB (doubled: gfx950 counts a
-        # 16-B-per-lane stream at half its bytes; the 4-B gathers are uncalibrated, so this is an upper
-        # bound) + WRITE_SIZE 37.5 KiB.  Algorithmic bytes are 14.75 MB: no wasted re-reads.
-        traffic = (2 * 7877.25 + 37.5) * 1024
+        # profiles/r01_pmc_icp_{fetch,write}_size.csv (this kernel, tools/pmc_icp.py): FETCH_SIZE
+        # 7348.5 KiB, doubled because gfx950 tallies 128-byte read requests at 64 bytes (guide, HBM
+        # section; calibrated there for 16-B-per-lane streams -- the 16-B-per-lane build of this kernel,
+        # profiles/r01_pmc_icp_px4_*.csv, reads 7305.25 KiB, so the same factor is applied here) +
+        # WRITE_SIZE 75 KiB (600 partial records).  Algorithmic bytes are 14.75 MB: no wasted re-reads.
+        traffic = (2 * 7348.5 + 75.0) * 1024
         roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": traffic, "kernel": "icp_kernel<2,256> level 0 (640x480)", "us_per_launch": us,
+                    "traffic": traffic, "kernel": "icp_kernel2<2,1,256,packed> level 0 (640x480)", "us_per_launch": us,
                     "bytes_per_launch": icp_step_bytes(n0),
                     "us_per_launch_l1": odom.timeIcpKernel(1, args.roofline_reps),
                     "us_per_launch_l2": odom.timeIcpKernel(2, args.roofline_reps)}

@@ -9,7 +9,7 @@
 //     v_pk_fma_f32 operate on a float pair at full rate): ~half the arithmetic instructions;
 //   * is branch free per pixel, with scheduling barriers around the two load groups, so there
 //     are exactly two memory round trips: 6 coalesced loads, then all gathers;
-//   * optionally gathers the model vertex + normal as two 16-byte loads from a pixel-interleaved
+//   * optionally gathers the model vertex + normal as two 12-byte loads from a pixel-interleaved
 //     copy (built once per frame by the transform kernel) instead of six 4-byte loads;
 //   * compares squared distances against exact squared thresholds (no sqrt per pixel unless the
 //     error map is being written);
@@ -84,7 +84,7 @@ struct MapView {  // planar 3-plane map: element (plane k, row y, col x) at base
 
 struct IcpArgs {
     MapView vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev;
-    const float4* prev_packed;  // optional: [pixel] {vertex xyz, -, normal xyz, -} (2 x float4), dense rows
+    const float* prev_packed;  // optional: [pixel] {vertex xyz, normal xyz} (24 bytes, two 12-byte loads), dense rows
     LevelIntr intr;
     float dist_thres, angle_thres;
     float dist_sq_max;   // largest x with sqrtf(x) <= dist_thres   (host: exact_sq_thresholds)
@@ -270,10 +270,14 @@ __device__ __forceinline__ void icp_block2(const OdomState* __restrict__ st, con
         f3t<T> vp[NV], np[NV];
         __builtin_amdgcn_sched_barrier(0);
         if (PACKED) {
-            float4 gv[PX], gn[PX];
+            struct f3pk {
+                float x, y, z;
+            };
+            f3pk gv[PX], gn[PX];
 #pragma unroll
             for (int q = 0; q < PX; ++q) {
-                const float4* src = a.prev_packed + 2 * ((size_t)pr[q / W].uy[q % W] * a.cols + pr[q / W].ux[q % W]);
+                const f3pk* src = reinterpret_cast<const f3pk*>(a.prev_packed) +
+                                  2 * ((size_t)pr[q / W].uy[q % W] * a.cols + pr[q / W].ux[q % W]);
                 gv[q] = src[0];
                 gn[q] = src[1];
             }
@@ -345,11 +349,13 @@ __device__ __forceinline__ void icp_block2(const OdomState* __restrict__ st, con
 
 // dense planar model maps -> the pixel-interleaved copy the packed gather reads
 __global__ __launch_bounds__(256) void pack_prev_kernel(const float* __restrict__ vmap, const float* __restrict__ nmap,
-                                                        int n, float4* __restrict__ out) {
+                                                        int n, float* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    out[2 * i] = make_float4(vmap[i], vmap[i + n], vmap[i + 2 * n], 0.f);
-    out[2 * i + 1] = make_float4(nmap[i], nmap[i + n], nmap[i + 2 * n], 0.f);
+    float2* o = reinterpret_cast<float2*>(out + 6 * (size_t)i);  // 24-byte records: 8-byte aligned
+    o[0] = make_float2(vmap[i], vmap[i + n]);
+    o[1] = make_float2(vmap[i + 2 * n], nmap[i]);
+    o[2] = make_float2(nmap[i + n], nmap[i + 2 * n]);
 }
 
 }  // namespace mmf

@@ -706,7 +706,7 @@ struct mmf_odom {
     int16_t *dIdx[MMF_NUM_PYRS], *dIdy[MMF_NUM_PYRS];
     float* cloud[MMF_NUM_PYRS];
     mmf_dataterm* corres[MMF_NUM_PYRS];
-    float4* prev_packed[MMF_NUM_PYRS];  // model vertex + normal, pixel interleaved (the ICP gather side)
+    float* prev_packed[MMF_NUM_PYRS];  // model vertex + normal, pixel interleaved 24-byte records (the ICP gather side)
     OdomState* state = nullptr;  // device
     OdomState* host_result = nullptr;  // pinned
     bool have_tmp = false;  // vmaps_tmp filled by an initICP* call (ordering contract)
@@ -769,7 +769,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
         o_dy[i] = carve(n * 2);
         o_cl[i] = carve(3 * n * 4);
         o_co[i] = carve(n * sizeof(mmf_dataterm));
-        o_pp[i] = carve(n * 2 * sizeof(float4));
+        o_pp[i] = carve(n * 6 * sizeof(float));
     }
     size_t o_state = carve(sizeof(OdomState));
     o->slab_bytes = off;
@@ -797,7 +797,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
         o->dIdy[i] = (int16_t*)(base + o_dy[i]);
         o->cloud[i] = (float*)(base + o_cl[i]);
         o->corres[i] = (mmf_dataterm*)(base + o_co[i]);
-        o->prev_packed[i] = (float4*)(base + o_pp[i]);
+        o->prev_packed[i] = (float*)(base + o_pp[i]);
     }
     o->state = (OdomState*)(base + o_state);
     MMF_HIP_TRY(hipHostMalloc(&o->host_result, sizeof(OdomState), hipHostMallocDefault));

@@ -23,5 +23,6 @@ g.buildDepthPyramid(dev(fc["depth"]))
 g.initICP(depthCutoff=15.0)
 g.initRGB(dev(fc["rgb"]))
 g.getIncrementalTransformation(pose[:3, 3], pose[:3, :3], False, 10.0, True, False, True)
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # GEN*1000000 + PX*10000 + BLOCK, 0 = shipped default
 for lvl in range(3):
-    print(lvl, g.timeIcpKernel(lvl, 20, 0))
+    print(lvl, g.timeIcpKernel(lvl, 20, variant))
