@@ -47,7 +47,7 @@ def setup_pair(gpu_ctx, orc, w, h, seed=1):
     return K, prev, cur, g, o
 
 
-@pytest.mark.parametrize("w,h", [(640, 480), (320, 240)])
+@pytest.mark.parametrize("w,h", [(640, 480), (320, 240), (100, 80)])
 def test_pyramids_bit_exact(gpu_ctx, orc, w, h):
     K, prev, cur, g, o = setup_pair(gpu_ctx, orc, w, h)
     for lvl in range(3):
@@ -64,8 +64,10 @@ def test_pyramids_bit_exact(gpu_ctx, orc, w, h):
     g.close()
 
 
+# 200x152 / 100x80: level 2 is 50 / 25 columns wide -- the 1-pixel-per-lane ICP kernel, the scalar
+# correspondence pass and 16-byte records inside the loop (the vector forms need cols % 4 == 0)
 @pytest.mark.parametrize("mode", MODES, ids=["icp+rgb+so3", "icp", "rgbOnly", "fast"])
-@pytest.mark.parametrize("w,h", [(640, 480), (320, 240)])
+@pytest.mark.parametrize("w,h", [(640, 480), (320, 240), (200, 152), (100, 80)])
 def test_incremental_transformation_matches_oracle(gpu_ctx, orc, w, h, mode):
     K, prev, cur, g, o = setup_pair(gpu_ctx, orc, w, h)
     icp_err = torch.zeros(h, w, device="cuda")
@@ -75,6 +77,10 @@ def test_incremental_transformation_matches_oracle(gpu_ctx, orc, w, h, mode):
     to, Ro = o.getIncrementalTransformation(prev[:3, 3], prev[:3, :3], want_err=True, **mode)
     so = o.stats()
     assert g.iterations_run == so.iterations_run and g.so3_iterations_run == so.so3_iterations_run
+    if np.isnan(to).any():  # a singular system (too few correspondences at a tiny size): NaN on both sides
+        assert np.isnan(tg).any() and np.isnan(Rg).any()
+        g.close()
+        return
     assert np.linalg.norm(tg - to) <= 2e-6, (tg, to)
     # rotation difference bounded through the matrix entries (acos of a float32 trace has a
     # ~3e-4 rad noise floor even for identical matrices); |dR|_max <= 2e-6 implies < 1e-5 rad
@@ -89,7 +95,7 @@ def test_incremental_transformation_matches_oracle(gpu_ctx, orc, w, h, mode):
     assert np.abs(A - Ao).max() <= 1e-4 * np.abs(Ao).max()
     # accuracy against the known motion (sanity, not parity): the step must reduce the pose error
     gt_t, gt_R = cur[:3, 3], cur[:3, :3]
-    if icp:
+    if icp and w >= 320:  # the tiny fallback-path sizes are parity cases only
         assert np.linalg.norm(tg - gt_t) < np.linalg.norm(prev[:3, 3] - gt_t)
         assert synth.rotation_angle(Rg.astype(np.float64), gt_R) < synth.rotation_angle(prev[:3, :3], gt_R)
     # error surfaces of the last level-0 iteration
