@@ -129,10 +129,13 @@ def main():
         if state["frame"] and k == 0:  # sequence wrapped: start a fresh map (the trajectory jumps back)
             mmf.reset()
         state["frame"] += 1
-        rgb_in.copy_(d_rgb[k])
-        depth_in.copy_(d_depth[k])
-        shard.broadcast_frame(rgb_in, depth_in, mask_in, src=0)  # no-op on one GPU
-        mmf.processFrame(rgb_in, depth_in, timestamp=i)
+        if world > 1:  # rank 0's sensor frame reaches every model owner (RCCL broadcast over xGMI)
+            rgb_in.copy_(d_rgb[k])
+            depth_in.copy_(d_depth[k])
+            shard.broadcast_frame(rgb_in, depth_in, mask_in, src=0)
+            mmf.processFrame(rgb_in, depth_in, timestamp=i)
+        else:  # inputs already resident in HBM
+            mmf.processFrame(d_rgb[k], d_depth[k], timestamp=i)
         pose = mmf.getCurrPose()
         if world > 1:
             od = mmf.getFrameOdometry()

@@ -52,3 +52,30 @@ np.savez_compressed(os.path.join(HERE, "odometry_160x120.npz"), rgb_prev=fp["rgb
                     pose_gt=cur.astype(np.float32), trans=t, rot=R, lastA=np.array(s.lastA), lastb=np.array(s.lastb),
                     lastICPCount=s.lastICPCount, lastICPError=s.lastICPError, lastRGBCount=s.lastRGBCount)
 print("wrote fixtures to", HERE)
+
+# 3. the surfel path on a 96x72 two-frame cycle: bilateral filter, initialise, predictIndices, fuse,
+#    predictIndices, clean, combinedPredict (the per-frame order of MultiMotionFusion::processFrame)
+from multimotionfusion_amd import synth  # noqa: E402
+
+w, h = 96, 72
+MAXD, CUTOFF, TIME_DELTA, CONF = 20.0, 15.0, 200, 10.0
+K = synth.intrinsics(w, h)
+poses = synth.trajectory(2, seed=5)
+f0, f1 = synth.render(poses[0], w, h, seed=0), synth.render(poses[1], w, h, seed=1)
+mask = np.zeros((h, w), np.uint8)
+fil0, fil1 = orc.bilateral_filter(f0["depth"], CUTOFF), orc.bilateral_filter(f1["depth"], CUTOFF)
+s0 = orc.surfel_initialise(f0["rgb"], f0["depth"], fil0, K, 1, MAXD)
+pose1 = poses[1].astype(np.float32)
+index, vc, ct, nr = orc.predict_indices(s0, pose1, K, w, h, MAXD, 2, TIME_DELTA)
+s_upd, new = orc.fuse(s0, f1["rgb"], f1["depth"], fil1, mask, index, vc, nr, pose1, K, 2, 1.0, 0, MAXD)
+index2, vc2, ct2, nr2 = orc.predict_indices(s_upd, pose1, K, w, h, MAXD, 2, TIME_DELTA)
+s1 = orc.clean(s_upd, new, pose1, K, w, h, 2, TIME_DELTA, CONF, 3.0, 0, index2, vc2, ct2, fil1, mask)
+s1c = s1.copy()
+s1c[:, 3] = 20.0  # confident, so the splat shows them
+image, vcp, nrp, tm = orc.combined_predict(s1c, pose1, K, w, h, MAXD, CONF, 2, 2, TIME_DELTA)
+np.savez_compressed(os.path.join(HERE, "surfel_cycle_96x72.npz"), rgb0=f0["rgb"], depth0=f0["depth"], rgb1=f1["rgb"],
+                    depth1=f1["depth"], pose0=poses[0].astype(np.float32), pose1=pose1,
+                    intr=np.array([K["fx"], K["fy"], K["cx"], K["cy"]], np.float32), filtered1=fil1,
+                    surfels_init=s0, index_after_fuse=index2, surfels_final=s1, splat_vertexConf=vcp,
+                    splat_image=image)
+print("wrote surfel fixture:", s0.shape[0], "->", s1.shape[0], "surfels")

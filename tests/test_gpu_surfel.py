@@ -125,3 +125,35 @@ def test_index_map_edge_cases(gpu_ctx, orc):
     m.predictIndices(10, MAXD, TIME_DELTA)
     assert not m.texture("index").any()
     m.close()
+
+
+def test_surfel_cycle_against_golden_fixture(gpu_ctx):
+    """The HIP surfel path on the committed fixture (tests/golden/surfel_cycle_96x72.npz): no oracle call, the
+    expected arrays travel with the repository."""
+    import os
+    from multimotionfusion_amd.model import Model, filterDepth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "surfel_cycle_96x72.npz"))
+    h, w = g["depth0"].shape
+    fx, fy, cx, cy = (float(v) for v in g["intr"])
+    m = Model(gpu_ctx, w, h, cx, cy, fx, fy, 0, CONF)
+    d_mask = dev(np.zeros((h, w), np.uint8))
+    d0, d1 = dev(g["depth0"]), dev(g["depth1"])
+    fil0, fil1 = filterDepth(gpu_ctx, d0, CUTOFF), filterDepth(gpu_ctx, d1, CUTOFF)
+    assert_bit_equal(fil1.cpu().numpy(), g["filtered1"], "filtered depth")
+    m.overridePose(g["pose0"])
+    m.initialise(dev(g["rgb0"]), d0, fil0, 1, MAXD)
+    assert_bit_equal(m.downloadMap(), g["surfels_init"], "initialise")
+    m.overridePose(g["pose1"])
+    m.predictIndices(2, MAXD, TIME_DELTA)
+    m.fuse(2, dev(g["rgb1"]), d_mask, d1, fil1, MAXD, 1.0)
+    m.predictIndices(2, MAXD, TIME_DELTA)
+    assert_bit_equal(m.texture("index").cpu().numpy().view(np.uint32), g["index_after_fuse"], "index map")
+    m.clean(2, TIME_DELTA, MAXD, fil1, d_mask, 3.0)
+    s1 = m.downloadMap()
+    assert_bit_equal(s1, g["surfels_final"], "surfels after clean")
+    s1[:, 3] = 20.0
+    m.uploadMap(s1)
+    m.combinedPredict(MAXD, 2, 2, TIME_DELTA)
+    assert_bit_equal(m.texture("vertexConf").cpu().numpy(), g["splat_vertexConf"], "splat vertexConf")
+    assert_bit_equal(m.texture("image").cpu().numpy(), g["splat_image"], "splat image")
+    m.close()

@@ -147,3 +147,27 @@ def test_fill_in_and_thumbnail(orc):
     assert np.array_equal(vo[..., 2], fil) and np.array_equal(io[..., :3], f["rgb"])
     assert orc.requires_fill_in(img0) is True
     assert orc.requires_fill_in(io) is False
+
+
+def test_surfel_cycle_golden_fixture(orc):
+    """tests/golden/surfel_cycle_96x72.npz (written by make_golden.py from this oracle) pins the surfel-path
+    restatement against silent changes: initialise -> predictIndices -> fuse -> predictIndices -> clean -> splat."""
+    g = np.load(os.path.join(REPO, "tests", "golden", "surfel_cycle_96x72.npz"))
+    h, w = g["depth0"].shape
+    K = dict(zip(("fx", "fy", "cx", "cy"), (float(v) for v in g["intr"])))
+    mask = np.zeros((h, w), np.uint8)
+    fil0, fil1 = orc.bilateral_filter(g["depth0"], 15.0), orc.bilateral_filter(g["depth1"], 15.0)
+    assert np.array_equal(fil1.view(np.uint32), g["filtered1"].view(np.uint32))
+    s0 = orc.surfel_initialise(g["rgb0"], g["depth0"], fil0, K, 1, MAXD)
+    assert np.array_equal(s0.view(np.uint32), g["surfels_init"].view(np.uint32))
+    pose1 = g["pose1"]
+    index, vc, ct, nr = orc.predict_indices(s0, pose1, K, w, h, MAXD, 2, 200)
+    s_upd, new = orc.fuse(s0, g["rgb1"], g["depth1"], fil1, mask, index, vc, nr, pose1, K, 2, 1.0, 0, MAXD)
+    index2, vc2, ct2, nr2 = orc.predict_indices(s_upd, pose1, K, w, h, MAXD, 2, 200)
+    assert np.array_equal(index2, g["index_after_fuse"])
+    s1 = orc.clean(s_upd, new, pose1, K, w, h, 2, 200, 10.0, 3.0, 0, index2, vc2, ct2, fil1, mask)
+    assert np.array_equal(s1.view(np.uint32), g["surfels_final"].view(np.uint32))
+    s1c = s1.copy()
+    s1c[:, 3] = 20.0
+    image, vcp, nrp, tm = orc.combined_predict(s1c, pose1, K, w, h, MAXD, 10.0, 2, 2, 200)
+    assert np.array_equal(vcp.view(np.uint32), g["splat_vertexConf"].view(np.uint32)) and np.array_equal(image, g["splat_image"])
