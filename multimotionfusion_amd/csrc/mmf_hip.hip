@@ -1371,7 +1371,7 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     for (int k = 0; k < 3; ++k) o_meas[k] = carve(npix * 16);
     for (int k = 0; k < 3; ++k) o_cand[k] = carve(npix * 16);
     const size_t o_fa = carve((cap + npix) * 4), o_fb = carve(npix * 4), o_pa = carve((cap + npix) * 4),
-                 o_pb = carve(npix * 4), o_bs = carve(((cap + npix) / kScanTile + 2) * 4), o_tot = carve(64),
+                 o_pb = carve(npix * 4), o_bs = carve(((cap + npix) / 256 + 2) * 4), o_tot = carve(64),
                  o_win = carve(cap * 4), o_ct = carve((cap + npix) * 8), o_keys = carve(npix * 8),
                  o_idx = carve(npix * 4), o_vc = carve(npix * 16), o_ctm = carve(npix * 16), o_nr = carve(npix * 16),
                  o_img = carve(npix * 4), o_vxc = carve(npix * 16), o_nrr = carve(npix * 16), o_tt = carve(npix * 2), o_sd = carve(npix * 4), o_ex = carve(npix * 52),
@@ -1401,6 +1401,8 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     m->export_rm = (void*)(b + o_ex);
     m->fill_vertex = (float4*)(b + o_fv), m->fill_normal = (float4*)(b + o_fn), m->fill_image = (uchar4*)(b + o_fi);
     hipLaunchKernelGGL(fill_u32_kernel, grid1d(cap), dim3(256), 0, c->stream, m->winner, cap, kNoWinner);
+    // the key image starts empty and every resolve kernel hands it back empty
+    hipLaunchKernelGGL(fill_u64_kernel, grid1d(npix), dim3(256), 0, c->stream, m->keys, npix, kEmptyKey);
     MMF_HIP_TRY(hipGetLastError());
     MMF_HIP_TRY(hipHostMalloc(&m->host_totals, 64, hipHostMallocDefault));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1497,7 +1499,6 @@ extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cut
     MMF_HIP_TRY(hipSetDevice(c->device));
     const size_t npix = (size_t)m->width * m->height;
     const IndexArgs a = model_index_args(m, time, depth_cutoff, time_delta);
-    hipLaunchKernelGGL(fill_u64_kernel, grid1d(npix), dim3(256), 0, c->stream, m->keys, npix, kEmptyKey);
     if (m->count)
         hipLaunchKernelGGL(index_map_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
                            m->keys);
@@ -1520,7 +1521,6 @@ extern "C" int mmf_model_combined_predict(mmf_model* m, float depth_cutoff, int 
     a.maxDepth = depth_cutoff;
     a.confThreshold = m->conf_threshold;
     a.time = time, a.maxTime = max_time, a.timeDelta = time_delta;
-    hipLaunchKernelGGL(fill_u64_kernel, grid1d(npix), dim3(256), 0, c->stream, m->keys, npix, kEmptyKey);
     if (m->count)
         hipLaunchKernelGGL(splat_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
                            m->keys);
@@ -1545,7 +1545,6 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
     a.maxDepth = depth_cutoff;
     a.confThreshold = conf_threshold;
     a.time = time, a.maxTime = max_time, a.timeDelta = time_delta;
-    hipLaunchKernelGGL(fill_u64_kernel, grid1d(npix), dim3(256), 0, c->stream, m->keys, npix, kEmptyKey);
     if (m->count)
         hipLaunchKernelGGL(splat_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
                            m->keys);
@@ -1600,14 +1599,11 @@ extern "C" int mmf_model_clean(mmf_model* m, int time, int time_delta, float dep
     a.npix = npix;
     const unsigned n = m->count + npix;
     hipLaunchKernelGGL(clean_flag_kernel, grid1d(n), dim3(256), 0, c->stream, m->set[m->cur], m->meas, m->flags_b, a,
-                       m->index, m->vertConf, m->colorTime, depth_filtered, mask, m->flags_a, m->conf_time);
-    MMF_HIP_TRY(hipGetLastError());
-    int rc = device_scan(c, m->flags_a, n, m->prefix_a, m->block_sums, &m->totals[0]);
-    if (rc) return rc;
+                       m->index, m->vertConf, m->colorTime, depth_filtered, mask, m->flags_a, m->conf_time, m->block_sums);
     hipLaunchKernelGGL(clean_scatter_kernel, grid1d(n), dim3(256), 0, c->stream, m->set[m->cur], m->meas, (int)m->count,
-                       npix, m->flags_a, m->prefix_a, m->conf_time, m->set[1 - m->cur], m->capacity);
+                       npix, m->flags_a, m->block_sums, m->conf_time, m->set[1 - m->cur], m->capacity, &m->totals[0]);
     MMF_HIP_TRY(hipGetLastError());
-    rc = model_read_totals(m);  // glGetQueryObjectuiv(countQuery) in the reference (Model.cpp:1166)
+    int rc = model_read_totals(m);  // glGetQueryObjectuiv(countQuery) in the reference (Model.cpp:1166)
     if (rc) return rc;
     m->count = m->host_totals[0] < (unsigned)m->capacity ? m->host_totals[0] : (unsigned)m->capacity;
     m->cur = 1 - m->cur;

@@ -419,13 +419,16 @@ __global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, 
 }
 
 // linear over the transposed images (it never needs a pixel's coordinates)
+// Every resolve kernel hands the key image back EMPTY (it is the only reader of a texel's key), so the
+// rasterising passes need no clearing launch in front of them.
 __global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexArgs a,
-                                                            const unsigned long long* __restrict__ keys,
+                                                            unsigned long long* __restrict__ keys,
                                                             unsigned* __restrict__ index, float4* __restrict__ vertConf,
                                                             float4* __restrict__ colorTime, float4* __restrict__ normRad) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.cols * a.rows) return;
     const unsigned long long k = keys[i];
+    if (k != kEmptyKey) keys[i] = kEmptyKey;
     if (k == kEmptyKey) {
         index[i] = 0;
         vertConf[i] = colorTime[i] = normRad[i] = make_float4(0, 0, 0, 0);
@@ -531,13 +534,14 @@ __global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, Spla
 }
 
 __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatArgs a,
-                                                            const unsigned long long* __restrict__ keys,
+                                                            unsigned long long* __restrict__ keys,
                                                             uchar4* __restrict__ image, float4* __restrict__ vertexConf,
                                                             float4* __restrict__ normalRadius,
                                                             unsigned short* __restrict__ time_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.cols * a.rows) return;
     const unsigned long long k = keys[i];
+    if (k != kEmptyKey) keys[i] = kEmptyKey;
     if (k == kEmptyKey) {
         image[i] = make_uchar4(0, 0, 0, 0);
         vertexConf[i] = normalRadius[i] = make_float4(0, 0, 0, 0);
@@ -562,11 +566,12 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatAr
 
 // depth_splat.frag (ModelProjection::synthesizeDepth): the winner's corrected_pos.z, 0 where cleared
 __global__ __launch_bounds__(256) void splat_depth_resolve_kernel(SurfelSoA s, SplatArgs a,
-                                                                  const unsigned long long* __restrict__ keys,
+                                                                  unsigned long long* __restrict__ keys,
                                                                   float* __restrict__ depth) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.cols * a.rows) return;
     const unsigned long long k = keys[i];
+    if (k != kEmptyKey) keys[i] = kEmptyKey;
     float z = 0.f;
     if (k != kEmptyKey) {
         const unsigned id = (unsigned)k;
@@ -762,24 +767,19 @@ struct CleanArgs {
 };
 
 // candidate e in [0, count + npix): existing surfel e, or pixel draw-index e - count.
-// Writes keep[e] and the two fields the shader modifies (confidence, timestamp).
-__global__ __launch_bounds__(256) void clean_flag_kernel(SurfelSoA s, SurfelSoA meas, const unsigned* __restrict__ new_flags,
-                                                         CleanArgs a, const unsigned* __restrict__ index,
-                                                         const float4* __restrict__ vertConf,
-                                                         const float4* __restrict__ colorTime,
-                                                         const float* __restrict__ depth_in, const uint8_t* __restrict__ mask,
-                                                         unsigned* __restrict__ keep, float2* __restrict__ conf_time) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= a.count + a.npix) return;
+// Returns keep(e) and writes the two fields the shader modifies (confidence, timestamp).
+__device__ __forceinline__ unsigned clean_flag_one(int e, SurfelSoA s, SurfelSoA meas, const unsigned* __restrict__ new_flags,
+                                                   const CleanArgs& a, const unsigned* __restrict__ index,
+                                                   const float4* __restrict__ vertConf,
+                                                   const float4* __restrict__ colorTime,
+                                                   const float* __restrict__ depth_in, const uint8_t* __restrict__ mask,
+                                                   float2* __restrict__ conf_time) {
     float4 vpos, vcol, vnrm;
     if (e < a.count) {
         vpos = s.pos[e], vcol = s.col[e], vnrm = s.nrm[e];
     } else {
         const int d = e - a.count;
-        if (!new_flags[d]) {
-            keep[e] = 0u;
-            return;
-        }
+        if (!new_flags[d]) return 0u;
         vpos = meas.pos[d], vcol = meas.col[d], vnrm = meas.nrm[d];
     }
     const int cols = a.cols, rows = a.rows;
@@ -897,19 +897,56 @@ __global__ __launch_bounds__(256) void clean_flag_kernel(SurfelSoA s, SurfelSoA 
         if (mask[t] != a.maskID && (wDepth > localPos.z - 0.05f && wDepth < localPos.z + 0.05f))
             vpos.w *= (0.5f + 0.5f * (1 - a.outlierCoeff / 10.0f));
     }
-    keep[e] = test ? 1u : 0u;
     conf_time[e] = make_float2(vpos.w, vcol.w);
+    return test ? 1u : 0u;
+}
+
+// keep[e] for every candidate, and -- so that the compaction needs no separate scan launches -- the
+// number of kept candidates of each 256-candidate workgroup in block_sums[blockIdx.x]
+__global__ __launch_bounds__(256) void clean_flag_kernel(SurfelSoA s, SurfelSoA meas, const unsigned* __restrict__ new_flags,
+                                                         CleanArgs a, const unsigned* __restrict__ index,
+                                                         const float4* __restrict__ vertConf,
+                                                         const float4* __restrict__ colorTime,
+                                                         const float* __restrict__ depth_in, const uint8_t* __restrict__ mask,
+                                                         unsigned* __restrict__ keep, float2* __restrict__ conf_time,
+                                                         unsigned* __restrict__ block_sums) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    unsigned k = 0u;
+    if (e < a.count + a.npix) {
+        k = clean_flag_one(e, s, meas, new_flags, a, index, vertConf, colorTime, depth_in, mask, conf_time);
+        keep[e] = k;
+    }
+    const int kept = __syncthreads_count((int)k);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (unsigned)kept;
 }
 
 // ordered compaction into the other surfel set (transform feedback of copy_unstable.geom)
+// The exclusive scan of keep[] is done here: a workgroup's base = the sum of the block_sums before it
+// (every workgroup adds them up itself: a few thousand words from L2 instead of three scan launches),
+// the rank inside the workgroup from wave ballots.  The last workgroup writes the new surfel count.
 __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelSoA meas, int count, int npix,
                                                             const unsigned* __restrict__ keep,
-                                                            const unsigned* __restrict__ prefix,
+                                                            const unsigned* __restrict__ block_sums,
                                                             const float2* __restrict__ conf_time, SurfelSoA dst,
-                                                            int capacity) {
+                                                            int capacity, unsigned* __restrict__ total_out) {
+    __shared__ unsigned wave_part[4], wave_kept[4];
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= count + npix || !keep[e]) return;
-    const unsigned k = prefix[e];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned kp = (e < count + npix) ? keep[e] : 0u;
+    unsigned part = 0;
+    for (unsigned j = threadIdx.x; j < blockIdx.x; j += 256) part += block_sums[j];
+    part = wave_sum_to_lane63(part);
+    const unsigned long long ballot = __ballot(kp != 0u);
+    if (lane == 63) wave_part[wave] = part;
+    if (lane == 0) wave_kept[wave] = (unsigned)__popcll(ballot);
+    __syncthreads();
+    unsigned base = wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3];
+    for (int w = 0; w < wave; ++w) base += wave_kept[w];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        *total_out = wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3] + wave_kept[0] + wave_kept[1] + wave_kept[2] +
+                     wave_kept[3];
+    if (!kp) return;
+    const unsigned k = base + (unsigned)__popcll(ballot & ((1ull << lane) - 1ull));
     if (k >= (unsigned)capacity) return;  // the reference's VBO is full: further primitives are dropped
     float4 p, c, n;
     if (e < count) {
