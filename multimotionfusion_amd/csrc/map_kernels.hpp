@@ -14,11 +14,10 @@ constexpr int kTileX = 64, kTileY = 4;
     const int y = blockIdx.y * kTileY + threadIdx.y
 
 // cudafuncs.cu:109-134 (computeVmapKernel); the mask test is commented out there (:119)
-__global__ __launch_bounds__(256) void create_vmap_kernel(const float* __restrict__ depth, int d_stride, int cols,
+__device__ __forceinline__ void create_vmap_px(int x, int y, const float* __restrict__ depth, int d_stride, int cols,
                                                           int rows, float* __restrict__ vmap, int v_stride,
                                                           float fx_inv, float fy_inv, float cx, float cy,
                                                           float cutoff) {
-    MMF_PIXEL_XY();
     if (x >= cols || y >= rows) return;
     const float z = depth[(size_t)y * d_stride + x];
     if (z != 0 && z < cutoff) {
@@ -29,11 +28,17 @@ __global__ __launch_bounds__(256) void create_vmap_kernel(const float* __restric
         vmap[(size_t)y * v_stride + x] = qnan();
     }
 }
+__global__ __launch_bounds__(256) void create_vmap_kernel(const float* __restrict__ depth, int d_stride, int cols,
+                                                          int rows, float* __restrict__ vmap, int v_stride,
+                                                          float fx_inv, float fy_inv, float cx, float cy,
+                                                          float cutoff) {
+    MMF_PIXEL_XY();
+    create_vmap_px(x, y, depth, d_stride, cols, rows, vmap, v_stride, fx_inv, fy_inv, cx, cy, cutoff);
+}
 
 // cudafuncs.cu:152-189 (computeNmapKernel)
-__global__ __launch_bounds__(256) void create_nmap_kernel(int rows, int cols, const float* __restrict__ vmap,
+__device__ __forceinline__ void create_nmap_px(int x, int y, int rows, int cols, const float* __restrict__ vmap,
                                                           int v_stride, float* __restrict__ nmap, int n_stride) {
-    MMF_PIXEL_XY();
     if (x >= cols || y >= rows) return;
     if (x == cols - 1 || y == rows - 1) {
         nmap[(size_t)y * n_stride + x] = qnan();
@@ -58,12 +63,16 @@ __global__ __launch_bounds__(256) void create_nmap_kernel(int rows, int cols, co
         nmap[(size_t)y * n_stride + x] = qnan();
     }
 }
+__global__ __launch_bounds__(256) void create_nmap_kernel(int rows, int cols, const float* __restrict__ vmap,
+                                                          int v_stride, float* __restrict__ nmap, int n_stride) {
+    MMF_PIXEL_XY();
+    create_nmap_px(x, y, rows, cols, vmap, v_stride, nmap, n_stride);
+}
 
 // cudafuncs.cu:207-249 (tranformMapsKernel); in place is fine (one pixel per lane)
-__global__ __launch_bounds__(256) void transform_maps_kernel(int rows, int cols, const float* vsrc, const float* nsrc,
+__device__ __forceinline__ void transform_maps_px(int x, int y, int rows, int cols, const float* vsrc, const float* nsrc,
                                                              int s_stride, m33 R, f3 t, float* vdst, float* ndst,
                                                              int d_stride) {
-    MMF_PIXEL_XY();
     if (x >= cols || y >= rows) return;
     f3 vs, vd = make_f3(qnan(), qnan(), qnan());
     vs.x = vsrc[(size_t)y * s_stride + x];
@@ -87,12 +96,17 @@ __global__ __launch_bounds__(256) void transform_maps_kernel(int rows, int cols,
     }
     ndst[(size_t)y * d_stride + x] = nd.x;
 }
+__global__ __launch_bounds__(256) void transform_maps_kernel(int rows, int cols, const float* vsrc, const float* nsrc,
+                                                             int s_stride, m33 R, f3 t, float* vdst, float* ndst,
+                                                             int d_stride) {
+    MMF_PIXEL_XY();
+    transform_maps_px(x, y, rows, cols, vsrc, nsrc, s_stride, R, t, vdst, ndst, d_stride);
+}
 
 // cudafuncs.cu:271-311 (copyMapsKernel): one float4 load per map per pixel (RGBA32F texel)
-__global__ __launch_bounds__(256) void copy_maps_kernel(int rows, int cols, const float4* __restrict__ vsrc,
+__device__ __forceinline__ void copy_maps_px(int x, int y, int rows, int cols, const float4* __restrict__ vsrc,
                                                         const float4* __restrict__ nsrc, float* __restrict__ vdst,
                                                         float* __restrict__ ndst, int d_stride) {
-    MMF_PIXEL_XY();
     if (x >= cols || y >= rows) return;
     const float4 v = vsrc[(size_t)y * cols + x];
     const float4 n = nsrc[(size_t)y * cols + x];
@@ -108,12 +122,17 @@ __global__ __launch_bounds__(256) void copy_maps_kernel(int rows, int cols, cons
     ndst[(size_t)(y + rows) * d_stride + x] = nd.y;
     ndst[(size_t)(y + 2 * rows) * d_stride + x] = nd.z;
 }
+__global__ __launch_bounds__(256) void copy_maps_kernel(int rows, int cols, const float4* __restrict__ vsrc,
+                                                        const float4* __restrict__ nsrc, float* __restrict__ vdst,
+                                                        float* __restrict__ ndst, int d_stride) {
+    MMF_PIXEL_XY();
+    copy_maps_px(x, y, rows, cols, vsrc, nsrc, vdst, ndst, d_stride);
+}
 
 // cudafuncs.cu:366-417 (resizeMapKernel<normalize>): float2 loads cover the 2x2 footprint
 template <bool NORMALIZE>
-__global__ __launch_bounds__(256) void resize_map_kernel(int drows, int dcols, int srows, const float* __restrict__ in,
+__device__ __forceinline__ void resize_map_px(int x, int y, int drows, int dcols, int srows, const float* __restrict__ in,
                                                          int i_stride, float* __restrict__ out, int o_stride) {
-    MMF_PIXEL_XY();
     if (x >= dcols || y >= drows) return;
     const int xs = x * 2, ys = y * 2;
     const float x00 = in[(size_t)(ys + 0) * i_stride + xs + 0];
@@ -141,6 +160,12 @@ __global__ __launch_bounds__(256) void resize_map_kernel(int drows, int dcols, i
     out[(size_t)(y + drows) * o_stride + x] = n.y;
     out[(size_t)(y + 2 * drows) * o_stride + x] = n.z;
 }
+template <bool NORMALIZE>
+__global__ __launch_bounds__(256) void resize_map_kernel(int drows, int dcols, int srows, const float* __restrict__ in,
+                                                         int i_stride, float* __restrict__ out, int o_stride) {
+    MMF_PIXEL_XY();
+    resize_map_px<NORMALIZE>(x, y, drows, dcols, srows, in, i_stride, out, o_stride);
+}
 
 // 5x5 binomial weights (cudafuncs.cu:517-521) = outer product of {1,4,6,4,1}.  The reference
 // cudaMallocs, uploads and frees this table on every call (:523-531); here the weight is
@@ -149,10 +174,9 @@ __device__ __forceinline__ float binom5(int k) { return k == 2 ? 6.f : ((k == 1 
 
 // cudafuncs.cu:333-364 (pyrDownKernelGaussF), quirks kept: int `count`, the window is
 // [max(0,2x-2), min(2x+3, cols-1)) and the weight index is mirrored from the clipped end (:358)
-__global__ __launch_bounds__(256) void pyrdown_gauss_f_kernel(const float* __restrict__ src, int s_stride, int scols,
+__device__ __forceinline__ void pyrdown_gauss_f_px(int x, int y, const float* __restrict__ src, int s_stride, int scols,
                                                               int srows, float* __restrict__ dst, int d_stride,
                                                               int dcols, int drows) {
-    MMF_PIXEL_XY();
     if (x >= dcols || y >= drows) return;
     const int tx = min(2 * x + 3, scols - 1);
     const int ty = min(2 * y + 3, srows - 1);
@@ -185,12 +209,17 @@ __global__ __launch_bounds__(256) void pyrdown_gauss_f_kernel(const float* __res
     }
     dst[(size_t)y * d_stride + x] = (float)(sum / (float)count);
 }
+__global__ __launch_bounds__(256) void pyrdown_gauss_f_kernel(const float* __restrict__ src, int s_stride, int scols,
+                                                              int srows, float* __restrict__ dst, int d_stride,
+                                                              int dcols, int drows) {
+    MMF_PIXEL_XY();
+    pyrdown_gauss_f_px(x, y, src, s_stride, scols, srows, dst, d_stride, dcols, drows);
+}
 
 // cudafuncs.cu:534-564 (pyrDownKernelIntensityGauss)
-__global__ __launch_bounds__(256) void pyrdown_uchar_gauss_kernel(const uint8_t* __restrict__ src, int s_stride,
+__device__ __forceinline__ void pyrdown_uchar_gauss_px(int x, int y, const uint8_t* __restrict__ src, int s_stride,
                                                                   int scols, int srows, uint8_t* __restrict__ dst,
                                                                   int d_stride, int dcols, int drows) {
-    MMF_PIXEL_XY();
     if (x >= dcols || y >= drows) return;
     const int tx = min(2 * x + 3, scols - 1);
     const int ty = min(2 * y + 3, srows - 1);
@@ -221,32 +250,46 @@ __global__ __launch_bounds__(256) void pyrdown_uchar_gauss_kernel(const uint8_t*
     const float q = sum / (float)count;
     dst[(size_t)y * d_stride + x] = (q != q) ? (uint8_t)0 : (uint8_t)(unsigned)q;
 }
+__global__ __launch_bounds__(256) void pyrdown_uchar_gauss_kernel(const uint8_t* __restrict__ src, int s_stride,
+                                                                  int scols, int srows, uint8_t* __restrict__ dst,
+                                                                  int d_stride, int dcols, int drows) {
+    MMF_PIXEL_XY();
+    pyrdown_uchar_gauss_px(x, y, src, s_stride, scols, srows, dst, d_stride, dcols, drows);
+}
 
 // cudafuncs.cu:602-613 (verticesToDepthKernel)
-__global__ __launch_bounds__(256) void vertices_to_depth_kernel(const float4* __restrict__ vmap_rgba, int cols, int rows,
+__device__ __forceinline__ void vertices_to_depth_px(int x, int y, const float4* __restrict__ vmap_rgba, int cols, int rows,
                                                                 float* __restrict__ dst, int d_stride, float cutoff) {
-    MMF_PIXEL_XY();
     if (x >= cols || y >= rows) return;
     const float z = vmap_rgba[(size_t)y * cols + x].z;
     dst[(size_t)y * d_stride + x] = (z > cutoff || z <= 0) ? qnan() : z;
 }
+__global__ __launch_bounds__(256) void vertices_to_depth_kernel(const float4* __restrict__ vmap_rgba, int cols, int rows,
+                                                                float* __restrict__ dst, int d_stride, float cutoff) {
+    MMF_PIXEL_XY();
+    vertices_to_depth_px(x, y, vmap_rgba, cols, rows, dst, d_stride, cutoff);
+}
 
 // cudafuncs.cu:624-637 (bgr2IntensityKernel): channel order as uploaded
-__global__ __launch_bounds__(256) void image_to_intensity_kernel(const uint8_t* __restrict__ img, int i_stride,
+__device__ __forceinline__ void image_to_intensity_px(int x, int y, const uint8_t* __restrict__ img, int i_stride,
                                                                  int channels, int cols, int rows,
                                                                  uint8_t* __restrict__ dst, int d_stride) {
-    MMF_PIXEL_XY();
     if (x >= cols || y >= rows) return;
     const uint8_t* p = img + (size_t)y * i_stride + (size_t)x * channels;
     const int value = (int)((float)p[0] * 0.114f + (float)p[1] * 0.299f + (float)p[2] * 0.587f);
     dst[(size_t)y * d_stride + x] = (uint8_t)value;
 }
+__global__ __launch_bounds__(256) void image_to_intensity_kernel(const uint8_t* __restrict__ img, int i_stride,
+                                                                 int channels, int cols, int rows,
+                                                                 uint8_t* __restrict__ dst, int d_stride) {
+    MMF_PIXEL_XY();
+    image_to_intensity_px(x, y, img, i_stride, channels, cols, rows, dst, d_stride);
+}
 
 // cudafuncs.cu:669-694 (applyKernel) with the tables of :702-708; border quirk kept
-__global__ __launch_bounds__(256) void derivative_kernel(const uint8_t* __restrict__ src, int s_stride, int cols,
+__device__ __forceinline__ void derivative_px(int x, int y, const uint8_t* __restrict__ src, int s_stride, int cols,
                                                          int rows, int16_t* __restrict__ dx, int dx_stride,
                                                          int16_t* __restrict__ dy, int dy_stride) {
-    MMF_PIXEL_XY();
     if (x >= cols || y >= rows) return;
     constexpr float gx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
     constexpr float gy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
@@ -275,18 +318,29 @@ __global__ __launch_bounds__(256) void derivative_kernel(const uint8_t* __restri
     dx[(size_t)y * dx_stride + x] = (int16_t)dxv;
     dy[(size_t)y * dy_stride + x] = (int16_t)dyv;
 }
+__global__ __launch_bounds__(256) void derivative_kernel(const uint8_t* __restrict__ src, int s_stride, int cols,
+                                                         int rows, int16_t* __restrict__ dx, int dx_stride,
+                                                         int16_t* __restrict__ dy, int dy_stride) {
+    MMF_PIXEL_XY();
+    derivative_px(x, y, src, s_stride, cols, rows, dx, dx_stride, dy, dy_stride);
+}
 
 // cudafuncs.cu:729-747 (projectPointsKernel); AoS float3 output, dense
-__global__ __launch_bounds__(256) void project_points_kernel(const float* __restrict__ depth, int d_stride, int cols,
+__device__ __forceinline__ void project_points_px(int x, int y, const float* __restrict__ depth, int d_stride, int cols,
                                                              int rows, float* __restrict__ cloud, float inv_fx,
                                                              float inv_fy, float cx, float cy) {
-    MMF_PIXEL_XY();
     if (x >= cols || y >= rows) return;
     const float z = depth[(size_t)y * d_stride + x];
     float* c = cloud + ((size_t)y * cols + x) * 3;
     c[0] = (float)((x - cx) * z * inv_fx);
     c[1] = (float)((y - cy) * z * inv_fy);
     c[2] = z;
+}
+__global__ __launch_bounds__(256) void project_points_kernel(const float* __restrict__ depth, int d_stride, int cols,
+                                                             int rows, float* __restrict__ cloud, float inv_fx,
+                                                             float inv_fy, float cx, float cy) {
+    MMF_PIXEL_XY();
+    project_points_px(x, y, depth, d_stride, cols, rows, cloud, inv_fx, inv_fy, cx, cy);
 }
 
 }  // namespace mmf

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "map_kernels.hpp"
+#include "prep_batch.hpp"
 #include "track_kernels.hpp"
 
 using namespace mmf;
@@ -717,6 +718,9 @@ struct mmf_odom {
     bool alias_inputs = false;
     const float *vtmp = nullptr, *ntmp = nullptr;  // what populateRGBDData / copyMaps read: own copy or alias
     const float* depth_l0 = nullptr;               // level 0 of the depth pyramid: own copy or alias
+    // set by odom_prepare_batched: gradients and point clouds are already built, and next_depth is
+    // last_depth (both come from the same prediction, RGBDOdometry.cpp:179 -- see odom_populate_rgbd)
+    bool prep_batched = false;
     mmf_odom_stats stats;
 };
 
@@ -857,6 +861,7 @@ extern "C" int mmf_odom_init_icp(mmf_odom* o, const float* const depth_pyr[MMF_N
 static int odom_take_prediction(mmf_odom* o, const float* vert_rgba, const float* norm_rgba, float** vdst,
                                 float** ndst) {
     mmf_ctx* c = o->ctx;
+    o->prep_batched = false;
     const size_t bytes = (size_t)4 * o->width * o->height * sizeof(float);
     // the reference copies both textures into vmaps_tmp / nmaps_tmp (RGBDOdometry.cpp:125,130);
     // vmaps_tmp is read again by initRGB*/populateRGBDData (:179)
@@ -915,6 +920,7 @@ extern "C" int mmf_odom_init_icp_model(mmf_odom* o, const float* vert_rgba, cons
 static int odom_populate_rgbd(mmf_odom* o, const uint8_t* rgb, size_t step, int channels, float** depths,
                               uint8_t** images) {
     mmf_ctx* c = o->ctx;
+    o->prep_batched = false;
     if (!o->have_tmp)
         return fail(MMF_ERR_STATE, "initRGB*/initRGBModel needs a preceding initICPModel / initICP(prediction): "
                                    "it reads vmaps_tmp (RGBDOdometry.cpp:197,202)");
@@ -963,6 +969,128 @@ extern "C" int mmf_odom_init_first_rgb(mmf_odom* o, const uint8_t* rgb, size_t s
     return MMF_OK;
 }
 
+// ---- the whole per-frame preparation in four launches (prep_batch.hpp) -------------------------
+struct PrepBuilder {
+    PrepBatch b;
+    int blocks = 0;
+    PrepBuilder() { b.njobs = 0; }
+    PrepJob& add(int op, int cols, int rows) {
+        PrepJob& j = b.job[b.njobs++];
+        std::memset(&j, 0, sizeof(j));
+        j.op = op;
+        j.cols = cols, j.rows = rows;
+        j.gx = (cols + kTileX - 1) / kTileX;
+        j.first_block = blocks;
+        blocks += j.gx * ((rows + kTileY - 1) / kTileY);
+        return j;
+    }
+    int launch(mmf_ctx* c) {
+        if (!b.njobs) return MMF_OK;
+        hipLaunchKernelGGL(prep_batch_kernel, dim3(blocks), tile_block(), 0, c->stream, b);
+        MMF_HIP_TRY(hipGetLastError());
+        return MMF_OK;
+    }
+};
+
+// Everything initICPModel + initRGBModel + generateCUDATextures/initICP + initRGB + the gradient and
+// point-cloud passes of getIncrementalTransformation compute (RGBDOdometry.cpp:108-235, 332-334;
+// Model.cpp:359-407), for inputs that stay untouched until tracking returns (the native orchestrator).
+static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float depth_cutoff, const uint8_t* rgb,
+                                int rgb_channels, const float* pred_vertex, const float* pred_normal,
+                                const uint8_t* pred_image, int pred_channels, const float pose[16]) {
+    mmf_ctx* c = o->ctx;
+    const int W = o->width, H = o->height;
+    const size_t n0 = (size_t)W * H;
+    // camera-frame model pyramids (before the transform into the global frame) live in the two 4*N-float
+    // staging images, which this path does not need as copies: 3*N*(1 + 1/4 + 1/16) floats each
+    float* uv[3] = {o->vmaps_tmp, o->vmaps_tmp + 3 * n0, o->vmaps_tmp + 3 * n0 + 3 * (n0 / 4)};
+    float* un[3] = {o->nmaps_tmp, o->nmaps_tmp + 3 * n0, o->nmaps_tmp + 3 * n0 + 3 * (n0 / 4)};
+    auto intr_f = [&](PrepJob& j, int lvl, bool cutoff_too, float cutoff) {
+        const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, lvl);
+        j.f[0] = 1.f / in.fx, j.f[1] = 1.f / in.fy, j.f[2] = in.cx, j.f[3] = in.cy;
+        if (cutoff_too) j.f[4] = cutoff;
+    };
+    auto pyr = [&](PrepBuilder& pb, int op, const void* src, void* dst, int lvl) {  // level lvl-1 -> lvl
+        PrepJob& j = pb.add(op, W >> lvl, H >> lvl);
+        j.src0 = src, j.dst0 = dst;
+        j.scols = W >> (lvl - 1), j.srows = H >> (lvl - 1);
+    };
+    auto level_jobs = [&](PrepBuilder& pb, int lvl) {  // jobs whose inputs are the level-lvl images
+        const int cols = W >> lvl, rows = H >> lvl;
+        PrepJob& t = pb.add(PREP_TRANSFORM_PACK, cols, rows);
+        t.src0 = uv[lvl], t.src1 = un[lvl];
+        t.dst0 = o->vmaps_g_prev[lvl], t.dst1 = o->nmaps_g_prev[lvl], t.dst2 = o->prev_packed[lvl];
+        const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+        for (int k = 0; k < 9; ++k) t.f[k] = R[k];
+        t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
+        PrepJob& d = pb.add(PREP_DERIV, cols, rows);
+        d.src0 = o->next_image[lvl], d.dst0 = o->dIdx[lvl], d.dst1 = o->dIdy[lvl];
+        PrepJob& p = pb.add(PREP_PROJECT, cols, rows);
+        p.src0 = o->last_depth[lvl], p.dst0 = o->cloud[lvl];
+        intr_f(p, lvl, false, 0.f);
+        PrepJob& nm = pb.add(PREP_NMAP, cols, rows);
+        nm.src0 = o->vmaps_curr[lvl], nm.dst0 = o->nmaps_curr[lvl];
+    };
+    auto vmap_job = [&](PrepBuilder& pb, int lvl, const float* depth) {
+        PrepJob& j = pb.add(PREP_VMAP, W >> lvl, H >> lvl);
+        j.src0 = depth, j.dst0 = o->vmaps_curr[lvl];
+        intr_f(j, lvl, true, depth_cutoff);
+    };
+    auto down_jobs = [&](PrepBuilder& pb, int lvl, const float* depth_src) {  // level lvl-1 -> lvl of every pyramid
+        pyr(pb, PREP_PYRDOWN_F, o->last_depth[lvl - 1], o->last_depth[lvl], lvl);
+        pyr(pb, PREP_PYRDOWN_U8, o->next_image[lvl - 1], o->next_image[lvl], lvl);
+        pyr(pb, PREP_PYRDOWN_U8, o->last_image[lvl - 1], o->last_image[lvl], lvl);
+        pyr(pb, PREP_RESIZE_V, uv[lvl - 1], uv[lvl], lvl);
+        pyr(pb, PREP_RESIZE_N, un[lvl - 1], un[lvl], lvl);
+        (void)depth_src;
+    };
+
+    o->depth_l0 = depth_filtered;
+    o->vtmp = pred_vertex, o->ntmp = pred_normal;
+    o->have_tmp = true;
+
+    {   // stage 1: inputs -> level 0 (and level 1 of the depth pyramid)
+        PrepBuilder pb;
+        pyr(pb, PREP_PYRDOWN_F, depth_filtered, o->depth_pyr[1], 1);
+        vmap_job(pb, 0, depth_filtered);
+        PrepJob& v = pb.add(PREP_V2D, W, H);
+        v.src0 = pred_vertex, v.dst0 = o->last_depth[0], v.f[0] = o->max_depth_rgb;
+        PrepJob& in = pb.add(PREP_INTENSITY, W, H);
+        in.src0 = rgb, in.dst0 = o->next_image[0], in.scols = W * rgb_channels, in.channels = rgb_channels;
+        PrepJob& il = pb.add(PREP_INTENSITY, W, H);
+        il.src0 = pred_image, il.dst0 = o->last_image[0], il.scols = W * pred_channels, il.channels = pred_channels;
+        PrepJob& cm = pb.add(PREP_COPY_MAPS, W, H);
+        cm.src0 = pred_vertex, cm.src1 = pred_normal, cm.dst0 = uv[0], cm.dst1 = un[0];
+        int rc = pb.launch(c);
+        if (rc) return rc;
+    }
+    {   // stage 2: level 0 -> level 1 (and level 2 of the depth pyramid)
+        PrepBuilder pb;
+        pyr(pb, PREP_PYRDOWN_F, o->depth_pyr[1], o->depth_pyr[2], 2);
+        vmap_job(pb, 1, o->depth_pyr[1]);
+        level_jobs(pb, 0);
+        down_jobs(pb, 1, nullptr);
+        int rc = pb.launch(c);
+        if (rc) return rc;
+    }
+    {   // stage 3: level 1 -> level 2
+        PrepBuilder pb;
+        vmap_job(pb, 2, o->depth_pyr[2]);
+        level_jobs(pb, 1);
+        down_jobs(pb, 2, nullptr);
+        int rc = pb.launch(c);
+        if (rc) return rc;
+    }
+    {   // stage 4: level 2
+        PrepBuilder pb;
+        level_jobs(pb, 2);
+        int rc = pb.launch(c);
+        if (rc) return rc;
+    }
+    o->prep_batched = true;
+    return MMF_OK;
+}
+
 static IcpArgs odom_icp_args(mmf_odom* o, int level, float* err_map) {
     const int cols = o->width >> level, rows = o->height >> level;
     IcpArgs a;
@@ -995,7 +1123,7 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
     const bool icp = !rgb_only && icp_weight > 0;  // :221-222
     const bool rgb = rgb_only || icp_weight < 100;
 
-    if (rgb)
+    if (rgb && !o->prep_batched)
         for (int i = 0; i < MMF_NUM_PYRS; ++i) {  // :230-235
             int rc = launch_derivative(c, o->next_image[i], o->width >> i, o->width >> i, o->height >> i, o->dIdx[i],
                                        o->width >> i, o->dIdy[i], o->width >> i);
@@ -1036,7 +1164,7 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
     for (int i = MMF_NUM_PYRS - 1; i >= 0; --i) {
         const int cols = o->width >> i, rows = o->height >> i;
         const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, i);
-        if (rgb) {  // :332-334
+        if (rgb && !o->prep_batched) {  // :332-334
             int rc = launch_project(c, o->last_depth[i], cols, cols, rows, in, o->cloud[i]);
             if (rc) return rc;
         }
@@ -1051,7 +1179,8 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
             bool res_vec4 = false;
             if (rgb) {  // :363-371
                 const float min_scale = (float)(std::pow((double)o->min_grad[i], 2.0) / std::pow((double)o->sobel_scale, 2.0));
-                ra = make_residual_args(min_scale, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0, o->next_depth[i], 0,
+                ra = make_residual_args(min_scale, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0,
+                                        o->prep_batched ? o->last_depth[i] : o->next_depth[i], 0,
                                         o->last_image[i], 0, o->next_image[i], 0, o->corres[i], o->max_depth_delta_rgb,
                                         cols, rows, last_l0 ? rgb_err_dev : nullptr, 0);
                 ra.intr = in;
@@ -1872,25 +2001,13 @@ extern "C" int mmf_fusion_process_frame(mmf_fusion* f, const uint8_t* rgb, const
             float pose[16];
             mmf_model_get_pose(f->model, pose);
             std::memcpy(f->last_pose, pose, sizeof(pose));  // lastPose = pose (Model.cpp:412)
-            rc = mmf_odom_build_depth_pyramid(f->odom, f->depth_filtered, 0);  // generateCUDATextures (:302)
-            if (rc) return rc;
+            // generateCUDATextures (:302) + Model::initICP (Model.cpp:390-407): initICPModel, initRGBModel,
+            // initICP, initRGB -- here as the four launches of odom_prepare_batched
             const mmf_model* m = f->model;
-            if (do_fill_in) {
-                rc = mmf_odom_init_icp_model(f->odom, (const float*)m->fill_vertex, (const float*)m->fill_normal,
-                                             g.max_depth_processed, pose);
-                if (rc) return rc;
-                rc = mmf_odom_init_rgb_model(f->odom, (const uint8_t*)m->fill_image, 0, 4);
-            } else {
-                rc = mmf_odom_init_icp_model(f->odom, (const float*)m->vertexConf, (const float*)m->normalRadius,
-                                             g.max_depth_processed, pose);
-                if (rc) return rc;
-                rc = mmf_odom_init_rgb_model(
-                    f->odom, (const uint8_t*)((g.frame_to_frame_rgb && g.fill_in) ? m->fill_image : m->image), 0, 4);
-            }
-            if (rc) return rc;
-            rc = mmf_odom_init_icp(f->odom, nullptr, nullptr, g.max_depth_processed);
-            if (rc) return rc;
-            rc = mmf_odom_init_rgb(f->odom, rgb, 0, 3);
+            const float* pv = (const float*)(do_fill_in ? m->fill_vertex : m->vertexConf);
+            const float* pn = (const float*)(do_fill_in ? m->fill_normal : m->normalRadius);
+            const uint8_t* pi = (const uint8_t*)((do_fill_in || (g.frame_to_frame_rgb && g.fill_in)) ? m->fill_image : m->image);
+            rc = odom_prepare_batched(f->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, pv, pn, pi, 4, pose);
             if (rc) return rc;
             float trans[3] = {pose[3], pose[7], pose[11]};
             float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};

@@ -1,0 +1,127 @@
+// prep_batch.hpp -- the per-frame preparation of the dense tracker (vertex / normal maps, depth and
+// intensity pyramids, gradients, point clouds, the model maps in the global frame) as FOUR launches.
+//
+// Each of those ~40 per-frame jobs (cudafuncs.cu:109-762 called from RGBDOdometry.cpp:108-235 and
+// Model.cpp:359-407) is a one-touch kernel over at most 640x480 pixels: 3-5 us each, almost all of
+// it the dependent-launch floor of the stream (~2.6 us).  They form a dependency chain only four deep
+// (inputs -> level 0 -> level 1 -> level 2), so every stage of the chain runs as ONE launch whose
+// workgroups pick their job from a table by block index.  The jobs call the same per-pixel functions
+// (map_kernels.hpp) as the stand-alone kernels, so the results are bit-identical.
+#pragma once
+#include "icp_kernels.hpp"
+#include "map_kernels.hpp"
+
+namespace mmf {
+
+enum PrepOp : int {
+    PREP_VMAP,            // src0 depth -> dst0 vmap                          f = {1/fx, 1/fy, cx, cy, cutoff}
+    PREP_NMAP,            // src0 vmap -> dst0 nmap
+    PREP_TRANSFORM_PACK,  // src0 vmap, src1 nmap -> dst0 vmap, dst1 nmap, dst2 packed records   f = {R[9], t[3]}
+    PREP_COPY_MAPS,       // src0, src1 RGBA32F prediction -> dst0, dst1 planar
+    PREP_RESIZE_V,        // src0 (scols x srows) -> dst0
+    PREP_RESIZE_N,
+    PREP_PYRDOWN_F,       // src0 (scols x srows) -> dst0
+    PREP_PYRDOWN_U8,
+    PREP_V2D,             // src0 RGBA32F vertices -> dst0 depth                f = {cutoff}
+    PREP_INTENSITY,       // src0 interleaved u8 (stride scols bytes, `channels`) -> dst0
+    PREP_DERIV,           // src0 u8 -> dst0 dIdx, dst1 dIdy
+    PREP_PROJECT,         // src0 depth -> dst0 AoS cloud                     f = {1/fx, 1/fy, cx, cy}
+};
+
+struct PrepJob {
+    int op;
+    int gx;           // 64-pixel tiles per row of this job's grid
+    int first_block;  // first workgroup of the launch that belongs to this job
+    int cols, rows;   // destination size in pixels (all internal buffers are dense: stride = cols)
+    int scols, srows; // source size where it differs (pyramid steps), or the source byte stride (PREP_INTENSITY)
+    int channels;
+    const void *src0, *src1;
+    void *dst0, *dst1, *dst2;
+    float f[12];
+};
+
+constexpr int kMaxPrepJobs = 12;
+struct PrepBatch {
+    int njobs;
+    PrepJob job[kMaxPrepJobs];
+};
+
+// transform_maps_px + pack_prev_kernel in one pass (same arithmetic; an invalid pixel's record is all NaN)
+__device__ __forceinline__ void transform_pack_px(int x, int y, int rows, int cols, const float* __restrict__ vsrc,
+                                                  const float* __restrict__ nsrc, m33 R, f3 t, float* __restrict__ vdst,
+                                                  float* __restrict__ ndst, float* __restrict__ packed) {
+    if (x >= cols || y >= rows) return;
+    f3 vs, vd = make_f3(qnan(), qnan(), qnan());
+    vs.x = vsrc[(size_t)y * cols + x];
+    if (!(vs.x != vs.x)) {
+        vs.y = vsrc[(size_t)(y + rows) * cols + x];
+        vs.z = vsrc[(size_t)(y + 2 * rows) * cols + x];
+        vd = R * vs + t;
+        vdst[(size_t)(y + rows) * cols + x] = vd.y;
+        vdst[(size_t)(y + 2 * rows) * cols + x] = vd.z;
+    }
+    vdst[(size_t)y * cols + x] = vd.x;
+    f3 ns, nd = make_f3(qnan(), qnan(), qnan());
+    ns.x = nsrc[(size_t)y * cols + x];
+    if (!(ns.x != ns.x)) {
+        ns.y = nsrc[(size_t)(y + rows) * cols + x];
+        ns.z = nsrc[(size_t)(y + 2 * rows) * cols + x];
+        nd = R * ns;
+        ndst[(size_t)(y + rows) * cols + x] = nd.y;
+        ndst[(size_t)(y + 2 * rows) * cols + x] = nd.z;
+    }
+    ndst[(size_t)y * cols + x] = nd.x;
+    float2* o = reinterpret_cast<float2*>(packed + 6 * ((size_t)y * cols + x));
+    o[0] = make_float2(vd.x, vd.y);
+    o[1] = make_float2(vd.z, nd.x);
+    o[2] = make_float2(nd.y, nd.z);
+}
+
+__global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
+    int j = 0;
+    for (int k = 1; k < b.njobs; ++k) j = (int)blockIdx.x >= b.job[k].first_block ? k : j;  // wave uniform
+    const PrepJob& J = b.job[j];
+    const int local = (int)blockIdx.x - J.first_block;
+    const int by = local / J.gx, bx = local - by * J.gx;
+    const int x = bx * kTileX + threadIdx.x, y = by * kTileY + threadIdx.y;
+    const int cols = J.cols, rows = J.rows;
+    switch (J.op) {
+        case PREP_VMAP:
+            create_vmap_px(x, y, (const float*)J.src0, cols, cols, rows, (float*)J.dst0, cols, J.f[0], J.f[1], J.f[2], J.f[3],
+                           J.f[4]);
+            break;
+        case PREP_NMAP: create_nmap_px(x, y, rows, cols, (const float*)J.src0, cols, (float*)J.dst0, cols); break;
+        case PREP_TRANSFORM_PACK: {
+            m33 R;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R.m[k] = J.f[k];
+            transform_pack_px(x, y, rows, cols, (const float*)J.src0, (const float*)J.src1, R, make_f3(J.f[9], J.f[10], J.f[11]),
+                              (float*)J.dst0, (float*)J.dst1, (float*)J.dst2);
+            break;
+        }
+        case PREP_COPY_MAPS:
+            copy_maps_px(x, y, rows, cols, (const float4*)J.src0, (const float4*)J.src1, (float*)J.dst0, (float*)J.dst1, cols);
+            break;
+        case PREP_RESIZE_V: resize_map_px<false>(x, y, rows, cols, J.srows, (const float*)J.src0, J.scols, (float*)J.dst0, cols); break;
+        case PREP_RESIZE_N: resize_map_px<true>(x, y, rows, cols, J.srows, (const float*)J.src0, J.scols, (float*)J.dst0, cols); break;
+        case PREP_PYRDOWN_F:
+            pyrdown_gauss_f_px(x, y, (const float*)J.src0, J.scols, J.scols, J.srows, (float*)J.dst0, cols, cols, rows);
+            break;
+        case PREP_PYRDOWN_U8:
+            pyrdown_uchar_gauss_px(x, y, (const uint8_t*)J.src0, J.scols, J.scols, J.srows, (uint8_t*)J.dst0, cols, cols, rows);
+            break;
+        case PREP_V2D: vertices_to_depth_px(x, y, (const float4*)J.src0, cols, rows, (float*)J.dst0, cols, J.f[0]); break;
+        case PREP_INTENSITY:
+            image_to_intensity_px(x, y, (const uint8_t*)J.src0, J.scols, J.channels, cols, rows, (uint8_t*)J.dst0, cols);
+            break;
+        case PREP_DERIV:
+            derivative_px(x, y, (const uint8_t*)J.src0, cols, cols, rows, (int16_t*)J.dst0, cols, (int16_t*)J.dst1, cols);
+            break;
+        case PREP_PROJECT:
+            project_points_px(x, y, (const float*)J.src0, cols, cols, rows, (float*)J.dst0, J.f[0], J.f[1], J.f[2], J.f[3]);
+            break;
+        default: break;
+    }
+}
+
+}  // namespace mmf
