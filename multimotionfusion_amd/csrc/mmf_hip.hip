@@ -463,6 +463,7 @@ extern "C" int mmf_so3_step(mmf_ctx* c, const uint8_t* last_image, size_t last_i
     a.n_stride = stride_elems(next_image_step, cols, 1);
     a.cols = cols;
     a.rows = rows;
+    a.cols_magic = (long long)cols * rows * cols < (1ll << 32) ? (unsigned)((1ull << 32) / (unsigned)cols) + 1u : 0u;
     a.intr = LevelIntr{0, 0, 0, 0};
     const int grid = reduce_grid(cols * rows, kBlock);
     hipLaunchKernelGGL((so3_kernel<FINISH_RAW>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state, a,
@@ -1151,6 +1152,7 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
         a.cols = cols;
         a.rows = rows;
         a.intr = b.so3_intr;
+        a.cols_magic = (unsigned)((1ull << 32) / (unsigned)cols) + 1u;
         const int grid = reduce_grid(cols * rows, kBlock);
         for (int i = 0; i < 10; ++i) {
             hipLaunchKernelGGL((so3_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), 0, c->stream, o->state, a,

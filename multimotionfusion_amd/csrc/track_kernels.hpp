@@ -700,46 +700,74 @@ struct So3Args {
     const uint8_t *last_image, *next_image;
     int l_stride, n_stride;
     int cols, rows;
+    unsigned cols_magic;  // floor(2^32 / cols) + 1
     LevelIntr intr;
 };
 
-__device__ __forceinline__ void so3_gradient(const uint8_t* img, int stride, int x, int y, float& gx, float& gy) {
-    const float actu = (float)img[(size_t)y * stride + x];  // reduce.cu:963-979
-    float back = (float)img[(size_t)y * stride + x - 1];
-    float fore = (float)img[(size_t)y * stride + x + 1];
-    gx = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
-    back = (float)img[(size_t)(y - 1) * stride + x];
-    fore = (float)img[(size_t)(y + 1) * stride + x];
-    gy = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+// the five taps of one central-difference gradient (reduce.cu:963-979), loaded from clamped addresses
+struct So3Taps {
+    uint8_t actu, left, right, up, down;
+};
+__device__ __forceinline__ So3Taps so3_load_taps(const uint8_t* img, int stride, int cols, int rows, int x, int y) {
+    const int xc = min(max(x, 1), cols - 2), yc = min(max(y, 1), rows - 2);  // found => 1 <= x < cols-1, same for y
+    So3Taps t;
+    t.actu = img[(size_t)yc * stride + xc];
+    t.left = img[(size_t)yc * stride + xc - 1];
+    t.right = img[(size_t)yc * stride + xc + 1];
+    t.up = img[(size_t)(yc - 1) * stride + xc];
+    t.down = img[(size_t)(yc + 1) * stride + xc];
+    return t;
+}
+__device__ __forceinline__ void so3_gradient(const So3Taps& t, float& gx, float& gy) {
+    const float actu = (float)t.actu;
+    gx = (((float)t.left + actu) / 2.0f) - (((float)t.right + actu) / 2.0f);
+    gy = (((float)t.up + actu) / 2.0f) - (((float)t.down + actu) / 2.0f);
 }
 
+// Load order as in rgb_step_kernel: the last-frame taps depend on nothing but the pixel, so they are
+// issued before the (cold) device state is read; the warped taps follow as one group; no load sits
+// under a data-dependent branch.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void so3_kernel(OdomState* __restrict__ st, So3Args a,
                                                      float* __restrict__ partials,
                                                      unsigned* __restrict__ ticket) {
     __shared__ GridReduceLds<float, kBlock> lds;
-    if (MODE == FINISH_GN && st->so3_done) return;
     float sum[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) sum[k] = 0.f;
     const int N = a.cols * a.rows, cols = a.cols, rows = a.rows;
-    const m33& B = *reinterpret_cast<const m33*>(st->imageBasis);
-    const m33& kinv = *reinterpret_cast<const m33*>(st->kinv);
-    const float* krlr = st->krlr;
+    int k = blockIdx.x * kBlock + threadIdx.x;
+    const bool live0 = k < N;
+    // k / cols by multiply-high; cols_magic == 0 (image too large for it) selects the plain division
+    auto row_of = [&](int i) { return a.cols_magic ? (int)__umulhi((unsigned)i, a.cols_magic) : i / cols; };
+    int y = row_of(live0 ? k : 0), x = (live0 ? k : 0) - y * cols;
+    So3Taps tl = so3_load_taps(a.last_image, a.l_stride, cols, rows, x, y);
+    __builtin_amdgcn_sched_barrier(0);
+    const int so3_done = MODE == FINISH_GN ? st->so3_done : 0;
+    m33 B, kinv;
+    float krlr[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) B.m[q] = st->imageBasis[q], kinv.m[q] = st->kinv[q], krlr[q] = st->krlr[q];
+    if (so3_done) return;
 
-    for (int k = blockIdx.x * kBlock + threadIdx.x; k < N; k += gridDim.x * kBlock) {
-        const int y = k / cols, x = k - y * cols;
+    for (bool first = true; k < N; k += gridDim.x * kBlock, first = false) {
+        if (!first) {  // images beyond the grid's single pass
+            y = row_of(k), x = k - y * cols;
+            tl = so3_load_taps(a.last_image, a.l_stride, cols, rows, x, y);
+        }
         const f3 unwarped = make_f3((float)x, (float)y, 1.0f);
         const f3 warped = B * unwarped;
         const int wx = float2int_rn(warped.x / warped.z);
         const int wy = float2int_rn(warped.y / warped.z);
         const bool found = (wx >= 1 && wx < cols - 1 && wy >= 1 && wy < rows - 1 && x >= 1 &&
                             x < cols - 1 && y >= 1 && y < rows - 1);
-        float row[4] = {0.f, 0.f, 0.f, 0.f};
-        if (found) {  // reduce.cu:1011-1046
+        const So3Taps tn = so3_load_taps(a.next_image, a.n_stride, cols, rows, found ? wx : 1, found ? wy : 1);
+        __builtin_amdgcn_sched_barrier(0);
+        float row[4];
+        {  // reduce.cu:1011-1046, branch free
             float gnx, gny, glx, gly;
-            so3_gradient(a.next_image, a.n_stride, wx, wy, gnx, gny);
-            so3_gradient(a.last_image, a.l_stride, x, y, glx, gly);
+            so3_gradient(tn, gnx, gny);
+            so3_gradient(tl, glx, gly);
             const float gx = (gnx + glx) / 2.0f;
             const float gy = (gny + gly) / 2.0f;
             const f3 point = kinv * unwarped;
@@ -752,10 +780,10 @@ __global__ __launch_bounds__(kBlock) void so3_kernel(OdomState* __restrict__ st,
             left.y = ((point.z * (E * gy + Bc * gx)) - (gy * H * y) - (gx * H * x)) / z2;
             left.z = ((point.z * (F * gy + C * gx)) - (gy * I * y) - (gx * I * x)) / z2;
             const f3 jac = cross(left, point);
-            row[0] = jac.x;
-            row[1] = jac.y;
-            row[2] = jac.z;
-            row[3] = -((float)a.next_image[(size_t)wy * a.n_stride + wx] - (float)a.last_image[(size_t)y * a.l_stride + x]);
+            row[0] = found ? jac.x : 0.f;
+            row[1] = found ? jac.y : 0.f;
+            row[2] = found ? jac.z : 0.f;
+            row[3] = found ? -((float)tn.actu - (float)tl.actu) : 0.f;
         }
         // member order of JtJJtrSO3 (types.cuh:154-162)
         sum[0] = sum[0] + row[0] * row[0];
