@@ -474,14 +474,17 @@ __global__ __launch_bounds__(kBlock) void track_producer_kernel(const OdomState*
     __shared__ GridReduceLds<float, kBlock> lds;
     // st->level_break is checked inside the blocks, after their state-independent loads are in flight
     using T = typename std::conditional<W == 2, v2f, float>::type;
-    if (blockIdx.x < icp_blocks) {
+    // the correspondence workgroups are the long pole of the launch (phase stamps): they take the
+    // FIRST block indices so that they are dispatched first
+    const unsigned res_blocks = gridDim.x - icp_blocks;
+    if (blockIdx.x >= res_blocks) {
+        const unsigned bid = blockIdx.x - res_blocks;
         if (ia.err_map)
-            icp_block2<T, 1, kBlock, PACKED, true, true>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
+            icp_block2<T, 1, kBlock, PACKED, true, true>(st, ia, icp_partials, lds, bid, icp_blocks);
         else
-            icp_block2<T, 1, kBlock, PACKED, false, true>(st, ia, icp_partials, lds, blockIdx.x, icp_blocks);
+            icp_block2<T, 1, kBlock, PACKED, false, true>(st, ia, icp_partials, lds, bid, icp_blocks);
     } else {
-        residual_block4<true>(st, ra, res_partials, reinterpret_cast<GridReduceLds<int, kBlock>&>(lds), blockIdx.x - icp_blocks,
-                        gridDim.x - icp_blocks);
+        residual_block4<true>(st, ra, res_partials, reinterpret_cast<GridReduceLds<int, kBlock>&>(lds), blockIdx.x, res_blocks);
     }
 }
 

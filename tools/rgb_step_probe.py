@@ -64,9 +64,9 @@ def probe(W, H):
     print("  mean per-workgroup phase (us): " + ", ".join(f"{n} {v:.2f}" for n, v in list(zip(NAMES[:5], ph.mean(axis=0)))[2:]))
     print(f"  finishing workgroup {last}: record sums {(s[last, 6] - s[last, 5]) * 0.01:.2f} us, solve + stores issued "
           f"{(s[last, 7] - s[last, 6]) * 0.01:.2f} us; kernel first start .. finish {(s[last, 7] - t0) * 0.01:.2f} us")
-    # correspondence-pass workgroups of the last producer launch: slots 8..13 of workgroups [N/512, N/512 + N/1024)
+    # correspondence-pass workgroups of the last producer launch: slots 8..13 of workgroups [0, N/1024)
     full = stamps.cpu().numpy().reshape(-1, 16)
-    r = full[W * H // 512:W * H // 512 + nb, 8:14]
+    r = full[:nb, 8:14]  # the correspondence workgroups take the first block indices
     r0 = r[:, 0].min()
     rp = np.diff(r, axis=1) * 0.01
     print(f"  residual workgroups of the last producer launch: first start .. last end {(r[:, 5].max() - r0) * 0.01:.2f} us; "
