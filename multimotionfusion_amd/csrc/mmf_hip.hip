@@ -410,6 +410,8 @@ extern "C" int mmf_rgb_step(mmf_ctx* c, const mmf_dataterm* corres_dev, float si
     MMF_HIP_TRY(hipMemcpyAsync(&c->scratch_state->sigmaVal, &c->host_state->sigmaVal, sizeof(float),
                                hipMemcpyHostToDevice, c->stream));
     RgbStepArgs a;
+    a.next_level = 0;
+    a.cols_magic = 0;
     a.residual_partials = nullptr;
     a.residual_records = 0;
     a.icp_partials = nullptr;
@@ -1163,6 +1165,7 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
 
     const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};  // :312-314
     bool first_level = true;
+    bool begin_folded = false;  // this level's gn_level_begin ran in the last rgb_step of the level before
     for (int i = MMF_NUM_PYRS - 1; i >= 0; --i) {
         const int cols = o->width >> i, rows = o->height >> i;
         const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, i);
@@ -1170,9 +1173,12 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
             int rc = launch_project(c, o->last_depth[i], cols, cols, rows, in, o->cloud[i]);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(gn_level_begin_kernel, dim3(1), dim3(64), 0, c->stream, o->state, first_level ? 1 : 0, in);
-        MMF_HIP_TRY(hipGetLastError());
+        if (!begin_folded) {
+            hipLaunchKernelGGL(gn_level_begin_kernel, dim3(1), dim3(64), 0, c->stream, o->state, first_level ? 1 : 0, in);
+            MMF_HIP_TRY(hipGetLastError());
+        }
         first_level = false;
+        begin_folded = false;
 
         for (int j = 0; j < iterations[i]; ++j) {
             const bool last_l0 = (i == 0 && j == iterations[i] - 1);
@@ -1245,6 +1251,14 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
                 a.rows = rows;
                 a.cols_magic = ra.cols_magic;
                 a.intr = in;
+                // the last step of a level also does the next level's gn_level_begin (one launch less per
+                // level).  Not with rgbOnly: its divergence `break` skips the finishing lane.
+                a.next_level = 0;
+                if (j == iterations[i] - 1 && i > 0 && iterations[i - 1] > 0 && !rgb_only) {
+                    a.next_level = 1;
+                    a.intr = level_intr(o->fx, o->fy, o->cx, o->cy, i - 1);  // only read by the finishing lane's rgb_prepare
+                    begin_folded = true;
+                }
                 const int grid = reduce_grid(cols * rows, kBlock * 4);  // width, height are multiples of 4
                 if (res_vec4)  // the 4-pixel correspondence pass wrote compact records
                     hipLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, true>), dim3(grid), dim3(kBlock), 0, c->stream,

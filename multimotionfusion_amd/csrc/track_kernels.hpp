@@ -528,7 +528,8 @@ struct RgbStepArgs {
     float sobel_scale;
     int cols, rows;
     unsigned cols_magic;  // floor(2^32 / cols) + 1
-    LevelIntr intr;
+    LevelIntr intr;       // intrinsics the finishing lane prepares the NEXT correspondence pass with
+    int next_level;       // 1: that pass belongs to the next pyramid level (gn_level_begin_kernel folded in)
 };
 
 // The two halves of one pass of rgbKernel (reduce.cu:504-535) over the PX records of a lane.
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
             st->sigma = res_sigma;
             st->rgbCount = res_count;
             st->sigmaVal = dec.sigmaVal;
-            st->st.lastRGBError = dec.tmpError;
+            st->st.lastRGBError = a.next_level ? FLT_MAX : dec.tmpError;  // RGBDOdometry.cpp:329 at a level start
             st->st.lastRGBCount = (float)res_count;
 #ifndef MMF_SKIP_SOLVE
             solve_and_update(st, si, lds.total, icp ? lds.total2 : nullptr, a.intr);
