@@ -92,10 +92,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # MMF_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks
+    # (ranks share devices round robin); the driver's runs use nccl = RCCL, one rank per GPU
+    backend = os.environ.get("MMF_BENCH_BACKEND", "nccl")
+    ndev = max(1, torch.cuda.device_count())
+    if backend != "nccl":
+        local_rank %= ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
 
@@ -112,9 +121,12 @@ def main():
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     d_rgb = [up(f["rgb"]) for f in frames]
     d_depth = [up(f["depth"]) for f in frames]
-    rgb_in = torch.empty_like(d_rgb[0])
-    depth_in = torch.empty_like(d_depth[0])
-    mask_in = torch.zeros(H, W, dtype=torch.uint8, device=dev)
+    # N > 1: two frame buffers, so that rank 0's broadcast of frame k + 1 (RCCL's own stream) overlaps the
+    # processing of frame k
+    rgb_in = [torch.empty_like(d_rgb[0]) for _ in range(2)]
+    depth_in = [torch.empty_like(d_depth[0]) for _ in range(2)]
+    mask_in = [torch.zeros(H, W, dtype=torch.uint8, device=dev) for _ in range(2)]
+    pending = {}
 
     ctx = Context(local_rank)
     from multimotionfusion_amd.fusion import MultiMotionFusion
@@ -130,20 +142,31 @@ def main():
             mmf.reset()
         state["frame"] += 1
         if world > 1:  # rank 0's sensor frame reaches every model owner (RCCL broadcast over xGMI)
-            rgb_in.copy_(d_rgb[k])
-            depth_in.copy_(d_depth[k])
-            shard.broadcast_frame(rgb_in, depth_in, mask_in, src=0)
-            mmf.processFrame(rgb_in, depth_in, timestamp=i)
+            def post(n):  # start the broadcast of sequence frame n into buffer n % 2
+                b, kk = n % 2, n % len(frames)
+                if rank == 0:
+                    rgb_in[b].copy_(d_rgb[kk])
+                    depth_in[b].copy_(d_depth[kk])
+                pending[n] = shard.broadcast_frame_async(rgb_in[b], depth_in[b], mask_in[b], src=0)
+            n = state["frame"] - 1
+            if n not in pending:
+                post(n)
+            for w in pending.pop(n):
+                w.wait()  # the compute stream waits for the collective; the host does not
+            post(n + 1)
+            mmf.processFrame(rgb_in[n % 2], depth_in[n % 2], timestamp=i)
         else:  # inputs already resident in HBM
             mmf.processFrame(d_rgb[k], d_depth[k], timestamp=i)
         pose = mmf.getCurrPose()
-        if world > 1:
+        if world > 1:  # every rank learns every model's pose (18 floats per rank), without a host round trip
             od = mmf.getFrameOdometry()
-            shard.gather_poses(pose, od.lastICPError, od.lastICPCount, dev)
+            state["poses"] = shard.gather_poses_async(pose, od.lastICPError, od.lastICPCount, dev)
         return pose
 
     def fence():
         if world > 1:
+            if state.get("poses") is not None:
+                state["poses"][0].wait()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -157,7 +180,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -210,7 +233,7 @@ def main():
             "icp_inliers_last": odom.lastICPCount,
             "surfels": n_surfels,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             result["cpu_baseline"] = cpu_baseline(frames, K, poses)
     fence()
     if rank == 0:

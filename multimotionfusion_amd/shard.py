@@ -34,6 +34,24 @@ def broadcast_frame(rgb: torch.Tensor, depth: torch.Tensor, mask: torch.Tensor, 
     dist.broadcast(mask, src=src)
 
 
+def broadcast_frame_async(rgb: torch.Tensor, depth: torch.Tensor, mask: torch.Tensor, src: int = 0):
+    """broadcast_frame without blocking: returns the work handles; `wait()` on them orders the current
+    stream after the collectives (no host synchronisation with nccl)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return []
+    return [dist.broadcast(t, src=src, async_op=True) for t in (rgb, depth, mask)]
+
+
+def gather_poses_async(pose: np.ndarray, icp_error: float, icp_count: float, device):
+    """Non-blocking gather_poses: returns (work handle, list of per-rank [18] tensors)."""
+    rec = torch.zeros(18, dtype=torch.float32)
+    rec[:16] = torch.from_numpy(np.asarray(pose, np.float32).reshape(16))
+    rec[16], rec[17] = float(icp_error), float(icp_count)
+    rec = rec.to(device, non_blocking=True)
+    out = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
+    return dist.all_gather(out, rec, async_op=True), out
+
+
 def gather_poses(pose: np.ndarray, icp_error: float, icp_count: float, device) -> np.ndarray:
     """all_gather of [16 pose floats, lastICPError, lastICPCount] -> array [world, 18]."""
     rec = torch.zeros(18, dtype=torch.float32, device=device)

@@ -60,6 +60,17 @@ def _worker(rank, world, port, out_dir):
     for r in range(world):
         assert abs(allp[r, 3] - (t[0] + r)) < 1e-5, (rank, r, allp[:, 3], t)  # every rank sees every rank's pose
         assert allp[r, 17] == s.lastICPCount
+    # the non-blocking forms bench.py uses to overlap the next frame's broadcast with tracking
+    rgb2 = rgb.clone() if rank == 0 else torch.zeros_like(rgb)
+    depth2 = depth.clone() if rank == 0 else torch.zeros_like(depth)
+    works = shard.broadcast_frame_async(rgb2, depth2, mask, src=0)
+    assert len(works) == 3
+    for wk in works:
+        wk.wait()
+    assert np.array_equal(rgb2.numpy(), ref["rgb"]) and np.array_equal(depth2.numpy(), ref["depth"])
+    work, parts = shard.gather_poses_async(pose, s.lastICPError, s.lastICPCount, torch.device("cpu"))
+    work.wait()
+    assert np.array_equal(torch.stack(parts).numpy(), allp)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), allp)
     dist.barrier()
     dist.destroy_process_group()
