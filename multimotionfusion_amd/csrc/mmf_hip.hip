@@ -998,9 +998,12 @@ struct PrepBuilder {
 // Everything initICPModel + initRGBModel + generateCUDATextures/initICP + initRGB + the gradient and
 // point-cloud passes of getIncrementalTransformation compute (RGBDOdometry.cpp:108-235, 332-334;
 // Model.cpp:359-407), for inputs that stay untouched until tracking returns (the native orchestrator).
+// `sel` (device, may be null): when *sel != 0 the prediction is read from the alt_* images instead.
 static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float depth_cutoff, const uint8_t* rgb,
                                 int rgb_channels, const float* pred_vertex, const float* pred_normal,
-                                const uint8_t* pred_image, int pred_channels, const float pose[16]) {
+                                const uint8_t* pred_image, int pred_channels, const float pose[16],
+                                const int* sel = nullptr, const float* alt_vertex = nullptr,
+                                const float* alt_normal = nullptr, const uint8_t* alt_image = nullptr) {
     mmf_ctx* c = o->ctx;
     const int W = o->width, H = o->height;
     const size_t n0 = (size_t)W * H;
@@ -1058,12 +1061,15 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
         vmap_job(pb, 0, depth_filtered);
         PrepJob& v = pb.add(PREP_V2D, W, H);
         v.src0 = pred_vertex, v.dst0 = o->last_depth[0], v.f[0] = o->max_depth_rgb;
+        v.sel = sel, v.alt0 = alt_vertex;
         PrepJob& in = pb.add(PREP_INTENSITY, W, H);
         in.src0 = rgb, in.dst0 = o->next_image[0], in.scols = W * rgb_channels, in.channels = rgb_channels;
         PrepJob& il = pb.add(PREP_INTENSITY, W, H);
         il.src0 = pred_image, il.dst0 = o->last_image[0], il.scols = W * pred_channels, il.channels = pred_channels;
+        il.sel = sel, il.alt0 = alt_image;
         PrepJob& cm = pb.add(PREP_COPY_MAPS, W, H);
         cm.src0 = pred_vertex, cm.src1 = pred_normal, cm.dst0 = uv[0], cm.dst1 = un[0];
+        cm.sel = sel, cm.alt0 = alt_vertex, cm.alt1 = alt_normal;
         int rc = pb.launch(c);
         if (rc) return rc;
     }
@@ -2009,10 +2015,14 @@ extern "C" int mmf_fusion_process_frame(mmf_fusion* f, const uint8_t* rgb, const
         f->tracking_ok = 1;
         if (bootstrap || !in_pose) {
             // Model::performTracking (Model.cpp:409-433) with Model::initICP (:390-407)
-            int do_fill_in = 0;
+            // requiresFillIn (:380, :877-895) decided on the device: the preparation jobs pick their
+            // sources from the flag, no host round trip
+            const mmf_model* mm = f->model;
+            int* fill_flag = reinterpret_cast<int*>(&mm->totals[3]);
             if (g.fill_in) {
-                rc = mmf_model_requires_fill_in(f->model, 0.75f, &do_fill_in);  // :380, :877-895
-                if (rc) return rc;
+                hipLaunchKernelGGL(thumbnail_flag_kernel, dim3(1), dim3(256), 0, c->stream, mm->image, mm->width, mm->height,
+                                   0.75f, fill_flag);
+                MMF_HIP_TRY(hipGetLastError());
             }
             float pose[16];
             mmf_model_get_pose(f->model, pose);
@@ -2020,10 +2030,11 @@ extern "C" int mmf_fusion_process_frame(mmf_fusion* f, const uint8_t* rgb, const
             // generateCUDATextures (:302) + Model::initICP (Model.cpp:390-407): initICPModel, initRGBModel,
             // initICP, initRGB -- here as the four launches of odom_prepare_batched
             const mmf_model* m = f->model;
-            const float* pv = (const float*)(do_fill_in ? m->fill_vertex : m->vertexConf);
-            const float* pn = (const float*)(do_fill_in ? m->fill_normal : m->normalRadius);
-            const uint8_t* pi = (const uint8_t*)((do_fill_in || (g.frame_to_frame_rgb && g.fill_in)) ? m->fill_image : m->image);
-            rc = odom_prepare_batched(f->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, pv, pn, pi, 4, pose);
+            const uint8_t* pi = (const uint8_t*)((g.frame_to_frame_rgb && g.fill_in) ? m->fill_image : m->image);
+            rc = odom_prepare_batched(f->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
+                                      (const float*)m->normalRadius, pi, 4, pose, g.fill_in ? fill_flag : nullptr,
+                                      (const float*)m->fill_vertex, (const float*)m->fill_normal,
+                                      (const uint8_t*)m->fill_image);
             if (rc) return rc;
             float trans[3] = {pose[3], pose[7], pose[11]};
             float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};

@@ -37,6 +37,10 @@ struct PrepJob {
     int channels;
     const void *src0, *src1;
     void *dst0, *dst1, *dst2;
+    // optional device-side choice of the sources: when sel != nullptr and *sel != 0 the job reads
+    // alt0 / alt1 instead of src0 / src1 (the fill-in decision, Model.cpp:380, taken on the device)
+    const int* sel;
+    const void *alt0, *alt1;
     float f[12];
 };
 
@@ -85,40 +89,43 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
     const int by = local / J.gx, bx = local - by * J.gx;
     const int x = bx * kTileX + threadIdx.x, y = by * kTileY + threadIdx.y;
     const int cols = J.cols, rows = J.rows;
+    const bool alt = J.sel != nullptr && *J.sel != 0;  // wave uniform
+    const void* src0 = alt ? J.alt0 : J.src0;
+    const void* src1 = alt ? J.alt1 : J.src1;
     switch (J.op) {
         case PREP_VMAP:
-            create_vmap_px(x, y, (const float*)J.src0, cols, cols, rows, (float*)J.dst0, cols, J.f[0], J.f[1], J.f[2], J.f[3],
+            create_vmap_px(x, y, (const float*)src0, cols, cols, rows, (float*)J.dst0, cols, J.f[0], J.f[1], J.f[2], J.f[3],
                            J.f[4]);
             break;
-        case PREP_NMAP: create_nmap_px(x, y, rows, cols, (const float*)J.src0, cols, (float*)J.dst0, cols); break;
+        case PREP_NMAP: create_nmap_px(x, y, rows, cols, (const float*)src0, cols, (float*)J.dst0, cols); break;
         case PREP_TRANSFORM_PACK: {
             m33 R;
 #pragma unroll
             for (int k = 0; k < 9; ++k) R.m[k] = J.f[k];
-            transform_pack_px(x, y, rows, cols, (const float*)J.src0, (const float*)J.src1, R, make_f3(J.f[9], J.f[10], J.f[11]),
+            transform_pack_px(x, y, rows, cols, (const float*)src0, (const float*)src1, R, make_f3(J.f[9], J.f[10], J.f[11]),
                               (float*)J.dst0, (float*)J.dst1, (float*)J.dst2);
             break;
         }
         case PREP_COPY_MAPS:
-            copy_maps_px(x, y, rows, cols, (const float4*)J.src0, (const float4*)J.src1, (float*)J.dst0, (float*)J.dst1, cols);
+            copy_maps_px(x, y, rows, cols, (const float4*)src0, (const float4*)src1, (float*)J.dst0, (float*)J.dst1, cols);
             break;
-        case PREP_RESIZE_V: resize_map_px<false>(x, y, rows, cols, J.srows, (const float*)J.src0, J.scols, (float*)J.dst0, cols); break;
-        case PREP_RESIZE_N: resize_map_px<true>(x, y, rows, cols, J.srows, (const float*)J.src0, J.scols, (float*)J.dst0, cols); break;
+        case PREP_RESIZE_V: resize_map_px<false>(x, y, rows, cols, J.srows, (const float*)src0, J.scols, (float*)J.dst0, cols); break;
+        case PREP_RESIZE_N: resize_map_px<true>(x, y, rows, cols, J.srows, (const float*)src0, J.scols, (float*)J.dst0, cols); break;
         case PREP_PYRDOWN_F:
-            pyrdown_gauss_f_px(x, y, (const float*)J.src0, J.scols, J.scols, J.srows, (float*)J.dst0, cols, cols, rows);
+            pyrdown_gauss_f_px(x, y, (const float*)src0, J.scols, J.scols, J.srows, (float*)J.dst0, cols, cols, rows);
             break;
         case PREP_PYRDOWN_U8:
-            pyrdown_uchar_gauss_px(x, y, (const uint8_t*)J.src0, J.scols, J.scols, J.srows, (uint8_t*)J.dst0, cols, cols, rows);
+            pyrdown_uchar_gauss_px(x, y, (const uint8_t*)src0, J.scols, J.scols, J.srows, (uint8_t*)J.dst0, cols, cols, rows);
             break;
-        case PREP_V2D: vertices_to_depth_px(x, y, (const float4*)J.src0, cols, rows, (float*)J.dst0, cols, J.f[0]); break;
+        case PREP_V2D: vertices_to_depth_px(x, y, (const float4*)src0, cols, rows, (float*)J.dst0, cols, J.f[0]); break;
         case PREP_INTENSITY:
-            image_to_intensity_px(x, y, (const uint8_t*)J.src0, J.scols, J.channels, cols, rows, (uint8_t*)J.dst0, cols);
+            image_to_intensity_px(x, y, (const uint8_t*)src0, J.scols, J.channels, cols, rows, (uint8_t*)J.dst0, cols);
             break;
         case PREP_DERIV:
-            derivative_px(x, y, (const uint8_t*)J.src0, cols, cols, rows, (int16_t*)J.dst0, cols, (int16_t*)J.dst1, cols);
+            derivative_px(x, y, (const uint8_t*)src0, cols, cols, rows, (int16_t*)J.dst0, cols, (int16_t*)J.dst1, cols);
             break;
         case PREP_PROJECT:
-            project_points_px(x, y, (const float*)J.src0, cols, cols, rows, (float*)J.dst0, J.f[0], J.f[1], J.f[2], J.f[3]);
+            project_points_px(x, y, (const float*)src0, cols, cols, rows, (float*)J.dst0, J.f[0], J.f[1], J.f[2], J.f[3]);
             break;
         default: break;
     }

@@ -1014,6 +1014,29 @@ __global__ __launch_bounds__(256) void thumbnail_count_kernel(const uchar4* __re
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned)__popcll(b));
 }
 
+// The same count by ONE workgroup, turned into the decision on the device: *flag = 1 when fewer than
+// `ratio` of the thumbnail samples are covered (MultiMotionFusion.cpp:877-895).  The native orchestrator
+// uses it to pick the tracker's source images without a host round trip.
+__global__ __launch_bounds__(256) void thumbnail_flag_kernel(const uchar4* __restrict__ image_pred, int cols, int rows,
+                                                             float ratio, int* __restrict__ flag) {
+    const int dc = cols / 20, dr = rows / 20;
+    int hits = 0;
+    for (int t = threadIdx.x; t < dc * dr; t += 256) {
+        const int j = t / dc, i = t - j * dc;
+        const float tx = (i + 0.5f) / dc, ty = (j + 0.5f) / dr;
+        const uchar4 p = image_pred[(size_t)texel(ty, rows) * cols + texel(tx, cols)];
+        hits += (p.x > 0 && p.y > 0 && p.z > 0) ? 1 : 0;
+    }
+    __shared__ int part[4];
+    hits = wave_sum_to_lane63(hits);
+    if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = hits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = part[0] + part[1] + part[2] + part[3];
+        *flag = ((float)total / (float)(dr * dc) < ratio) ? 1 : 0;
+    }
+}
+
 __global__ void fill_u64_kernel(unsigned long long* p, size_t n, unsigned long long v) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
