@@ -103,6 +103,7 @@ class OracleFusion:
             self.odom.initFirstRGB(rgb)
         else:
             do_fill = o.requires_fill_in(self.image, 0.75)
+            self.fill_in_taken = bool(do_fill)
             self.last_pose = self.pose.copy()
             if do_fill:
                 self.odom.initICPModel(self.fillVertex, self.fillNormal, self.pose)

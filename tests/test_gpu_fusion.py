@@ -48,6 +48,34 @@ def test_process_frame_sequence(gpu_ctx, orc, w, h, nframes):
     g.close()
 
 
+def test_process_frame_fill_in_branch(gpu_ctx, orc):
+    """A first frame with 45 % of its depth missing leaves the model covering < 75 % of the view, so the
+    next frame's tracker must run against the fill-in images (Model.cpp:380-407); the decision is taken on
+    the device here and by requiresFillIn in the oracle orchestration."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h = 320, 240
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(4, seed=11)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    frames[0]["depth"] = frames[0]["depth"].copy()
+    frames[0]["depth"][:, : int(0.45 * w)] = 0.0
+    g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    o = OracleFusion(orc, w, h, K)
+    taken = []
+    for i, f in enumerate(frames):
+        g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=i)
+        o.process_frame(f["rgb"], f["depth"])
+        if i:
+            taken.append(o.fill_in_taken)
+        pg = g.getCurrPose()
+        assert np.abs(pg[:3, 3] - o.pose[:3, 3]).max() <= 1e-5, (i, pg[:3, 3], o.pose[:3, 3])
+        assert np.abs(pg[:3, :3] - o.pose[:3, :3]).max() <= 1e-5
+        ng, no = g.getBackgroundModel().lastCount(), o.surfels.shape[0]
+        assert abs(ng - no) <= max(8, 0.002 * no), (i, ng, no)
+    assert taken[0] is True, taken  # the branch under test was exercised
+    g.close()
+
+
 def test_process_frame_rejects_bad_input(gpu_ctx):
     from multimotionfusion_amd import MmfError
     from multimotionfusion_amd.fusion import MultiMotionFusion
