@@ -85,3 +85,49 @@ def test_process_frame_rejects_bad_input(gpu_ctx):
         g.processFrame(torch.zeros(48, 64, 3, dtype=torch.uint8, device="cuda"),
                        torch.zeros(48, 64, device="cuda"), timestamp=-1)
     g.close()
+
+
+def test_batched_preparation_matches_the_separate_kernels(gpu_ctx):
+    """The orchestrator prepares a frame's tracking inputs with four batched launches (prep_batch.hpp); the
+    public RGBDOdometry init* calls use one kernel per job.  Same per-pixel functions, so every pyramid
+    buffer must agree bit for bit."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    from multimotionfusion_amd.model import filterDepth
+    from multimotionfusion_amd.odometry import RGBDOdometry
+    from helpers import assert_bit_equal
+    w, h = 320, 240
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(2, seed=13)
+    f0, f1 = (synth.render(p, w, h, seed=i) for i, p in enumerate(poses))
+    g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    g.processFrame(dev(f0["rgb"]), dev(f0["depth"]), timestamp=0)
+    m = g.getBackgroundModel()
+    # what the tracker of frame 1 will be prepared from: after one frame the surfels are still unstable,
+    # the splat shows nothing and the fill-in images are used (Model.cpp:380-407)
+    names = ("fillVertex", "fillNormal", "fillImage") if m.requiresFillIn(0.75) else ("vertexConf", "normalRadius", "image")
+    vc, nr, img = (m.texture(n).clone() for n in names)
+    pose0 = g.getCurrPose().astype(np.float32)
+    d_rgb1, d_depth1 = dev(f1["rgb"]), dev(f1["depth"])
+    g.processFrame(d_rgb1, d_depth1, timestamp=1)
+    batched = g.getFrameOdometry()
+
+    ref = RGBDOdometry(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    ref.initFirstRGB(dev(f0["rgb"]))
+    ref.initICPModel(vc, nr, 20.0, pose0)
+    ref.initRGBModel(img)
+    ref.buildDepthPyramid(filterDepth(gpu_ctx, d_depth1, 15.0))
+    ref.initICP(depthCutoff=20.0)
+    ref.initRGB(d_rgb1)
+    ref.getIncrementalTransformation(pose0[:3, 3], pose0[:3, :3], False, 10.0, True, False, True)  # gradients, clouds
+    for lvl in range(3):
+        rows = h >> lvl
+        for name in ("vmaps_curr", "nmaps_curr", "vmaps_g_prev", "nmaps_g_prev"):
+            a, b = batched.download(name, lvl), ref.download(name, lvl)
+            valid = ~np.isnan(b[:rows])
+            assert_bit_equal(np.isnan(a[:rows]), np.isnan(b[:rows]), f"{name}[{lvl}] validity")
+            for p in range(3):
+                assert_bit_equal(a[p * rows:(p + 1) * rows][valid], b[p * rows:(p + 1) * rows][valid], f"{name}[{lvl}] plane {p}")
+        for name in ("last_depth", "last_image", "dIdx", "dIdy", "cloud") + (("depth_pyr",) if lvl else ()):
+            assert_bit_equal(batched.download(name, lvl), ref.download(name, lvl), f"{name}[{lvl}]")
+    ref.close()
+    g.close()
