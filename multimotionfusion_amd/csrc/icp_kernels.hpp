@@ -5,8 +5,9 @@
 // instructions per pixel (2.2 us of pure issue time over 1024 SIMDs), four dependent memory round
 // trips (hipcc sank the normal loads and split the gathers behind the `found` branch), a 32-bit
 // integer division per pass and a 174-instruction DPP reduction per wave.  This version:
-//   * computes TWO pixels per lane in packed registers (v_pk_mul_f32 / v_pk_add_f32 /
-//     v_pk_fma_f32 operate on a float pair at full rate): ~half the arithmetic instructions;
+//   * computes TWO pixels per lane (in packed registers: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32),
+//     sharing the per-lane scalar work; a packed op costs what its two scalar ops cost on gfx950
+//     (the 1-pixel instantiation times the same), so this halves the instruction stream, not the time;
 //   * is branch free per pixel, with scheduling barriers around the two load groups, so there
 //     are exactly two memory round trips: 6 coalesced loads, then all gathers;
 //   * optionally gathers the model vertex + normal as two 12-byte loads from a pixel-interleaved

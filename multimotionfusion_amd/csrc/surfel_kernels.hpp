@@ -159,10 +159,12 @@ __global__ __launch_bounds__(256) void bilateral_filter_kernel(const float* __re
     out[y * cols + x] = sum1 / sum2;
 }
 
-// Two horizontally adjacent pixels per lane in packed registers (v_pk_mul_f32 / v_pk_add_f32 work on a
-// float pair at full rate): the filter is pure instruction issue -- 169 taps x ~50 instructions per
-// pixel, 64 us at 640x480 -- so packing the exponential's polynomial halves it.  Bit-identical to the
-// kernel above: the same float operations in the same order per pixel, with two exact rewrites of
+// Two horizontally adjacent pixels per lane: the filter is pure instruction issue -- 169 taps x ~50
+// instructions per pixel, 64 us at 640x480.  Sharing the per-tap scalar work (tap loads, spatial term,
+// loop control) between two pixels and the two exact rewrites below bring it to 47 us.  The pair is
+// written with packed registers (v_pk_mul_f32 / v_pk_add_f32); measured, a packed op costs what its two
+// scalar ops cost on gfx950 (an unpacked build of the same kernel: 48 us), so the packing itself is
+// neutral.  Bit-identical to the kernel above: the same float operations in the same order per pixel, with two exact rewrites of
 // mmf_expf for its argument range here (x <= 0 or NaN):
 //   * the `x > 88.7` overflow test can never fire;
 //   * (p * 2^(n/2)) * 2^(n - n/2) == ldexpf(p, n): the first product is exact (p in [0.5, 2],
