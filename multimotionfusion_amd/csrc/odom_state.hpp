@@ -418,15 +418,17 @@ __device__ inline void solve_and_update(OdomState* st, const SolveIn& si, const 
     double Rup[9];
     const double rvec[3] = {result[3], result[4], result[5]};
     rodrigues(rvec, Rup);
-    // resultRt <- [Rup | result(0..2); 0 0 0 1] * resultRt, both with a (0 0 0 1) last row
+    // resultRt <- [Rup | result(0..2); 0 0 0 1] * resultRt, both with a (0 0 0 1) last row.  The
+    // translation column multiplies that last row as in the reference's full 4x4 product
+    // (OdometryProvider.h:81-88): for finite numbers it adds an exact 0 or result[r], but a non-finite
+    // solution (singular system, e.g. a frame without any correspondence) must poison the whole
+    // matrix the way it does there, not only its translation.
     {
         double nr[12];
         for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 4; ++c) {
-                double s = Rup[r * 3 + 0] * resultRt[c] + Rup[r * 3 + 1] * resultRt[4 + c] + Rup[r * 3 + 2] * resultRt[8 + c];
-                if (c == 3) s += result[r];
-                nr[r * 4 + c] = s;
-            }
+            for (int c = 0; c < 4; ++c)
+                nr[r * 4 + c] = Rup[r * 3 + 0] * resultRt[c] + Rup[r * 3 + 1] * resultRt[4 + c] +
+                                Rup[r * 3 + 2] * resultRt[8 + c] + result[r] * resultRt[12 + c];
         for (int k = 0; k < 12; ++k) resultRt[k] = nr[k];
     }
 

@@ -131,3 +131,29 @@ def test_batched_preparation_matches_the_separate_kernels(gpu_ctx):
             assert_bit_equal(batched.download(name, lvl), ref.download(name, lvl), f"{name}[{lvl}]")
     ref.close()
     g.close()
+
+
+def test_process_frame_survives_a_frame_without_depth(gpu_ctx, orc):
+    """An all-invalid depth frame gives the tracker no correspondences: the normal equations are singular and
+    the pose becomes NaN in the reference's arithmetic.  The kernels must neither fault nor disagree with the
+    oracle orchestration about it, and the object must stay usable (reset)."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h = 160, 120
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(3, seed=17)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    frames[1]["depth"] = np.zeros_like(frames[1]["depth"])
+    g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    o = OracleFusion(orc, w, h, K)
+    for i, f in enumerate(frames):
+        g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=i)
+        o.process_frame(f["rgb"], f["depth"])
+        pg = g.getCurrPose()
+        assert np.array_equal(np.isnan(pg), np.isnan(o.pose)), (i, pg, o.pose)
+        ok = ~np.isnan(o.pose)
+        assert np.abs(pg[ok] - o.pose[ok]).max() <= 1e-5
+        assert g.getBackgroundModel().lastCount() == o.surfels.shape[0] or not ok.all()
+    g.reset()
+    g.processFrame(dev(frames[0]["rgb"]), dev(frames[0]["depth"]), timestamp=0)
+    assert g.getBackgroundModel().lastCount() > 0.8 * w * h and np.isfinite(g.getCurrPose()).all()
+    g.close()
