@@ -141,3 +141,43 @@ def test_multi_frame_tracking_follows_ground_truth(gpu_ctx):
         assert np.linalg.norm(t - poses[i][:3, 3]) < 4e-3, (i, t, poses[i][:3, 3])
         assert synth.rotation_angle(R.astype(np.float64), poses[i][:3, :3]) < 4e-3
     g.close()
+
+
+def test_far_off_start_pose_and_divergence_guard(gpu_ctx, orc):
+    """Tracking from a model pose 0.6 m away from the origin (large global-frame coordinates in the ICP
+    rows), with the divergence guard of RGBDOdometry.cpp:464-467 (keep the previous pose when the step
+    exceeds 0.3 m) evaluated on the device: whichever way the oracle goes, the device loop must go too."""
+    from multimotionfusion_amd.odometry import RGBDOdometry
+    w, h = 320, 240
+    K, prev, cur, fp, fc = frame_pair(w, h)
+    start = prev.astype(np.float32).copy()
+    start[0, 3] += 0.6
+    outs = []
+    for side in ("gpu", "oracle"):
+        if side == "gpu":
+            od = RGBDOdometry(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+            up = dev
+        else:
+            od = orc.Odometry(w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+            up = lambda a: a  # noqa: E731
+        od.initFirstRGB(up(fp["rgb"]))
+        if side == "gpu":
+            od.initICPModel(up(fp["vertex"]), up(fp["normal"]), 15.0, start)
+            od.initRGBModel(up(fp["rgb"]))
+            od.buildDepthPyramid(up(fc["depth"]))
+            od.initICP(depthCutoff=15.0)
+        else:
+            od.initICPModel(fp["vertex"], fp["normal"], start)
+            od.initRGBModel(fp["rgb"])
+            od.initICP(fc["depth"], 15.0)
+        od.initRGB(up(fc["rgb"]))
+        outs.append(od.getIncrementalTransformation(start[:3, 3], start[:3, :3], False, 10.0, True, False, True))
+        if side == "gpu":
+            od.close()
+    (tg, Rg), (to, Ro) = outs
+    reverted = np.array_equal(to, start[:3, 3])
+    assert np.array_equal(tg, start[:3, 3]) == reverted, (tg, to, start[:3, 3])
+    if reverted:
+        assert np.array_equal(Rg, Ro)
+    else:
+        assert np.allclose(tg, to, atol=1e-4) or (np.isnan(tg).any() and np.isnan(to).any())
