@@ -209,6 +209,32 @@ def main():
                     "bytes_per_launch": icp_step_bytes(n0),
                     "us_per_launch_l1": odom.timeIcpKernel(1, args.roofline_reps),
                     "us_per_launch_l2": odom.timeIcpKernel(2, args.roofline_reps)}
+        # the two surfel projections named in the north star, timed the same way (HIP events on the stream,
+        # back to back; both are idempotent on the current map): achieved = algorithmic bytes of
+        # SURVEY.md 8(d) / launch-pair time.  Reported beside the contract's roofline object, not in it.
+        model = mmf.getBackgroundModel()
+        tick = mmf.getTick()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def timed(fn, reps=50):
+            for _ in range(3):
+                fn()
+            ev0.record()
+            for _ in range(reps):
+                fn()
+            ev1.record()
+            ev1.synchronize()
+            return ev0.elapsed_time(ev1) * 1e3 / reps
+
+        us_idx = timed(lambda: model.predictIndices(tick, 20.0, 200))
+        us_spl = timed(lambda: model.combinedPredict(20.0, tick, tick, 200))
+        b_idx, b_spl = 48 * n_surfels + 52 * n0, 48 * n_surfels + 38 * n0
+        surfel_passes = {
+            "predictIndices": {"us": us_idx, "bytes": b_idx, "GBps": b_idx / us_idx / 1e3, "frac": b_idx / us_idx / 1e3 / 8000.0,
+                               "kernels": "index_map_kernel + index_resolve_kernel"},
+            "combinedPredict": {"us": us_spl, "bytes": b_spl, "GBps": b_spl / us_spl / 1e3, "frac": b_spl / us_spl / 1e3 / 8000.0,
+                                "kernels": "splat_kernel + splat_resolve_kernel"},
+        }
         result = {
             "metric": "frames/sec @ 640x480 (dense ICP+RGB tracking); ICP JtJ-reduce achieved HBM GB/s vs peak",
             "value": world * args.steps / elapsed,
@@ -228,6 +254,7 @@ def main():
                                    "clean, splat + fill-in; one rigid-body model per GPU",
                        "width": W, "height": H, "models_per_gpu": 1, "parallelism": f"model-shard x{world}"},
             "roofline": roofline,
+            "surfel_passes": surfel_passes,
             "device": ctx.device_name(),
             "last_frame_translation_error_m": t_err,
             "icp_inliers_last": odom.lastICPCount,
