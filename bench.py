@@ -24,7 +24,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-W, H = 640, 480
+W, H = 640, 480  # BASELINE.json configs[1]; MMF_BENCH_SIZE=1280x960 rehearses config 5's frame size
+if os.environ.get("MMF_BENCH_SIZE"):
+    W, H = (int(v) for v in os.environ["MMF_BENCH_SIZE"].lower().split("x"))
 ICP_WEIGHT = 10.0  # GUI default (GUI/MainController.cpp:333-345)
 DEPTH_CUTOFF = 15.0
 N_FRAMES = 30  # frames of the synthetic sequence; the map is reset when the sequence wraps
@@ -205,7 +207,7 @@ def main():
         # WRITE_SIZE 75 KiB (600 partial records).  Algorithmic bytes are 14.75 MB: no wasted re-reads.
         traffic = (2 * 7348.5 + 75.0) * 1024
         roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": traffic, "kernel": "icp_kernel2<2,1,256,packed> level 0 (640x480)", "us_per_launch": us,
+                    "traffic": traffic, "kernel": f"icp_kernel2<2,1,256,packed> level 0 ({W}x{H})", "us_per_launch": us,
                     "bytes_per_launch": icp_step_bytes(n0),
                     "us_per_launch_l1": odom.timeIcpKernel(1, args.roofline_reps),
                     "us_per_launch_l2": odom.timeIcpKernel(2, args.roofline_reps)}
@@ -236,7 +238,7 @@ def main():
                                 "kernels": "splat_kernel + splat_resolve_kernel"},
         }
         result = {
-            "metric": "frames/sec @ 640x480 (dense ICP+RGB tracking); ICP JtJ-reduce achieved HBM GB/s vs peak",
+            "metric": f"frames/sec @ {W}x{H} (dense ICP+RGB tracking); ICP JtJ-reduce achieved HBM GB/s vs peak",
             "value": world * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -248,7 +250,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "640x480 synthetic RGB-D sequence through MultiMotionFusion::processFrame, static "
+            "config": {"workload": f"{W}x{H} synthetic RGB-D sequence through MultiMotionFusion::processFrame, static "
                                    "scene (no segmentation): bilateral filter, dense ICP+RGB odometry (SO3 + 4/5/10 "
                                    "Gauss-Newton iterations, icpWeight 10) against the surfel splat, index map, fuse, "
                                    "clean, splat + fill-in; one rigid-body model per GPU",

@@ -1625,11 +1625,12 @@ extern "C" int mmf_model_initialise(mmf_model* m, const uint8_t* rgb, const floa
     rc = device_scan(c, m->flags_b, npix, m->prefix_b, m->block_sums, &m->totals[1]);
     if (rc) return rc;
     hipLaunchKernelGGL(init_scatter_kernel, grid1d(npix), dim3(256), 0, c->stream, npix, m->meas, m->flags_a,
-                       m->prefix_a, m->cand2, m->flags_b, m->prefix_b, m->set[m->cur]);
+                       m->prefix_a, m->cand2, m->flags_b, m->prefix_b, m->set[m->cur], (unsigned)m->capacity);
     MMF_HIP_TRY(hipGetLastError());
     rc = model_read_totals(m);
     if (rc) return rc;
-    m->count = m->host_totals[0];  // "both raw and filtered have the same amount of vertices" (Model.cpp:292)
+    // "both raw and filtered have the same amount of vertices" (Model.cpp:292); capped by the buffer
+    m->count = m->host_totals[0] < (unsigned)m->capacity ? m->host_totals[0] : (unsigned)m->capacity;
     return MMF_OK;
 }
 

@@ -373,18 +373,24 @@ __global__ __launch_bounds__(256) void feedback_kernel(const uint8_t* __restrict
 __global__ __launch_bounds__(256) void init_scatter_kernel(int n, SurfelSoA raw, const unsigned* __restrict__ raw_flags,
                                                            const unsigned* __restrict__ raw_prefix, SurfelSoA fil,
                                                            const unsigned* __restrict__ fil_flags,
-                                                           const unsigned* __restrict__ fil_prefix, SurfelSoA dst) {
+                                                           const unsigned* __restrict__ fil_prefix, SurfelSoA dst,
+                                                           unsigned capacity) {
     const int d = blockIdx.x * 256 + threadIdx.x;
     if (d >= n) return;
+    // the model's vertex buffer holds `capacity` surfels (Model::MAX_VERTICES, Model.cpp:119-126): like
+    // GL transform feedback into a full buffer, primitives beyond it are dropped (a 1280x960 first frame
+    // has more valid pixels than that)
     if (raw_flags[d]) {
         const unsigned k = raw_prefix[d];
-        dst.pos[k] = raw.pos[d];
-        float4 col = raw.col[d];
-        col.y = 0;
-        col.z = 1;
-        dst.col[k] = col;
+        if (k < capacity) {
+            dst.pos[k] = raw.pos[d];
+            float4 col = raw.col[d];
+            col.y = 0;
+            col.z = 1;
+            dst.col[k] = col;
+        }
     }
-    if (fil_flags[d]) dst.nrm[fil_prefix[d]] = fil.nrm[d];
+    if (fil_flags[d] && fil_prefix[d] < capacity) dst.nrm[fil_prefix[d]] = fil.nrm[d];
 }
 
 // ---- index map --------------------------------------------------------------------------------

@@ -157,3 +157,35 @@ def test_surfel_cycle_against_golden_fixture(gpu_ctx):
     assert_bit_equal(m.texture("vertexConf").cpu().numpy(), g["splat_vertexConf"], "splat vertexConf")
     assert_bit_equal(m.texture("image").cpu().numpy(), g["splat_image"], "splat image")
     m.close()
+
+
+def test_surfel_capacity_is_a_hard_limit(gpu_ctx, orc):
+    """Model::MAX_VERTICES bounds the vertex buffer (Model.cpp:119-126): a first frame with more valid pixels
+    than that keeps the first `capacity` surfels of the draw order (GL transform feedback into a full buffer
+    drops the rest) -- found the hard way at 1280x960, where a frame has more pixels than 1024^2 / 1 surfels.
+    Later passes must respect the limit too."""
+    from multimotionfusion_amd.model import Model, filterDepth
+    w, h, cap = 160, 120, 5000
+    K = synth.intrinsics(w, h)
+    m = Model(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], 0, CONF, max_surfels=cap)
+    poses = synth.trajectory(2, seed=5)
+    f0, f1 = synth.render(poses[0], w, h, seed=0), synth.render(poses[1], w, h, seed=1)
+    d0 = dev(f0["depth"])
+    fil0 = filterDepth(gpu_ctx, d0, CUTOFF)
+    m.overridePose(poses[0])
+    m.initialise(dev(f0["rgb"]), d0, fil0, 1, MAXD)
+    s = orc.surfel_initialise(f0["rgb"], f0["depth"], orc.bilateral_filter(f0["depth"], CUTOFF), K, 1, MAXD)
+    assert s.shape[0] > cap and m.lastCount() == cap
+    assert_bit_equal(m.downloadMap(), s[:cap], "first `capacity` surfels of the draw order")
+    # a full fuse / clean cycle on the full buffer: new surfels have nowhere to go, nothing may fault
+    d1 = dev(f1["depth"])
+    fil1 = filterDepth(gpu_ctx, d1, CUTOFF)
+    m.overridePose(poses[1])
+    m.predictIndices(2, MAXD, TIME_DELTA)
+    m.fuse(2, dev(f1["rgb"]), dev(np.zeros((h, w), np.uint8)), d1, fil1, MAXD, 1.0)
+    m.predictIndices(2, MAXD, TIME_DELTA)
+    m.clean(2, TIME_DELTA, MAXD, fil1, dev(np.zeros((h, w), np.uint8)), 3.0)
+    assert 0 < m.lastCount() <= cap
+    m.combinedPredict(MAXD, 2, 2, TIME_DELTA)
+    assert m.downloadMap().shape[0] == m.lastCount()
+    m.close()
