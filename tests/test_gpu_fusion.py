@@ -17,7 +17,9 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("w,h,nframes", [(320, 240, 6), (640, 480, 4)])
+# 200x152 / 100x80: pyramid levels that are not multiples of 4 (or even) wide -- scalar fallbacks of the
+# tracker inside the batched orchestration
+@pytest.mark.parametrize("w,h,nframes", [(320, 240, 6), (640, 480, 4), (200, 152, 3), (100, 80, 3)])
 def test_process_frame_sequence(gpu_ctx, orc, w, h, nframes):
     from multimotionfusion_amd.fusion import MultiMotionFusion
     K = synth.intrinsics(w, h)
@@ -38,13 +40,14 @@ def test_process_frame_sequence(gpu_ctx, orc, w, h, nframes):
             assert np.array_equal(g.getBackgroundModel().downloadMap(), o.surfels)
         # accuracy against the known trajectory (relative to the first camera)
         gt = np.linalg.inv(poses[0]) @ poses[i]
-        assert np.linalg.norm(pg[:3, 3] - gt[:3, 3]) < 0.01, (i, pg[:3, 3], gt[:3, 3])
-        assert synth.rotation_angle(pg[:3, :3].astype(np.float64), gt[:3, :3]) < 0.01
+        if w >= 320:  # the small fallback-path sizes are parity cases only
+            assert np.linalg.norm(pg[:3, 3] - gt[:3, 3]) < 0.01, (i, pg[:3, 3], gt[:3, 3])
+            assert synth.rotation_angle(pg[:3, :3].astype(np.float64), gt[:3, :3]) < 0.01
     sg, so = g.getBackgroundModel().downloadMap(), o.surfels
     assert np.allclose(sg[:, :3].mean(0), so[:, :3].mean(0), atol=1e-3)
     assert abs(sg[:, 3].mean() - so[:, 3].mean()) < 1e-2
     od = g.getFrameOdometry()
-    assert od.iterations_run == 19 and od.lastICPCount > 0.5 * w * h
+    assert od.iterations_run == 19 and (w < 320 or od.lastICPCount > 0.5 * w * h)
     g.close()
 
 
