@@ -310,6 +310,17 @@ mmf_model *mmf_fusion_model(mmf_fusion *f);
 mmf_odom *mmf_fusion_odometry(mmf_fusion *f);
 const float *mmf_fusion_depth_filtered(mmf_fusion *f);
 
+/* ---- keypoint descriptor matching ------------------------------------
+ * PointTracker::addKeypoints, Core/Utils/PointTracker.cpp:100-114:
+ *     cv::BFMatcher(cv::NORM_L2, true).match(current, previous, matches);   // query, train
+ *     keep when min_feature_distance < epsilon || match.distance <= min_feature_distance
+ * query [nq x dim], train [nt x dim]: dense float32 rows on the device (SuperPoint: dim = 256);
+ * dim must be a multiple of 8.  train_idx [nq] receives the matched train row or -1, distance [nq]
+ * the L2 distance of a match (0 when unmatched); both on the device.  The nq x nt Gram matrix runs
+ * on the f32 matrix cores (csrc/match_kernels.hpp).  Asynchronous on the context's stream. */
+int mmf_match_descriptors(mmf_ctx *ctx, const float *query, int nq, const float *train, int nt, int dim,
+                          float max_distance, int *train_idx, float *distance);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,8 @@ struct mmf_ctx {
     OdomState* scratch_state = nullptr;  // for the stand-alone *Step entry points
     OdomState* host_state = nullptr;     // pinned staging
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* match_ws = nullptr;  // descriptor matcher workspace: norms + arg-min keys, grown on demand
+    size_t match_ws_rows = 0;
     char arch[64] = {0};
 };
 
@@ -117,6 +119,7 @@ extern "C" void mmf_ctx_destroy(mmf_ctx* c) {
     (void)hipHostFree(c->host_state);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    (void)hipFree(c->match_ws);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1866,6 +1869,47 @@ extern "C" int mmf_model_texture(mmf_model* m, const char* name, void** dev_ptr,
     else return fail(MMF_ERR_INVALID, "mmf_model_texture: unknown name '" + s + "'");
     *dev_ptr = p;
     *bytes = b;
+    return MMF_OK;
+}
+
+// =============================================================================================
+// Keypoint descriptor matching (Core/Utils/PointTracker.cpp:100-114) on the f32 matrix cores
+// =============================================================================================
+#include "match_kernels.hpp"
+
+extern "C" int mmf_match_descriptors(mmf_ctx* c, const float* query, int nq, const float* train, int nt, int dim,
+                                     float max_distance, int* train_idx, float* distance) {
+    MMF_REQUIRE(c && (query || nq == 0) && (train || nt == 0) && (train_idx || nq == 0) && (distance || nq == 0),
+                "mmf_match_descriptors: null argument");
+    MMF_REQUIRE(nq >= 0 && nt >= 0 && dim > 0 && dim % 8 == 0, "mmf_match_descriptors: dim must be a positive multiple of 8");
+    MMF_REQUIRE(((uintptr_t)query & 15u) == 0 && ((uintptr_t)train & 15u) == 0, "mmf_match_descriptors: 16-byte aligned rows");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    if (nq == 0) return MMF_OK;
+    // workspace: [qn | tn] floats, then [row keys | col keys]
+    const size_t rows = (size_t)nq + (size_t)nt;
+    if (rows > c->match_ws_rows) {
+        MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->match_ws);
+        c->match_ws = nullptr;
+        c->match_ws_rows = 0;
+        const size_t cap = rows + rows / 2 + 256;
+        MMF_HIP_TRY(hipMalloc(&c->match_ws, cap * (sizeof(float) + sizeof(unsigned long long))));
+        c->match_ws_rows = cap;
+    }
+    unsigned long long* keys = static_cast<unsigned long long*>(c->match_ws);
+    float* norms = reinterpret_cast<float*>(keys + c->match_ws_rows);
+    unsigned long long *row_best = keys, *col_best = keys + nq;
+    float *qn = norms, *tn = norms + nq;
+    hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, keys, rows, kNoMatchKey);
+    if (nt > 0) {
+        hipLaunchKernelGGL(row_norms_kernel, dim3((nq + 255) / 256), dim3(256), 0, c->stream, query, nq, dim, qn);
+        hipLaunchKernelGGL(row_norms_kernel, dim3((nt + 255) / 256), dim3(256), 0, c->stream, train, nt, dim, tn);
+        hipLaunchKernelGGL(match_tile_kernel, dim3((nt + 31) / 32, (nq + 31) / 32), dim3(64), 0, c->stream, query, train, qn, tn,
+                           nq, nt, dim, row_best, col_best);
+    }
+    hipLaunchKernelGGL(match_cross_check_kernel, dim3((nq + 255) / 256), dim3(256), 0, c->stream, row_best, col_best, nq,
+                       max_distance, train_idx, distance);
+    MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }
 

@@ -154,6 +154,9 @@ void orc_combined_predict(const orc_surfel *s, int count, const float pose[16], 
 void orc_synthesize_depth(const orc_surfel *s, int count, const float pose[16], float cx, float cy, float fx,
                           float fy, int cols, int rows, float maxDepth, float confThreshold, int time,
                           int maxTime, int timeDelta, float *depth_out);
+/* keypoint descriptor matcher (mmf_oracle_match.c): cv::BFMatcher(NORM_L2, crossCheck).match + distance gate */
+int orc_match_descriptors(const float *query, int nq, const float *train, int nt, int dim, float max_distance,
+                          int *train_idx, float *distance);
 int orc_fuse(orc_surfel *s, int count, const uint8_t *rgb, const float *depth_raw, const float *depth_filtered,
              const uint8_t *mask, const uint32_t *index, const float *vertConf, const float *normRad,
              const float pose[16], float cx, float cy, float fx, float fy, int cols, int rows, int time,

@@ -18,7 +18,7 @@ def build(force=False, march=None, out=None):
     target = out or "liboracle.so"
     path = os.path.join(_DIR, target)
     src_m = max(os.path.getmtime(os.path.join(_DIR, f))
-                for f in ("mmf_oracle.c", "mmf_oracle_surfel.c", "mmf_oracle.h", "Makefile"))
+                for f in ("mmf_oracle.c", "mmf_oracle_surfel.c", "mmf_oracle_match.c", "mmf_oracle.h", "Makefile"))
     if not force and os.path.exists(path) and os.path.getmtime(path) >= src_m:
         return path
     cmd = ["make", "-C", _DIR, f"OUT={target}", "-B"]
@@ -454,3 +454,16 @@ def requires_fill_in(image_pred, ratio=0.75):
     rows, cols = ip.shape[:2]
     lib().orc_requires_fill_in.restype = C.c_int
     return bool(lib().orc_requires_fill_in(_pu8(ip), cols, rows, _cf(ratio)))
+
+
+def match_descriptors(query, train, max_distance=0.0):
+    """cv::BFMatcher(NORM_L2, crossCheck=True).match(query, train) + the distance gate of PointTracker.cpp:108.
+    Returns (train_idx [nq] int32, -1 = unmatched; distance [nq] float32)."""
+    q, t = _f(query), _f(train)
+    nq, nt = q.shape[0], t.shape[0]
+    dim = q.shape[1] if nq else (t.shape[1] if nt else 0)
+    idx = np.full(nq, -1, np.int32)
+    dist = np.zeros(nq, np.float32)
+    lib().orc_match_descriptors(_pf(q), nq, _pf(t), nt, dim, _cf(max_distance), idx.ctypes.data_as(C.POINTER(C.c_int)),
+                                _pf(dist))
+    return idx, dist
