@@ -237,6 +237,25 @@ def main():
             "combinedPredict": {"us": us_spl, "bytes": b_spl, "GBps": b_spl / us_spl / 1e3, "frac": b_spl / us_spl / 1e3 / 8000.0,
                                 "kernels": "splat_kernel + splat_resolve_kernel"},
         }
+        # the keypoint descriptor matcher, the one MFMA kernel beside the path:
+        # 1024 x 1024 descriptors of 256 floats, 2 * nq * nt * dim flops on v_mfma_f32_32x32x2_f32
+        from multimotionfusion_amd.matcher import matchDescriptors
+        gen = torch.Generator(device="cpu").manual_seed(0)
+        dq = torch.nn.functional.normalize(torch.randn(1024, 256, generator=gen), dim=1).to(dev)
+        dt = torch.nn.functional.normalize(torch.randn(1024, 256, generator=gen), dim=1).to(dev)
+        matchDescriptors(ctx, dq, dt, 0.7)  # sizes the workspace
+        m_idx = torch.empty(1024, dtype=torch.int32, device=dev)
+        m_dist = torch.empty(1024, dtype=torch.float32, device=dev)
+        from multimotionfusion_amd.cudafuncs import _p
+
+        def match_raw():  # the C entry point with preallocated outputs: the Python wrapper's allocations would dominate
+            ctx.lib.mmf_match_descriptors(ctx.handle, _p(dq), 1024, _p(dt), 1024, 256, 0.7, _p(m_idx), _p(m_dist))
+
+        us_match = timed(match_raw, reps=100)
+        flops = 2.0 * 1024 * 1024 * 256
+        matcher = {"us": us_match, "nq": 1024, "nt": 1024, "dim": 256, "TFLOPs": flops / us_match / 1e6,
+                   "frac_f32_mfma_peak": flops / us_match / 1e6 / 157.3, "launches": 4,
+                   "kernels": "fill + row_norms_kernel (MFMA) + match_tile_kernel (MFMA) + match_cross_check_kernel"}
         result = {
             "metric": f"frames/sec @ {W}x{H} (dense ICP+RGB tracking); ICP JtJ-reduce achieved HBM GB/s vs peak",
             "value": world * args.steps / elapsed,
@@ -257,6 +276,7 @@ def main():
                        "width": W, "height": H, "models_per_gpu": 1, "parallelism": f"model-shard x{world}"},
             "roofline": roofline,
             "surfel_passes": surfel_passes,
+            "matcher": matcher,
             "device": ctx.device_name(),
             "last_frame_translation_error_m": t_err,
             "icp_inliers_last": odom.lastICPCount,

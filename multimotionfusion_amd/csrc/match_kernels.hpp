@@ -34,14 +34,61 @@ __device__ __forceinline__ float from_ordered_bits(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
-// |x_r|^2 of every descriptor row as an fmaf chain in index order (one lane per row)
-__global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ x, int n, int dim, float* __restrict__ out) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
-    const float* p = x + (size_t)r * dim;
-    float s = 0.f;
-    for (int k = 0; k < dim; ++k) s = __builtin_fmaf(p[k], p[k], s);
-    out[r] = s;
+// 32 x 32 tile of A B^T on the f32 matrix cores: rows `ra`, `rb` of this lane's operands (lane & 31 picks
+// the row, lane >> 5 the parity of k).  A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]:
+// one MFMA consumes k, k + 1, so the accumulation is the fmaf chain over k = 0, 1, 2, ... of the oracle.
+// The operands of the next 16 k are loaded (64 bytes per lane and operand) before the eight MFMAs of the
+// current 16 are issued: with one wave per SIMD nothing else would hide the load latency.
+__device__ __forceinline__ f32x16 gram_tile(const float* __restrict__ ra, const float* __restrict__ rb, int dim, int h) {
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    float4 a[4], b[4], an[4], bn[4];
+    auto load = [&](int k, float4 (&x)[4], float4 (&y)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // dim % 8 == 0: a 16-float block may run 8 floats past the row's end -> clamp (those MFMAs are skipped)
+            const int kk = min(k + 4 * u, dim - 4);
+            x[u] = *reinterpret_cast<const float4*>(ra + kk);
+            y[u] = *reinterpret_cast<const float4*>(rb + kk);
+        }
+    };
+    load(0, a, b);
+    for (int k = 0; k < dim; k += 16) {
+        if (k + 16 < dim) load(k + 16, an, bn);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k + 4 * u < dim) {  // wave uniform
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[u].y : a[u].x, h ? b[u].y : b[u].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a[u].w : a[u].z, h ? b[u].w : b[u].z, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = an[u], b[u] = bn[u];
+    }
+    return acc;
+}
+
+// |x_r|^2 of every descriptor row = the diagonal of X X^T, taken from diagonal 32 x 32 MFMA tiles so that it
+// is the same fmaf chain as the oracle's (a lane-per-row scalar loop took 30 us per set for 1024 rows).
+// One wave per 32 rows of the concatenation [query ; train]; out = [qn ; tn].
+__global__ __launch_bounds__(64) void row_norms_kernel(const float* __restrict__ q, int nq, const float* __restrict__ t, int nt,
+                                                       int dim, float* __restrict__ qn, float* __restrict__ tn) {
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int qblocks = (nq + 31) / 32;
+    const bool is_q = (int)blockIdx.x < qblocks;
+    const float* x = is_q ? q : t;
+    const int n = is_q ? nq : nt, i0 = (is_q ? blockIdx.x : blockIdx.x - qblocks) * 32;
+    float* out = is_q ? qn : tn;
+    const float* row = x + (size_t)min(i0 + r, n - 1) * dim;
+    const f32x16 acc = gram_tile(row, row, dim, h);
+    // C/D layout: col = lane & 31, row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5): the diagonal element of
+    // column r sits in the lane whose half h holds row r
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int lr = (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (lr == r && i0 + r < n) out[i0 + r] = acc[v];
+    }
 }
 
 // one wave (64 threads) per 32 x 32 tile; grid = (ceil(nt / 32), ceil(nq / 32)); dim % 8 == 0
@@ -54,20 +101,7 @@ __global__ __launch_bounds__(64) void match_tile_kernel(const float* __restrict_
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
     // operand rows of this lane (clamped: rows past the end are computed and masked afterwards)
-    const float* qa = q + (size_t)min(i0 + r, nq - 1) * dim;
-    const float* tb = t + (size_t)min(j0 + r, nt - 1) * dim;
-    f32x16 acc;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-    // A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]: one MFMA consumes k, k + 1
-    for (int k = 0; k < dim; k += 8) {
-        const float4 a0 = *reinterpret_cast<const float4*>(qa + k), a1 = *reinterpret_cast<const float4*>(qa + k + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(tb + k), b1 = *reinterpret_cast<const float4*>(tb + k + 4);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a0.y : a0.x, h ? b0.y : b0.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a0.w : a0.z, h ? b0.w : b0.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a1.y : a1.x, h ? b1.y : b1.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a1.w : a1.z, h ? b1.w : b1.z, acc, 0, 0, 0);
-    }
+    const f32x16 acc = gram_tile(q + (size_t)min(i0 + r, nq - 1) * dim, t + (size_t)min(j0 + r, nt - 1) * dim, dim, h);
     // C/D layout: col = lane & 31, row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)
     const int col = j0 + r;
     const float tnc = tn[min(col, nt - 1)];
@@ -94,7 +128,7 @@ __global__ __launch_bounds__(64) void match_tile_kernel(const float* __restrict_
     }
 }
 
-// crossCheck + distance gate (PointTracker.cpp:108); also hands the key arrays back empty
+// crossCheck + distance gate (PointTracker.cpp:108)
 __global__ __launch_bounds__(256) void match_cross_check_kernel(unsigned long long* __restrict__ row_best,
                                                                 const unsigned long long* __restrict__ col_best, int nq,
                                                                 float max_distance, int* __restrict__ train_idx,

@@ -1902,8 +1902,8 @@ extern "C" int mmf_match_descriptors(mmf_ctx* c, const float* query, int nq, con
     float *qn = norms, *tn = norms + nq;
     hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, keys, rows, kNoMatchKey);
     if (nt > 0) {
-        hipLaunchKernelGGL(row_norms_kernel, dim3((nq + 255) / 256), dim3(256), 0, c->stream, query, nq, dim, qn);
-        hipLaunchKernelGGL(row_norms_kernel, dim3((nt + 255) / 256), dim3(256), 0, c->stream, train, nt, dim, tn);
+        hipLaunchKernelGGL(row_norms_kernel, dim3((nq + 31) / 32 + (nt + 31) / 32), dim3(64), 0, c->stream, query, nq, train, nt,
+                           dim, qn, tn);
         hipLaunchKernelGGL(match_tile_kernel, dim3((nt + 31) / 32, (nq + 31) / 32), dim3(64), 0, c->stream, query, train, qn, tn,
                            nq, nt, dim, row_best, col_best);
     }
