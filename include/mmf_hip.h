@@ -321,6 +321,22 @@ const float *mmf_fusion_depth_filtered(mmf_fusion *f);
 int mmf_match_descriptors(mmf_ctx *ctx, const float *query, int nq, const float *train, int nt, int dim,
                           float max_distance, int *train_idx, float *distance);
 
+/* ---- keypoint-based pose initialisation: RigidRANSAC (Core/Utils/RigidRANSAC.h:6-32, .cpp:73-180) ----
+ * Host code, like the reference's (a few dozen keypoint tracks): p0, p1 are HOST arrays of n 3-D points
+ * (row-major n x 3), mask an optional n-byte selection; T receives the row-major 4x4 of T_01 with
+ * p0 ~ T_01 p1.  mmf_rigid_fit = the free function fit() (RigidRANSAC.cpp:73-120).  A mmf_ransac object owns
+ * the std::default_random_engine of the reference's class, so successive estimates continue its sequence.
+ * estimate(): error = mean inlier distance of the best model (+inf when none beat the initial all-points
+ * fit); inlier (optional, n bytes) flags the rows of the HASH-SORTED correspondence order used internally
+ * (RigidRANSAC.cpp:36-58), exactly what Result::inlier holds in the reference; *has_inlier = 0 when empty. */
+typedef struct mmf_ransac mmf_ransac;
+int mmf_rigid_fit(const float *p0, const float *p1, int n, const unsigned char *mask, float T[16]);
+int mmf_rigid_apply(const float T[16], const float *p0, const float *p1, int n, float *distance);
+int mmf_ransac_create(int iterations, float inlier_threshold, float inlier_fraction, mmf_ransac **out);
+void mmf_ransac_destroy(mmf_ransac *r);
+int mmf_ransac_estimate(mmf_ransac *r, const float *p0, const float *p1, int n, const unsigned char *mask,
+                        float T[16], float *error, unsigned char *inlier, int *has_inlier);
+
 #ifdef __cplusplus
 }
 #endif

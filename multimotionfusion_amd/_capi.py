@@ -101,6 +101,11 @@ SIGNATURES = {
     "mmf_model_combined_predict": (_i, [_vp, _f, _i, _i, _i]),
     "mmf_model_synthesize_depth": (_i, [_vp, _f, _f, _i, _i, _i]),
     "mmf_match_descriptors": (_i, [_vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp]),
+    "mmf_rigid_fit": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "mmf_rigid_apply": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "mmf_ransac_create": (_i, [_i, _f, _f, _vp]),
+    "mmf_ransac_destroy": (None, [_vp]),
+    "mmf_ransac_estimate": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mmf_model_fuse": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _f, _f]),
     "mmf_model_clean": (_i, [_vp, _i, _i, _f, _vp, _vp, _f]),
     "mmf_model_perform_fill_in": (_i, [_vp, _vp, _vp, _i, _i]),

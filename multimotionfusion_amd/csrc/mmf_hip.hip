@@ -1913,6 +1913,64 @@ extern "C" int mmf_match_descriptors(mmf_ctx* c, const float* query, int nq, con
     return MMF_OK;
 }
 
+// =============================================================================================
+// RigidRANSAC (Core/Utils/RigidRANSAC.{h,cpp}): host code, see rigid_ransac.hpp
+// =============================================================================================
+#include "rigid_ransac.hpp"
+
+struct mmf_ransac {
+    mmf::RigidRANSAC impl;
+    mmf_ransac(int it, float thr, float frac) : impl(it, thr, frac) {}
+};
+
+static void isometry_to_4x4(const mmf::Isometry3f& T, float out[16]) {
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) out[r * 4 + c] = T.R[r * 3 + c];
+        out[r * 4 + 3] = T.t[r];
+    }
+    out[12] = out[13] = out[14] = 0.f;
+    out[15] = 1.f;
+}
+
+extern "C" int mmf_rigid_fit(const float* p0, const float* p1, int n, const unsigned char* mask, float T[16]) {
+    MMF_REQUIRE(p0 && p1 && T && n > 0, "mmf_rigid_fit: bad argument");
+    isometry_to_4x4(mmf::rigid_fit(p0, p1, n, mask), T);
+    return MMF_OK;
+}
+
+extern "C" int mmf_rigid_apply(const float T[16], const float* p0, const float* p1, int n, float* distance) {
+    MMF_REQUIRE(T && p0 && p1 && distance && n >= 0, "mmf_rigid_apply: bad argument");
+    mmf::Isometry3f I;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) I.R[r * 3 + c] = T[r * 4 + c];
+        I.t[r] = T[r * 4 + 3];
+    }
+    mmf::rigid_apply(I, p0, p1, n, distance);
+    return MMF_OK;
+}
+
+extern "C" int mmf_ransac_create(int iterations, float inlier_threshold, float inlier_fraction, mmf_ransac** out) {
+    MMF_REQUIRE(out && iterations >= 0, "mmf_ransac_create: bad argument");
+    *out = new (std::nothrow) mmf_ransac(iterations, inlier_threshold, inlier_fraction);
+    MMF_REQUIRE(*out != nullptr, "mmf_ransac_create: out of host memory");
+    return MMF_OK;
+}
+
+extern "C" void mmf_ransac_destroy(mmf_ransac* r) { delete r; }
+
+extern "C" int mmf_ransac_estimate(mmf_ransac* r, const float* p0, const float* p1, int n, const unsigned char* mask,
+                                   float T[16], float* error, unsigned char* inlier, int* has_inlier) {
+    MMF_REQUIRE(r && p0 && p1 && T && error, "mmf_ransac_estimate: null argument");
+    MMF_REQUIRE(n >= 3, "mmf_ransac_estimate: needs at least 3 correspondences (RigidRANSAC.cpp:133)");
+    const mmf::RigidRANSAC::Result res = r->impl.estimate(p0, p1, n, mask);
+    isometry_to_4x4(res.transformation, T);
+    *error = res.error;
+    if (has_inlier) *has_inlier = res.inlier.empty() ? 0 : 1;
+    if (inlier)
+        for (int i = 0; i < n; ++i) inlier[i] = res.inlier.empty() ? 0 : res.inlier[i];
+    return MMF_OK;
+}
+
 #ifdef MMF_STAMPS
 // diagnostic builds only (tools/rgb_step_probe.py): phase-stamp buffer of the instrumented kernels
 extern "C" int mmf_debug_set_stamps(void* dev_buf) {
