@@ -255,7 +255,7 @@ def main():
         flops = 2.0 * 1024 * 1024 * 256
         matcher = {"us": us_match, "nq": 1024, "nt": 1024, "dim": 256, "TFLOPs": flops / us_match / 1e6,
                    "frac_f32_mfma_peak": flops / us_match / 1e6 / 157.3, "launches": 4,
-                   "kernels": "fill + row_norms_kernel (MFMA) + match_tile_kernel (MFMA) + match_cross_check_kernel"}
+                   "kernels": "fill + row_norms_kernel (MFMA) + match_tile64_kernel (MFMA, LDS-shared 64x64 tiles) + match_cross_check_kernel"}
         result = {
             "metric": f"frames/sec @ {W}x{H} (dense ICP+RGB tracking); ICP JtJ-reduce achieved HBM GB/s vs peak",
             "value": world * args.steps / elapsed,

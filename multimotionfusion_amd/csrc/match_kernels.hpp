@@ -128,6 +128,85 @@ __global__ __launch_bounds__(64) void match_tile_kernel(const float* __restrict_
     }
 }
 
+// The same tile arithmetic with operand sharing: a 256-thread workgroup owns a 64 x 64 block of the
+// distance matrix (wave w the 32 x 32 quadrant (w >> 1, w & 1)) and stages 32-wide k slabs of its 64 query
+// and 64 train rows through LDS, double buffered, so every descriptor element is fetched from L2 once per
+// workgroup instead of once per tile (4x less traffic: the one-wave kernel re-read 134 MB for 2 MB of
+// descriptors at 1024 x 1024 x 256 and was bound by it).  Slabs and the k inside them are consumed in
+// ascending order: the accumulation is the same fmaf chain, the results stay bit-identical.  dim % 32 == 0.
+constexpr int kMatchSlab = 32, kMatchPitch = kMatchSlab + 1;  // +1 float: rows of a slab fall into different banks
+
+__global__ __launch_bounds__(256) void match_tile64_kernel(const float* __restrict__ q, const float* __restrict__ t,
+                                                           const float* __restrict__ qn, const float* __restrict__ tn,
+                                                           int nq, int nt, int dim,
+                                                           unsigned long long* __restrict__ row_best,
+                                                           unsigned long long* __restrict__ col_best) {
+    __shared__ float As[2][64][kMatchPitch], Bs[2][64][kMatchPitch];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wr = w >> 1, wc = w & 1;
+    const int I0 = blockIdx.y * 64, J0 = blockIdx.x * 64;
+    // loader role: thread -> (row = tid >> 2, two float4 columns (tid & 3) and (tid & 3) + 4) of both slabs
+    const int lrow = tid >> 2, lc = (tid & 3) * 4;
+    const float* qa = q + (size_t)min(I0 + lrow, nq - 1) * dim + lc;
+    const float* tb = t + (size_t)min(J0 + lrow, nt - 1) * dim + lc;
+    float4 ga[2], gb[2];
+    auto fetch = [&](int k) {
+        ga[0] = *reinterpret_cast<const float4*>(qa + k), ga[1] = *reinterpret_cast<const float4*>(qa + k + 16);
+        gb[0] = *reinterpret_cast<const float4*>(tb + k), gb[1] = *reinterpret_cast<const float4*>(tb + k + 16);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float* a = &As[buf][lrow][lc + 16 * u];
+            float* b = &Bs[buf][lrow][lc + 16 * u];
+            a[0] = ga[u].x, a[1] = ga[u].y, a[2] = ga[u].z, a[3] = ga[u].w;
+            b[0] = gb[u].x, b[1] = gb[u].y, b[2] = gb[u].z, b[3] = gb[u].w;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int nslabs = dim / kMatchSlab;
+    for (int s = 0; s < nslabs; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslabs) fetch((s + 1) * kMatchSlab);  // in flight during the 16 MFMAs below
+        const float* ar = &As[buf][wr * 32 + r][h];
+        const float* br = &Bs[buf][wc * 32 + r][h];
+#pragma unroll
+        for (int kk = 0; kk < kMatchSlab; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[kk], br[kk], acc, 0, 0, 0);
+        if (s + 1 < nslabs) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue per quadrant, as in match_tile_kernel; the operand slabs are dead: reuse As as 4 x [32][33]
+    float(*tile)[kMatchPitch] = reinterpret_cast<float(*)[kMatchPitch]>(&As[0][0][0]) + w * 32;
+    const int i0 = I0 + wr * 32, j0 = J0 + wc * 32;
+    const int col = j0 + r;
+    const float tnc = tn[min(col, nt - 1)];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int lr = (v & 3) + 8 * (v >> 2) + 4 * h, row = i0 + lr;
+        const float d2 = (qn[min(row, nq - 1)] + tnc) - 2.0f * acc[v];
+        tile[lr][r] = (row < nq && col < nt) ? d2 : __builtin_inff();
+    }
+    __syncthreads();
+    float best = __builtin_inff();
+    int arg = -1;
+#pragma unroll 8
+    for (int sidx = 0; sidx < 32; ++sidx) {
+        const float d = h ? tile[sidx][r] : tile[r][sidx];
+        if (d < best) best = d, arg = sidx;  // first minimum
+    }
+    if (arg < 0) return;
+    if (!h) {
+        if (i0 + r < nq) atomicMin(&row_best[i0 + r], ((unsigned long long)ordered_bits(best) << 32) | (unsigned)(j0 + arg));
+    } else {
+        if (j0 + r < nt) atomicMin(&col_best[j0 + r], ((unsigned long long)ordered_bits(best) << 32) | (unsigned)(i0 + arg));
+    }
+}
+
 // crossCheck + distance gate (PointTracker.cpp:108)
 __global__ __launch_bounds__(256) void match_cross_check_kernel(unsigned long long* __restrict__ row_best,
                                                                 const unsigned long long* __restrict__ col_best, int nq,

@@ -1904,8 +1904,12 @@ extern "C" int mmf_match_descriptors(mmf_ctx* c, const float* query, int nq, con
     if (nt > 0) {
         hipLaunchKernelGGL(row_norms_kernel, dim3((nq + 31) / 32 + (nt + 31) / 32), dim3(64), 0, c->stream, query, nq, train, nt,
                            dim, qn, tn);
-        hipLaunchKernelGGL(match_tile_kernel, dim3((nt + 31) / 32, (nq + 31) / 32), dim3(64), 0, c->stream, query, train, qn, tn,
-                           nq, nt, dim, row_best, col_best);
+        if (dim % kMatchSlab == 0)  // 64 x 64 workgroup tiles with LDS-shared operands
+            hipLaunchKernelGGL(match_tile64_kernel, dim3((nt + 63) / 64, (nq + 63) / 64), dim3(256), 0, c->stream, query, train,
+                               qn, tn, nq, nt, dim, row_best, col_best);
+        else
+            hipLaunchKernelGGL(match_tile_kernel, dim3((nt + 31) / 32, (nq + 31) / 32), dim3(64), 0, c->stream, query, train, qn,
+                               tn, nq, nt, dim, row_best, col_best);
     }
     hipLaunchKernelGGL(match_cross_check_kernel, dim3((nq + 255) / 256), dim3(256), 0, c->stream, row_best, col_best, nq,
                        max_distance, train_idx, distance);
