@@ -253,18 +253,40 @@ __device__ inline void so3_prepare_store(OdomState* st, const double* resultR, c
     }
 }
 
-// after a so3 reduction: RGBDOdometry.cpp:281-308
-__device__ inline void so3_finish(OdomState* st, const float* tot, const LevelIntr& in) {
-    // entry loads
-    const float lastError = st->so3_lastError, lastCount = st->so3_lastCount;
-    const int it = st->st.so3_iterations_run;
+// The SO3 pre-alignment's solver state (what RGBDOdometry.cpp:237-310 keeps in locals): it lives in the
+// device state between the launches of the per-iteration kernel and in ONE lane's registers for the whole
+// loop of the persistent kernel.
+struct So3State {
+    float lastError, lastCount;  // so3_lastError / so3_lastCount
+    int iterations, done;
+    float statError, statCount;  // lastSO3Error / lastSO3Count (public statistics)
     double resultR[9], lastResultR[9];
     float R_lr[9];
+    float imageBasis[9], kinv[9], krlr[9];  // kernel parameters of the next iteration
+};
+__device__ inline So3State so3_load(const OdomState* st) {
+    So3State s;
+    s.lastError = st->so3_lastError, s.lastCount = st->so3_lastCount;
+    s.iterations = st->st.so3_iterations_run, s.done = st->so3_done;
+    s.statError = st->st.lastSO3Error, s.statCount = st->st.lastSO3Count;
     for (int k = 0; k < 9; ++k) {
-        resultR[k] = st->resultR[k];
-        lastResultR[k] = st->lastResultR[k];
-        R_lr[k] = st->R_lr[k];
+        s.resultR[k] = st->resultR[k], s.lastResultR[k] = st->lastResultR[k], s.R_lr[k] = st->R_lr[k];
+        s.imageBasis[k] = st->imageBasis[k], s.kinv[k] = st->kinv[k], s.krlr[k] = st->krlr[k];
     }
+    return s;
+}
+__device__ inline void so3_store(OdomState* st, const So3State& s) {
+    st->so3_lastError = s.lastError, st->so3_lastCount = s.lastCount;
+    st->st.so3_iterations_run = s.iterations, st->so3_done = s.done;
+    st->st.lastSO3Error = s.statError, st->st.lastSO3Count = s.statCount;
+    for (int k = 0; k < 9; ++k) {
+        st->resultR[k] = s.resultR[k], st->lastResultR[k] = s.lastResultR[k], st->R_lr[k] = s.R_lr[k];
+        st->imageBasis[k] = s.imageBasis[k], st->kinv[k] = s.kinv[k], st->krlr[k] = s.krlr[k];
+    }
+}
+
+// after a so3 reduction: RGBDOdometry.cpp:281-308
+__device__ inline void so3_step(So3State& s, const float* tot, const LevelIntr& in) {
     float jtj[9], jtr[3];
     int shift = 0;  // reduce.cu:1135-1146
     for (int i = 0; i < 3; ++i)
@@ -277,18 +299,18 @@ __device__ inline void so3_finish(OdomState* st, const float* tot, const LevelIn
         }
     const float r0 = tot[9], r1 = tot[10];
     const float err = sqrtf(r0) / r1;
-    st->st.so3_iterations_run = it + 1;
-    if (err < lastError && fabsf(lastError - r1) < 0.001) {
+    s.iterations += 1;
+    if (err < s.lastError && fabsf(s.lastError - r1) < 0.001) {
         // "converged" (the reference compares the error with the COUNT, :285)
-        st->st.lastSO3Error = err;
-        st->st.lastSO3Count = r1;
-        st->so3_done = 1;
+        s.statError = err;
+        s.statCount = r1;
+        s.done = 1;
         return;
-    } else if (err > lastError + 0.001) {  // diverging: roll back
-        st->st.lastSO3Error = lastError;
-        st->st.lastSO3Count = lastCount;
-        for (int k = 0; k < 9; ++k) st->resultR[k] = lastResultR[k];
-        st->so3_done = 1;
+    } else if (err > s.lastError + 0.001) {  // diverging: roll back
+        s.statError = s.lastError;
+        s.statCount = s.lastCount;
+        for (int k = 0; k < 9; ++k) s.resultR[k] = s.lastResultR[k];
+        s.done = 1;
         return;
     }
     float delta[3];
@@ -298,24 +320,24 @@ __device__ inline void so3_finish(OdomState* st, const float* tot, const LevelIn
     float rotUpdatef[9];
     rodrigues(dd, rotUpdate);
     for (int k = 0; k < 9; ++k) rotUpdatef[k] = (float)rotUpdate[k];
-    matmul<3, float>(rotUpdatef, R_lr, R_lr);
+    matmul<3, float>(rotUpdatef, s.R_lr, s.R_lr);
     double newR[9];
-    for (int k = 0; k < 9; ++k) newR[k] = R_lr[k];
-    float B[9], ki[9], kr[9];
-    so3_prepare(newR, in, B, ki, kr);
-    // exit stores
-    st->st.lastSO3Error = err;
-    st->st.lastSO3Count = r1;
-    st->so3_lastError = err;
-    st->so3_lastCount = r1;
+    for (int k = 0; k < 9; ++k) newR[k] = s.R_lr[k];
+    so3_prepare(newR, in, s.imageBasis, s.kinv, s.krlr);
+    s.statError = err;
+    s.statCount = r1;
+    s.lastError = err;
+    s.lastCount = r1;
     for (int k = 0; k < 9; ++k) {
-        st->lastResultR[k] = resultR[k];
-        st->R_lr[k] = R_lr[k];
-        st->resultR[k] = newR[k];
-        st->imageBasis[k] = B[k];
-        st->kinv[k] = ki[k];
-        st->krlr[k] = kr[k];
+        s.lastResultR[k] = s.resultR[k];
+        s.resultR[k] = newR[k];
     }
+}
+
+__device__ inline void so3_finish(OdomState* st, const float* tot, const LevelIntr& in) {
+    So3State s = so3_load(st);
+    so3_step(s, tot, in);
+    so3_store(st, s);
 }
 
 // KRK^-1 and K t of the inverse running transform (RGBDOdometry.cpp:348-358)
