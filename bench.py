@@ -51,7 +51,7 @@ def cpu_baseline(frames, K, poses):
     tp = prev[:3, 3].astype(np.float32)
     Rpi = np.linalg.inv(Rp).astype(np.float32)
     per_level = []
-    reps_by_level = (12, 24, 48)
+    reps_by_level = (4000, 8000, 16000)  # ~2 s of wall time on all host cores (a few hundred core-seconds)
     for lvl in range(3):
         d = 1 << lvl
         args = (Rp, tp, o.buffer("vmaps_curr", lvl), o.buffer("nmaps_curr", lvl), Rpi, tp, K["fx"] / d, K["fy"] / d,
@@ -72,7 +72,7 @@ def cpu_baseline(frames, K, poses):
         "cores": orc.omp_threads(libpath),
         "kind": "port",
         "sample": ("oracle icp_step (OpenMP, f32 accumulators) on the same 640x480 synthetic frame pair: median of "
-                   "12/24/48 reps at L0/L1/L2; value = 1/(10*t0+5*t1+4*t2), the ICP reduction schedule of one frame "
+                   "4000/8000/16000 reps at L0/L1/L2 (~2 s of wall time on every host core); value = 1/(10*t0+5*t1+4*t2), the ICP reduction schedule of one frame "
                    "only (no RGB term, no pyramids)"),
         "ms_per_step_l0": per_level[0] * 1e3,
         "gbps_l0": icp_step_bytes(W * H) / per_level[0] / 1e9,
