@@ -160,3 +160,19 @@ def test_process_frame_survives_a_frame_without_depth(gpu_ctx, orc):
     g.processFrame(dev(frames[0]["rgb"]), dev(frames[0]["depth"]), timestamp=0)
     assert g.getBackgroundModel().lastCount() > 0.8 * w * h and np.isfinite(g.getCurrPose()).all()
     g.close()
+
+
+def test_cpp_shims_run_on_the_device(tmp_path):
+    """The C++ classes with the reference's names (cpp/*.h) against libmmf_hip.so on the GPU: construct
+    MultiMotionFusion / RGBDOdometry / Model, push an invalid frame (must print "invalid image data" and return
+    false like MultiMotionFusion.cpp:209-212)."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(repo, "multimotionfusion_amd")
+    exe = tmp_path / "shim_link_check"
+    subprocess.run(["g++", "-std=c++17", os.path.join(repo, "tests", "cpp", "shim_link_check.cpp"), "-o", str(exe), f"-L{pkg}",
+                    "-lmmf_hip", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe), "gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "invalid image data" in r.stderr and "processFrame(bad)=0 tick=1 surfels=0" in r.stdout
