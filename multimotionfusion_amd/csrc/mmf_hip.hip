@@ -1416,6 +1416,10 @@ struct mmf_model {
     int capacity = 0;
     float pose[16];
     unsigned count = 0;  // host copy of the number of surfels in set[cur]
+    // After clean() the new count is on its way to host_totals (asynchronous copy on the stream); until a host
+    // decision needs it, launches are sized by count_bound and read the exact value from totals[0] on the device.
+    bool count_pending = false;
+    unsigned count_bound = 0;
 
     void* slab = nullptr;
     size_t slab_bytes = 0;
@@ -1583,8 +1587,19 @@ extern "C" int mmf_model_get_pose(mmf_model* m, float pose[16]) {
     std::memcpy(pose, m->pose, sizeof(m->pose));
     return MMF_OK;
 }
+// makes m->count exact again (after the stream has passed the clean pass that produced it)
+static int model_resolve_count(mmf_model* m) {
+    if (!m->count_pending) return MMF_OK;
+    MMF_HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    m->count = m->host_totals[0] < (unsigned)m->capacity ? m->host_totals[0] : (unsigned)m->capacity;
+    m->count_pending = false;
+    return MMF_OK;
+}
+
 extern "C" int mmf_model_count(mmf_model* m, unsigned* count) {
     MMF_REQUIRE(m && count, "mmf_model_count: null argument");
+    const int rc_count = model_resolve_count(m);
+    if (rc_count) return rc_count;
     *count = m->count;
     return MMF_OK;
 }
@@ -1634,6 +1649,7 @@ extern "C" int mmf_model_initialise(mmf_model* m, const uint8_t* rgb, const floa
     if (rc) return rc;
     // "both raw and filtered have the same amount of vertices" (Model.cpp:292); capped by the buffer
     m->count = m->host_totals[0] < (unsigned)m->capacity ? m->host_totals[0] : (unsigned)m->capacity;
+    m->count_pending = false;
     return MMF_OK;
 }
 
@@ -1650,6 +1666,7 @@ static IndexArgs model_index_args(mmf_model* m, int time, float depth_cutoff, in
 // ModelProjection::predictIndices (ModelProjection.cpp:94-143)
 extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cutoff, int time_delta) {
     MMF_REQUIRE(m != nullptr, "mmf_model_predict_indices: null model");
+    if (int rc0 = model_resolve_count(m)) return rc0;
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     const size_t npix = (size_t)m->width * m->height;
@@ -1676,9 +1693,12 @@ extern "C" int mmf_model_combined_predict(mmf_model* m, float depth_cutoff, int 
     a.maxDepth = depth_cutoff;
     a.confThreshold = m->conf_threshold;
     a.time = time, a.maxTime = max_time, a.timeDelta = time_delta;
-    if (m->count)
-        hipLaunchKernelGGL(splat_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
-                           m->keys);
+    // right after clean() the exact count may still be in flight to the host: size the launch by the bound
+    // and let the kernel read the count on the device instead of waiting for it
+    const unsigned launch_count = m->count_pending ? m->count_bound : m->count;
+    if (launch_count)
+        hipLaunchKernelGGL(splat_kernel, grid1d(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
+                           m->keys, m->count_pending ? m->totals : nullptr);
     hipLaunchKernelGGL(splat_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->image,
                        m->vertexConf, m->normalRadius, m->time_tex);
     MMF_HIP_TRY(hipGetLastError());
@@ -1700,9 +1720,10 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
     a.maxDepth = depth_cutoff;
     a.confThreshold = conf_threshold;
     a.time = time, a.maxTime = max_time, a.timeDelta = time_delta;
+    if (int rc0 = model_resolve_count(m)) return rc0;
     if (m->count)
         hipLaunchKernelGGL(splat_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
-                           m->keys);
+                           m->keys, nullptr);
     hipLaunchKernelGGL(splat_depth_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys,
                        m->synth_depth);
     MMF_HIP_TRY(hipGetLastError());
@@ -1713,6 +1734,7 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
 extern "C" int mmf_model_fuse(mmf_model* m, int time, const uint8_t* rgb, const uint8_t* mask, const float* depth_raw,
                               const float* depth_filtered, float depth_cutoff, float weighting) {
     MMF_REQUIRE(m && rgb && mask && depth_raw && depth_filtered, "mmf_model_fuse: null argument");
+    if (int rc0 = model_resolve_count(m)) return rc0;
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     const int npix = m->width * m->height;
@@ -1739,6 +1761,7 @@ extern "C" int mmf_model_clean(mmf_model* m, int time, int time_delta, float dep
                                const uint8_t* mask, float outlier_coeff) {
     (void)depth_cutoff;  // only consumed by the deformation part, which never runs (nodes == 0)
     MMF_REQUIRE(m && depth_filtered && mask, "mmf_model_clean: null argument");
+    if (int rc0 = model_resolve_count(m)) return rc0;
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     const int npix = m->width * m->height;
@@ -1758,9 +1781,11 @@ extern "C" int mmf_model_clean(mmf_model* m, int time, int time_delta, float dep
     hipLaunchKernelGGL(clean_scatter_kernel, grid1d(n), dim3(256), 0, c->stream, m->set[m->cur], m->meas, (int)m->count,
                        npix, m->flags_a, m->block_sums, m->conf_time, m->set[1 - m->cur], m->capacity, &m->totals[0]);
     MMF_HIP_TRY(hipGetLastError());
-    int rc = model_read_totals(m);  // glGetQueryObjectuiv(countQuery) in the reference (Model.cpp:1166)
-    if (rc) return rc;
-    m->count = m->host_totals[0] < (unsigned)m->capacity ? m->host_totals[0] : (unsigned)m->capacity;
+    // glGetQueryObjectuiv(countQuery) in the reference (Model.cpp:1166) stalls for the count; here it travels
+    // to the host asynchronously and is picked up by the next call that needs it on the host
+    MMF_HIP_TRY(hipMemcpyAsync(m->host_totals, m->totals, 16, hipMemcpyDeviceToHost, c->stream));
+    m->count_bound = n < (unsigned)m->capacity ? n : (unsigned)m->capacity;
+    m->count_pending = true;
     m->cur = 1 - m->cur;
     return MMF_OK;
 }
@@ -1798,6 +1823,7 @@ extern "C" int mmf_model_requires_fill_in(mmf_model* m, float ratio, int* result
 // Model::downloadMap (Model.cpp:1353-1384): 48-byte AoS surfels {pos+conf, colour/time, normal+radius}
 extern "C" int mmf_model_download_map(mmf_model* m, float* host_aos, unsigned max_surfels, unsigned* count_out) {
     MMF_REQUIRE(m && host_aos && count_out, "mmf_model_download_map: null argument");
+    if (int rc0 = model_resolve_count(m)) return rc0;
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     const unsigned n = m->count < max_surfels ? m->count : max_surfels;
@@ -1822,6 +1848,7 @@ extern "C" int mmf_model_upload_map(mmf_model* m, const float* host_aos, unsigne
     MMF_REQUIRE(m && (host_aos || count == 0) && count <= (unsigned)m->capacity, "mmf_model_upload_map: bad argument");
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
+    if (int rc0 = model_resolve_count(m)) return rc0;  // lets an in-flight count land before it is replaced
     m->count = count;
     if (!count) return MMF_OK;
     float4* stage = nullptr;

@@ -526,9 +526,13 @@ __device__ __forceinline__ bool splat_fragment(const SplatFrag& f, const SplatAr
     return true;
 }
 
+// `count_dev` (optional): the exact surfel count where the previous clean pass left it on the device;
+// `count` is then only the bound the grid was sized by.
 __global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, SplatArgs a,
-                                                    unsigned long long* __restrict__ keys) {
+                                                    unsigned long long* __restrict__ keys,
+                                                    const unsigned* __restrict__ count_dev) {
     const int id = blockIdx.x * 256 + threadIdx.x;
+    if (count_dev != nullptr) count = min((unsigned)count, *count_dev);
     if (id >= count) return;
     const SplatFrag f = splat_setup(s.pos[id], s.col[id], s.nrm[id], a);
     if (!f.ok) return;
