@@ -157,6 +157,17 @@ void orc_synthesize_depth(const orc_surfel *s, int count, const float pose[16], 
 /* keypoint descriptor matcher (mmf_oracle_match.c): cv::BFMatcher(NORM_L2, crossCheck).match + distance gate */
 int orc_match_descriptors(const float *query, int nq, const float *train, int nt, int dim, float max_distance,
                           int *train_idx, float *distance);
+/* SuperPoint network + keypoint post-processing (mmf_oracle_superpoint.c; channels-last activations) */
+void orc_sp_conv(const float *in, int H, int W, int in_stride, int cin, const float *w, const float *bias, int cout, int taps,
+                 int relu, float *out);
+void orc_sp_maxpool2(const float *in, int H, int W, int C, float *out);
+void orc_sp_input(const uint8_t *img, int H, int W, int channels, float *out);
+void orc_sp_l2_normalize(float *desc, int npix, int C);
+int orc_sp_forward(const float *input, int H, int W, const float *const *weights, float *semi, float *desc);
+void orc_sp_heatmap(const float *semi, int Hc, int Wc, float *heat);
+int orc_sp_keypoints(const float *heat, int H, int W, float conf_thresh, int nms_dist, int border, int max_out, int *xy,
+                     float *conf);
+void orc_sp_sample_descriptors(const float *desc, int Hc, int Wc, const int *xy, int n, int H, int W, float *out);
 int orc_fuse(orc_surfel *s, int count, const uint8_t *rgb, const float *depth_raw, const float *depth_filtered,
              const uint8_t *mask, const uint32_t *index, const float *vertConf, const float *normRad,
              const float pose[16], float cx, float cy, float fx, float fy, int cols, int rows, int time,

@@ -18,7 +18,8 @@ def build(force=False, march=None, out=None):
     target = out or "liboracle.so"
     path = os.path.join(_DIR, target)
     src_m = max(os.path.getmtime(os.path.join(_DIR, f))
-                for f in ("mmf_oracle.c", "mmf_oracle_surfel.c", "mmf_oracle_match.c", "mmf_oracle.h", "Makefile"))
+                for f in ("mmf_oracle.c", "mmf_oracle_surfel.c", "mmf_oracle_match.c", "mmf_oracle_superpoint.c", "mmf_oracle.h",
+                          "Makefile"))
     if not force and os.path.exists(path) and os.path.getmtime(path) >= src_m:
         return path
     cmd = ["make", "-C", _DIR, f"OUT={target}", "-B"]
@@ -467,3 +468,102 @@ def match_descriptors(query, train, max_distance=0.0):
     lib().orc_match_descriptors(_pf(q), nq, _pf(t), nt, dim, _cf(max_distance), idx.ctypes.data_as(C.POINTER(C.c_int)),
                                 _pf(dist))
     return idx, dist
+
+
+# ---- SuperPoint (mmf_oracle_superpoint.c) ----------------------------------------------------------------
+SP_LAYERS = (("conv1a", 1, 64, 3), ("conv1b", 64, 64, 3), ("conv2a", 64, 64, 3), ("conv2b", 64, 64, 3),
+             ("conv3a", 64, 128, 3), ("conv3b", 128, 128, 3), ("conv4a", 128, 128, 3), ("conv4b", 128, 128, 3),
+             ("convPa", 128, 256, 3), ("convPb", 256, 65, 1), ("convDa", 128, 256, 3), ("convDb", 256, 256, 1))
+
+
+def sp_random_weights(seed=0, scale=1.0):
+    """He-initialised random SuperPointNet weights in PyTorch layout: [(w [Cout,Cin,k,k], b [Cout])] * 12.
+    There is no network access for the MagicLeap checkpoint, so tests and the bench run on these."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _, cin, cout, k in SP_LAYERS:
+        std = scale * np.sqrt(2.0 / (cin * k * k))
+        out.append((rng.normal(0, std, (cout, cin, k, k)).astype(np.float32),
+                    rng.normal(0, 0.05, cout).astype(np.float32)))
+    return out
+
+
+def _sp_weight_ptrs(weights):
+    flat = []
+    for w, b in weights:
+        flat += [np.ascontiguousarray(w, np.float32), np.ascontiguousarray(b, np.float32)]
+    arr = (C.POINTER(C.c_float) * 24)(*[_pf(a) for a in flat])
+    return arr, flat
+
+
+def sp_conv(x, w, b, relu):
+    """x [H,W,Cin] channels-last, w [Cout,Cin,k,k] -> [H,W,Cout]"""
+    x, w, b = _f(x), _f(w), _f(b)
+    H, W, cin = x.shape
+    cout, taps = w.shape[0], w.shape[2] * w.shape[3]
+    out = np.empty((H, W, cout), np.float32)
+    lib().orc_sp_conv(_pf(x), H, W, cin, cin, _pf(w), _pf(b), cout, taps, int(relu), _pf(out))
+    return out
+
+
+def sp_input(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty((H, W), np.float32)
+    lib().orc_sp_input(_pu8(img), H, W, ch, _pf(out))
+    return out
+
+
+def sp_forward(inp, weights):
+    """inp [H,W] float32 in [0,1] -> (semi [H/8,W/8,65], desc [H/8,W/8,256] L2-normalised)"""
+    inp = _f(inp)
+    H, W = inp.shape
+    semi = np.empty((H // 8, W // 8, 65), np.float32)
+    desc = np.empty((H // 8, W // 8, 256), np.float32)
+    arr, keep = _sp_weight_ptrs(weights)
+    lib().orc_sp_forward.restype = C.c_int
+    rc = lib().orc_sp_forward(_pf(inp), H, W, arr, _pf(semi), _pf(desc))
+    if rc:
+        raise ValueError("SuperPoint needs an image whose sides are multiples of 8")
+    del keep
+    return semi, desc
+
+
+def sp_heatmap(semi):
+    semi = _f(semi)
+    Hc, Wc = semi.shape[:2]
+    heat = np.empty((Hc * 8, Wc * 8), np.float32)
+    lib().orc_sp_heatmap(_pf(semi), Hc, Wc, _pf(heat))
+    return heat
+
+
+def sp_keypoints(heat, conf_thresh=0.015, nms_dist=4, border=4):
+    heat = _f(heat)
+    H, W = heat.shape
+    xy = np.empty((H * W, 2), np.int32)
+    conf = np.empty(H * W, np.float32)
+    lib().orc_sp_keypoints.restype = C.c_int
+    n = lib().orc_sp_keypoints(_pf(heat), H, W, _cf(conf_thresh), nms_dist, border, H * W,
+                               xy.ctypes.data_as(C.POINTER(C.c_int)), _pf(conf))
+    return xy[:n].copy(), conf[:n].copy()
+
+
+def sp_sample_descriptors(desc, xy, H, W):
+    desc = _f(desc)
+    xy = np.ascontiguousarray(xy, np.int32)
+    Hc, Wc = desc.shape[:2]
+    out = np.empty((xy.shape[0], 256), np.float32)
+    lib().orc_sp_sample_descriptors(_pf(desc), Hc, Wc, xy.ctypes.data_as(C.POINTER(C.c_int)), xy.shape[0], H, W, _pf(out))
+    return out
+
+
+def sp_get_features(img, weights, conf_thresh=0.015, nms_dist=4, border=4):
+    """SuperPoint::getFeatures as MultiMotionFusion.cpp:233 consumes it: (coordinates [n,2] float64 normalised
+    to [0,1), descriptors [n,256] float64), strongest keypoint first."""
+    inp = sp_input(img)
+    H, W = inp.shape
+    semi, desc = sp_forward(inp, weights)
+    xy, _ = sp_keypoints(sp_heatmap(semi), conf_thresh, nms_dist, border)
+    d = sp_sample_descriptors(desc, xy, H, W)
+    return xy.astype(np.float64) / np.array([W, H], np.float64), d.astype(np.float64)
