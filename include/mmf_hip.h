@@ -321,6 +321,40 @@ const float *mmf_fusion_depth_filtered(mmf_fusion *f);
 int mmf_match_descriptors(mmf_ctx *ctx, const float *query, int nq, const float *train, int nt, int dim,
                           float max_distance, int *train_idx, float *distance);
 
+/* ---- SuperPoint keypoint network --------------------------------------------
+ * Replaces the un-vendored super_point_inference package as the reference uses it:
+ *     kp_predictor = std::make_shared<SuperPoint>(keypoint_predictor_path);       Core/MultiMotionFusion.cpp:78
+ *     std::tie(coordinates[i], descriptors[i]) = kp_predictor->getFeatures(img);  Core/MultiMotionFusion.cpp:233
+ * weights: 24 HOST arrays {weight, bias} of conv1a conv1b conv2a conv2b conv3a conv3b conv4a conv4b convPa
+ * convPb convDa convDb in PyTorch layout [Cout][Cin][k][k] / [Cout] (the state dict of SuperPointNet.pt;
+ * reading the file is the caller's business).  The object serves images up to max_width x max_height
+ * (sides multiples of 8) and returns at most max_keypoints keypoints.  The 3x3 and 1x1 convolutions run
+ * on the f32 matrix cores (csrc/superpoint_kernels.hpp). */
+typedef struct mmf_superpoint mmf_superpoint;
+int mmf_superpoint_create(mmf_ctx *ctx, const float *const *weights, int max_width, int max_height,
+                          int max_keypoints, mmf_superpoint **out);
+void mmf_superpoint_destroy(mmf_superpoint *sp);
+/* the network alone: image = DEVICE pointer to interleaved u8 (1 = grey, 3 / 4 = RGB[A]); leaves the detector
+ * logits [H/8][W/8][65], the normalised coarse descriptors [H/8][W/8][256] and the heat map [H][W] on the
+ * device.  Asynchronous on the context's stream. */
+int mmf_superpoint_forward(mmf_superpoint *sp, const uint8_t *image, int width, int height, int channels);
+/* copy a result of the last forward pass to the host: which = 0 logits, 1 coarse descriptors, 2 heat map;
+ * count must be the exact number of floats.  Synchronous. */
+int mmf_superpoint_download(mmf_superpoint *sp, int which, float *host, size_t count);
+/* SuperPoint::getFeatures: forward pass, heat >= conf_thresh, greedy non-maximum suppression (Chebyshev
+ * radius nms_dist, strongest first), border band removed, descriptors sampled bilinearly and normalised.
+ * xy [max_keypoints][2] (pixels), conf [max_keypoints], desc [max_keypoints][256]: HOST arrays, strongest
+ * keypoint first; *count = keypoints written.  The reference's `coordinates` are xy / (width, height)
+ * (PointTracker.cpp:40-41).  Synchronous. */
+int mmf_superpoint_get_features(mmf_superpoint *sp, const uint8_t *image, int width, int height, int channels,
+                                float conf_thresh, int nms_dist, int border, int *xy, float *conf, float *desc,
+                                int *count);
+/* one convolution layer (tests / tools): in [H][W][cin], out [H][W][cout] (or [H/2][W/2][cout] with pool) on
+ * the device, channels-last; w [cout][cin][k][k], bias [cout] on the HOST; taps = 9 (3x3, zero pad 1) or 1;
+ * cin a multiple of 32; nt = output-channel tiles of 32 per workgroup (1, 2, 4; 0 = automatic). Synchronous. */
+int mmf_superpoint_conv(mmf_ctx *ctx, const float *in, int height, int width, int cin, const float *w,
+                        const float *bias, int cout, int taps, int relu, int pool, int nt, float *out);
+
 /* ---- keypoint-based pose initialisation: RigidRANSAC (Core/Utils/RigidRANSAC.h:6-32, .cpp:73-180) ----
  * Host code, like the reference's (a few dozen keypoint tracks): p0, p1 are HOST arrays of n 3-D points
  * (row-major n x 3), mask an optional n-byte selection; T receives the row-major 4x4 of T_01 with

@@ -101,6 +101,12 @@ SIGNATURES = {
     "mmf_model_combined_predict": (_i, [_vp, _f, _i, _i, _i]),
     "mmf_model_synthesize_depth": (_i, [_vp, _f, _f, _i, _i, _i]),
     "mmf_match_descriptors": (_i, [_vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp]),
+    "mmf_superpoint_create": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_vp)]),
+    "mmf_superpoint_destroy": (None, [_vp]),
+    "mmf_superpoint_forward": (_i, [_vp, _vp, _i, _i, _i]),
+    "mmf_superpoint_download": (_i, [_vp, _i, _vp, _sz]),
+    "mmf_superpoint_get_features": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _ip]),
+    "mmf_superpoint_conv": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mmf_rigid_fit": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mmf_rigid_apply": (_i, [_vp, _vp, _vp, _i, _vp]),
     "mmf_ransac_create": (_i, [_i, _f, _f, _vp]),

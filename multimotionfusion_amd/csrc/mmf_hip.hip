@@ -2002,6 +2002,11 @@ extern "C" int mmf_ransac_estimate(mmf_ransac* r, const float* p0, const float* 
     return MMF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// SuperPoint keypoint network (Core/MultiMotionFusion.cpp:78,233)
+// ---------------------------------------------------------------------------------------------
+#include "superpoint_host.hpp"
+
 #ifdef MMF_STAMPS
 // diagnostic builds only (tools/rgb_step_probe.py): phase-stamp buffer of the instrumented kernels
 extern "C" int mmf_debug_set_stamps(void* dev_buf) {

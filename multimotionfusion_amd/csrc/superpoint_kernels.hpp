@@ -1,0 +1,377 @@
+// superpoint_kernels.hpp -- the SuperPoint keypoint network and its post-processing on gfx950.
+//
+// What the reference gets from `SuperPoint::getFeatures` (Core/MultiMotionFusion.cpp:78,233; the network
+// itself lives in the un-vendored super_point_inference package and runs through libtorch there):
+//   VGG encoder (8 x conv3x3+ReLU, three 2x2 max pools), detector head (conv3x3+ReLU, conv1x1 -> 65),
+//   descriptor head (conv3x3+ReLU, conv1x1 -> 256, L2 normalised), softmax + depth-to-space heat map,
+//   greedy non-maximum suppression, bilinear descriptor sampling.
+//
+// The convolutions are the only dense contractions of the whole project and run on the matrix cores as an
+// implicit GEMM in f32 (v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulate -- the reference computes in
+// fp32, so no reduced-precision operand is introduced):
+//   * activations are channels-last [H][W][C], so the K dimension (tap, channel) is contiguous per pixel;
+//   * one workgroup (4 waves) owns an 8 x 16 pixel tile and 32*NT output channels; wave w owns rows 2w, 2w+1.
+//     The 32 MFMA rows of a wave are eight 2x2 pixel blocks (row = 4*block + 2*dy + dx), which puts the four
+//     pixels of a max-pool window into ONE lane's accumulator registers: the pool is a 4-way max in the
+//     epilogue and the un-pooled activation never exists in memory;
+//   * K is walked in blocks of 32 input channels x 9 taps.  The 10 x 18 pixel halo of a block is staged once
+//     in LDS (34.5 KB) and serves all nine taps by address offset; the weights of one (block, tap) step are
+//     4*NT KB, double-buffered, pre-packed on the host in exactly the order the lanes read;
+//   * LDS images are laid out for conflict-free ds_read_b128: a pixel is 36 floats (32 + 4 pad), a halo row
+//     24 pixels (18 + 6 pad) -- with these strides the 16 lanes of every b128 group hit 16 distinct 16-B
+//     slots (MI355X_MICROARCH.md, LDS).  The channels of a pixel are stored even/odd de-interleaved in groups
+//     of 8 so that one b128 read hands a lane its operand for four consecutive MFMAs;
+//   * the accumulation order of one output is a single fmaf chain (block, tap, channel) -- see the oracle's
+//     header -- which the MFMA reproduces exactly, so parity is bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mmf_math.h"
+
+namespace mmf {
+
+typedef float sp_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kSpTileH = 8, kSpTileW = 16;  // output pixels per workgroup
+constexpr int kSpRowPix = 24;               // LDS pixels per halo row (18 used; 24 = 8 mod 16 keeps b128 reads conflict free)
+constexpr int kSpPixF4 = 9;                 // LDS float4 per pixel (32 channels + 4 floats pad)
+constexpr int kSpKBlock = 32;               // input channels per K block
+
+struct SpConvArgs {
+    const float* in;     // [H][W][in_stride], first `cin` channels used
+    const float* wpack;  // packed weights (sp_pack_weights on the host)
+    const float* bias;   // [cout]
+    float* out;          // [H or H/2][W or W/2][out_stride]
+    int in_stride, out_stride;
+    int H, W, cin, cout;
+    int relu;
+};
+
+template <int NT, int TAPS, bool POOL>
+__global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
+    constexpr int HALO = TAPS == 9 ? 1 : 0;
+    constexpr int HR = kSpTileH + 2 * HALO, HC = kSpTileW + 2 * HALO;
+    constexpr int UNITS = HR * HC * 4;  // (pixel, 8-channel group) staging units of one K block
+    constexpr int UPT = (UNITS + 255) / 256;
+    __shared__ float4 lds_a[10 * kSpRowPix * kSpPixF4];
+    __shared__ float4 lds_b[2][256 * NT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * kSpTileW, y0 = blockIdx.y * kSpTileH, z = blockIdx.z;
+    const int chunks = p.cin / kSpKBlock, steps = chunks * TAPS;
+    const float4* __restrict__ wp = reinterpret_cast<const float4*>(p.wpack) + (size_t)z * steps * 256 * NT;
+
+    // staging addresses of this thread's units (the same for every K block, which only shifts the channel)
+    int a_src[UPT], a_dst[UPT];
+#pragma unroll
+    for (int j = 0; j < UPT; ++j) {
+        const int u = tid + 256 * j;
+        const int pix = u >> 2, q = u & 3;
+        const int r = pix / HC, c = pix - r * HC;
+        const int gy = y0 - HALO + r, gx = x0 - HALO + c;
+        const bool inside = u < UNITS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        a_src[j] = inside ? (gy * p.W + gx) * p.in_stride + 8 * q : -1;
+        a_dst[j] = u < UNITS ? (r * kSpRowPix + c) * kSpPixF4 + 2 * q : -1;
+    }
+    float4 a_lo[UPT], a_hi[UPT], b_reg[NT];
+    auto load_a = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < UPT; ++j) {
+            a_lo[j] = a_hi[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_src[j] >= 0) {
+                const float4* s = reinterpret_cast<const float4*>(p.in + a_src[j] + chunk * kSpKBlock);
+                a_lo[j] = s[0], a_hi[j] = s[1];
+            }
+        }
+    };
+    auto store_a = [&]() {  // even channels of the group of 8 first, then the odd ones
+#pragma unroll
+        for (int j = 0; j < UPT; ++j)
+            if (a_dst[j] >= 0) {
+                lds_a[a_dst[j]] = make_float4(a_lo[j].x, a_lo[j].z, a_hi[j].x, a_hi[j].z);
+                lds_a[a_dst[j] + 1] = make_float4(a_lo[j].y, a_lo[j].w, a_hi[j].y, a_hi[j].w);
+            }
+    };
+    auto load_b = [&](int step) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b_reg[t] = wp[(size_t)step * 256 * NT + tid + 256 * t];
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) lds_b[buf][tid + 256 * t] = b_reg[t];
+    };
+
+    // MFMA row of this lane: i = 4*block + 2*dy + dx; the lane half kh supplies the odd k of each pair
+    const int i = lane & 31, kh = lane >> 5;
+    const int a_base = ((2 * wave + ((i >> 1) & 1)) * kSpRowPix + 2 * (i >> 2) + (i & 1)) * kSpPixF4 + kh;
+    const int b_base = kh * 32 + i;
+
+    sp_f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+    load_a(0);
+    load_b(0);
+    store_a();
+    store_b(0);
+    __syncthreads();
+
+    for (int chunk = 0, step = 0; chunk < chunks; ++chunk) {
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap, ++step) {
+            const bool more = step + 1 < steps;
+            const bool next_chunk = tap == TAPS - 1 && more;
+            if (more) load_b(step + 1);
+            if (next_chunk) load_a(chunk + 1);
+            const int tap_off = TAPS == 9 ? ((tap / 3) * kSpRowPix + tap % 3) * kSpPixF4 : 0;
+            const float4* __restrict__ bt = lds_b[step & 1];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 a = lds_a[a_base + tap_off + 2 * g];
+                float4 b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[t] = bt[(g * NT + t) * 64 + b_base];
+                // k ascending within every accumulator's chain; the NT independent chains interleave
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+            }
+            if (next_chunk) {
+                __syncthreads();  // every wave is done with this block's halo
+                store_a();
+            }
+            if (more) store_b((step + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: accumulator register v of lane (n, kh) is MFMA row (v&3) + 8*(v>>2) + 4*kh = pixel block
+    // 2*(v>>2) + kh, (dy, dx) = ((v>>1)&1, v&1); column n = output channel
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = (z * NT + t) * 32 + i;
+        const bool co_ok = co < p.cout;
+        const float bias = co_ok ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const int bx = 2 * blk + kh;
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = acc[t][4 * blk + k] + bias;
+                if (p.relu) o[k] = o[k] < 0.f ? 0.f : o[k];
+            }
+            if (POOL) {
+                const int py = (y0 >> 1) + wave, px = (x0 >> 1) + bx;
+                const float m0 = o[0] > o[1] ? o[0] : o[1], m1 = o[2] > o[3] ? o[2] : o[3];
+                if (co_ok && py < (p.H >> 1) && px < (p.W >> 1))
+                    p.out[((size_t)py * (p.W >> 1) + px) * p.out_stride + co] = m0 > m1 ? m0 : m1;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int oy = y0 + 2 * wave + (k >> 1), ox = x0 + 2 * bx + (k & 1);
+                    if (co_ok && oy < p.H && ox < p.W) p.out[((size_t)oy * p.W + ox) * p.out_stride + co] = o[k];
+                }
+            }
+        }
+    }
+}
+
+// ---- network input: [0,1] grey from 1- or 3-channel u8 --------------------------------------------------
+__global__ __launch_bounds__(256) void sp_input_kernel(const uint8_t* __restrict__ img, int npix, int channels,
+                                                       float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    if (channels == 1) {
+        out[i] = (float)img[i] / 255.0f;
+    } else {
+        const uint8_t* px = img + (size_t)i * channels;
+        out[i] = ((0.299f * (float)px[0] + 0.587f * (float)px[1]) + 0.114f * (float)px[2]) / 255.0f;
+    }
+}
+
+// ---- conv1a: one input channel, 64 outputs.  K = 9 is no contraction to speak of: VALU, four lanes per pixel
+// (16 output channels each) so that a wave stores 4 KB contiguous per instruction group ---------------------
+__global__ __launch_bounds__(256) void sp_conv1a_kernel(const float* __restrict__ in, int H, int W,
+                                                        const float* __restrict__ w_tap_co /* [9][64] */,
+                                                        const float* __restrict__ bias, float* __restrict__ out) {
+    __shared__ float4 wl[9 * 16];
+    if (threadIdx.x < 9 * 16) wl[threadIdx.x] = reinterpret_cast<const float4*>(w_tap_co)[threadIdx.x];
+    __syncthreads();
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int pix = gid >> 2, q = gid & 3;
+    if (pix >= H * W) return;
+    const int y = pix / W, x = pix - y * W;
+    float v[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        v[tap] = inside ? in[(size_t)yy * W + xx] : 0.f;
+    }
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c = 0; c < 16; c += 4) {
+            const float4 w = wl[tap * 16 + 4 * q + (c >> 2)];
+            acc[c] = fmaf(v[tap], w.x, acc[c]), acc[c + 1] = fmaf(v[tap], w.y, acc[c + 1]);
+            acc[c + 2] = fmaf(v[tap], w.z, acc[c + 2]), acc[c + 3] = fmaf(v[tap], w.w, acc[c + 3]);
+        }
+    float4* o = reinterpret_cast<float4*>(out + (size_t)pix * 64 + 16 * q);
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r[k] = acc[c + k] + bias[16 * q + c + k];
+            r[k] = r[k] < 0.f ? 0.f : r[k];
+        }
+        o[c >> 2] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// ---- L2 normalisation over channels (the chain of squares is sequential, as in the oracle) ----------------
+template <int C>
+__global__ __launch_bounds__(64) void sp_l2_normalize_kernel(float* __restrict__ desc, int npix) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= npix) return;
+    float4* d = reinterpret_cast<float4*>(desc + (size_t)p * C);
+    float s = 0.f;
+    for (int c = 0; c < C / 4; ++c) {
+        const float4 v = d[c];
+        s = fmaf(v.x, v.x, s), s = fmaf(v.y, v.y, s), s = fmaf(v.z, v.z, s), s = fmaf(v.w, v.w, s);
+    }
+    const float n = sqrtf(s);
+    for (int c = 0; c < C / 4; ++c) {
+        float4 v = d[c];
+        v.x = v.x / n, v.y = v.y / n, v.z = v.z / n, v.w = v.w / n;
+        d[c] = v;
+    }
+}
+
+// ---- heat map: softmax over the 65 logits of a cell (+1e-5 in the denominator), dustbin dropped, 8x8
+// depth-to-space -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sp_heatmap_kernel(const float* __restrict__ semi, int Hc, int Wc,
+                                                        float* __restrict__ heat) {
+    const int cell = blockIdx.x * 64 + threadIdx.x;
+    if (cell >= Hc * Wc) return;
+    const int hc = cell / Wc, wc = cell - hc * Wc;
+    const float* s = semi + (size_t)cell * 65;
+    float e[65], sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 65; ++c) {
+        e[c] = mmf_expf(s[c]);
+        sum = sum + e[c];
+    }
+    sum = sum + 0.00001f;
+    const int W = Wc * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float4* o = reinterpret_cast<float4*>(heat + (size_t)(hc * 8 + r) * W + wc * 8);
+        o[0] = make_float4(e[8 * r] / sum, e[8 * r + 1] / sum, e[8 * r + 2] / sum, e[8 * r + 3] / sum);
+        o[1] = make_float4(e[8 * r + 4] / sum, e[8 * r + 5] / sum, e[8 * r + 6] / sum, e[8 * r + 7] / sum);
+    }
+}
+
+// ---- greedy non-maximum suppression as a fixed point --------------------------------------------------------
+// nms_fast visits candidates strongest first and keeps one iff no KEPT stronger candidate lies within the
+// Chebyshev radius.  That outcome is the unique fixed point of: "kept iff every stronger candidate in the
+// window is suppressed; suppressed iff some stronger candidate in the window is kept".  Decisions are final
+// once taken, so the passes may update in place; priority = (confidence desc, row-major index asc).
+enum : uint8_t { SP_NONE = 0, SP_UNDECIDED = 1, SP_SUPPRESSED = 2, SP_KEPT = 3 };
+
+__global__ __launch_bounds__(256) void sp_nms_init_kernel(const float* __restrict__ heat, int n, float conf_thresh,
+                                                          uint8_t* __restrict__ state) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) state[i] = heat[i] >= conf_thresh ? SP_UNDECIDED : SP_NONE;
+}
+
+__global__ __launch_bounds__(256) void sp_nms_pass_kernel(const float* __restrict__ heat, int H, int W, int dist,
+                                                          uint8_t* state, unsigned* __restrict__ undecided) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    if (__builtin_nontemporal_load(&state[i]) != SP_UNDECIDED) return;
+    const int y = i / W, x = i - y * W;
+    const float ci = heat[i];
+    bool stronger_kept = false, stronger_open = false;
+    for (int yy = max(y - dist, 0); yy <= min(y + dist, H - 1); ++yy)
+        for (int xx = max(x - dist, 0); xx <= min(x + dist, W - 1); ++xx) {
+            const int j = yy * W + xx;
+            const uint8_t sj = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sj == SP_NONE || sj == SP_SUPPRESSED || j == i) continue;
+            const float cj = heat[j];
+            if (!(cj > ci || (cj == ci && j < i))) continue;
+            stronger_kept |= sj == SP_KEPT;
+            stronger_open |= sj == SP_UNDECIDED;
+        }
+    if (stronger_kept)
+        __hip_atomic_store(&state[i], (uint8_t)SP_SUPPRESSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (!stronger_open)
+        __hip_atomic_store(&state[i], (uint8_t)SP_KEPT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        atomicAdd(undecided, 1u);
+}
+
+// kept and outside the border band -> flag (row-major order)
+__global__ __launch_bounds__(256) void sp_keep_flag_kernel(const uint8_t* __restrict__ state, int H, int W, int border,
+                                                           unsigned* __restrict__ flags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i - y * W;
+    flags[i] = (state[i] == SP_KEPT && x >= border && x < W - border && y >= border && y < H - border) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void sp_keep_scatter_kernel(const unsigned* __restrict__ flags,
+                                                              const unsigned* __restrict__ prefix,
+                                                              const float* __restrict__ heat, int n, int W, int max_out,
+                                                              int* __restrict__ xy, float* __restrict__ conf) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const unsigned k = prefix[i];
+    if (k >= (unsigned)max_out) return;
+    xy[2 * k] = i % W, xy[2 * k + 1] = i / W;
+    conf[k] = heat[i];
+}
+
+// ---- descriptor sampling: one workgroup per keypoint, one thread per channel ------------------------------
+__global__ __launch_bounds__(256) void sp_sample_kernel(const float* __restrict__ desc, int Hc, int Wc,
+                                                        const int* __restrict__ xy, int H, int W,
+                                                        float* __restrict__ out) {
+    __shared__ float vals[256];
+    __shared__ float norm;
+    const int k = blockIdx.x, c = threadIdx.x;
+    const float gx = (float)xy[2 * k] / ((float)W / 2.0f) - 1.0f, gy = (float)xy[2 * k + 1] / ((float)H / 2.0f) - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(Wc - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(Hc - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - x0f, wx0 = (x0f + 1.0f) - ix, wy1 = iy - y0f, wy0 = (y0f + 1.0f) - iy;
+    const float wnw = wx0 * wy0, wne = wx1 * wy0, wsw = wx0 * wy1, wse = wx1 * wy1;
+    const bool x0ok = x0 >= 0 && x0 < Wc, x1ok = x1 >= 0 && x1 < Wc, y0ok = y0 >= 0 && y0 < Hc, y1ok = y1 >= 0 && y1 < Hc;
+    const float nw = (x0ok && y0ok) ? desc[((size_t)y0 * Wc + x0) * 256 + c] : 0.f;
+    const float ne = (x1ok && y0ok) ? desc[((size_t)y0 * Wc + x1) * 256 + c] : 0.f;
+    const float sw = (x0ok && y1ok) ? desc[((size_t)y1 * Wc + x0) * 256 + c] : 0.f;
+    const float se = (x1ok && y1ok) ? desc[((size_t)y1 * Wc + x1) * 256 + c] : 0.f;
+    const float v = ((nw * wnw + ne * wne) + sw * wsw) + se * wse;
+    vals[c] = v;
+    __syncthreads();
+    if (c == 0) {
+        float s = 0.f;
+        for (int q = 0; q < 256; ++q) s = fmaf(vals[q], vals[q], s);
+        norm = sqrtf(s);
+    }
+    __syncthreads();
+    out[(size_t)k * 256 + c] = v / norm;
+}
+
+}  // namespace mmf

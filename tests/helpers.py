@@ -18,7 +18,7 @@ def frame_pair(width, height, seed=1, **kw):
 
 def bits(a):
     a = np.ascontiguousarray(a)
-    return a.view({4: np.uint32, 2: np.uint16, 1: np.uint8}[a.dtype.itemsize])
+    return a.view({8: np.uint64, 4: np.uint32, 2: np.uint16, 1: np.uint8}[a.dtype.itemsize])
 
 
 def assert_bit_equal(a, b, what=""):
