@@ -220,8 +220,8 @@ extern "C" int mmf_superpoint_forward(mmf_superpoint* sp, const uint8_t* image, 
     sp_launch_conv(s, sp->L[8], sp->head, 512, sp->semi, 65, H / 8, W / 8);     // convPb
     sp_launch_conv(s, sp->L[9], sp->head + 256, 512, sp->desc, 256, H / 8, W / 8);  // convDb
     const int ncell = npix / 64;
-    hipLaunchKernelGGL((sp_l2_normalize_kernel<256>), dim3((ncell + 63) / 64), dim3(64), 0, s, sp->desc, ncell);
-    hipLaunchKernelGGL(sp_heatmap_kernel, dim3((ncell + 63) / 64), dim3(64), 0, s, sp->semi, H / 8, W / 8, sp->heat);
+    hipLaunchKernelGGL((sp_l2_normalize_kernel<256>), dim3((ncell + 3) / 4), dim3(256), 0, s, sp->desc, ncell);
+    hipLaunchKernelGGL(sp_heatmap_kernel, dim3((ncell + 3) / 4), dim3(256), 0, s, sp->semi, H / 8, W / 8, sp->heat);
     MMF_HIP_TRY(hipGetLastError());
     sp->cur_w = W, sp->cur_h = H;
     return MMF_OK;

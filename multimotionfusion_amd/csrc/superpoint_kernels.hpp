@@ -15,8 +15,10 @@
 //     pixels of a max-pool window into ONE lane's accumulator registers: the pool is a 4-way max in the
 //     epilogue and the un-pooled activation never exists in memory;
 //   * K is walked in blocks of 32 input channels x 9 taps.  The 10 x 18 pixel halo of a block is staged once
-//     in LDS (34.5 KB) and serves all nine taps by address offset; the weights of one (block, tap) step are
-//     4*NT KB, double-buffered, pre-packed on the host in exactly the order the lanes read;
+//     in LDS (34.5 KB) and serves all nine taps by address offset.  The weights never touch LDS: they are
+//     pre-packed on the host in exactly the order the lanes consume them, so every wave streams its B
+//     operands as 1 KB coalesced loads from L2/L1 (all workgroups walk the same few hundred KB) two MFMA
+//     groups ahead of their use -- the K loop has no barrier except the two around a halo refill;
 //   * LDS images are laid out for conflict-free ds_read_b128: a pixel is 36 floats (32 + 4 pad), a halo row
 //     24 pixels (18 + 6 pad) -- with these strides the 16 lanes of every b128 group hit 16 distinct 16-B
 //     slots (MI355X_MICROARCH.md, LDS).  The channels of a pixel are stored even/odd de-interleaved in groups
@@ -54,13 +56,16 @@ __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
     constexpr int HR = kSpTileH + 2 * HALO, HC = kSpTileW + 2 * HALO;
     constexpr int UNITS = HR * HC * 4;  // (pixel, 8-channel group) staging units of one K block
     constexpr int UPT = (UNITS + 255) / 256;
-    __shared__ float4 lds_a[10 * kSpRowPix * kSpPixF4];
-    __shared__ float4 lds_b[2][256 * NT];
+    constexpr int GROUPS = TAPS * 4;  // MFMA groups (8 channels of one tap) per K block
+    __shared__ float4 lds_a[HR * kSpRowPix * kSpPixF4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * kSpTileW, y0 = blockIdx.y * kSpTileH, z = blockIdx.z;
-    const int chunks = p.cin / kSpKBlock, steps = chunks * TAPS;
-    const float4* __restrict__ wp = reinterpret_cast<const float4*>(p.wpack) + (size_t)z * steps * 256 * NT;
+    const int chunks = p.cin / kSpKBlock;
+    const int last_group = chunks * GROUPS - 1;
+    // this lane's weight operands: one float4 per (group, output tile), 1 KB contiguous per wave and load
+    const float4* __restrict__ wp =
+        reinterpret_cast<const float4*>(p.wpack) + (size_t)z * chunks * GROUPS * NT * 64 + lane;
 
     // staging addresses of this thread's units (the same for every K block, which only shifts the channel)
     int a_src[UPT], a_dst[UPT];
@@ -74,38 +79,25 @@ __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
         a_src[j] = inside ? (gy * p.W + gx) * p.in_stride + 8 * q : -1;
         a_dst[j] = u < UNITS ? (r * kSpRowPix + c) * kSpPixF4 + 2 * q : -1;
     }
-    float4 a_lo[UPT], a_hi[UPT], b_reg[NT];
-    auto load_a = [&](int chunk) {
-#pragma unroll
-        for (int j = 0; j < UPT; ++j) {
-            a_lo[j] = a_hi[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_src[j] >= 0) {
-                const float4* s = reinterpret_cast<const float4*>(p.in + a_src[j] + chunk * kSpKBlock);
-                a_lo[j] = s[0], a_hi[j] = s[1];
-            }
-        }
-    };
-    auto store_a = [&]() {  // even channels of the group of 8 first, then the odd ones
-#pragma unroll
-        for (int j = 0; j < UPT; ++j)
-            if (a_dst[j] >= 0) {
-                lds_a[a_dst[j]] = make_float4(a_lo[j].x, a_lo[j].z, a_hi[j].x, a_hi[j].z);
-                lds_a[a_dst[j] + 1] = make_float4(a_lo[j].y, a_lo[j].w, a_hi[j].y, a_hi[j].w);
-            }
-    };
-    auto load_b = [&](int step) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b_reg[t] = wp[(size_t)step * 256 * NT + tid + 256 * t];
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) lds_b[buf][tid + 256 * t] = b_reg[t];
-    };
+    float4 a_lo[UPT], a_hi[UPT];
+#define SP_LOAD_A(chunk)                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < UPT; ++j) {                                                       \
+        a_lo[j] = a_hi[j] = make_float4(0.f, 0.f, 0.f, 0.f);                                                \
+        if (a_src[j] >= 0) {                                                                                \
+            const float4* s_ = reinterpret_cast<const float4*>(p.in + a_src[j] + (chunk) * kSpKBlock);      \
+            a_lo[j] = s_[0], a_hi[j] = s_[1];                                                               \
+        }                                                                                                   \
+    }
+    // even channels of a group of 8 first, then the odd ones
+#define SP_STORE_A()                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < UPT; ++j) if (a_dst[j] >= 0) {                                    \
+        lds_a[a_dst[j]] = make_float4(a_lo[j].x, a_lo[j].z, a_hi[j].x, a_hi[j].z);                          \
+        lds_a[a_dst[j] + 1] = make_float4(a_lo[j].y, a_lo[j].w, a_hi[j].y, a_hi[j].w);                      \
+    }
 
     // MFMA row of this lane: i = 4*block + 2*dy + dx; the lane half kh supplies the odd k of each pair
     const int i = lane & 31, kh = lane >> 5;
     const int a_base = ((2 * wave + ((i >> 1) & 1)) * kSpRowPix + 2 * (i >> 2) + (i & 1)) * kSpPixF4 + kh;
-    const int b_base = kh * 32 + i;
 
     sp_f32x16 acc[NT];
 #pragma unroll
@@ -113,45 +105,79 @@ __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
 
-    load_a(0);
-    load_b(0);
-    store_a();
-    store_b(0);
+    // weights: straight from L2/L1 into registers, two groups ahead of their use (every wave of the chip
+    // walks the same few hundred KB, so they stay cache resident); no LDS copy and no barrier per step
+    float4 b[3][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[0][t] = wp[(size_t)t * 64], b[1][t] = wp[(size_t)(min(1, last_group) * NT + t) * 64];
+    SP_LOAD_A(0);
+    SP_STORE_A();
     __syncthreads();
 
-    for (int chunk = 0, step = 0; chunk < chunks; ++chunk) {
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+#ifdef SP_PROBE_NO_STAGE  // diagnostic builds only (tools/sp_conv_probe.hip): results are wrong, only the time matters
+        const bool more = false;
+#else
+        const bool more = chunk + 1 < chunks;
+#endif
+        if (more) SP_LOAD_A(chunk + 1);  // lands during this block's MFMAs
+        float4 a[2];
+        a[0] = lds_a[a_base];
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap, ++step) {
-            const bool more = step + 1 < steps;
-            const bool next_chunk = tap == TAPS - 1 && more;
-            if (more) load_b(step + 1);
-            if (next_chunk) load_a(chunk + 1);
-            const int tap_off = TAPS == 9 ? ((tap / 3) * kSpRowPix + tap % 3) * kSpPixF4 : 0;
-            const float4* __restrict__ bt = lds_b[step & 1];
+        for (int q = 0; q < GROUPS; ++q) {
+            const int gi = chunk * GROUPS + q;
+            {  // operands of the next two groups
+                const int gn = min(gi + 2, last_group);
+#ifndef SP_PROBE_NO_B
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 a = lds_a[a_base + tap_off + 2 * g];
-                float4 b[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) b[t] = bt[(g * NT + t) * 64 + b_base];
-                // k ascending within every accumulator's chain; the NT independent chains interleave
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) b[(q + 2) % 3][t] = wp[(size_t)(gn * NT + t) * 64];
+#endif
+#ifndef SP_PROBE_NO_A
+                if (q + 1 < GROUPS) {
+                    const int tap = (q + 1) >> 2, g = (q + 1) & 3;
+                    const int tap_off = TAPS == 9 ? ((tap / 3) * kSpRowPix + tap % 3) * kSpPixF4 : 0;
+                    a[(q + 1) & 1] = lds_a[a_base + tap_off + 2 * g];
+                }
+#else
+                a[(q + 1) & 1] = a[q & 1];
+                (void)gn;
+#endif
             }
-            if (next_chunk) {
-                __syncthreads();  // every wave is done with this block's halo
-                store_a();
-            }
-            if (more) store_b((step + 1) & 1);
+            const float4 av = a[q & 1];
+            // k ascending within every accumulator's chain; the NT independent chains interleave.  The
+            // scheduling fences keep the operand loads above ahead of this group's MFMAs (left alone, the
+            // compiler sinks them to just before their use and serialises the chains)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[q % 3][t].x, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[q % 3][t].y, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[q % 3][t].z, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[q % 3][t].w, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (GROUPS % 3 != 0) {  // keep the rotation of the three weight buffers aligned with q = 0
+#pragma unroll
+            for (int r = 0; r < (3 - GROUPS % 3) % 3; ++r)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 t0 = b[0][t];
+                    b[0][t] = b[2][t], b[2][t] = b[1][t], b[1][t] = t0;
+                }
+        }
+        if (more) {
+            __syncthreads();  // every wave is done with this block's halo
+            SP_STORE_A();
             __syncthreads();
         }
     }
+#undef SP_LOAD_A
+#undef SP_STORE_A
 
     // epilogue: accumulator register v of lane (n, kh) is MFMA row (v&3) + 8*(v>>2) + 4*kh = pixel block
     // 2*(v>>2) + kh, (dy, dx) = ((v>>1)&1, v&1); column n = output channel
@@ -241,47 +267,48 @@ __global__ __launch_bounds__(256) void sp_conv1a_kernel(const float* __restrict_
     }
 }
 
-// ---- L2 normalisation over channels (the chain of squares is sequential, as in the oracle) ----------------
+__device__ __forceinline__ float sp_lane_value(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// ---- L2 normalisation over channels: one wave per pixel, lane L holds channels 4L..4L+3.  The chain of
+// squares is sequential (as in the oracle); every lane walks it on broadcast values, so all lanes end with
+// the same norm and no LDS or barrier is involved --------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(64) void sp_l2_normalize_kernel(float* __restrict__ desc, int npix) {
-    const int p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= npix) return;
-    float4* d = reinterpret_cast<float4*>(desc + (size_t)p * C);
+__global__ __launch_bounds__(256) void sp_l2_normalize_kernel(float* __restrict__ desc, int npix) {
+    static_assert(C == 256, "one float4 per lane");
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= npix) return;  // wave uniform
+    float4* d = reinterpret_cast<float4*>(desc + (size_t)p * C) + lane;
+    float4 v = *d;
     float s = 0.f;
-    for (int c = 0; c < C / 4; ++c) {
-        const float4 v = d[c];
-        s = fmaf(v.x, v.x, s), s = fmaf(v.y, v.y, s), s = fmaf(v.z, v.z, s), s = fmaf(v.w, v.w, s);
+#pragma unroll
+    for (int l = 0; l < 64; ++l) {
+        const float x = sp_lane_value(v.x, l), y = sp_lane_value(v.y, l), z = sp_lane_value(v.z, l), w = sp_lane_value(v.w, l);
+        s = fmaf(x, x, s), s = fmaf(y, y, s), s = fmaf(z, z, s), s = fmaf(w, w, s);
     }
     const float n = sqrtf(s);
-    for (int c = 0; c < C / 4; ++c) {
-        float4 v = d[c];
-        v.x = v.x / n, v.y = v.y / n, v.z = v.z / n, v.w = v.w / n;
-        d[c] = v;
-    }
+    v.x = v.x / n, v.y = v.y / n, v.z = v.z / n, v.w = v.w / n;
+    *d = v;
 }
 
 // ---- heat map: softmax over the 65 logits of a cell (+1e-5 in the denominator), dustbin dropped, 8x8
-// depth-to-space -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void sp_heatmap_kernel(const float* __restrict__ semi, int Hc, int Wc,
+// depth-to-space.  One wave per cell, lane c owns logit c (lane 0 also the dustbin); the sum runs in channel
+// order on broadcast values ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sp_heatmap_kernel(const float* __restrict__ semi, int Hc, int Wc,
                                                         float* __restrict__ heat) {
-    const int cell = blockIdx.x * 64 + threadIdx.x;
-    if (cell >= Hc * Wc) return;
+    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (cell >= Hc * Wc) return;  // wave uniform
     const int hc = cell / Wc, wc = cell - hc * Wc;
     const float* s = semi + (size_t)cell * 65;
-    float e[65], sum = 0.f;
+    const float e = mmf_expf(s[lane]);
+    const float dust = mmf_expf(s[64]);  // same address in every lane
+    float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < 65; ++c) {
-        e[c] = mmf_expf(s[c]);
-        sum = sum + e[c];
-    }
+    for (int c = 0; c < 64; ++c) sum = sum + sp_lane_value(e, c);
+    sum = sum + dust;
     sum = sum + 0.00001f;
-    const int W = Wc * 8;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        float4* o = reinterpret_cast<float4*>(heat + (size_t)(hc * 8 + r) * W + wc * 8);
-        o[0] = make_float4(e[8 * r] / sum, e[8 * r + 1] / sum, e[8 * r + 2] / sum, e[8 * r + 3] / sum);
-        o[1] = make_float4(e[8 * r + 4] / sum, e[8 * r + 5] / sum, e[8 * r + 6] / sum, e[8 * r + 7] / sum);
-    }
+    heat[(size_t)(hc * 8 + (lane >> 3)) * (Wc * 8) + wc * 8 + (lane & 7)] = e / sum;
 }
 
 // ---- greedy non-maximum suppression as a fixed point --------------------------------------------------------
