@@ -256,6 +256,19 @@ def main():
         matcher = {"us": us_match, "nq": 1024, "nt": 1024, "dim": 256, "TFLOPs": flops / us_match / 1e6,
                    "frac_f32_mfma_peak": flops / us_match / 1e6 / 157.3, "launches": 4,
                    "kernels": "fill + row_norms_kernel (MFMA) + match_tile64_kernel (MFMA, LDS-shared 64x64 tiles) + match_cross_check_kernel"}
+        # the SuperPoint keypoint network (north star: "the only true dense contractions ... on MFMA"): one
+        # forward pass (12 convolutions + normalisation + heat map) on an image of the bench size, random-init
+        # weights, f32 operands on v_mfma_f32_32x32x2_f32; flops = convolution multiply-adds * 2
+        from multimotionfusion_amd.superpoint import SuperPoint, forward_flops, random_weights
+        kp = SuperPoint(ctx, random_weights(0), max_width=W, max_height=H)
+        us_sp = timed(lambda: kp.enqueue(d_rgb[0]), reps=30)
+        fl_sp = float(forward_flops(W, H))
+        superpoint = {"us": us_sp, "GFLOP": fl_sp / 1e9, "TFLOPs": fl_sp / us_sp / 1e6,
+                      "frac_f32_mfma_peak": fl_sp / us_sp / 1e6 / 157.3, "launches": 15, "dtype": "f32",
+                      "kernels": "sp_input + sp_conv1a (VALU) + 10 x sp_conv_mfma_kernel (implicit GEMM, fused ReLU / "
+                                 "2x2 max pool) + sp_l2_normalize + sp_heatmap",
+                      "weights": "random-init SuperPointNet architecture"}
+        kp.close()
         result = {
             "metric": f"frames/sec @ {W}x{H} (dense ICP+RGB tracking); ICP JtJ-reduce achieved HBM GB/s vs peak",
             "value": world * args.steps / elapsed,
@@ -277,6 +290,7 @@ def main():
             "roofline": roofline,
             "surfel_passes": surfel_passes,
             "matcher": matcher,
+            "superpoint": superpoint,
             "device": ctx.device_name(),
             "last_frame_translation_error_m": t_err,
             "icp_inliers_last": odom.lastICPCount,

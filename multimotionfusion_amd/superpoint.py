@@ -17,6 +17,28 @@ LAYERS = ("conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", 
           "convDb")
 
 
+SHAPES = ((1, 64, 3), (64, 64, 3), (64, 64, 3), (64, 64, 3), (64, 128, 3), (128, 128, 3), (128, 128, 3), (128, 128, 3),
+          (128, 256, 3), (256, 65, 1), (128, 256, 3), (256, 256, 1))  # (Cin, Cout, k) of LAYERS
+
+
+def random_weights(seed=0):
+    """He-initialised weights of the SuperPointNet architecture (there is no network access for the MagicLeap
+    checkpoint): what bench.py and tools/ run the network on."""
+    rng = np.random.default_rng(seed)
+    return [(rng.normal(0, np.sqrt(2.0 / (ci * k * k)), (co, ci, k, k)).astype(np.float32),
+             rng.normal(0, 0.05, co).astype(np.float32)) for ci, co, k in SHAPES]
+
+
+def forward_flops(width, height):
+    """multiply-adds * 2 of one forward pass (convolutions only)"""
+    total, h, w = 0, height, width
+    for i, (ci, co, k) in enumerate(SHAPES):
+        if i in (2, 4, 6):
+            h, w = h // 2, w // 2
+        total += 2 * h * w * ci * co * k * k
+    return total
+
+
 def load_weights(path):
     """The 12 (weight, bias) pairs of a SuperPointNet checkpoint: a TorchScript archive (what the reference's
     `-model SuperPointNet.pt` points at) or a plain state dict.  File plumbing only."""

@@ -1,12 +1,16 @@
 // Compile/link check of the C++ shims (multimotionfusion_amd/cpp/*.h) against libmmf_hip.so.
 // Run with an argument on a GPU box to push two synthetic-free frames through processFrame.
+#include <hip/hip_runtime_api.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <tuple>
 #include <vector>
 
 #include "../../multimotionfusion_amd/cpp/MultiMotionFusion.h"
 #include "../../multimotionfusion_amd/cpp/RigidRANSAC.h"
+#include "../../multimotionfusion_amd/cpp/SuperPoint.h"
 
 int main(int argc, char** argv) {
     if (argc < 2) {  // CPU containers: the check is that everything above compiles and links
@@ -31,5 +35,24 @@ int main(int argc, char** argv) {
     Model bg = mmf.getBackgroundModel();
     std::printf("processFrame(bad)=%d tick=%d surfels=%u pose00=%g icpCount=%g\n", (int)r, mmf.getTick(), bg.lastCount(),
                 pose[0], odom.lastICPCount);
-    return (r == false && mmf.getTick() == 1 && bg.lastCount() == 0) ? 0 : 2;
+    // SuperPoint with all-zero weights: every heat value is 1/65 >= 0.015, so the greedy suppression leaves a
+    // regular grid of keypoints whose normalised coordinates lie in [0, 1)
+    static const size_t wsize[12] = {64 * 9, 64 * 64 * 9, 64 * 64 * 9, 64 * 64 * 9, 128 * 64 * 9, 128 * 128 * 9,
+                                     128 * 128 * 9, 128 * 128 * 9, 256 * 128 * 9, 65 * 256, 256 * 128 * 9, 256 * 256};
+    std::vector<std::vector<float>> store;
+    std::vector<const float*> weights;
+    for (int l = 0; l < 12; ++l) {
+        store.emplace_back(wsize[l], 0.f), store.emplace_back(256, 0.f);
+    }
+    for (auto& v : store) weights.push_back(v.data());
+    SuperPoint kp(ctx, weights.data(), 64, 48, 256);
+    unsigned char* img = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&img), 64 * 48) != hipSuccess || hipMemset(img, 0, 64 * 48) != hipSuccess) return 3;
+    std::vector<double> coordinates, descriptors;
+    std::tie(coordinates, descriptors) = kp.getFeatures(img, 64, 48, 1);
+    (void)hipFree(img);
+    bool kp_ok = !coordinates.empty() && descriptors.size() == coordinates.size() / 2 * 256;
+    for (double c : coordinates) kp_ok = kp_ok && c >= 0.0 && c < 1.0;
+    std::printf("keypoints=%zu\n", coordinates.size() / 2);
+    return (r == false && mmf.getTick() == 1 && bg.lastCount() == 0 && kp_ok) ? 0 : 2;
 }

@@ -65,7 +65,7 @@ def test_cpp_shims_compile_and_link(tmp_path):
     pkg = os.path.join(REPO, "multimotionfusion_amd")
     exe = tmp_path / "shim_link_check"
     cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", os.path.join(REPO, "tests", "cpp", "shim_link_check.cpp"),
-           "-o", str(exe), f"-L{pkg}", "-lmmf_hip", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+           "-D__HIP_PLATFORM_AMD__", "-isystem", "/opt/rocm/include", "-o", str(exe), f"-L{pkg}", "-lmmf_hip", "-lamdhip64", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
     subprocess.run(cmd, check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert out.strip() == "abi 1"

@@ -165,14 +165,16 @@ def test_process_frame_survives_a_frame_without_depth(gpu_ctx, orc):
 def test_cpp_shims_run_on_the_device(tmp_path):
     """The C++ classes with the reference's names (cpp/*.h) against libmmf_hip.so on the GPU: construct
     MultiMotionFusion / RGBDOdometry / Model, push an invalid frame (must print "invalid image data" and return
-    false like MultiMotionFusion.cpp:209-212)."""
+    false like MultiMotionFusion.cpp:209-212), run SuperPoint::getFeatures."""
     import os
     import subprocess
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pkg = os.path.join(repo, "multimotionfusion_amd")
     exe = tmp_path / "shim_link_check"
-    subprocess.run(["g++", "-std=c++17", os.path.join(repo, "tests", "cpp", "shim_link_check.cpp"), "-o", str(exe), f"-L{pkg}",
-                    "-lmmf_hip", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
+    subprocess.run(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-isystem", "/opt/rocm/include",
+                    os.path.join(repo, "tests", "cpp", "shim_link_check.cpp"), "-o", str(exe), f"-L{pkg}", "-lmmf_hip",
+                    "-lamdhip64", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
     r = subprocess.run([str(exe), "gpu"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "invalid image data" in r.stderr and "processFrame(bad)=0 tick=1 surfels=0" in r.stdout
+    assert "keypoints=" in r.stdout and "keypoints=0" not in r.stdout

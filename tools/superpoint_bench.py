@@ -9,26 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimotionfusion_amd.cudafuncs import Context  # noqa: E402
-from multimotionfusion_amd.superpoint import LAYERS, SuperPoint  # noqa: E402
-
-SHAPES = ((1, 64, 3), (64, 64, 3), (64, 64, 3), (64, 64, 3), (64, 128, 3), (128, 128, 3), (128, 128, 3), (128, 128, 3),
-          (128, 256, 3), (256, 65, 1), (128, 256, 3), (256, 256, 1))
-
-
-def random_weights(seed=0):
-    rng = np.random.default_rng(seed)
-    return [(rng.normal(0, np.sqrt(2.0 / (ci * k * k)), (co, ci, k, k)).astype(np.float32),
-             rng.normal(0, 0.05, co).astype(np.float32)) for ci, co, k in SHAPES]
-
-
-def flops(W, H):
-    total, h, w = 0, H, W
-    for i, (ci, co, k) in enumerate(SHAPES):
-        if i in (2, 4, 6):
-            h, w = h // 2, w // 2
-        total += 2 * h * w * ci * co * k * k
-    return total
-
+from multimotionfusion_amd.superpoint import SuperPoint, forward_flops, random_weights  # noqa: E402
 
 def main():
     W = int(sys.argv[1]) if len(sys.argv) > 1 else 640
@@ -48,7 +29,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    fl = flops(W, H)
+    fl = forward_flops(W, H)
     print(f"forward {W}x{H}: {ms * 1e3:.1f} us, {fl / 1e9:.2f} GFLOP, {fl / ms / 1e9:.2f} TFLOP/s "
           f"({fl / ms / 1e9 / 157.3 * 100:.1f}% of the f32 MFMA peak)")
     t0 = time.perf_counter()
