@@ -355,6 +355,27 @@ int mmf_superpoint_get_features(mmf_superpoint *sp, const uint8_t *image, int wi
 int mmf_superpoint_conv(mmf_ctx *ctx, const float *in, int height, int width, int cin, const float *w,
                         const float *bias, int cout, int taps, int relu, int pool, int nt, float *out);
 
+/* ---- super-pixel resampling for the segmentation ------------------------------
+ * Slic::downsample<float>(image, channel) (Core/Segmentation/Slic.h:48-83), Slic::downsampleThresholded<float>
+ * (:87-126), Slic::downsample() (Slic.cpp:82-112) and Slic::upsample<unsigned char> (Slic.h:133-146), which
+ * Segmentation.cpp:177-178,218-221,683 runs on the CPU after downloading the full-resolution ICP-error and
+ * vertex-confidence textures of every model.  labels = gSLICr's segmentation mask (int32 [height][width],
+ * values in [0, n), n = (width / spixel_size) * (height / spixel_size)); everything is a DEVICE pointer and
+ * the calls are asynchronous on the context's stream.  Results are those of the reference's loops bit for
+ * bit: float sums run in pixel order, the in-place division and the empty-super-pixel substitution
+ * (resampleEmptyIndex, including its spixelY quirk) are reproduced.
+ *   image [height][width][channels] float32, `channel` selected (the ICP-error map: channels 1; the
+ *   vertex-confidence map: channels 4, channel 3); thresholded != 0: only values > min_threshold count
+ *   (the depth map with 0.02); out [n] float32; counts_out (optional) [n] int32 = spixelCounts. */
+int mmf_slic_downsample(mmf_ctx *ctx, const int *labels, int width, int height, int spixel_size, const float *image,
+                        int channels, int channel, int thresholded, float min_threshold, float *out, int *counts_out);
+/* rgb [height][width][channels] u8 (3 or 4); out [n][3] u8 = integer means of input channels (2, 1, 0) */
+int mmf_slic_downsample_rgb(mmf_ctx *ctx, const int *labels, int width, int height, int spixel_size, const uint8_t *rgb,
+                            int channels, uint8_t *out);
+/* out[i] = map[labels[i]] */
+int mmf_slic_upsample_u8(mmf_ctx *ctx, const int *labels, int width, int height, const uint8_t *map, int nspix,
+                         uint8_t *out);
+
 /* ---- keypoint-based pose initialisation: RigidRANSAC (Core/Utils/RigidRANSAC.h:6-32, .cpp:73-180) ----
  * Host code, like the reference's (a few dozen keypoint tracks): p0, p1 are HOST arrays of n 3-D points
  * (row-major n x 3), mask an optional n-byte selection; T receives the row-major 4x4 of T_01 with

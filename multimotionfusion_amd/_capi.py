@@ -107,6 +107,9 @@ SIGNATURES = {
     "mmf_superpoint_download": (_i, [_vp, _i, _vp, _sz]),
     "mmf_superpoint_get_features": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _ip]),
     "mmf_superpoint_conv": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mmf_slic_downsample": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "mmf_slic_downsample_rgb": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "mmf_slic_upsample_u8": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),
     "mmf_rigid_fit": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mmf_rigid_apply": (_i, [_vp, _vp, _vp, _i, _vp]),
     "mmf_ransac_create": (_i, [_i, _f, _f, _vp]),

@@ -65,6 +65,8 @@ struct mmf_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void* match_ws = nullptr;  // descriptor matcher workspace: norms + arg-min keys, grown on demand
     size_t match_ws_rows = 0;
+    void* slic_ws = nullptr;  // super-pixel resampling workspace (boxes, counts, sums), grown on demand
+    size_t slic_ws_n = 0;
     char arch[64] = {0};
 };
 
@@ -120,6 +122,7 @@ extern "C" void mmf_ctx_destroy(mmf_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     (void)hipFree(c->match_ws);
+    (void)hipFree(c->slic_ws);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -2006,6 +2009,95 @@ extern "C" int mmf_ransac_estimate(mmf_ransac* r, const float* p0, const float* 
 // SuperPoint keypoint network (Core/MultiMotionFusion.cpp:78,233)
 // ---------------------------------------------------------------------------------------------
 #include "superpoint_host.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// Super-pixel resampling for the segmentation (Core/Segmentation/Slic.h:48-146)
+// ---------------------------------------------------------------------------------------------
+#include "slic_kernels.hpp"
+
+struct SlicWs {
+    mmf::SlicBox* box;
+    int *counts, *dcounts, *rgb_sums;
+    float* sums;
+};
+
+static int slic_workspace(mmf_ctx* c, int n, SlicWs* ws) {
+    if ((size_t)n > c->slic_ws_n) {
+        MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->slic_ws);
+        c->slic_ws = nullptr, c->slic_ws_n = 0;
+        const size_t cap = (size_t)n + n / 2 + 64;
+        MMF_HIP_TRY(hipMalloc(&c->slic_ws, cap * (sizeof(mmf::SlicBox) + 6 * sizeof(int))));
+        c->slic_ws_n = cap;
+    }
+    const size_t cap = c->slic_ws_n;
+    ws->box = static_cast<mmf::SlicBox*>(c->slic_ws);
+    ws->counts = reinterpret_cast<int*>(ws->box + cap);
+    ws->dcounts = ws->counts + cap;
+    ws->rgb_sums = ws->dcounts + cap;
+    ws->sums = reinterpret_cast<float*>(ws->rgb_sums + 3 * cap);
+    return MMF_OK;
+}
+
+static int slic_check(const int* labels, int width, int height, int spixel_size, const char* who) {
+    if (!labels || width <= 0 || height <= 0) return fail(MMF_ERR_INVALID, std::string(who) + ": bad label image");
+    // Slic::Slic asserts spixelSize in (10, 256) (Slic.cpp:23)
+    if (!(spixel_size > 10 && spixel_size < 256) || width / spixel_size < 1 || height / spixel_size < 1)
+        return fail(MMF_ERR_INVALID, std::string(who) + ": super-pixel size must be in (10, 256) and fit the image");
+    return MMF_OK;
+}
+
+extern "C" int mmf_slic_downsample(mmf_ctx* c, const int* labels, int width, int height, int spixel_size, const float* image,
+                                   int channels, int channel, int thresholded, float min_threshold, float* out,
+                                   int* counts_out) {
+    MMF_REQUIRE(c && image && out, "mmf_slic_downsample: null argument");
+    MMF_REQUIRE(channels >= 1 && channel >= 0 && channel < channels, "mmf_slic_downsample: bad channel");
+    if (int rc = slic_check(labels, width, height, spixel_size, "mmf_slic_downsample")) return rc;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const int spx = width / spixel_size, spy = height / spixel_size, n = spx * spy, npix = width * height;
+    SlicWs ws;
+    if (int rc = slic_workspace(c, n, &ws)) return rc;
+    using namespace mmf;
+    hipLaunchKernelGGL(slic_reset_kernel, grid1d(n), dim3(256), 0, c->stream, n, ws.box, ws.counts, ws.rgb_sums);
+    hipLaunchKernelGGL(slic_census_kernel, grid1d(npix), dim3(256), 0, c->stream, labels, width, height, n, ws.box, ws.counts,
+                       (const uint8_t*)nullptr, 0, ws.rgb_sums);
+    hipLaunchKernelGGL(slic_sum_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, labels, width, n, image, channels, channel,
+                       thresholded ? 1 : 0, min_threshold, ws.box, ws.sums, ws.dcounts);
+    hipLaunchKernelGGL(slic_finish_kernel, grid1d(n), dim3(256), 0, c->stream, labels, width, height, spixel_size, spx, spy,
+                       ws.counts, thresholded ? ws.dcounts : ws.counts, ws.sums, out);
+    MMF_HIP_TRY(hipGetLastError());
+    if (counts_out) MMF_HIP_TRY(hipMemcpyAsync(counts_out, ws.counts, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    return MMF_OK;
+}
+
+extern "C" int mmf_slic_downsample_rgb(mmf_ctx* c, const int* labels, int width, int height, int spixel_size,
+                                       const uint8_t* rgb, int channels, uint8_t* out) {
+    MMF_REQUIRE(c && rgb && out, "mmf_slic_downsample_rgb: null argument");
+    MMF_REQUIRE(channels == 3 || channels == 4, "mmf_slic_downsample_rgb: 3 or 4 channels");
+    if (int rc = slic_check(labels, width, height, spixel_size, "mmf_slic_downsample_rgb")) return rc;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const int spx = width / spixel_size, spy = height / spixel_size, n = spx * spy, npix = width * height;
+    SlicWs ws;
+    if (int rc = slic_workspace(c, n, &ws)) return rc;
+    using namespace mmf;
+    hipLaunchKernelGGL(slic_reset_kernel, grid1d(n), dim3(256), 0, c->stream, n, ws.box, ws.counts, ws.rgb_sums);
+    hipLaunchKernelGGL(slic_census_kernel, grid1d(npix), dim3(256), 0, c->stream, labels, width, height, n, ws.box, ws.counts,
+                       rgb, channels, ws.rgb_sums);
+    hipLaunchKernelGGL(slic_finish_rgb_kernel, grid1d(n), dim3(256), 0, c->stream, labels, width, height, spixel_size, spx, spy,
+                       ws.counts, ws.rgb_sums, out);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+extern "C" int mmf_slic_upsample_u8(mmf_ctx* c, const int* labels, int width, int height, const uint8_t* map, int nspix,
+                                    uint8_t* out) {
+    MMF_REQUIRE(c && labels && map && out && width > 0 && height > 0 && nspix > 0, "mmf_slic_upsample_u8: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const int npix = width * height;
+    hipLaunchKernelGGL(mmf::slic_upsample_u8_kernel, grid1d(npix), dim3(256), 0, c->stream, labels, npix, nspix, map, out);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
 
 #ifdef MMF_STAMPS
 // diagnostic builds only (tools/rgb_step_probe.py): phase-stamp buffer of the instrumented kernels

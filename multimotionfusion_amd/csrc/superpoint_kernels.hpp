@@ -50,6 +50,24 @@ struct SpConvArgs {
     int relu;
 };
 
+#ifdef SP_PROBE_STAMPS  // diagnostic builds only (tools/sp_conv_probe.hip): per-workgroup phase stamps
+__device__ unsigned long long* g_sp_stamps = nullptr;
+#define SP_STAMP(i)                                                                                              \
+    do {                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if (g_sp_stamps && threadIdx.x == 0) {                                                                   \
+            unsigned long long t_;                                                                               \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+            g_sp_stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = t_;        \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+#else
+#define SP_STAMP(i) \
+    do {            \
+    } while (0)
+#endif
+
 template <int NT, int TAPS, bool POOL>
 __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
     constexpr int HALO = TAPS == 9 ? 1 : 0;
@@ -59,6 +77,7 @@ __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
     constexpr int GROUPS = TAPS * 4;  // MFMA groups (8 channels of one tap) per K block
     __shared__ float4 lds_a[HR * kSpRowPix * kSpPixF4];
 
+    SP_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * kSpTileW, y0 = blockIdx.y * kSpTileH, z = blockIdx.z;
     const int chunks = p.cin / kSpKBlock;
@@ -113,6 +132,7 @@ __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
     SP_LOAD_A(0);
     SP_STORE_A();
     __syncthreads();
+    SP_STAMP(1);
 
     for (int chunk = 0; chunk < chunks; ++chunk) {
 #ifdef SP_PROBE_NO_STAGE  // diagnostic builds only (tools/sp_conv_probe.hip): results are wrong, only the time matters
@@ -178,6 +198,7 @@ __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
     }
 #undef SP_LOAD_A
 #undef SP_STORE_A
+    SP_STAMP(2);
 
     // epilogue: accumulator register v of lane (n, kh) is MFMA row (v&3) + 8*(v>>2) + 4*kh = pixel block
     // 2*(v>>2) + kh, (dy, dx) = ((v>>1)&1, v&1); column n = output channel
@@ -209,6 +230,7 @@ __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
             }
         }
     }
+    SP_STAMP(3);
 }
 
 // ---- network input: [0,1] grey from 1- or 3-channel u8 --------------------------------------------------

@@ -168,6 +168,12 @@ void orc_sp_heatmap(const float *semi, int Hc, int Wc, float *heat);
 int orc_sp_keypoints(const float *heat, int H, int W, float conf_thresh, int nms_dist, int border, int max_out, int *xy,
                      float *conf);
 void orc_sp_sample_descriptors(const float *desc, int Hc, int Wc, const int *xy, int n, int H, int W, float *out);
+/* super-pixel resampling for the segmentation (mmf_oracle_slic.c; Slic.h:48-146, Slic.cpp:72-112) */
+void orc_slic_counts(const int *labels, int npix, int nspix, int *counts);
+void orc_slic_downsample(const int *labels, int width, int height, int S, const float *image, int channels, int channel,
+                         int thresholded, float min_threshold, float *out);
+void orc_slic_downsample_rgb(const int *labels, int width, int height, int S, const uint8_t *rgb, int channels, uint8_t *out);
+void orc_slic_upsample_u8(const int *labels, int npix, const uint8_t *map, uint8_t *out);
 int orc_fuse(orc_surfel *s, int count, const uint8_t *rgb, const float *depth_raw, const float *depth_filtered,
              const uint8_t *mask, const uint32_t *index, const float *vertConf, const float *normRad,
              const float pose[16], float cx, float cy, float fx, float fy, int cols, int rows, int time,

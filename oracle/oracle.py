@@ -18,7 +18,7 @@ def build(force=False, march=None, out=None):
     target = out or "liboracle.so"
     path = os.path.join(_DIR, target)
     src_m = max(os.path.getmtime(os.path.join(_DIR, f))
-                for f in ("mmf_oracle.c", "mmf_oracle_surfel.c", "mmf_oracle_match.c", "mmf_oracle_superpoint.c", "mmf_oracle.h",
+                for f in ("mmf_oracle.c", "mmf_oracle_surfel.c", "mmf_oracle_match.c", "mmf_oracle_superpoint.c", "mmf_oracle_slic.c", "mmf_oracle.h",
                           "Makefile"))
     if not force and os.path.exists(path) and os.path.getmtime(path) >= src_m:
         return path
@@ -567,3 +567,44 @@ def sp_get_features(img, weights, conf_thresh=0.015, nms_dist=4, border=4):
     xy, _ = sp_keypoints(sp_heatmap(semi), conf_thresh, nms_dist, border)
     d = sp_sample_descriptors(desc, xy, H, W)
     return xy.astype(np.float64) / np.array([W, H], np.float64), d.astype(np.float64)
+
+
+# ---- super-pixel resampling (mmf_oracle_slic.c) ---------------------------------------------------------------
+def _pi32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def slic_counts(labels, nspix):
+    labels = np.ascontiguousarray(labels, np.int32)
+    counts = np.empty(nspix, np.int32)
+    lib().orc_slic_counts(_pi32(labels), labels.size, nspix, _pi32(counts))
+    return counts
+
+
+def slic_downsample(labels, S, image, channel=0, threshold=None):
+    """Slic::downsample<float>(image, channel) / downsampleThresholded<float>(image, threshold) -> [H/S, W/S]"""
+    labels = np.ascontiguousarray(labels, np.int32)
+    image = _f(image)
+    H, W = labels.shape
+    ch = 1 if image.ndim == 2 else image.shape[2]
+    out = np.empty((H // S, W // S), np.float32)
+    lib().orc_slic_downsample(_pi32(labels), W, H, S, _pf(image), ch, channel, int(threshold is not None),
+                              _cf(0.0 if threshold is None else threshold), _pf(out))
+    return out
+
+
+def slic_downsample_rgb(labels, S, rgb):
+    labels = np.ascontiguousarray(labels, np.int32)
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    H, W = labels.shape
+    out = np.empty((H // S, W // S, 3), np.uint8)
+    lib().orc_slic_downsample_rgb(_pi32(labels), W, H, S, _pu8(rgb), rgb.shape[2], _pu8(out))
+    return out
+
+
+def slic_upsample_u8(labels, small):
+    labels = np.ascontiguousarray(labels, np.int32)
+    small = np.ascontiguousarray(small, np.uint8)
+    out = np.empty(labels.shape, np.uint8)
+    lib().orc_slic_upsample_u8(_pi32(labels), labels.size, _pu8(small), _pu8(out))
+    return out

@@ -128,3 +128,20 @@ class OracleFusion:
                                    self.outlier_coeff, 0, index, vc, ct, fil, self.mask)
         self.predict(rgb, fil)
         self.tick += 1
+
+
+def slic_like_labels(W, H, S, seed=0, empty_every=0):
+    """A gSLICr-like segmentation mask: grid cells of size S with wobbling borders; `empty_every` > 0 hands
+    every k-th super-pixel's pixels to its left/upper neighbour, so that label does not occur at all."""
+    rng = np.random.default_rng(seed)
+    spx, spy = W // S, H // S
+    yy, xx = np.mgrid[0:H, 0:W]
+    jx = (3.0 * np.sin(yy / 7.0 + seed) + rng.integers(-2, 3, (H, W))).astype(np.int64)
+    jy = (3.0 * np.cos(xx / 5.0 + seed) + rng.integers(-2, 3, (H, W))).astype(np.int64)
+    cx = np.clip((xx + jx) // S, 0, spx - 1)
+    cy = np.clip((yy + jy) // S, 0, spy - 1)
+    labels = (cy * spx + cx).astype(np.int32)
+    if empty_every:
+        for s in range(empty_every, spx * spy, empty_every):
+            labels[labels == s] = s - 1 if s % spx else max(s - spx, 0)
+    return labels

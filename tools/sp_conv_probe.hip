@@ -32,6 +32,13 @@ int main(int argc, char** argv) {
     a.in = in, a.wpack = wp, a.bias = bias, a.out = out, a.in_stride = cin, a.out_stride = cout;
     a.H = H, a.W = W, a.cin = cin, a.cout = cout, a.relu = 1;
     const dim3 grid((W + 15) / 16, (H + 7) / 8, (cout + 32 * PROBE_NT - 1) / (32 * PROBE_NT));
+#ifdef SP_PROBE_STAMPS
+    const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+    unsigned long long* stamps;
+    hipMalloc(&stamps, nwg * 64);
+    hipMemset(stamps, 0, nwg * 64);
+    hipMemcpyToSymbol(HIP_SYMBOL(mmf::g_sp_stamps), &stamps, sizeof(stamps));
+#endif
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((mmf::sp_conv_mfma_kernel<PROBE_NT, 9, PROBE_POOL>), grid, dim3(256), 0, 0, a);
@@ -44,5 +51,30 @@ int main(int argc, char** argv) {
     const double us = ms * 1e3 / reps, fl = 2.0 * H * W * cin * cout * 9;
     printf("%dx%d %d->%d NT=%d: %.1f us  %.1f TFLOP/s (%.1f%% of 157.3)\n", W, H, cin, cout, PROBE_NT, us, fl / us / 1e6,
            fl / us / 1e6 / 157.3 * 100);
+#ifdef SP_PROBE_STAMPS
+    {  // last launch's stamps: 100 MHz real-time ticks (10 ns)
+        std::vector<unsigned long long> hs(nwg * 8);
+        hipMemcpy(hs.data(), stamps, nwg * 64, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double pro = 0, loop = 0, epi = 0;
+        for (size_t w = 0; w < nwg; ++w) {
+            const unsigned long long* q = &hs[w * 8];
+            t0 = q[0] < t0 ? q[0] : t0, t1 = q[3] > t1 ? q[3] : t1;
+            pro += (double)(q[1] - q[0]), loop += (double)(q[2] - q[1]), epi += (double)(q[3] - q[2]);
+        }
+        printf("stamps: kernel span %.1f us; per workgroup mean prologue %.2f us, K loop %.2f us, epilogue %.2f us\n",
+               (t1 - t0) * 0.01, pro / nwg * 0.01, loop / nwg * 0.01, epi / nwg * 0.01);
+        // concurrency profile: workgroups inside their K loop, sampled every 10 us
+        for (unsigned long long t = t0; t < t1; t += 1000) {
+            int in_loop = 0, alive = 0;
+            for (size_t w = 0; w < nwg; ++w) {
+                const unsigned long long* q = &hs[w * 8];
+                alive += q[0] <= t && t < q[3];
+                in_loop += q[1] <= t && t < q[2];
+            }
+            printf("  t=%5.0f us alive %4d in-loop %4d\n", (t - t0) * 0.01, alive, in_loop);
+        }
+    }
+#endif
     return 0;
 }
