@@ -178,3 +178,39 @@ def test_cpp_shims_run_on_the_device(tmp_path):
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "invalid image data" in r.stderr and "processFrame(bad)=0 tick=1 surfels=0" in r.stdout
     assert "keypoints=" in r.stdout and "keypoints=0" not in r.stdout
+
+
+def test_klg_replay_equals_direct_processing(gpu_ctx, tmp_path):
+    """A synthetic sequence written as .klg (millimetre depth, zlib; raw colour), replayed through the reader +
+    processFrame loop of tools/replay_klg.py, gives the very trajectory of feeding the same (quantised) frames
+    directly, and the pose log has the reference's line format."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    from multimotionfusion_amd.klg import KlgLogReader, write_klg, write_pose_log
+    w, h, n = 320, 240, 5
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=3)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    path = str(tmp_path / "seq.klg")
+    write_klg(path, [(1000 + 33 * i, f["depth"], f["rgb"]) for i, f in enumerate(frames)] + [(0, frames[0]["depth"], frames[0]["rgb"])])
+    reader = KlgLogReader(path, w, h)
+    g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    log = []
+    while reader.hasMore():
+        ts, depth, rgb = reader.getNext()
+        g.processFrame(dev(rgb), dev(depth), timestamp=ts)
+        log.append((ts, g.getCurrPose().copy()))
+    g.close()
+    reader.close()
+    assert len(log) == n
+    d = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    for i, f in enumerate(frames):
+        quantised = np.rint(f["depth"].astype(np.float64) * 1000.0).astype(np.uint16).astype(np.float32) * np.float32(0.001)
+        d.processFrame(dev(f["rgb"]), dev(quantised), timestamp=i)
+        assert np.array_equal(d.getCurrPose(), log[i][1]), i
+    d.close()
+    gt = np.linalg.inv(poses[0]) @ poses[-1]
+    assert np.linalg.norm(log[-1][1][:3, 3] - gt[:3, 3]) < 0.01
+    out = str(tmp_path / "poses-0.txt")
+    write_pose_log(out, log)
+    lines = open(out).read().splitlines()
+    assert len(lines) == n and lines[0] == "1000 0 0 0 0 0 0 1" and all(len(l.split()) == 8 for l in lines)
