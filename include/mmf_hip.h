@@ -302,6 +302,15 @@ void mmf_fusion_destroy(mmf_fusion *f);
  * the reference returns false (:209-212). */
 int mmf_fusion_process_frame(mmf_fusion *f, const uint8_t *rgb, const float *depth, long long timestamp,
                              const float *in_pose, float weight_multiplier, int bootstrap);
+/* processFrame with the tracker initialised from keypoint tracks: odom_cfg.init == "kp"
+ * (MultiMotionFusion.cpp:312-384).  init_transform = RigidRANSAC::Result::transformation of
+ * Model::getLastTrackTransform (row-major 4x4, mmf_ransac_estimate): the camera model's pose becomes
+ * pose * init_transform (:331), the map is predicted / fused / cleaned once at that pose with weight_multiplier
+ * as the fusion weight (:352-366), then the dense tracker refines the pose when icp_refine != 0 (:377-381;
+ * odom_cfg.icp_refine), else the initial pose is kept (:382-385).  On the first frame (tick 1) the
+ * transformation is ignored, as in the reference.  Fails in frame-to-frame RGB mode (:370). */
+int mmf_fusion_process_frame_init(mmf_fusion *f, const uint8_t *rgb, const float *depth, long long timestamp,
+                                  const float *init_transform, int icp_refine, float weight_multiplier);
 /* getCurrPose / getTick / getBackgroundModel (MultiMotionFusion.h:130-160) */
 int mmf_fusion_reset(mmf_fusion *f); /* empty map, identity pose, tick = 1 (a freshly constructed object) */
 int mmf_fusion_get_pose(mmf_fusion *f, float pose[16]);

@@ -129,6 +129,20 @@ class MultiMotionFusion {
         mmf::check(rc, "mmf_fusion_process_frame");
         return false;
     }
+    // the same frame step with odom_cfg.init == "kp" (MultiMotionFusion.cpp:312-384): trackTransform is
+    // RigidRANSAC::Result::transformation of Model::getLastTrackTransform (row-major 4x4), icpRefine is
+    // odom_cfg.icp_refine.  In the reference this is selected by the OdometryConfig passed to the constructor.
+    bool processFrame(const FrameDataDevice& frame, const float trackTransform[16], const bool icpRefine,
+                      const float weightMultiplier = 1.f) {
+        const int rc = mmf_fusion_process_frame_init(f_, frame.rgb, frame.depth, frame.timestamp, trackTransform, icpRefine,
+                                                     weightMultiplier);
+        if (rc == MMF_ERR_INVALID) {
+            std::fprintf(stderr, "%s\n", mmf_last_error());
+            return false;
+        }
+        mmf::check(rc, "mmf_fusion_process_frame_init");
+        return false;
+    }
     void getCurrPose(float pose[16]) const { mmf::check(mmf_fusion_get_pose(f_, pose), "mmf_fusion_get_pose"); }
     int getTick() const { return mmf_fusion_tick(f_); }
     Model getBackgroundModel() { return Model(mmf_fusion_model(f_)); }

@@ -2226,8 +2226,11 @@ static float fusion_weight(const float* pose, const float* last_pose, float mult
     return (w > minWeight ? w : minWeight) * multiplier;
 }
 
-extern "C" int mmf_fusion_process_frame(mmf_fusion* f, const uint8_t* rgb, const float* depth, long long timestamp,
-                                        const float* in_pose, float weight_multiplier, int bootstrap) {
+// init_transform (optional): odom_cfg.init == "kp" -- the tracker starts from pose * init_transform
+// (MultiMotionFusion.cpp:312-384); icp_refine = odom_cfg.icp_refine
+static int fusion_process_frame_impl(mmf_fusion* f, const uint8_t* rgb, const float* depth, long long timestamp,
+                                     const float* in_pose, float weight_multiplier, int bootstrap,
+                                     const float* init_transform, int icp_refine) {
     MMF_REQUIRE(f != nullptr, "mmf_fusion_process_frame: null fusion object");
     if (!rgb || !depth || timestamp < 0)  // MultiMotionFusion.cpp:209-212
         return fail(MMF_ERR_INVALID, "invalid image data");
@@ -2244,7 +2247,35 @@ extern "C" int mmf_fusion_process_frame(mmf_fusion* f, const uint8_t* rgb, const
         if (rc) return rc;
     } else {
         f->tracking_ok = 1;
-        if (bootstrap || !in_pose) {
+        if ((bootstrap || !in_pose) && init_transform) {
+            // initialise by track transformation (:312-376): Tnew = pose * T for the camera model (:331), then one
+            // predict / fuse / clean round at that pose with weightMultiplier as the fusion weight (:352-366)
+            MMF_REQUIRE(!g.frame_to_frame_rgb, "ICP initialisation not supported in frame-to-frame mode");  // :370
+            float pose[16], tnew[16];
+            mmf_model_get_pose(f->model, pose);
+            for (int r = 0; r < 4; ++r)
+                for (int k = 0; k < 4; ++k) {
+                    float acc = 0.f;
+                    for (int q = 0; q < 4; ++q) acc = acc + pose[r * 4 + q] * init_transform[q * 4 + k];
+                    tnew[r * 4 + k] = acc;
+                }
+            mmf_model_set_pose(f->model, tnew);  // model->overridePose(Tnew) (:350)
+            rc = fusion_predict(f, rgb);
+            if (rc) return rc;
+            rc = mmf_model_predict_indices(f->model, f->tick, g.max_depth_processed, g.time_delta);
+            if (rc) return rc;
+            rc = mmf_model_fuse(f->model, f->tick, rgb, f->mask, depth, f->depth_filtered, g.max_depth_processed,
+                                weight_multiplier);
+            if (rc) return rc;
+            rc = mmf_model_predict_indices(f->model, f->tick, g.max_depth_processed, g.time_delta);
+            if (rc) return rc;
+            rc = mmf_model_clean(f->model, f->tick, g.time_delta, g.max_depth_processed, f->depth_filtered, f->mask,
+                                 g.outlier_coeff);
+            if (rc) return rc;
+        }
+        if ((bootstrap || !in_pose) && init_transform && !icp_refine) {
+            // no refinement, use the initial pose directly (:382-385)
+        } else if (bootstrap || !in_pose) {
             // Model::performTracking (Model.cpp:409-433) with Model::initICP (:390-407)
             // requiresFillIn (:380, :877-895) decided on the device: the preparation jobs pick their
             // sources from the flag, no host round trip
@@ -2306,6 +2337,17 @@ extern "C" int mmf_fusion_process_frame(mmf_fusion* f, const uint8_t* rgb, const
     if (rc) return rc;
     f->tick++;  // :825
     return MMF_OK;
+}
+
+extern "C" int mmf_fusion_process_frame(mmf_fusion* f, const uint8_t* rgb, const float* depth, long long timestamp,
+                                        const float* in_pose, float weight_multiplier, int bootstrap) {
+    return fusion_process_frame_impl(f, rgb, depth, timestamp, in_pose, weight_multiplier, bootstrap, nullptr, 1);
+}
+
+extern "C" int mmf_fusion_process_frame_init(mmf_fusion* f, const uint8_t* rgb, const float* depth, long long timestamp,
+                                             const float* init_transform, int icp_refine, float weight_multiplier) {
+    MMF_REQUIRE(init_transform != nullptr, "mmf_fusion_process_frame_init: null transformation");
+    return fusion_process_frame_impl(f, rgb, depth, timestamp, nullptr, weight_multiplier, 0, init_transform, icp_refine);
 }
 
 extern "C" int mmf_fusion_get_pose(mmf_fusion* f, float pose[16]) {

@@ -36,8 +36,17 @@ class MultiMotionFusion:
         self._odom.handle = C.c_void_p(ctx.lib.mmf_fusion_odometry(h))
         self._odom.close = lambda: None
 
-    def processFrame(self, rgb, depth, timestamp=0, inPose=None, weightMultiplier=1.0, bootstrap=False):
-        """MultiMotionFusion::processFrame: rgb [H,W,3] uint8, depth [H,W] float32 (CUDA tensors)."""
+    def processFrame(self, rgb, depth, timestamp=0, inPose=None, weightMultiplier=1.0, bootstrap=False, initTransform=None,
+                     icpRefine=True):
+        """MultiMotionFusion::processFrame: rgb [H,W,3] uint8, depth [H,W] float32 (CUDA tensors).
+        initTransform: `-init kp` (MultiMotionFusion.cpp:312-384) -- the 4x4 of Model::getLastTrackTransform, applied
+        to the pose before the dense tracker (which then refines it when icpRefine, `-icp_refine`)."""
+        if initTransform is not None:
+            assert inPose is None and not bootstrap
+            T = np.ascontiguousarray(np.asarray(initTransform, np.float32).reshape(16))
+            check(self.ctx.lib.mmf_fusion_process_frame_init(self.handle, _p(rgb), _p(depth), int(timestamp), fptr(T),
+                                                             int(bool(icpRefine)), float(weightMultiplier)))
+            return
         pose = None
         if inPose is not None:
             pose = np.ascontiguousarray(np.asarray(inPose, np.float32).reshape(16))

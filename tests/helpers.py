@@ -95,13 +95,37 @@ class OracleFusion:
         wv = np.float32(1.0) - np.float32(weighting / np.float32(0.01))
         return float(np.float32(max(wv, np.float32(0.5)) * np.float32(multiplier)))
 
-    def process_frame(self, rgb, depth, weight_multiplier=1.0):
+    def fuse_and_clean(self, rgb, depth, fil, weight):
+        o = self.orc
+        index, vc, ct, nr = o.predict_indices(self.surfels, self.pose, self.K, self.w, self.h, self.max_depth,
+                                              self.tick, self.time_delta)
+        s_upd, new = o.fuse(self.surfels, rgb, depth, fil, self.mask, index, vc, nr, self.pose, self.K, self.tick,
+                            weight, 0, self.max_depth)
+        index, vc, ct, nr = o.predict_indices(s_upd, self.pose, self.K, self.w, self.h, self.max_depth, self.tick,
+                                              self.time_delta)
+        self.surfels = o.clean(s_upd, new, self.pose, self.K, self.w, self.h, self.tick, self.time_delta, self.conf,
+                               self.outlier_coeff, 0, index, vc, ct, fil, self.mask)
+
+    def process_frame(self, rgb, depth, weight_multiplier=1.0, init_transform=None, icp_refine=True):
         o = self.orc
         fil = o.bilateral_filter(depth, self.depth_cutoff)
         if self.tick == 1:
             self.surfels = o.surfel_initialise(rgb, depth, fil, self.K, self.tick, self.max_depth)
             self.odom.initFirstRGB(rgb)
         else:
+            if init_transform is not None:  # MultiMotionFusion.cpp:312-376
+                T = np.asarray(init_transform, np.float32)
+                tnew = np.zeros((4, 4), np.float32)
+                for r in range(4):
+                    for c in range(4):
+                        acc = np.float32(0)
+                        for k in range(4):
+                            acc = np.float32(acc + np.float32(self.pose[r, k] * T[k, c]))
+                        tnew[r, c] = acc
+                self.pose = tnew
+                self.predict(rgb, fil)
+                self.fuse_and_clean(rgb, depth, fil, float(np.float32(weight_multiplier)))
+        if self.tick > 1 and (init_transform is None or icp_refine):
             do_fill = o.requires_fill_in(self.image, 0.75)
             self.fill_in_taken = bool(do_fill)
             self.last_pose = self.pose.copy()
@@ -117,15 +141,9 @@ class OracleFusion:
                                                           True, False, True)
             self.pose = np.eye(4, dtype=np.float32)
             self.pose[:3, :3], self.pose[:3, 3] = R, t
+        if self.tick > 1:
             self.predict(rgb, fil)
-            index, vc, ct, nr = o.predict_indices(self.surfels, self.pose, self.K, self.w, self.h, self.max_depth,
-                                                  self.tick, self.time_delta)
-            s_upd, new = o.fuse(self.surfels, rgb, depth, fil, self.mask, index, vc, nr, self.pose, self.K, self.tick,
-                                self.fusion_weight(weight_multiplier), 0, self.max_depth)
-            index, vc, ct, nr = o.predict_indices(s_upd, self.pose, self.K, self.w, self.h, self.max_depth, self.tick,
-                                                  self.time_delta)
-            self.surfels = o.clean(s_upd, new, self.pose, self.K, self.w, self.h, self.tick, self.time_delta, self.conf,
-                                   self.outlier_coeff, 0, index, vc, ct, fil, self.mask)
+            self.fuse_and_clean(rgb, depth, fil, self.fusion_weight(weight_multiplier))
         self.predict(rgb, fil)
         self.tick += 1
 

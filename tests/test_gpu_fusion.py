@@ -214,3 +214,46 @@ def test_klg_replay_equals_direct_processing(gpu_ctx, tmp_path):
     write_pose_log(out, log)
     lines = open(out).read().splitlines()
     assert len(lines) == n and lines[0] == "1000 0 0 0 0 0 0 1" and all(len(l.split()) == 8 for l in lines)
+
+
+@pytest.mark.parametrize("icp_refine", [True, False])
+def test_process_frame_keypoint_initialisation(gpu_ctx, orc, icp_refine):
+    """`-init kp` (MultiMotionFusion.cpp:312-384): the pose is first moved by the keypoint-track transformation,
+    the map fused once at that pose, then (with -icp_refine) the dense tracker refines it.  The transformation
+    here is the true inter-frame motion, slightly perturbed -- what RigidRANSAC delivers on good tracks."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h, n = 320, 240, 4
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=11)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    o = OracleFusion(orc, w, h, K)
+    for i, f in enumerate(frames):
+        T = None
+        if i > 0:
+            T = (np.linalg.inv(poses[i - 1]) @ poses[i]).astype(np.float32)
+            T[:3, 3] += np.float32(0.0005) * np.array([1, -1, 0.5], np.float32)
+        g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=i, initTransform=T, icpRefine=icp_refine)
+        o.process_frame(f["rgb"], f["depth"], init_transform=T, icp_refine=icp_refine)
+        pg = g.getCurrPose()
+        assert np.abs(pg - o.pose).max() <= 1e-5, (i, pg, o.pose)
+        ng, no = g.getBackgroundModel().lastCount(), o.surfels.shape[0]
+        assert abs(ng - no) <= max(8, 0.002 * no), (i, ng, no)
+        gt = np.linalg.inv(poses[0]) @ poses[i]
+        assert np.linalg.norm(pg[:3, 3] - gt[:3, 3]) < (0.01 if icp_refine else 0.005 * (i + 1))
+    if not icp_refine:  # the pose is exactly the chain of the given transformations
+        assert g.getFrameOdometry().iterations_run == 0
+    g.close()
+
+
+def test_keypoint_initialisation_is_refused_in_frame_to_frame_mode(gpu_ctx):
+    from multimotionfusion_amd import MmfError
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h = 320, 240
+    K = synth.intrinsics(w, h)
+    f = synth.render(synth.trajectory(1, seed=1)[0], w, h, seed=0)
+    g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], frame_to_frame_rgb=1)
+    g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=0)
+    with pytest.raises(MmfError):  # MultiMotionFusion.cpp:370
+        g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=1, initTransform=np.eye(4))
+    g.close()
