@@ -31,21 +31,49 @@ __global__ __launch_bounds__(256) void slic_reset_kernel(int n, SlicBox* __restr
 
 // spixelCounts (Slic.cpp:76-79) + the bounding box of every label (+ the RGB sums of Slic.cpp:93-94 when
 // rgb != nullptr).  Labels outside [0, n) are ignored (the reference would write out of bounds).
+// A wave covers 64 consecutive pixels, which belong to a handful of labels in runs: only the first lane of a
+// run touches memory (5 atomics per run instead of per pixel -- the per-pixel form spent 200 us at 640x480
+// queueing on 1200 addresses); integer run sums come from a wave prefix sum.
+__device__ __forceinline__ int slic_wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(v, d);
+        v += lane >= d ? up : 0;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void slic_census_kernel(const int* __restrict__ labels, int W, int H, int n,
                                                           SlicBox* box, int* counts, const uint8_t* __restrict__ rgb,
                                                           int channels, int* rgb_sums) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= W * H) return;
-    const int s = labels[i];
-    if (s < 0 || s >= n) return;
-    const int y = i / W, x = i - y * W;
-    atomicAdd(&counts[s], 1);
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const bool live = i < W * H;
+    const int s = live ? labels[i] : -1;
+    const int y = live ? i / W : -1, x = live ? i - y * W : -1;
+    // run starts: the label or the image row changes (lane 0 always starts one)
+    const int prev_s = __shfl_up(s, 1), prev_y = __shfl_up(y, 1);
+    const bool start = lane == 0 || prev_s != s || prev_y != y;
+    const unsigned long long starts = __ballot(start);
+    const unsigned long long later = lane == 63 ? 0ull : (starts >> (lane + 1)) << (lane + 1);
+    const int next_start = later ? __ffsll((long long)later) - 1 : 64;
+    const int len = next_start - lane;  // meaningful in start lanes
+    int c0 = 0, c1 = 0, c2 = 0;
+    if (rgb != nullptr) {  // wave uniform
+        if (live) {
+            const uint8_t* px = rgb + (size_t)i * channels;
+            c0 = px[2], c1 = px[1], c2 = px[0];
+        }
+        const int p0 = slic_wave_inclusive_scan(c0, lane), p1 = slic_wave_inclusive_scan(c1, lane);
+        const int p2 = slic_wave_inclusive_scan(c2, lane);
+        const int last = next_start - 1;  // last lane of this lane's run (for start lanes)
+        c0 = __shfl(p0, last) - (p0 - c0), c1 = __shfl(p1, last) - (p1 - c1), c2 = __shfl(p2, last) - (p2 - c2);
+    }
+    if (!live || !start || s < 0 || s >= n) return;
+    atomicAdd(&counts[s], len);
     atomicMin(&box[s].min_x, x), atomicMin(&box[s].min_y, y);
-    atomicMax(&box[s].max_x, x), atomicMax(&box[s].max_y, y);
+    atomicMax(&box[s].max_x, x + len - 1), atomicMax(&box[s].max_y, y);
     if (rgb != nullptr) {
-        const uint8_t* px = rgb + (size_t)i * channels;
-        atomicAdd(&rgb_sums[3 * s], (int)px[2]), atomicAdd(&rgb_sums[3 * s + 1], (int)px[1]);
-        atomicAdd(&rgb_sums[3 * s + 2], (int)px[0]);
+        atomicAdd(&rgb_sums[3 * s], c0), atomicAdd(&rgb_sums[3 * s + 1], c1), atomicAdd(&rgb_sums[3 * s + 2], c2);
     }
 }
 
