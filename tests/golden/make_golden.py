@@ -79,3 +79,29 @@ np.savez_compressed(os.path.join(HERE, "surfel_cycle_96x72.npz"), rgb0=f0["rgb"]
                     surfels_init=s0, index_after_fuse=index2, surfels_final=s1, splat_vertexConf=vcp,
                     splat_image=image)
 print("wrote surfel fixture:", s0.shape[0], "->", s1.shape[0], "surfels")
+
+# 4. SuperPoint on a 64x48 image (weights from the seeded generator, not stored: 5 MB) and the super-pixel
+#    resampling of a 160x128 map
+import hashlib  # noqa: E402
+
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from helpers import slic_like_labels  # noqa: E402
+
+rng = np.random.default_rng(2024)
+img = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+weights = orc.sp_random_weights(seed=4)
+wsum = hashlib.sha256(b"".join(a.tobytes() for w, b in weights for a in (w, b))).hexdigest()
+semi, desc = orc.sp_forward(orc.sp_input(img), weights)
+heat = orc.sp_heatmap(semi)
+xy, conf = orc.sp_keypoints(heat)
+kdesc = orc.sp_sample_descriptors(desc, xy, 48, 64)
+labels = slic_like_labels(160, 128, 16, seed=3, empty_every=7)
+smap = rng.random((128, 160), dtype=np.float32)
+sdepth = smap * 3.0
+sdepth[rng.random((128, 160)) < 0.3] = 0.0
+srgb = rng.integers(0, 256, (128, 160, 3), dtype=np.uint8)
+np.savez_compressed(os.path.join(HERE, "superpoint_slic.npz"), image=img, weights_seed=4, weights_sha256=wsum, semi=semi,
+                    desc=desc, heat=heat, xy=xy, conf=conf, kdesc=kdesc, labels=labels, smap=smap, sdepth=sdepth, srgb=srgb,
+                    low=orc.slic_downsample(labels, 16, smap), low_depth=orc.slic_downsample(labels, 16, sdepth, threshold=0.02),
+                    low_rgb=orc.slic_downsample_rgb(labels, 16, srgb))
+print("wrote superpoint_slic.npz")

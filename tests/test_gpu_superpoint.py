@@ -152,3 +152,27 @@ def test_forward_rejects_bad_sizes(net):
         sp.forward(np.zeros((50, 64), np.uint8))      # not a multiple of 8
     with pytest.raises(MmfError):
         sp.forward(np.zeros((240, 320), np.uint8))    # larger than the object was created for
+
+
+def test_golden_fixture(gpu_ctx, orc):
+    """the committed fixture (tests/golden/superpoint_slic.npz): the HIP path against stored outputs, without the
+    oracle in the loop (only its seeded weight generator)"""
+    import os
+    from multimotionfusion_amd import slic
+    from multimotionfusion_amd.superpoint import SuperPoint
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "superpoint_slic.npz"))
+    sp = SuperPoint(gpu_ctx, orc.sp_random_weights(seed=int(g["weights_seed"])), max_width=64, max_height=48, max_keypoints=512)
+    semi, desc, heat = sp.forward(g["image"])
+    assert_bit_equal(semi, g["semi"], "logits")
+    assert_bit_equal(desc, g["desc"], "coarse descriptors")
+    assert_bit_equal(heat, g["heat"], "heat map")
+    xy, conf, kdesc = sp.keypoints(g["image"])
+    assert_bit_equal(xy, g["xy"], "keypoints")
+    assert_bit_equal(conf, g["conf"], "confidences")
+    assert_bit_equal(kdesc, g["kdesc"], "descriptors")
+    sp.close()
+    labels = dev(g["labels"])
+    assert_bit_equal(slic.downsample(gpu_ctx, labels, 16, dev(g["smap"])).cpu().numpy(), g["low"], "super-pixel means")
+    assert_bit_equal(slic.downsample(gpu_ctx, labels, 16, dev(g["sdepth"]), threshold=0.02).cpu().numpy(), g["low_depth"],
+                     "thresholded means")
+    assert_bit_equal(slic.downsample_rgb(gpu_ctx, labels, 16, dev(g["srgb"])).cpu().numpy(), g["low_rgb"], "RGB means")

@@ -134,3 +134,25 @@ def test_get_features_contract():
     assert coords.shape[0] > 0
     assert np.all((coords >= 0) & (coords < 1))
     assert np.allclose(np.linalg.norm(descs, axis=1), 1.0, atol=1e-5)
+
+
+def test_golden_fixture():
+    """tests/golden/superpoint_slic.npz (make_golden.py section 4) pins the oracle's SuperPoint and super-pixel
+    outputs bit for bit; the weights are regenerated from their seed and checked by hash."""
+    import hashlib
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "superpoint_slic.npz"))
+    weights = orc.sp_random_weights(seed=int(g["weights_seed"]))
+    assert hashlib.sha256(b"".join(a.tobytes() for w, b in weights for a in (w, b))).hexdigest() == str(g["weights_sha256"])
+    semi, desc = orc.sp_forward(orc.sp_input(g["image"]), weights)
+    assert np.array_equal(semi.view(np.uint32), g["semi"].view(np.uint32))
+    assert np.array_equal(desc.view(np.uint32), g["desc"].view(np.uint32))
+    heat = orc.sp_heatmap(semi)
+    assert np.array_equal(heat.view(np.uint32), g["heat"].view(np.uint32))
+    xy, conf = orc.sp_keypoints(heat)
+    assert np.array_equal(xy, g["xy"]) and np.array_equal(conf, g["conf"])
+    assert np.array_equal(orc.sp_sample_descriptors(desc, xy, 48, 64).view(np.uint32), g["kdesc"].view(np.uint32))
+    assert np.array_equal(orc.slic_downsample(g["labels"], 16, g["smap"]).view(np.uint32), g["low"].view(np.uint32))
+    assert np.array_equal(orc.slic_downsample(g["labels"], 16, g["sdepth"], threshold=0.02).view(np.uint32),
+                          g["low_depth"].view(np.uint32))
+    assert np.array_equal(orc.slic_downsample_rgb(g["labels"], 16, g["srgb"]), g["low_rgb"])
