@@ -71,6 +71,22 @@ static void sp_launch_conv(hipStream_t s, const SpLayer& L, const float* in, int
         sp_launch_nt<1>(s, grid, L.taps, L.pool, a);
 }
 
+static SpConvArgs sp_conv_args(const SpLayer& L, const float* in, int in_stride, float* out, int out_stride, int H, int W) {
+    SpConvArgs a;
+    a.in = in, a.wpack = L.wpack, a.bias = L.bias, a.out = out;
+    a.in_stride = in_stride, a.out_stride = out_stride;
+    a.H = H, a.W = W, a.cin = L.cin, a.cout = L.cout, a.relu = L.relu ? 1 : 0;
+    return a;
+}
+
+// the two 1x1 heads (both NT = 1, no ReLU, same image) as one launch
+static void sp_launch_head_pair(hipStream_t s, const SpConvArgs& a, const SpConvArgs& b) {
+    SpConvPair q;
+    q.a = a, q.b = b, q.za = (a.cout + 31) / 32;
+    const dim3 grid((a.W + kSpTileW - 1) / kSpTileW, (a.H + kSpTileH - 1) / kSpTileH, q.za + (b.cout + 31) / 32);
+    hipLaunchKernelGGL((sp_conv_mfma_pair_kernel<1, 1, false>), grid, dim3(256), 0, s, q);
+}
+
 }  // namespace mmf
 
 struct mmf_superpoint {
@@ -217,8 +233,13 @@ extern "C" int mmf_superpoint_forward(mmf_superpoint* sp, const uint8_t* image, 
     sp_launch_conv(s, sp->L[5], sp->act1, 128, sp->act0, 128, H / 8, W / 8);    // conv4a
     sp_launch_conv(s, sp->L[6], sp->act0, 128, sp->act1, 128, H / 8, W / 8);    // conv4b
     sp_launch_conv(s, sp->L[7], sp->act1, 128, sp->head, 512, H / 8, W / 8);    // convPa | convDa
-    sp_launch_conv(s, sp->L[8], sp->head, 512, sp->semi, 65, H / 8, W / 8);     // convPb
-    sp_launch_conv(s, sp->L[9], sp->head + 256, 512, sp->desc, 256, H / 8, W / 8);  // convDb
+    if (sp->L[8].nt == 1 && sp->L[9].nt == 1) {  // convPb + convDb: one launch
+        sp_launch_head_pair(s, sp_conv_args(sp->L[8], sp->head, 512, sp->semi, 65, H / 8, W / 8),
+                            sp_conv_args(sp->L[9], sp->head + 256, 512, sp->desc, 256, H / 8, W / 8));
+    } else {
+        sp_launch_conv(s, sp->L[8], sp->head, 512, sp->semi, 65, H / 8, W / 8);         // convPb
+        sp_launch_conv(s, sp->L[9], sp->head + 256, 512, sp->desc, 256, H / 8, W / 8);  // convDb
+    }
     const int ncell = npix / 64;
     hipLaunchKernelGGL((sp_l2_normalize_kernel<256>), dim3((ncell + 3) / 4), dim3(256), 0, s, sp->desc, ncell);
     hipLaunchKernelGGL(sp_heatmap_kernel, dim3((ncell + 3) / 4), dim3(256), 0, s, sp->semi, H / 8, W / 8, sp->heat);

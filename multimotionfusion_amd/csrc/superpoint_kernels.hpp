@@ -69,7 +69,7 @@ __device__ unsigned long long* g_sp_stamps = nullptr;
 #endif
 
 template <int NT, int TAPS, bool POOL>
-__global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
+__device__ __forceinline__ void sp_conv_mfma_body(const SpConvArgs& p, const int z) {
     constexpr int HALO = TAPS == 9 ? 1 : 0;
     constexpr int HR = kSpTileH + 2 * HALO, HC = kSpTileW + 2 * HALO;
     constexpr int UNITS = HR * HC * 4;  // (pixel, 8-channel group) staging units of one K block
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
 
     SP_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * kSpTileW, y0 = blockIdx.y * kSpTileH, z = blockIdx.z;
+    const int x0 = blockIdx.x * kSpTileW, y0 = blockIdx.y * kSpTileH;
     const int chunks = p.cin / kSpKBlock;
     const int last_group = chunks * GROUPS - 1;
     // this lane's weight operands: one float4 per (group, output tile), 1 KB contiguous per wave and load
@@ -231,6 +231,26 @@ __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
         }
     }
     SP_STAMP(3);
+}
+
+template <int NT, int TAPS, bool POOL>
+__global__ __launch_bounds__(256) void sp_conv_mfma_kernel(SpConvArgs p) {
+    sp_conv_mfma_body<NT, TAPS, POOL>(p, blockIdx.z);
+}
+
+// two layers of the same shape class in one launch (the two 1x1 heads: independent of each other, each too
+// small to fill the chip): the first `za` z-slices belong to layer a, the rest to layer b
+struct SpConvPair {
+    SpConvArgs a, b;
+    int za;
+};
+
+template <int NT, int TAPS, bool POOL>
+__global__ __launch_bounds__(256) void sp_conv_mfma_pair_kernel(SpConvPair q) {
+    if ((int)blockIdx.z < q.za)  // workgroup uniform
+        sp_conv_mfma_body<NT, TAPS, POOL>(q.a, blockIdx.z);
+    else
+        sp_conv_mfma_body<NT, TAPS, POOL>(q.b, blockIdx.z - q.za);
 }
 
 // ---- network input: [0,1] grey from 1- or 3-channel u8 --------------------------------------------------
