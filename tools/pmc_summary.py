@@ -18,8 +18,8 @@ if "End_Timestamp" in df.columns:
     df["us"] = (df["End_Timestamp"] - df["Start_Timestamp"]) / 1e3
     t["us"] = df.groupby("key")["us"].mean()
 if "GRBM_GUI_ACTIVE" in t.columns and "us" in t.columns:
-    t["MHz"] = t["GRBM_GUI_ACTIVE"] / t["us"]
+    t["MHz"] = t["GRBM_GUI_ACTIVE"] / 8 / t["us"]  # rocprofv3 reports the sum over the 8 XCDs
 if "GRBM_GUI_ACTIVE" in t.columns and "SQ_VALU_MFMA_BUSY_CYCLES" in t.columns:
-    t["MfmaUtil%"] = 100.0 * t["SQ_VALU_MFMA_BUSY_CYCLES"] / (t["GRBM_GUI_ACTIVE"] * 1024)
+    t["MfmaUtil%"] = 100.0 * t["SQ_VALU_MFMA_BUSY_CYCLES"] / (t["GRBM_GUI_ACTIVE"] / 8 * 1024)  # 1024 SIMDs
 pd.set_option("display.width", 250, "display.max_columns", 30, "display.max_colwidth", 70, "display.float_format", "{:.1f}".format)
 print(t.to_string())
