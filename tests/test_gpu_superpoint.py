@@ -176,3 +176,30 @@ def test_golden_fixture(gpu_ctx, orc):
     assert_bit_equal(slic.downsample(gpu_ctx, labels, 16, dev(g["sdepth"]), threshold=0.02).cpu().numpy(), g["low_depth"],
                      "thresholded means")
     assert_bit_equal(slic.downsample_rgb(gpu_ctx, labels, 16, dev(g["srgb"])).cpu().numpy(), g["low_rgb"], "RGB means")
+
+
+def test_network_bit_exact_at_the_bench_size(gpu_ctx, orc):
+    """640x480 (BASELINE's frame size): the whole forward pass against the oracle, plus properties that hold at
+    any size -- every cell's 64 heat values and its dustbin share sum to 1 - 1e-5/sum, descriptors have unit norm"""
+    from multimotionfusion_amd.superpoint import SuperPoint
+    weights = orc.sp_random_weights(seed=9)
+    sp = SuperPoint(gpu_ctx, weights, max_width=640, max_height=480, max_keypoints=4096)
+    rng = np.random.default_rng(640)
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    semi, desc, heat = sp.forward(img)
+    o_semi, o_desc = orc.sp_forward(orc.sp_input(img), weights)
+    assert_bit_equal(semi, o_semi, "detector logits 640x480")
+    assert_bit_equal(desc, o_desc, "coarse descriptors 640x480")
+    assert_bit_equal(heat, orc.sp_heatmap(o_semi), "heat map 640x480")
+    cells = heat.reshape(60, 8, 80, 8).transpose(0, 2, 1, 3).reshape(60, 80, 64).astype(np.float64)
+    e = np.exp(semi.astype(np.float64))
+    dust = e[:, :, 64] / (e.sum(axis=2) + 1e-5)
+    assert np.abs(cells.sum(axis=2) + dust - 1.0).max() < 1e-4
+    assert np.abs(np.linalg.norm(desc.astype(np.float64), axis=2) - 1.0).max() < 1e-5
+    xy, conf, kdesc = sp.keypoints(img)
+    o_xy, o_conf = orc.sp_keypoints(orc.sp_heatmap(o_semi), sp.conf_thresh, sp.nms_dist, sp.border)
+    assert_bit_equal(xy, o_xy[:4096], "keypoints 640x480")
+    assert_bit_equal(conf, o_conf[:4096], "confidences 640x480")
+    d = np.abs(xy[:, None, :].astype(np.int64) - xy[None, :, :]).max(axis=2) + np.eye(len(xy), dtype=np.int64) * 99
+    assert d.min() > sp.nms_dist  # survivors are farther apart than the suppression radius
+    sp.close()
