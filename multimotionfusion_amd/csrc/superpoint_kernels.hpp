@@ -129,9 +129,11 @@ __device__ __forceinline__ void sp_conv_mfma_body(const SpConvArgs& p, const int
     float4 b[3][NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) b[0][t] = wp[(size_t)t * 64], b[1][t] = wp[(size_t)(min(1, last_group) * NT + t) * 64];
+#ifndef SP_PROBE_NO_PROLOGUE
     SP_LOAD_A(0);
     SP_STORE_A();
     __syncthreads();
+#endif
     SP_STAMP(1);
 
     for (int chunk = 0; chunk < chunks; ++chunk) {
@@ -216,6 +218,10 @@ __device__ __forceinline__ void sp_conv_mfma_body(const SpConvArgs& p, const int
                 o[k] = acc[t][4 * blk + k] + bias;
                 if (p.relu) o[k] = o[k] < 0.f ? 0.f : o[k];
             }
+#ifdef SP_PROBE_NO_EPILOGUE
+            if (o[0] + o[1] + o[2] + o[3] == 123.456f) p.out[co] = o[0];  // keeps the accumulators alive, never stores
+            continue;
+#endif
             if (POOL) {
                 const int py = (y0 >> 1) + wave, px = (x0 >> 1) + bx;
                 const float m0 = o[0] > o[1] ? o[0] : o[1], m1 = o[2] > o[3] ? o[2] : o[3];
