@@ -264,8 +264,8 @@ def main():
         us_sp = timed(lambda: kp.enqueue(d_rgb[0]), reps=30)
         fl_sp = float(forward_flops(W, H))
         superpoint = {"us": us_sp, "GFLOP": fl_sp / 1e9, "TFLOPs": fl_sp / us_sp / 1e6,
-                      "frac_f32_mfma_peak": fl_sp / us_sp / 1e6 / 157.3, "launches": 14, "dtype": "f32",
-                      "kernels": "sp_input + sp_conv1a (VALU) + 8 x sp_conv_mfma_kernel + 1 x sp_conv_mfma_pair_kernel (implicit GEMM, fused ReLU / "
+                      "frac_f32_mfma_peak": fl_sp / us_sp / 1e6 / 157.3, "launches": 13, "dtype": "f32",
+                      "kernels": "sp_conv1a (grey + 1->64, VALU) + 8 x sp_conv_mfma_kernel + 1 x sp_conv_mfma_pair_kernel (implicit GEMM, fused ReLU / "
                                  "2x2 max pool) + sp_l2_normalize + sp_heatmap",
                       "weights": "random-init SuperPointNet architecture"}
         kp.close()

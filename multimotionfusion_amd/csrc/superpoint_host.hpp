@@ -95,7 +95,7 @@ struct mmf_superpoint {
     float *w1a = nullptr, *b1a = nullptr;  // conv1a: [9][64] + [64]
     // conv1b conv2a conv2b conv3a conv3b conv4a conv4b, {convPa | convDa} fused (512 outputs), convPb, convDb
     mmf::SpLayer L[10];
-    float *inp = nullptr, *act0 = nullptr, *act1 = nullptr, *head = nullptr, *semi = nullptr, *desc = nullptr, *heat = nullptr;
+    float *act0 = nullptr, *act1 = nullptr, *head = nullptr, *semi = nullptr, *desc = nullptr, *heat = nullptr;
     uint8_t* image = nullptr;  // staging for host images
     uint8_t* state = nullptr;
     unsigned *flags = nullptr, *prefix = nullptr, *block_sums = nullptr, *counters = nullptr;
@@ -181,7 +181,7 @@ extern "C" int mmf_superpoint_create(mmf_ctx* c, const float* const* weights, in
         off = align_up(off + bytes, 256);
         return at;
     };
-    const size_t o_inp = carve(npix * 4), o_act0 = carve(npix * 64 * 4), o_act1 = carve(npix / 4 * 64 * 4);
+    const size_t o_act0 = carve(npix * 64 * 4), o_act1 = carve(npix / 4 * 64 * 4);
     const size_t o_head = carve(ncell * 512 * 4), o_semi = carve(ncell * 65 * 4), o_desc = carve(ncell * 256 * 4);
     const size_t o_heat = carve(npix * 4), o_image = carve(npix * 4), o_state = carve(npix);
     const size_t o_flags = carve(npix * 4), o_prefix = carve(npix * 4);
@@ -200,7 +200,7 @@ extern "C" int mmf_superpoint_create(mmf_ctx* c, const float* const* weights, in
         return rc;
     }
     char* base = static_cast<char*>(sp->slab);
-    sp->inp = (float*)(base + o_inp), sp->act0 = (float*)(base + o_act0), sp->act1 = (float*)(base + o_act1);
+    sp->act0 = (float*)(base + o_act0), sp->act1 = (float*)(base + o_act1);
     sp->head = (float*)(base + o_head), sp->semi = (float*)(base + o_semi), sp->desc = (float*)(base + o_desc);
     sp->heat = (float*)(base + o_heat), sp->image = (uint8_t*)(base + o_image), sp->state = (uint8_t*)(base + o_state);
     sp->flags = (unsigned*)(base + o_flags), sp->prefix = (unsigned*)(base + o_prefix);
@@ -223,8 +223,8 @@ extern "C" int mmf_superpoint_forward(mmf_superpoint* sp, const uint8_t* image, 
     hipStream_t s = c->stream;
     const int H = height, W = width, npix = H * W;
     using namespace mmf;
-    hipLaunchKernelGGL(sp_input_kernel, grid1d(npix), dim3(256), 0, s, image, npix, channels, sp->inp);
-    hipLaunchKernelGGL(sp_conv1a_kernel, grid1d((size_t)npix * 4), dim3(256), 0, s, sp->inp, H, W, sp->w1a, sp->b1a, sp->act0);
+    hipLaunchKernelGGL(sp_conv1a_kernel, grid1d((size_t)npix * 4), dim3(256), 0, s, image, channels, H, W, sp->w1a, sp->b1a,
+                       sp->act0);
     sp_launch_conv(s, sp->L[0], sp->act0, 64, sp->act1, 64, H, W);              // conv1b + pool
     sp_launch_conv(s, sp->L[1], sp->act1, 64, sp->act0, 64, H / 2, W / 2);      // conv2a
     sp_launch_conv(s, sp->L[2], sp->act0, 64, sp->act1, 64, H / 2, W / 2);      // conv2b + pool

@@ -259,22 +259,17 @@ __global__ __launch_bounds__(256) void sp_conv_mfma_pair_kernel(SpConvPair q) {
         sp_conv_mfma_body<NT, TAPS, POOL>(q.b, blockIdx.z - q.za);
 }
 
-// ---- network input: [0,1] grey from 1- or 3-channel u8 --------------------------------------------------
-__global__ __launch_bounds__(256) void sp_input_kernel(const uint8_t* __restrict__ img, int npix, int channels,
-                                                       float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix) return;
-    if (channels == 1) {
-        out[i] = (float)img[i] / 255.0f;
-    } else {
-        const uint8_t* px = img + (size_t)i * channels;
-        out[i] = ((0.299f * (float)px[0] + 0.587f * (float)px[1]) + 0.114f * (float)px[2]) / 255.0f;
-    }
+// ---- network input: [0,1] grey from 1-, 3- or 4-channel u8 (first three channels = R, G, B) ---------------
+__device__ __forceinline__ float sp_grey(const uint8_t* __restrict__ img, size_t i, int channels) {
+    if (channels == 1) return (float)img[i] / 255.0f;
+    const uint8_t* px = img + i * channels;
+    return ((0.299f * (float)px[0] + 0.587f * (float)px[1]) + 0.114f * (float)px[2]) / 255.0f;
 }
 
 // ---- conv1a: one input channel, 64 outputs.  K = 9 is no contraction to speak of: VALU, four lanes per pixel
-// (16 output channels each) so that a wave stores 4 KB contiguous per instruction group ---------------------
-__global__ __launch_bounds__(256) void sp_conv1a_kernel(const float* __restrict__ in, int H, int W,
+// (16 output channels each) so that a wave stores 4 KB contiguous per instruction group.  The grey conversion
+// of the nine taps happens here (a few flops per tap; no separate input plane, no extra launch) ---------------
+__global__ __launch_bounds__(256) void sp_conv1a_kernel(const uint8_t* __restrict__ img, int channels, int H, int W,
                                                         const float* __restrict__ w_tap_co /* [9][64] */,
                                                         const float* __restrict__ bias, float* __restrict__ out) {
     __shared__ float4 wl[9 * 16];
@@ -289,7 +284,7 @@ __global__ __launch_bounds__(256) void sp_conv1a_kernel(const float* __restrict_
     for (int tap = 0; tap < 9; ++tap) {
         const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
         const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        v[tap] = inside ? in[(size_t)yy * W + xx] : 0.f;
+        v[tap] = inside ? sp_grey(img, (size_t)yy * W + xx, channels) : 0.f;
     }
     float acc[16];
 #pragma unroll
