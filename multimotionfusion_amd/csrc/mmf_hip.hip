@@ -2104,6 +2104,7 @@ extern "C" int mmf_slic_upsample_u8(mmf_ctx* c, const int* labels, int width, in
 extern "C" int mmf_debug_set_stamps(void* dev_buf) {
     unsigned long long* p = static_cast<unsigned long long*>(dev_buf);
     MMF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_mmf_dbg), &p, sizeof(p)));
+    MMF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_mmf_dbg_solve), &p, sizeof(p)));
     return MMF_OK;
 }
 #endif

@@ -410,6 +410,18 @@ __device__ inline SolveIn load_solve_in(const OdomState* st) {
     return s;
 }
 
+#ifdef MMF_STAMPS  // diagnostic builds only (tools/rgb_step_probe.py): stamps inside the solve
+__device__ unsigned long long* g_mmf_dbg_solve = nullptr;
+#define MMF_SOLVE_STAMP(i)                                                                       \
+    do {                                                                                         \
+        if (g_mmf_dbg_solve) g_mmf_dbg_solve[blockIdx.x * 16 + (i)] = wall_clock64();             \
+    } while (0)
+#else
+#define MMF_SOLVE_STAMP(i) \
+    do {                   \
+    } while (0)
+#endif
+
 __device__ inline void solve_and_update(OdomState* st, const SolveIn& si, const float* tot_rgb, const float* tot_icp,
                                         const LevelIntr& in) {
     const double w = si.w;
@@ -434,8 +446,10 @@ __device__ inline void solve_and_update(OdomState* st, const SolveIn& si, const 
         for (int k = 0; k < 36; ++k) A[k] = A_rgb[k];
         for (int k = 0; k < 6; ++k) b[k] = b_rgb[k];
     }
+    MMF_SOLVE_STAMP(1);
     double result[6];
     ldlt_solve_recip<6>(A, b, result);
+    MMF_SOLVE_STAMP(2);
 
     double Rup[9];
     const double rvec[3] = {result[3], result[4], result[5]};
@@ -454,6 +468,7 @@ __device__ inline void solve_and_update(OdomState* st, const SolveIn& si, const 
         for (int k = 0; k < 12; ++k) resultRt[k] = nr[k];
     }
 
+    MMF_SOLVE_STAMP(14);
     float Ro[9], to[3], RoT[9], ti[3], Rcurr[9], tcurr[3];
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) Ro[r * 3 + c] = (float)resultRt[r * 4 + c];
@@ -473,6 +488,7 @@ __device__ inline void solve_and_update(OdomState* st, const SolveIn& si, const 
     float krkinv[9], kt[3];
     rgb_prepare(resultRt, in, krkinv, kt);  // parameters of the next iteration's correspondence pass
 
+    MMF_SOLVE_STAMP(15);
     // exit stores
     st->st.iterations_run = iters + 1;
     for (int k = 0; k < 36; ++k) st->st.lastA[k] = A[k];

@@ -55,8 +55,9 @@ def probe(W, H):
     nb = (W * H + 1023) // 1024
     s = s[:nb]
     t0 = s[:, 0].min()
+    solve = s[:, [6, 1, 2, 14, 15, 7]].copy()  # inside the finishing lane's solve (slots 1, 2, 14, 15)
     s[:, 1] = s[:, 0]
-    s[:, 2] = s[:, 0]  # stamps 1, 2 are no longer taken: phase 2 spans start .. gathers landed + state consumed
+    s[:, 2] = s[:, 0]  # phase 2 spans start .. gathers landed + state consumed
     ph = np.diff(s[:, :6], axis=1) * 0.01  # us
     last = int(np.argmax(s[:, 7]))
     print(f"{W}x{H}: {nb} workgroups; first start .. last arrive {(s[:, 5].max() - t0) * 0.01:.2f} us, "
@@ -64,6 +65,9 @@ def probe(W, H):
     print("  mean per-workgroup phase (us): " + ", ".join(f"{n} {v:.2f}" for n, v in list(zip(NAMES[:5], ph.mean(axis=0)))[2:]))
     print(f"  finishing workgroup {last}: record sums {(s[last, 6] - s[last, 5]) * 0.01:.2f} us, solve + stores issued "
           f"{(s[last, 7] - s[last, 6]) * 0.01:.2f} us; kernel first start .. finish {(s[last, 7] - t0) * 0.01:.2f} us")
+    sv = np.diff(solve[last]) * 0.01
+    print("  solve of the finishing lane (us): " + ", ".join(f"{n} {v:.2f}" for n, v in zip(
+        ["unpack + combine A, b", "6x6 LDLT", "rodrigues + resultRt", "pose compose + next K R K^-1", "stores issued"], sv)))
     # correspondence-pass workgroups of the last producer launch: slots 8..13 of workgroups [0, N/1024)
     full = stamps.cpu().numpy().reshape(-1, 16)
     r = full[:nb, 8:14]  # the correspondence workgroups take the first block indices
