@@ -127,6 +127,7 @@ SIGNATURES = {
     "mmf_fusion_destroy": (None, [_vp]),
     "mmf_fusion_process_frame": (_i, [_vp, _vp, _vp, C.c_longlong, _fp, _f, _i]),
     "mmf_fusion_process_frame_init": (_i, [_vp, _vp, _vp, C.c_longlong, _fp, _i, _f]),
+    "mmf_fusion_prefetch_frame": (_i, [_vp, _vp, _vp]),
     "mmf_fusion_reset": (_i, [_vp]),
     "mmf_fusion_get_pose": (_i, [_vp, _fp]),
     "mmf_fusion_tick": (_i, [_vp]),

@@ -143,6 +143,11 @@ class MultiMotionFusion {
         mmf::check(rc, "mmf_fusion_process_frame_init");
         return false;
     }
+    // not in the reference: start the next frame's input-side work (filter, pyramids, gradients) on a second
+    // stream while the current frame is still being fused; pass the same frame to processFrame afterwards
+    void prefetchFrame(const FrameDataDevice& next) {
+        mmf::check(mmf_fusion_prefetch_frame(f_, next.rgb, next.depth), "mmf_fusion_prefetch_frame");
+    }
     void getCurrPose(float pose[16]) const { mmf::check(mmf_fusion_get_pose(f_, pose), "mmf_fusion_get_pose"); }
     int getTick() const { return mmf_fusion_tick(f_); }
     Model getBackgroundModel() { return Model(mmf_fusion_model(f_)); }

@@ -993,9 +993,9 @@ struct PrepBuilder {
         blocks += j.gx * ((rows + kTileY - 1) / kTileY);
         return j;
     }
-    int launch(mmf_ctx* c) {
+    int launch(hipStream_t stream) {
         if (!b.njobs) return MMF_OK;
-        hipLaunchKernelGGL(prep_batch_kernel, dim3(blocks), tile_block(), 0, c->stream, b);
+        hipLaunchKernelGGL(prep_batch_kernel, dim3(blocks), tile_block(), 0, stream, b);
         MMF_HIP_TRY(hipGetLastError());
         return MMF_OK;
     }
@@ -1005,12 +1005,21 @@ struct PrepBuilder {
 // point-cloud passes of getIncrementalTransformation compute (RGBDOdometry.cpp:108-235, 332-334;
 // Model.cpp:359-407), for inputs that stay untouched until tracking returns (the native orchestrator).
 // `sel` (device, may be null): when *sel != 0 the prediction is read from the alt_* images instead.
+// `side`: the jobs split into those that depend only on the NEW sensor frame (filtered depth, RGB: vertex / normal
+// maps, depth and intensity pyramids, gradients) and those that depend on the model's prediction and pose.
+// The orchestrator can run the first group for frame t+1 on a second stream while frame t is still being fused
+// (mmf_fusion_prefetch_frame); PREP_ALL is both groups in the same four launches.
+enum PrepSide { PREP_ALL = 0, PREP_INPUT_SIDE = 1, PREP_MODEL_SIDE = 2 };
+
 static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float depth_cutoff, const uint8_t* rgb,
                                 int rgb_channels, const float* pred_vertex, const float* pred_normal,
                                 const uint8_t* pred_image, int pred_channels, const float pose[16],
                                 const int* sel = nullptr, const float* alt_vertex = nullptr,
-                                const float* alt_normal = nullptr, const uint8_t* alt_image = nullptr) {
+                                const float* alt_normal = nullptr, const uint8_t* alt_image = nullptr,
+                                int side = PREP_ALL, hipStream_t stream = nullptr) {
     mmf_ctx* c = o->ctx;
+    if (stream == nullptr) stream = c->stream;
+    const bool in_side = side != PREP_MODEL_SIDE, model_side = side != PREP_INPUT_SIDE;
     const int W = o->width, H = o->height;
     const size_t n0 = (size_t)W * H;
     // camera-frame model pyramids (before the transform into the global frame) live in the two 4*N-float
@@ -1029,19 +1038,23 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
     };
     auto level_jobs = [&](PrepBuilder& pb, int lvl) {  // jobs whose inputs are the level-lvl images
         const int cols = W >> lvl, rows = H >> lvl;
-        PrepJob& t = pb.add(PREP_TRANSFORM_PACK, cols, rows);
-        t.src0 = uv[lvl], t.src1 = un[lvl];
-        t.dst0 = o->vmaps_g_prev[lvl], t.dst1 = o->nmaps_g_prev[lvl], t.dst2 = o->prev_packed[lvl];
-        const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
-        for (int k = 0; k < 9; ++k) t.f[k] = R[k];
-        t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
-        PrepJob& d = pb.add(PREP_DERIV, cols, rows);
-        d.src0 = o->next_image[lvl], d.dst0 = o->dIdx[lvl], d.dst1 = o->dIdy[lvl];
-        PrepJob& p = pb.add(PREP_PROJECT, cols, rows);
-        p.src0 = o->last_depth[lvl], p.dst0 = o->cloud[lvl];
-        intr_f(p, lvl, false, 0.f);
-        PrepJob& nm = pb.add(PREP_NMAP, cols, rows);
-        nm.src0 = o->vmaps_curr[lvl], nm.dst0 = o->nmaps_curr[lvl];
+        if (model_side) {
+            PrepJob& t = pb.add(PREP_TRANSFORM_PACK, cols, rows);
+            t.src0 = uv[lvl], t.src1 = un[lvl];
+            t.dst0 = o->vmaps_g_prev[lvl], t.dst1 = o->nmaps_g_prev[lvl], t.dst2 = o->prev_packed[lvl];
+            const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+            for (int k = 0; k < 9; ++k) t.f[k] = R[k];
+            t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
+            PrepJob& p = pb.add(PREP_PROJECT, cols, rows);
+            p.src0 = o->last_depth[lvl], p.dst0 = o->cloud[lvl];
+            intr_f(p, lvl, false, 0.f);
+        }
+        if (in_side) {
+            PrepJob& d = pb.add(PREP_DERIV, cols, rows);
+            d.src0 = o->next_image[lvl], d.dst0 = o->dIdx[lvl], d.dst1 = o->dIdy[lvl];
+            PrepJob& nm = pb.add(PREP_NMAP, cols, rows);
+            nm.src0 = o->vmaps_curr[lvl], nm.dst0 = o->nmaps_curr[lvl];
+        }
     };
     auto vmap_job = [&](PrepBuilder& pb, int lvl, const float* depth) {
         PrepJob& j = pb.add(PREP_VMAP, W >> lvl, H >> lvl);
@@ -1049,60 +1062,70 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
         intr_f(j, lvl, true, depth_cutoff);
     };
     auto down_jobs = [&](PrepBuilder& pb, int lvl, const float* depth_src) {  // level lvl-1 -> lvl of every pyramid
-        pyr(pb, PREP_PYRDOWN_F, o->last_depth[lvl - 1], o->last_depth[lvl], lvl);
-        pyr(pb, PREP_PYRDOWN_U8, o->next_image[lvl - 1], o->next_image[lvl], lvl);
-        pyr(pb, PREP_PYRDOWN_U8, o->last_image[lvl - 1], o->last_image[lvl], lvl);
-        pyr(pb, PREP_RESIZE_V, uv[lvl - 1], uv[lvl], lvl);
-        pyr(pb, PREP_RESIZE_N, un[lvl - 1], un[lvl], lvl);
+        if (in_side) pyr(pb, PREP_PYRDOWN_U8, o->next_image[lvl - 1], o->next_image[lvl], lvl);
+        if (model_side) {
+            pyr(pb, PREP_PYRDOWN_F, o->last_depth[lvl - 1], o->last_depth[lvl], lvl);
+            pyr(pb, PREP_PYRDOWN_U8, o->last_image[lvl - 1], o->last_image[lvl], lvl);
+            pyr(pb, PREP_RESIZE_V, uv[lvl - 1], uv[lvl], lvl);
+            pyr(pb, PREP_RESIZE_N, un[lvl - 1], un[lvl], lvl);
+        }
         (void)depth_src;
     };
 
-    o->depth_l0 = depth_filtered;
-    o->vtmp = pred_vertex, o->ntmp = pred_normal;
-    o->have_tmp = true;
+    if (model_side) {
+        o->depth_l0 = depth_filtered;
+        o->vtmp = pred_vertex, o->ntmp = pred_normal;
+        o->have_tmp = true;
+    }
 
     {   // stage 1: inputs -> level 0 (and level 1 of the depth pyramid)
         PrepBuilder pb;
-        pyr(pb, PREP_PYRDOWN_F, depth_filtered, o->depth_pyr[1], 1);
-        vmap_job(pb, 0, depth_filtered);
-        PrepJob& v = pb.add(PREP_V2D, W, H);
-        v.src0 = pred_vertex, v.dst0 = o->last_depth[0], v.f[0] = o->max_depth_rgb;
-        v.sel = sel, v.alt0 = alt_vertex;
-        PrepJob& in = pb.add(PREP_INTENSITY, W, H);
-        in.src0 = rgb, in.dst0 = o->next_image[0], in.scols = W * rgb_channels, in.channels = rgb_channels;
-        PrepJob& il = pb.add(PREP_INTENSITY, W, H);
-        il.src0 = pred_image, il.dst0 = o->last_image[0], il.scols = W * pred_channels, il.channels = pred_channels;
-        il.sel = sel, il.alt0 = alt_image;
-        PrepJob& cm = pb.add(PREP_COPY_MAPS, W, H);
-        cm.src0 = pred_vertex, cm.src1 = pred_normal, cm.dst0 = uv[0], cm.dst1 = un[0];
-        cm.sel = sel, cm.alt0 = alt_vertex, cm.alt1 = alt_normal;
-        int rc = pb.launch(c);
+        if (in_side) {
+            pyr(pb, PREP_PYRDOWN_F, depth_filtered, o->depth_pyr[1], 1);
+            vmap_job(pb, 0, depth_filtered);
+            PrepJob& in = pb.add(PREP_INTENSITY, W, H);
+            in.src0 = rgb, in.dst0 = o->next_image[0], in.scols = W * rgb_channels, in.channels = rgb_channels;
+        }
+        if (model_side) {
+            PrepJob& v = pb.add(PREP_V2D, W, H);
+            v.src0 = pred_vertex, v.dst0 = o->last_depth[0], v.f[0] = o->max_depth_rgb;
+            v.sel = sel, v.alt0 = alt_vertex;
+            PrepJob& il = pb.add(PREP_INTENSITY, W, H);
+            il.src0 = pred_image, il.dst0 = o->last_image[0], il.scols = W * pred_channels, il.channels = pred_channels;
+            il.sel = sel, il.alt0 = alt_image;
+            PrepJob& cm = pb.add(PREP_COPY_MAPS, W, H);
+            cm.src0 = pred_vertex, cm.src1 = pred_normal, cm.dst0 = uv[0], cm.dst1 = un[0];
+            cm.sel = sel, cm.alt0 = alt_vertex, cm.alt1 = alt_normal;
+        }
+        int rc = pb.launch(stream);
         if (rc) return rc;
     }
     {   // stage 2: level 0 -> level 1 (and level 2 of the depth pyramid)
         PrepBuilder pb;
-        pyr(pb, PREP_PYRDOWN_F, o->depth_pyr[1], o->depth_pyr[2], 2);
-        vmap_job(pb, 1, o->depth_pyr[1]);
+        if (in_side) {
+            pyr(pb, PREP_PYRDOWN_F, o->depth_pyr[1], o->depth_pyr[2], 2);
+            vmap_job(pb, 1, o->depth_pyr[1]);
+        }
         level_jobs(pb, 0);
         down_jobs(pb, 1, nullptr);
-        int rc = pb.launch(c);
+        int rc = pb.launch(stream);
         if (rc) return rc;
     }
     {   // stage 3: level 1 -> level 2
         PrepBuilder pb;
-        vmap_job(pb, 2, o->depth_pyr[2]);
+        if (in_side) vmap_job(pb, 2, o->depth_pyr[2]);
         level_jobs(pb, 1);
         down_jobs(pb, 2, nullptr);
-        int rc = pb.launch(c);
+        int rc = pb.launch(stream);
         if (rc) return rc;
     }
     {   // stage 4: level 2
         PrepBuilder pb;
         level_jobs(pb, 2);
-        int rc = pb.launch(c);
+        int rc = pb.launch(stream);
         if (rc) return rc;
     }
-    o->prep_batched = true;
+    if (model_side) o->prep_batched = true;
     return MMF_OK;
 }
 
@@ -1608,17 +1631,23 @@ extern "C" int mmf_model_count(mmf_model* m, unsigned* count) {
 }
 
 // MultiMotionFusion::filterDepth (MultiMotionFusion.cpp:897-904)
-extern "C" int mmf_filter_depth(mmf_ctx* c, const float* depth, int cols, int rows, float max_depth, float* out) {
+static int filter_depth_on(mmf_ctx* c, hipStream_t stream, const float* depth, int cols, int rows, float max_depth,
+                           float* out) {
     MMF_REQUIRE(c && depth && out && cols > 0 && rows > 0, "mmf_filter_depth: bad argument");
     MMF_HIP_TRY(hipSetDevice(c->device));
     if (cols % 2 == 0 && ((uintptr_t)depth & 7u) == 0 && ((uintptr_t)out & 7u) == 0)  // two pixels per lane
-        hipLaunchKernelGGL(bilateral_filter2_kernel, tile_grid(cols / 2, rows), tile_block(), 0, c->stream, depth, cols,
-                           rows, max_depth, out);
+        hipLaunchKernelGGL(bilateral_filter2_kernel, tile_grid(cols / 2, rows), tile_block(), 0, stream, depth, cols, rows,
+                           max_depth, out);
     else
-        hipLaunchKernelGGL(bilateral_filter_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, depth, cols, rows,
+        hipLaunchKernelGGL(bilateral_filter_kernel, tile_grid(cols, rows), tile_block(), 0, stream, depth, cols, rows,
                            max_depth, out);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
+}
+
+extern "C" int mmf_filter_depth(mmf_ctx* c, const float* depth, int cols, int rows, float max_depth, float* out) {
+    MMF_REQUIRE(c != nullptr, "mmf_filter_depth: bad argument");
+    return filter_depth_on(c, c->stream, depth, cols, rows, max_depth, out);
 }
 
 static int model_read_totals(mmf_model* m) {
@@ -2120,11 +2149,24 @@ struct mmf_fusion {
     int width = 0, height = 0;
     mmf_model* model = nullptr;   // globalModel
     mmf_odom* odom = nullptr;     // its frameToModel
-    float* depth_filtered = nullptr;
+    float* depth_filtered = nullptr;  // = filtered[cur]
     uint8_t* mask = nullptr;      // all zeros: static scene (MultiMotionFusion.cpp:268-275)
     int tick = 1;                 // MultiMotionFusion.cpp:36
     float last_pose[16];
     int tracking_ok = 1;
+    // next-frame prefetch (mmf_fusion_prefetch_frame): the filter and the input-side preparation of frame t+1 run
+    // on `side` while frame t is fused on the context's stream.  Two filtered-depth buffers: frame t's fuse /
+    // clean / fill-in read one while frame t+1's filter writes the other.
+    float* filtered[2] = {nullptr, nullptr};
+    int cur = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_inputs_free = nullptr;    // context stream: enqueued work no longer reads the odometry's input-side
+                                            // buffers nor filtered[1 - cur]
+    hipEvent_t ev_prefetch_done = nullptr;  // side stream: the prefetch has been enqueued up to here
+    bool inputs_free_recorded = false;
+    bool pre_valid = false;
+    const uint8_t* pre_rgb = nullptr;
+    const float* pre_depth = nullptr;
 };
 
 extern "C" int mmf_fusion_default_config(mmf_fusion_config* cfg) {
@@ -2170,7 +2212,12 @@ extern "C" int mmf_fusion_create(mmf_ctx* c, int width, int height, float cx, fl
     // between the init* calls of a frame and the end of its tracking
     f->odom->alias_inputs = true;
     const size_t npix = (size_t)width * height;
-    MMF_HIP_TRY(hipMalloc(&f->depth_filtered, npix * 4));
+    MMF_HIP_TRY(hipMalloc(&f->filtered[0], npix * 4));
+    MMF_HIP_TRY(hipMalloc(&f->filtered[1], npix * 4));
+    f->depth_filtered = f->filtered[0];
+    MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+    MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_inputs_free, hipEventDisableTiming));
+    MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch_done, hipEventDisableTiming));
     MMF_HIP_TRY(hipMalloc(&f->mask, npix));
     MMF_HIP_TRY(hipMemsetAsync(f->mask, 0, npix, c->stream));
     for (int i = 0; i < 16; ++i) f->last_pose[i] = (i % 5 == 0) ? 1.f : 0.f;
@@ -2182,10 +2229,15 @@ extern "C" void mmf_fusion_destroy(mmf_fusion* f) {
     if (!f) return;
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
+    if (f->side) (void)hipStreamSynchronize(f->side);
     mmf_model_destroy(f->model);
     mmf_odom_destroy(f->odom);
-    (void)hipFree(f->depth_filtered);
+    (void)hipFree(f->filtered[0]);
+    (void)hipFree(f->filtered[1]);
     (void)hipFree(f->mask);
+    if (f->ev_inputs_free) (void)hipEventDestroy(f->ev_inputs_free);
+    if (f->ev_prefetch_done) (void)hipEventDestroy(f->ev_prefetch_done);
+    if (f->side) (void)hipStreamDestroy(f->side);
     delete f;
 }
 
@@ -2238,14 +2290,28 @@ static int fusion_process_frame_impl(mmf_fusion* f, const uint8_t* rgb, const fl
     mmf_ctx* c = f->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     const mmf_fusion_config& g = f->cfg;
-    int rc = mmf_filter_depth(c, depth, f->width, f->height, g.depth_cutoff, f->depth_filtered);  // :262
-    if (rc) return rc;
+    int rc = MMF_OK;
+    bool prefetched = false;
+    if (f->pre_valid) {  // whatever was prefetched has to be complete before this frame touches the same buffers
+        MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch_done, 0));
+        prefetched = f->pre_rgb == rgb && f->pre_depth == depth;
+        f->pre_valid = false;
+    }
+    if (prefetched) {  // the filter (:262) and the input-side preparation already ran on the side stream
+        f->cur ^= 1;
+        f->depth_filtered = f->filtered[f->cur];
+    } else {
+        rc = mmf_filter_depth(c, depth, f->width, f->height, g.depth_cutoff, f->depth_filtered);  // :262
+        if (rc) return rc;
+    }
 
     if (f->tick == 1) {  // :290-296
         rc = mmf_model_initialise(f->model, rgb, depth, f->depth_filtered, f->tick, g.max_depth_processed);
         if (rc) return rc;
         rc = mmf_odom_init_first_rgb(f->odom, rgb, 0, 3);
         if (rc) return rc;
+        MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
+        f->inputs_free_recorded = true;
     } else {
         f->tracking_ok = 1;
         if ((bootstrap || !in_pose) && init_transform) {
@@ -2297,7 +2363,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const uint8_t* rgb, const fl
             rc = odom_prepare_batched(f->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
                                       (const float*)m->normalRadius, pi, 4, pose, g.fill_in ? fill_flag : nullptr,
                                       (const float*)m->fill_vertex, (const float*)m->fill_normal,
-                                      (const uint8_t*)m->fill_image);
+                                      (const uint8_t*)m->fill_image, prefetched ? PREP_MODEL_SIDE : PREP_ALL);
             if (rc) return rc;
             float trans[3] = {pose[3], pose[7], pose[11]};
             float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
@@ -2315,6 +2381,11 @@ static int fusion_process_frame_impl(mmf_fusion* f, const uint8_t* rgb, const fl
             std::memcpy(f->last_pose, pose, sizeof(pose));
             mmf_model_set_pose(f->model, in_pose);  // globalModel->overridePose(*inPose) (:670)
         }
+
+        // from here on nothing enqueued reads the odometry's input-side buffers or the other filtered-depth
+        // buffer: the next frame's prefetch may start
+        MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
+        f->inputs_free_recorded = true;
 
         rc = fusion_predict(f, rgb);  // :675
         if (rc) return rc;
@@ -2351,6 +2422,29 @@ extern "C" int mmf_fusion_process_frame_init(mmf_fusion* f, const uint8_t* rgb, 
     return fusion_process_frame_impl(f, rgb, depth, timestamp, nullptr, weight_multiplier, 0, init_transform, icp_refine);
 }
 
+// The filter and the input-side preparation (vertex / normal maps, depth and intensity pyramids, gradients) of the
+// NEXT frame, enqueued on a second stream so that they run while the current frame is still being fused.
+// rgb / depth must stay unchanged until the mmf_fusion_process_frame call that consumes them (same pointers).
+extern "C" int mmf_fusion_prefetch_frame(mmf_fusion* f, const uint8_t* rgb, const float* depth) {
+    MMF_REQUIRE(f && rgb && depth, "mmf_fusion_prefetch_frame: null argument");
+    mmf_ctx* c = f->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    if (f->pre_valid) MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch_done, 0));  // replaced before use
+    f->pre_valid = false;
+    if (f->inputs_free_recorded) MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_inputs_free, 0));
+    const mmf_fusion_config& g = f->cfg;
+    float* target = f->filtered[1 - f->cur];
+    int rc = filter_depth_on(c, f->side, depth, f->width, f->height, g.depth_cutoff, target);
+    if (rc) return rc;
+    const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    rc = odom_prepare_batched(f->odom, target, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity, nullptr,
+                              nullptr, nullptr, nullptr, PREP_INPUT_SIDE, f->side);
+    if (rc) return rc;
+    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch_done, f->side));
+    f->pre_valid = true, f->pre_rgb = rgb, f->pre_depth = depth;
+    return MMF_OK;
+}
+
 extern "C" int mmf_fusion_get_pose(mmf_fusion* f, float pose[16]) {
     MMF_REQUIRE(f && pose, "mmf_fusion_get_pose: null argument");
     return mmf_model_get_pose(f->model, pose);
@@ -2360,6 +2454,10 @@ extern "C" int mmf_fusion_get_pose(mmf_fusion* f, float pose[16]) {
 // MultiMotionFusion does, MultiMotionFusion.cpp:21-97)
 extern "C" int mmf_fusion_reset(mmf_fusion* f) {
     MMF_REQUIRE(f != nullptr, "mmf_fusion_reset: null fusion object");
+    if (f->pre_valid) {  // a prefetched frame belongs to the sequence that ends here
+        MMF_HIP_TRY(hipStreamWaitEvent(f->ctx->stream, f->ev_prefetch_done, 0));
+        f->pre_valid = false;
+    }
     f->tick = 1;
     f->model->count = 0;
     for (int i = 0; i < 16; ++i) f->model->pose[i] = f->last_pose[i] = (i % 5 == 0) ? 1.f : 0.f;

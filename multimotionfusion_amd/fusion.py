@@ -54,6 +54,11 @@ class MultiMotionFusion:
                                                     fptr(pose) if pose is not None else None,
                                                     float(weightMultiplier), int(bool(bootstrap))))
 
+    def prefetchFrame(self, rgb, depth):
+        """Start the depth filter and the input-side preparation of the NEXT frame on a second stream (they overlap
+        the fusion of the current one).  The next processFrame call must get the same tensors, unchanged."""
+        check(self.ctx.lib.mmf_fusion_prefetch_frame(self.handle, _p(rgb), _p(depth)))
+
     def reset(self):
         check(self.ctx.lib.mmf_fusion_reset(self.handle))
 

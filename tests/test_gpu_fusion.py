@@ -257,3 +257,38 @@ def test_keypoint_initialisation_is_refused_in_frame_to_frame_mode(gpu_ctx):
     with pytest.raises(MmfError):  # MultiMotionFusion.cpp:370
         g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=1, initTransform=np.eye(4))
     g.close()
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (640, 480)])
+def test_prefetched_frames_give_the_same_bits(gpu_ctx, w, h):
+    """mmf_fusion_prefetch_frame runs the next frame's filter and input-side preparation on a second stream while
+    the current frame is fused: same kernels on the same inputs, so poses and surfels must be bit-identical to
+    frame-by-frame processing -- also when a prefetch is discarded (other pointers) or issued twice."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    n = 6
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=13)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    rgb = [dev(f["rgb"]) for f in frames]
+    depth = [dev(f["depth"]) for f in frames]
+    a = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    ref_poses = []
+    for i in range(n):
+        a.processFrame(rgb[i], depth[i], timestamp=i)
+        ref_poses.append(a.getCurrPose().copy())
+    ref_map = a.getBackgroundModel().downloadMap()
+    a.close()
+    b = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    b.prefetchFrame(rgb[0], depth[0])  # before the very first frame
+    for i in range(n):
+        b.processFrame(rgb[i], depth[i], timestamp=i)
+        if i + 1 < n:
+            if i == 2:  # a prefetch that is replaced before use, and one for a frame that never comes
+                b.prefetchFrame(rgb[0], depth[0])
+            if i != 3:  # frame 4 is processed without a prefetch
+                b.prefetchFrame(rgb[i + 1], depth[i + 1])
+            else:
+                b.prefetchFrame(rgb[0], depth[0])  # discarded: processFrame gets other pointers
+        assert np.array_equal(b.getCurrPose(), ref_poses[i]), i
+    assert np.array_equal(b.getBackgroundModel().downloadMap().view(np.uint32), ref_map.view(np.uint32))
+    b.close()
