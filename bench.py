@@ -161,7 +161,7 @@ def main():
         else:  # inputs already resident in HBM
             mmf.processFrame(d_rgb[k], d_depth[k], timestamp=i)
             kn = state["frame"] % len(frames)
-            if PREFETCH and kn != 0:  # the next frame's filter + pyramids overlap this frame's fusion (second stream)
+            if PREFETCH and kn != 0:  # the next frame's filter, pyramids and SO3 pre-alignment overlap this frame's fusion
                 mmf.prefetchFrame(d_rgb[kn], d_depth[kn])
         pose = mmf.getCurrPose()
         if world > 1:  # every rank learns every model's pose (18 floats per rank), without a host round trip
@@ -306,8 +306,8 @@ def main():
             "config": {"workload": f"{W}x{H} synthetic RGB-D sequence through MultiMotionFusion::processFrame, static "
                                    "scene (no segmentation): bilateral filter, dense ICP+RGB odometry (SO3 + 4/5/10 "
                                    "Gauss-Newton iterations, icpWeight 10) against the surfel splat, index map, fuse, "
-                                   "clean, splat + fill-in; one rigid-body model per GPU; the next frame's depth filter and input "
-                                   "pyramids run on a second stream during the current frame's fusion",
+                                   "clean, splat + fill-in; one rigid-body model per GPU; the next frame's depth filter, input "
+                                   "pyramids and SO3 pre-alignment run on two side streams during the current frame's fusion",
                        "width": W, "height": H, "models_per_gpu": 1, "parallelism": f"model-shard x{world}"},
             "roofline": roofline,
             "surfel_passes": surfel_passes,

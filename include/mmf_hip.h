@@ -311,9 +311,10 @@ int mmf_fusion_process_frame(mmf_fusion *f, const uint8_t *rgb, const float *dep
  * transformation is ignored, as in the reference.  Fails in frame-to-frame RGB mode (:370). */
 int mmf_fusion_process_frame_init(mmf_fusion *f, const uint8_t *rgb, const float *depth, long long timestamp,
                                   const float *init_transform, int icp_refine, float weight_multiplier);
-/* Overlap across frames: enqueue the depth filter and the input-side preparation of the NEXT frame (vertex /
- * normal maps, depth and intensity pyramids, gradients -- everything that depends on the sensor frame only) on a
- * second stream, where they run while the current frame is still being fused.  The following
+/* Overlap across frames: enqueue the work of the NEXT frame that depends on the sensor frame only -- the depth
+ * filter, vertex / normal maps and the depth pyramid on one side stream; the intensity pyramid, the gradients and
+ * the SO3 pre-alignment (last frame's image against this one's) on another -- where they run while the current
+ * frame is still being fused.  The following
  * mmf_fusion_process_frame(_init) call with the SAME rgb / depth pointers picks the results up instead of
  * recomputing them (same kernels, same bits); with other pointers the prefetch is discarded.  rgb / depth must
  * stay unchanged until that call.  Optional: without it every frame is processed on its own. */

@@ -730,6 +730,7 @@ struct mmf_odom {
     // set by odom_prepare_batched: gradients and point clouds are already built, and next_depth is
     // last_depth (both come from the same prediction, RGBDOdometry.cpp:179 -- see odom_populate_rgbd)
     bool prep_batched = false;
+    bool so3_prefetched = false;  // this frame's SO3 pre-alignment already ran (odom_prefetch_so3)
     mmf_odom_stats stats;
 };
 
@@ -1009,7 +1010,7 @@ struct PrepBuilder {
 // maps, depth and intensity pyramids, gradients) and those that depend on the model's prediction and pose.
 // The orchestrator can run the first group for frame t+1 on a second stream while frame t is still being fused
 // (mmf_fusion_prefetch_frame); PREP_ALL is both groups in the same four launches.
-enum PrepSide { PREP_ALL = 0, PREP_INPUT_SIDE = 1, PREP_MODEL_SIDE = 2 };
+enum PrepSide { PREP_INPUT_IMAGE = 1, PREP_INPUT_DEPTH = 2, PREP_MODEL_SIDE = 4, PREP_ALL = 7 };
 
 static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float depth_cutoff, const uint8_t* rgb,
                                 int rgb_channels, const float* pred_vertex, const float* pred_normal,
@@ -1019,7 +1020,8 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
                                 int side = PREP_ALL, hipStream_t stream = nullptr) {
     mmf_ctx* c = o->ctx;
     if (stream == nullptr) stream = c->stream;
-    const bool in_side = side != PREP_MODEL_SIDE, model_side = side != PREP_INPUT_SIDE;
+    const bool in_img = (side & PREP_INPUT_IMAGE) != 0, in_depth = (side & PREP_INPUT_DEPTH) != 0;
+    const bool model_side = (side & PREP_MODEL_SIDE) != 0;
     const int W = o->width, H = o->height;
     const size_t n0 = (size_t)W * H;
     // camera-frame model pyramids (before the transform into the global frame) live in the two 4*N-float
@@ -1049,9 +1051,11 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
             p.src0 = o->last_depth[lvl], p.dst0 = o->cloud[lvl];
             intr_f(p, lvl, false, 0.f);
         }
-        if (in_side) {
+        if (in_img) {
             PrepJob& d = pb.add(PREP_DERIV, cols, rows);
             d.src0 = o->next_image[lvl], d.dst0 = o->dIdx[lvl], d.dst1 = o->dIdy[lvl];
+        }
+        if (in_depth) {
             PrepJob& nm = pb.add(PREP_NMAP, cols, rows);
             nm.src0 = o->vmaps_curr[lvl], nm.dst0 = o->nmaps_curr[lvl];
         }
@@ -1062,7 +1066,7 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
         intr_f(j, lvl, true, depth_cutoff);
     };
     auto down_jobs = [&](PrepBuilder& pb, int lvl, const float* depth_src) {  // level lvl-1 -> lvl of every pyramid
-        if (in_side) pyr(pb, PREP_PYRDOWN_U8, o->next_image[lvl - 1], o->next_image[lvl], lvl);
+        if (in_img) pyr(pb, PREP_PYRDOWN_U8, o->next_image[lvl - 1], o->next_image[lvl], lvl);
         if (model_side) {
             pyr(pb, PREP_PYRDOWN_F, o->last_depth[lvl - 1], o->last_depth[lvl], lvl);
             pyr(pb, PREP_PYRDOWN_U8, o->last_image[lvl - 1], o->last_image[lvl], lvl);
@@ -1080,9 +1084,11 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
 
     {   // stage 1: inputs -> level 0 (and level 1 of the depth pyramid)
         PrepBuilder pb;
-        if (in_side) {
+        if (in_depth) {
             pyr(pb, PREP_PYRDOWN_F, depth_filtered, o->depth_pyr[1], 1);
             vmap_job(pb, 0, depth_filtered);
+        }
+        if (in_img) {
             PrepJob& in = pb.add(PREP_INTENSITY, W, H);
             in.src0 = rgb, in.dst0 = o->next_image[0], in.scols = W * rgb_channels, in.channels = rgb_channels;
         }
@@ -1102,7 +1108,7 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
     }
     {   // stage 2: level 0 -> level 1 (and level 2 of the depth pyramid)
         PrepBuilder pb;
-        if (in_side) {
+        if (in_depth) {
             pyr(pb, PREP_PYRDOWN_F, o->depth_pyr[1], o->depth_pyr[2], 2);
             vmap_job(pb, 1, o->depth_pyr[1]);
         }
@@ -1113,7 +1119,7 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
     }
     {   // stage 3: level 1 -> level 2
         PrepBuilder pb;
-        if (in_side) vmap_job(pb, 2, o->depth_pyr[2]);
+        if (in_depth) vmap_job(pb, 2, o->depth_pyr[2]);
         level_jobs(pb, 1);
         down_jobs(pb, 2, nullptr);
         int rc = pb.launch(stream);
@@ -1148,6 +1154,39 @@ static IcpArgs odom_icp_args(mmf_odom* o, int level, float* err_map) {
     return a;
 }
 
+// the ten launches of the SO3 pre-alignment (RGBDOdometry.cpp:239-310): last frame's image against this frame's
+// at level 2 -- no model, no pose
+static int odom_enqueue_so3(mmf_odom* o, hipStream_t stream) {
+    mmf_ctx* c = o->ctx;
+    const int lvl = 2, cols = o->width >> lvl, rows = o->height >> lvl;
+    So3Args a;
+    a.last_image = o->last_next_image[lvl];
+    a.next_image = o->next_image[lvl];
+    a.l_stride = a.n_stride = cols;
+    a.cols = cols;
+    a.rows = rows;
+    a.intr = level_intr(o->fx, o->fy, o->cx, o->cy, 2);
+    a.cols_magic = (unsigned)((1ull << 32) / (unsigned)cols) + 1u;
+    const int grid = reduce_grid(cols * rows, kBlock);
+    for (int i = 0; i < 10; ++i) {
+        hipLaunchKernelGGL((so3_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), 0, stream, o->state, a, c->partials_f,
+                           c->ticket);
+        MMF_HIP_TRY(hipGetLastError());
+    }
+    return MMF_OK;
+}
+
+// the SO3 pre-alignment of the NEXT frame ahead of its tracking, on `stream` (after that frame's intensity
+// pyramid): its begin part, then the ten launches; getIncrementalTransformation then skips both
+static int odom_prefetch_so3(mmf_odom* o, hipStream_t stream) {
+    hipLaunchKernelGGL(so3_begin_kernel, dim3(1), dim3(64), 0, stream, o->state, level_intr(o->fx, o->fy, o->cx, o->cy, 2));
+    MMF_HIP_TRY(hipGetLastError());
+    int rc = odom_enqueue_so3(o, stream);
+    if (rc) return rc;
+    o->so3_prefetched = true;
+    return MMF_OK;
+}
+
 // RGBDOdometry::getIncrementalTransformation (RGBDOdometry.cpp:217-477), device resident:
 // every kernel below is enqueued back to back on the context's stream; the data-dependent
 // `break`s of the reference (:285-292, :376-378) become flags in the device state that make the
@@ -1177,26 +1216,15 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
     b.so3 = so3 ? 1 : 0;
     b.icp_weight = icp_weight;
     b.so3_intr = level_intr(o->fx, o->fy, o->cx, o->cy, 2);
+    b.so3_prefetched = (so3 && o->so3_prefetched) ? 1 : 0;
     hipLaunchKernelGGL(odom_begin_kernel, dim3(1), dim3(64), 0, c->stream, o->state, b);
     MMF_HIP_TRY(hipGetLastError());
 
-    if (so3) {  // :239-310
-        const int lvl = 2, cols = o->width >> lvl, rows = o->height >> lvl;
-        So3Args a;
-        a.last_image = o->last_next_image[lvl];
-        a.next_image = o->next_image[lvl];
-        a.l_stride = a.n_stride = cols;
-        a.cols = cols;
-        a.rows = rows;
-        a.intr = b.so3_intr;
-        a.cols_magic = (unsigned)((1ull << 32) / (unsigned)cols) + 1u;
-        const int grid = reduce_grid(cols * rows, kBlock);
-        for (int i = 0; i < 10; ++i) {
-            hipLaunchKernelGGL((so3_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), 0, c->stream, o->state, a,
-                               c->partials_f, c->ticket);
-            MMF_HIP_TRY(hipGetLastError());
-        }
+    if (so3 && !o->so3_prefetched) {  // :239-310
+        int rc = odom_enqueue_so3(o, c->stream);
+        if (rc) return rc;
     }
+    o->so3_prefetched = false;
 
     const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};  // :312-314
     bool first_level = true;
@@ -2159,7 +2187,9 @@ struct mmf_fusion {
     // clean / fill-in read one while frame t+1's filter writes the other.
     float* filtered[2] = {nullptr, nullptr};
     int cur = 0;
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr;   // depth chain: filter, depth pyramid, vertex / normal maps
+    hipStream_t side2 = nullptr;  // image chain: intensity pyramid, gradients, SO3 pre-alignment
+    hipEvent_t ev_prefetch2_done = nullptr;
     hipEvent_t ev_inputs_free = nullptr;    // context stream: enqueued work no longer reads the odometry's input-side
                                             // buffers nor filtered[1 - cur]
     hipEvent_t ev_prefetch_done = nullptr;  // side stream: the prefetch has been enqueued up to here
@@ -2216,6 +2246,8 @@ extern "C" int mmf_fusion_create(mmf_ctx* c, int width, int height, float cx, fl
     MMF_HIP_TRY(hipMalloc(&f->filtered[1], npix * 4));
     f->depth_filtered = f->filtered[0];
     MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+    MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking));
+    MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch2_done, hipEventDisableTiming));
     MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_inputs_free, hipEventDisableTiming));
     MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch_done, hipEventDisableTiming));
     MMF_HIP_TRY(hipMalloc(&f->mask, npix));
@@ -2230,6 +2262,7 @@ extern "C" void mmf_fusion_destroy(mmf_fusion* f) {
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
     if (f->side) (void)hipStreamSynchronize(f->side);
+    if (f->side2) (void)hipStreamSynchronize(f->side2);
     mmf_model_destroy(f->model);
     mmf_odom_destroy(f->odom);
     (void)hipFree(f->filtered[0]);
@@ -2238,6 +2271,8 @@ extern "C" void mmf_fusion_destroy(mmf_fusion* f) {
     if (f->ev_inputs_free) (void)hipEventDestroy(f->ev_inputs_free);
     if (f->ev_prefetch_done) (void)hipEventDestroy(f->ev_prefetch_done);
     if (f->side) (void)hipStreamDestroy(f->side);
+    if (f->ev_prefetch2_done) (void)hipEventDestroy(f->ev_prefetch2_done);
+    if (f->side2) (void)hipStreamDestroy(f->side2);
     delete f;
 }
 
@@ -2294,9 +2329,12 @@ static int fusion_process_frame_impl(mmf_fusion* f, const uint8_t* rgb, const fl
     bool prefetched = false;
     if (f->pre_valid) {  // whatever was prefetched has to be complete before this frame touches the same buffers
         MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch_done, 0));
+        MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch2_done, 0));
         prefetched = f->pre_rgb == rgb && f->pre_depth == depth;
         f->pre_valid = false;
     }
+    // a prefetched SO3 pre-alignment only counts for the frame it was computed for, and only when that frame is tracked
+    if (!prefetched || f->tick == 1 || (in_pose && !bootstrap) || (init_transform && !icp_refine)) f->odom->so3_prefetched = false;
     if (prefetched) {  // the filter (:262) and the input-side preparation already ran on the side stream
         f->cur ^= 1;
         f->depth_filtered = f->filtered[f->cur];
@@ -2429,16 +2467,31 @@ extern "C" int mmf_fusion_prefetch_frame(mmf_fusion* f, const uint8_t* rgb, cons
     MMF_REQUIRE(f && rgb && depth, "mmf_fusion_prefetch_frame: null argument");
     mmf_ctx* c = f->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
-    if (f->pre_valid) MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch_done, 0));  // replaced before use
-    f->pre_valid = false;
-    if (f->inputs_free_recorded) MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_inputs_free, 0));
+    f->pre_valid = false;  // an earlier prefetch is simply overwritten: same streams, same order
+    if (f->inputs_free_recorded) {
+        MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_inputs_free, 0));
+        MMF_HIP_TRY(hipStreamWaitEvent(f->side2, f->ev_inputs_free, 0));
+    }
     const mmf_fusion_config& g = f->cfg;
-    float* target = f->filtered[1 - f->cur];
-    int rc = filter_depth_on(c, f->side, depth, f->width, f->height, g.depth_cutoff, target);
-    if (rc) return rc;
     const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    hipStream_t img_stream = f->side2;
+    // image chain (second side stream): intensity pyramid + gradients, then the SO3 pre-alignment, which needs
+    // nothing but this frame's and the last frame's level-2 images
+    int rc = odom_prepare_batched(f->odom, nullptr, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity,
+                                  nullptr, nullptr, nullptr, nullptr, PREP_INPUT_IMAGE, img_stream);
+    if (rc) return rc;
+    f->odom->so3_prefetched = false;
+    if (g.so3 && f->tick > 1) {  // a model exists: the frame will be tracked, SO3 first
+        rc = odom_prefetch_so3(f->odom, img_stream);
+        if (rc) return rc;
+    }
+    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch2_done, img_stream));
+    // depth chain (first side stream): filter, depth pyramid, vertex and normal maps
+    float* target = f->filtered[1 - f->cur];
+    rc = filter_depth_on(c, f->side, depth, f->width, f->height, g.depth_cutoff, target);
+    if (rc) return rc;
     rc = odom_prepare_batched(f->odom, target, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity, nullptr,
-                              nullptr, nullptr, nullptr, PREP_INPUT_SIDE, f->side);
+                              nullptr, nullptr, nullptr, PREP_INPUT_DEPTH, f->side);
     if (rc) return rc;
     MMF_HIP_TRY(hipEventRecord(f->ev_prefetch_done, f->side));
     f->pre_valid = true, f->pre_rgb = rgb, f->pre_depth = depth;
@@ -2456,8 +2509,10 @@ extern "C" int mmf_fusion_reset(mmf_fusion* f) {
     MMF_REQUIRE(f != nullptr, "mmf_fusion_reset: null fusion object");
     if (f->pre_valid) {  // a prefetched frame belongs to the sequence that ends here
         MMF_HIP_TRY(hipStreamWaitEvent(f->ctx->stream, f->ev_prefetch_done, 0));
+        MMF_HIP_TRY(hipStreamWaitEvent(f->ctx->stream, f->ev_prefetch2_done, 0));
         f->pre_valid = false;
     }
+    f->odom->so3_prefetched = false;
     f->tick = 1;
     f->model->count = 0;
     for (int i = 0; i < 16; ++i) f->model->pose[i] = f->last_pose[i] = (i % 5 == 0) ? 1.f : 0.f;

@@ -819,7 +819,32 @@ struct BeginArgs {
     int rgb_only, icp, rgb, so3;
     float icp_weight;
     LevelIntr so3_intr;  // level 2
+    int so3_prefetched;  // the SO3 pre-alignment of this frame already ran (so3_begin_kernel + the so3 launches)
 };
+
+// the SO3 part of the beginning (RGBDOdometry.cpp:239-255): depends on the two images only, so the orchestrator
+// can run it -- and the pre-alignment itself -- ahead of the rest (mmf_fusion_prefetch_frame)
+__device__ __forceinline__ void so3_begin(OdomState* st, const LevelIntr& so3_intr, int so3) {
+    for (int k = 0; k < 9; ++k) {
+        const double e = (k % 4 == 0) ? 1.0 : 0.0;
+        st->resultR[k] = e;
+        st->lastResultR[k] = e;
+        st->R_lr[k] = (float)e;
+    }
+    st->so3_lastError = FLT_MAX / 2;
+    st->so3_lastCount = FLT_MAX / 2;
+    st->so3_done = so3 ? 0 : 1;
+    st->st.so3_iterations_run = 0;
+    if (so3) {
+        const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        so3_prepare_store(st, I3, so3_intr);
+    }
+}
+
+__global__ void so3_begin_kernel(OdomState* st, LevelIntr so3_intr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    so3_begin(st, so3_intr, 1);
+}
 
 // RGBDOdometry.cpp:221-228, 237, 252-255, 316-328
 __global__ void odom_begin_kernel(OdomState* st, BeginArgs a) {
@@ -832,22 +857,9 @@ __global__ void odom_begin_kernel(OdomState* st, BeginArgs a) {
     st->rgb = a.rgb;
     st->so3 = a.so3;
     st->icp_weight = a.icp_weight;
-    for (int k = 0; k < 9; ++k) {
-        const double e = (k % 4 == 0) ? 1.0 : 0.0;
-        st->resultR[k] = e;
-        st->lastResultR[k] = e;
-        st->R_lr[k] = (float)e;
-    }
-    st->so3_lastError = FLT_MAX / 2;
-    st->so3_lastCount = FLT_MAX / 2;
-    st->so3_done = a.so3 ? 0 : 1;
     st->level_break = 0;
     st->st.iterations_run = 0;
-    st->st.so3_iterations_run = 0;
-    if (a.so3) {
-        const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        so3_prepare_store(st, I3, a.so3_intr);
-    }
+    if (!a.so3_prefetched) so3_begin(st, a.so3_intr, a.so3);
 }
 
 // start of a pyramid level: RGBDOdometry.cpp:320-328 (first level only), :344, :348-358
