@@ -2245,11 +2245,8 @@ extern "C" int mmf_fusion_create(mmf_ctx* c, int width, int height, float cx, fl
     MMF_HIP_TRY(hipMalloc(&f->filtered[0], npix * 4));
     MMF_HIP_TRY(hipMalloc(&f->filtered[1], npix * 4));
     f->depth_filtered = f->filtered[0];
-    MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
-    MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking));
-    MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch2_done, hipEventDisableTiming));
+    // the side streams and events of the prefetch are created by its first call
     MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_inputs_free, hipEventDisableTiming));
-    MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch_done, hipEventDisableTiming));
     MMF_HIP_TRY(hipMalloc(&f->mask, npix));
     MMF_HIP_TRY(hipMemsetAsync(f->mask, 0, npix, c->stream));
     for (int i = 0; i < 16; ++i) f->last_pose[i] = (i % 5 == 0) ? 1.f : 0.f;
@@ -2467,6 +2464,12 @@ extern "C" int mmf_fusion_prefetch_frame(mmf_fusion* f, const uint8_t* rgb, cons
     MMF_REQUIRE(f && rgb && depth, "mmf_fusion_prefetch_frame: null argument");
     mmf_ctx* c = f->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
+    if (f->side == nullptr) {  // first use
+        MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+        MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking));
+        MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch_done, hipEventDisableTiming));
+        MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch2_done, hipEventDisableTiming));
+    }
     f->pre_valid = false;  // an earlier prefetch is simply overwritten: same streams, same order
     if (f->inputs_free_recorded) {
         MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_inputs_free, 0));
