@@ -292,3 +292,40 @@ def test_prefetched_frames_give_the_same_bits(gpu_ctx, w, h):
         assert np.array_equal(b.getCurrPose(), ref_poses[i]), i
     assert np.array_equal(b.getBackgroundModel().downloadMap().view(np.uint32), ref_map.view(np.uint32))
     b.close()
+
+
+def test_prefetch_with_frames_that_are_not_tracked(gpu_ctx):
+    """a prefetched SO3 pre-alignment must not leak into a later frame when the frame it was computed for is not
+    tracked (pose given by the caller, keypoint initialisation without refinement)"""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h, n = 320, 240, 6
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=17)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    rgb = [dev(f["rgb"]) for f in frames]
+    depth = [dev(f["depth"]) for f in frames]
+    rel = [np.linalg.inv(poses[0]) @ p for p in poses]
+
+    def run(prefetch):
+        g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+        out = []
+        for i in range(n):
+            if i == 2:    # the caller dictates the pose: no tracking
+                g.processFrame(rgb[i], depth[i], timestamp=i, inPose=rel[i].astype(np.float32))
+            elif i == 4:  # keypoint transformation taken as it is: no tracking either
+                T = (np.linalg.inv(poses[i - 1]) @ poses[i]).astype(np.float32)
+                g.processFrame(rgb[i], depth[i], timestamp=i, initTransform=T, icpRefine=False)
+            else:
+                g.processFrame(rgb[i], depth[i], timestamp=i)
+            if prefetch and i + 1 < n:
+                g.prefetchFrame(rgb[i + 1], depth[i + 1])
+            out.append(g.getCurrPose().copy())
+        surfels = g.getBackgroundModel().downloadMap()
+        g.close()
+        return out, surfels
+
+    ref, ref_map = run(False)
+    got, got_map = run(True)
+    for i in range(n):
+        assert np.array_equal(ref[i], got[i]), i
+    assert np.array_equal(ref_map.view(np.uint32), got_map.view(np.uint32))
