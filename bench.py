@@ -258,8 +258,8 @@ def main():
         us_match = timed(match_raw, reps=100)
         flops = 2.0 * 1024 * 1024 * 256
         matcher = {"us": us_match, "nq": 1024, "nt": 1024, "dim": 256, "TFLOPs": flops / us_match / 1e6,
-                   "frac_f32_mfma_peak": flops / us_match / 1e6 / 157.3, "launches": 4,
-                   "kernels": "fill + row_norms_kernel (MFMA) + match_tile64_kernel (MFMA, LDS-shared 64x64 tiles) + match_cross_check_kernel"}
+                   "frac_f32_mfma_peak": flops / us_match / 1e6 / 157.3, "launches": 3,
+                   "kernels": "row_norms_kernel (MFMA; also resets the arg-min keys) + match_tile64_kernel (MFMA, LDS-shared 64x64 tiles) + match_cross_check_kernel"}
         # the SuperPoint keypoint network (north star: "the only true dense contractions ... on MFMA"): one
         # forward pass (12 convolutions + normalisation + heat map) on an image of the bench size, random-init
         # weights, f32 operands on v_mfma_f32_32x32x2_f32; flops = convolution multiply-adds * 2

@@ -72,14 +72,18 @@ __device__ __forceinline__ f32x16 gram_tile(const float* __restrict__ ra, const 
 // |x_r|^2 of every descriptor row = the diagonal of X X^T, taken from diagonal 32 x 32 MFMA tiles so that it
 // is the same fmaf chain as the oracle's (a lane-per-row scalar loop took 30 us per set for 1024 rows).
 // One wave per 32 rows of the concatenation [query ; train]; out = [qn ; tn].
+// also resets the arg-min keys of its rows (row_best for query blocks, col_best for train blocks) to `empty`
 __global__ __launch_bounds__(64) void row_norms_kernel(const float* __restrict__ q, int nq, const float* __restrict__ t, int nt,
-                                                       int dim, float* __restrict__ qn, float* __restrict__ tn) {
+                                                       int dim, float* __restrict__ qn, float* __restrict__ tn,
+                                                       unsigned long long* __restrict__ row_best,
+                                                       unsigned long long* __restrict__ col_best, unsigned long long empty) {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int qblocks = (nq + 31) / 32;
     const bool is_q = (int)blockIdx.x < qblocks;
     const float* x = is_q ? q : t;
     const int n = is_q ? nq : nt, i0 = (is_q ? blockIdx.x : blockIdx.x - qblocks) * 32;
     float* out = is_q ? qn : tn;
+    if (h == 0 && i0 + r < n) (is_q ? row_best : col_best)[i0 + r] = empty;
     const float* row = x + (size_t)min(i0 + r, n - 1) * dim;
     const f32x16 acc = gram_tile(row, row, dim, h);
     // C/D layout: col = lane & 31, row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5): the diagonal element of

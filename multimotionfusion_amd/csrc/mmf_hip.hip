@@ -1987,10 +1987,11 @@ extern "C" int mmf_match_descriptors(mmf_ctx* c, const float* query, int nq, con
     float* norms = reinterpret_cast<float*>(keys + c->match_ws_rows);
     unsigned long long *row_best = keys, *col_best = keys + nq;
     float *qn = norms, *tn = norms + nq;
-    hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, keys, rows, kNoMatchKey);
-    if (nt > 0) {
+    if (nt == 0)  // nothing to match against: every query stays unmatched
+        hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, keys, rows, kNoMatchKey);
+    if (nt > 0) {  // the norms kernel also resets the arg-min keys
         hipLaunchKernelGGL(row_norms_kernel, dim3((nq + 31) / 32 + (nt + 31) / 32), dim3(64), 0, c->stream, query, nq, train, nt,
-                           dim, qn, tn);
+                           dim, qn, tn, row_best, col_best, kNoMatchKey);
         if (dim % kMatchSlab == 0)  // 64 x 64 workgroup tiles with LDS-shared operands
             hipLaunchKernelGGL(match_tile64_kernel, dim3((nt + 63) / 64, (nq + 63) / 64), dim3(256), 0, c->stream, query, train,
                                qn, tn, nq, nt, dim, row_best, col_best);
