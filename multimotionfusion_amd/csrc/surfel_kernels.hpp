@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void bilateral_filter_kernel(const float* __re
 
 // Two horizontally adjacent pixels per lane: the filter is pure instruction issue -- 169 taps x ~50
 // instructions per pixel, 64 us at 640x480.  Sharing the per-tap scalar work (tap loads, spatial term,
-// loop control) between two pixels and the two exact rewrites below bring it to 47 us.  The pair is
+// loop control) between two pixels and the two exact rewrites below bring it to 47 us, the explicit fmaf steps
+// of mmf_expf (v_pk_fma_f32 here) to 38 us.  The pair is
 // written with packed registers (v_pk_mul_f32 / v_pk_add_f32); measured, a packed op costs what its two
 // scalar ops cost on gfx950 (an unpacked build of the same kernel: 48 us), so the packing itself is
 // neutral.  Bit-identical to the kernel above: the same float operations in the same order per pixel, with two exact rewrites of
@@ -183,22 +184,23 @@ __device__ __forceinline__ void expf_nonpositive2(const v2fs (&x)[NT], v2fs (&e)
     for (int k = 0; k < NT; ++k) n[k] = x[k] * 1.44269504088896341f;
 #pragma unroll
     for (int k = 0; k < NT; ++k) n[k] = v2fs{rintf(n[k].x), rintf(n[k].y)};
+    auto c2 = [](float c) { return v2fs{c, c}; };
 #pragma unroll
-    for (int k = 0; k < NT; ++k) r[k] = x[k] - n[k] * 0.693359375f;
+    for (int k = 0; k < NT; ++k) r[k] = __builtin_elementwise_fma(n[k], c2(-0.693359375f), x[k]);
 #pragma unroll
-    for (int k = 0; k < NT; ++k) r[k] = r[k] - n[k] * -2.12194440e-4f;
+    for (int k = 0; k < NT; ++k) r[k] = __builtin_elementwise_fma(n[k], c2(2.12194440e-4f), r[k]);
 #pragma unroll
-    for (int k = 0; k < NT; ++k) p[k] = v2fs{1.9875691500e-4f, 1.9875691500e-4f} * r[k] + 1.3981999507e-3f;
+    for (int k = 0; k < NT; ++k) p[k] = __builtin_elementwise_fma(c2(1.9875691500e-4f), r[k], c2(1.3981999507e-3f));
 #pragma unroll
-    for (int k = 0; k < NT; ++k) p[k] = p[k] * r[k] + 8.3334519073e-3f;
+    for (int k = 0; k < NT; ++k) p[k] = __builtin_elementwise_fma(p[k], r[k], c2(8.3334519073e-3f));
 #pragma unroll
-    for (int k = 0; k < NT; ++k) p[k] = p[k] * r[k] + 4.1665795894e-2f;
+    for (int k = 0; k < NT; ++k) p[k] = __builtin_elementwise_fma(p[k], r[k], c2(4.1665795894e-2f));
 #pragma unroll
-    for (int k = 0; k < NT; ++k) p[k] = p[k] * r[k] + 1.6666665459e-1f;
+    for (int k = 0; k < NT; ++k) p[k] = __builtin_elementwise_fma(p[k], r[k], c2(1.6666665459e-1f));
 #pragma unroll
-    for (int k = 0; k < NT; ++k) p[k] = p[k] * r[k] + 5.0000001201e-1f;
+    for (int k = 0; k < NT; ++k) p[k] = __builtin_elementwise_fma(p[k], r[k], c2(5.0000001201e-1f));
 #pragma unroll
-    for (int k = 0; k < NT; ++k) p[k] = p[k] * (r[k] * r[k]) + r[k] + 1.0f;
+    for (int k = 0; k < NT; ++k) p[k] = __builtin_elementwise_fma(p[k], r[k] * r[k], r[k]) + 1.0f;
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
         e[k] = v2fs{ldexpf(p[k].x, (int)n[k].x), ldexpf(p[k].y, (int)n[k].y)};
