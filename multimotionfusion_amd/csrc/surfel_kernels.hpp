@@ -946,9 +946,27 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
     __shared__ unsigned wave_part[4], wave_kept[4];
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned kp = (e < count + npix) ? keep[e] : 0u;
+    // one memory round trip: the keep flag, this thread's share of the block sums (ten loads in flight; a loop
+    // with a wait per iteration cost the late workgroups ~5 us) and, for the old surfels -- nearly all of which
+    // survive -- the surfel itself, all issued before anything is consumed
+    const bool live = e < count + npix, old = e < count;
+    const unsigned kp = live ? keep[e] : 0u;
+    constexpr int kSumsPerThread = 10;  // 2560 workgroups = 655 k elements without the tail loop
+    unsigned bs[kSumsPerThread];
+#pragma unroll
+    for (int u = 0; u < kSumsPerThread; ++u) {
+        const unsigned j = threadIdx.x + 256u * u;
+        bs[u] = j < blockIdx.x ? block_sums[j] : 0u;
+    }
+    float4 p, c, n;
+    float2 ct;
+    if (old) p = s.pos[e], c = s.col[e], n = s.nrm[e];
+    if (live) ct = conf_time[e];
+    __builtin_amdgcn_sched_barrier(0);
     unsigned part = 0;
-    for (unsigned j = threadIdx.x; j < blockIdx.x; j += 256) part += block_sums[j];
+#pragma unroll
+    for (int u = 0; u < kSumsPerThread; ++u) part += bs[u];
+    for (unsigned j = threadIdx.x + 256u * kSumsPerThread; j < blockIdx.x; j += 256) part += block_sums[j];
     part = wave_sum_to_lane63(part);
     const unsigned long long ballot = __ballot(kp != 0u);
     if (lane == 63) wave_part[wave] = part;
@@ -962,14 +980,10 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
     if (!kp) return;
     const unsigned k = base + (unsigned)__popcll(ballot & ((1ull << lane) - 1ull));
     if (k >= (unsigned)capacity) return;  // the reference's VBO is full: further primitives are dropped
-    float4 p, c, n;
-    if (e < count) {
-        p = s.pos[e], c = s.col[e], n = s.nrm[e];
-    } else {
+    if (!old) {  // a new measurement that survives (few): fetched now
         const int d = e - count;
         p = meas.pos[d], c = meas.col[d], n = meas.nrm[d];
     }
-    const float2 ct = conf_time[e];
     p.w = ct.x;
     c.w = ct.y;
     dst.pos[k] = p;
