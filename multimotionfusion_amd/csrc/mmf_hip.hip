@@ -1741,7 +1741,9 @@ extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cut
 }
 
 // ModelProjection::combinedPredict(ACTIVE) (ModelProjection.cpp:187-269); Model.h:210-214
-extern "C" int mmf_model_combined_predict(mmf_model* m, float depth_cutoff, int time, int max_time, int time_delta) {
+// fill_rgb / fill_depth != nullptr: Model::performFillIn in the same pass as the resolve (the orchestrator's predict)
+static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, int max_time, int time_delta,
+                                  const uint8_t* fill_rgb, const float* fill_depth, int frame_to_frame_rgb, int lost) {
     MMF_REQUIRE(m != nullptr, "mmf_model_combined_predict: null model");
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
@@ -1759,10 +1761,19 @@ extern "C" int mmf_model_combined_predict(mmf_model* m, float depth_cutoff, int 
     if (launch_count)
         hipLaunchKernelGGL(splat_kernel, grid1d(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
                            m->keys, m->count_pending ? m->totals : nullptr);
-    hipLaunchKernelGGL(splat_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->image,
-                       m->vertexConf, m->normalRadius, m->time_tex);
+    if (fill_rgb && fill_depth)
+        hipLaunchKernelGGL(splat_resolve_fill_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys,
+                           m->image, m->vertexConf, m->normalRadius, m->time_tex, fill_depth, fill_rgb, lost ? 1 : 0,
+                           (lost || frame_to_frame_rgb) ? 1 : 0, m->fill_vertex, m->fill_normal, m->fill_image);
+    else
+        hipLaunchKernelGGL(splat_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->image,
+                           m->vertexConf, m->normalRadius, m->time_tex);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
+}
+
+extern "C" int mmf_model_combined_predict(mmf_model* m, float depth_cutoff, int time, int max_time, int time_delta) {
+    return model_combined_predict(m, depth_cutoff, time, max_time, time_delta, nullptr, nullptr, 0, 0);
 }
 
 // ModelProjection::synthesizeDepth (ModelProjection.cpp:275-335): same sprites and depth test as
@@ -2281,11 +2292,10 @@ extern "C" const float* mmf_fusion_depth_filtered(mmf_fusion* f) { return f ? f-
 
 // MultiMotionFusion::predict (MultiMotionFusion.cpp:863-875)
 static int fusion_predict(mmf_fusion* f, const uint8_t* rgb) {
-    int rc = mmf_model_combined_predict(f->model, f->cfg.max_depth_processed, f->tick, f->tick, f->cfg.time_delta);
-    if (rc) return rc;
-    if (f->cfg.fill_in)
-        rc = mmf_model_perform_fill_in(f->model, rgb, f->depth_filtered, f->cfg.frame_to_frame_rgb, /*lost*/ 0);
-    return rc;
+    if (f->cfg.fill_in)  // combinedPredict + performFillIn in one pass
+        return model_combined_predict(f->model, f->cfg.max_depth_processed, f->tick, f->tick, f->cfg.time_delta, rgb,
+                                      f->depth_filtered, f->cfg.frame_to_frame_rgb, /*lost*/ 0);
+    return mmf_model_combined_predict(f->model, f->cfg.max_depth_processed, f->tick, f->tick, f->cfg.time_delta);
 }
 
 // Model::computeFusionWeight (Model.cpp:876-891): the norm of rodrigues2(R) is the rotation angle

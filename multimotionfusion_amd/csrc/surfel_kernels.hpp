@@ -547,20 +547,23 @@ __global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, Spla
         }
 }
 
-__global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatArgs a,
-                                                            unsigned long long* __restrict__ keys,
-                                                            uchar4* __restrict__ image, float4* __restrict__ vertexConf,
-                                                            float4* __restrict__ normalRadius,
-                                                            unsigned short* __restrict__ time_out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.cols * a.rows) return;
+struct SplatTexel {
+    uchar4 image;
+    float4 vertexConf, normalRadius;
+    unsigned short time;
+};
+
+// the splat images' texel i from the depth-test winner (and the key handed back empty)
+__device__ __forceinline__ SplatTexel splat_resolve_px(int i, const SurfelSoA& s, const SplatArgs& a,
+                                                       unsigned long long* __restrict__ keys) {
+    SplatTexel t;
     const unsigned long long k = keys[i];
     if (k != kEmptyKey) keys[i] = kEmptyKey;
     if (k == kEmptyKey) {
-        image[i] = make_uchar4(0, 0, 0, 0);
-        vertexConf[i] = normalRadius[i] = make_float4(0, 0, 0, 0);
-        time_out[i] = 0;
-        return;
+        t.image = make_uchar4(0, 0, 0, 0);
+        t.vertexConf = t.normalRadius = make_float4(0, 0, 0, 0);
+        t.time = 0;
+        return t;
     }
     const unsigned id = (unsigned)k;
     const int py = i / a.cols, px = i - py * a.cols;
@@ -570,12 +573,26 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatAr
     unsigned d24;
     splat_fragment(f, a, px, py, z, d24);  // the winner's own fragment: same arithmetic as in splat_kernel
     const v3 rgb = decode_color(col.x);
-    image[i] = make_uchar4((unsigned char)(int)roundf(rgb.x * 255.0f), (unsigned char)(int)roundf(rgb.y * 255.0f),
-                           (unsigned char)(int)roundf(rgb.z * 255.0f), 255);
+    t.image = make_uchar4((unsigned char)(int)roundf(rgb.x * 255.0f), (unsigned char)(int)roundf(rgb.y * 255.0f),
+                          (unsigned char)(int)roundf(rgb.z * 255.0f), 255);
     const float fcx = px + 0.5f, fcy = py + 0.5f;
-    vertexConf[i] = make_float4((fcx - a.c.cx) * z * (1.f / a.c.fx), (fcy - a.c.cy) * z * (1.f / a.c.fy), z, p.w);
-    normalRadius[i] = make_float4(f.nrm.x, f.nrm.y, f.nrm.z, f.rad);
-    time_out[i] = (unsigned short)(unsigned)col.z;
+    t.vertexConf = make_float4((fcx - a.c.cx) * z * (1.f / a.c.fx), (fcy - a.c.cy) * z * (1.f / a.c.fy), z, p.w);
+    t.normalRadius = make_float4(f.nrm.x, f.nrm.y, f.nrm.z, f.rad);
+    t.time = (unsigned short)(unsigned)col.z;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatArgs a,
+                                                            unsigned long long* __restrict__ keys,
+                                                            uchar4* __restrict__ image, float4* __restrict__ vertexConf,
+                                                            float4* __restrict__ normalRadius,
+                                                            unsigned short* __restrict__ time_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.cols * a.rows) return;
+    const SplatTexel t = splat_resolve_px(i, s, a, keys);
+    image[i] = t.image;
+    vertexConf[i] = t.vertexConf, normalRadius[i] = t.normalRadius;
+    time_out[i] = t.time;
 }
 
 // depth_splat.frag (ModelProjection::synthesizeDepth): the winner's corrected_pos.z, 0 where cleared
@@ -992,24 +1009,21 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
 }
 
 // ---- fill-in (fill_vertex.frag, fill_normal.frag, fill_rgb.frag) + thumbnail count ------------------
-__global__ __launch_bounds__(256) void fill_in_kernel(const float4* __restrict__ vertex_pred, const float4* __restrict__ normal_pred,
-                                                      const uchar4* __restrict__ image_pred, const float* __restrict__ depth_fil,
-                                                      const uint8_t* __restrict__ rgb, int cols, int rows, Cam c,
-                                                      int passthrough_geom, int passthrough_rgb, float4* __restrict__ vertex_out,
-                                                      float4* __restrict__ normal_out, uchar4* __restrict__ image_out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= cols * rows) return;
+// one texel of the three fill-in passes from the prediction's values at that texel
+__device__ __forceinline__ void fill_in_px(int i, const float4 vp, const float4 np, const uchar4 e,
+                                           const float* __restrict__ depth_fil, const uint8_t* __restrict__ rgb, int cols,
+                                           int rows, const Cam& c, int passthrough_geom, int passthrough_rgb,
+                                           float4* __restrict__ vertex_out, float4* __restrict__ normal_out,
+                                           uchar4* __restrict__ image_out) {
     const int py = i / cols, px = i - py * cols;
     const float tx = (px + 0.5f) / cols, ty = (py + 0.5f) / rows;
     const int ix = (int)(tx * cols), iy = (int)(ty * rows);
-    const float4 vp = vertex_pred[i];
     if (vp.z == 0 || passthrough_geom == 1) {
         const float z = depth_fil[texel(ty, rows) * cols + texel(tx, cols)];
         vertex_out[i] = make_float4((ix - c.cx) * z * c.ifx, (iy - c.cy) * z * c.ify, z, 1.f);
     } else {
         vertex_out[i] = vp;
     }
-    const float4 np = normal_pred[i];
     if (np.z == 0 || passthrough_geom == 1) {
         const v3 p = get_vertex(depth_fil, cols, rows, tx, ty, (float)ix, (float)iy, c);
         const v3 vx = get_vertex(depth_fil, cols, rows, tx + (1.0f / cols), ty, (float)(ix + 1), (float)iy, c);
@@ -1019,11 +1033,42 @@ __global__ __launch_bounds__(256) void fill_in_kernel(const float4* __restrict__
     } else {
         normal_out[i] = np;
     }
-    const uchar4 e = image_pred[i];
     if (e.x / 255.0f + e.y / 255.0f + e.z / 255.0f == 0 || passthrough_rgb == 1)
         image_out[i] = make_uchar4(rgb[3 * i + 0], rgb[3 * i + 1], rgb[3 * i + 2], 255);
     else
         image_out[i] = e;
+}
+
+__global__ __launch_bounds__(256) void fill_in_kernel(const float4* __restrict__ vertex_pred, const float4* __restrict__ normal_pred,
+                                                      const uchar4* __restrict__ image_pred, const float* __restrict__ depth_fil,
+                                                      const uint8_t* __restrict__ rgb, int cols, int rows, Cam c,
+                                                      int passthrough_geom, int passthrough_rgb, float4* __restrict__ vertex_out,
+                                                      float4* __restrict__ normal_out, uchar4* __restrict__ image_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cols * rows) return;
+    fill_in_px(i, vertex_pred[i], normal_pred[i], image_pred[i], depth_fil, rgb, cols, rows, c, passthrough_geom,
+               passthrough_rgb, vertex_out, normal_out, image_out);
+}
+
+// combinedPredict's resolve and performFillIn in one pass over the image (MultiMotionFusion::predict runs them
+// back to back, MultiMotionFusion.cpp:863-875): the fill-in takes the prediction's texel from registers instead of
+// reading the three images back
+__global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, SplatArgs a, unsigned long long* __restrict__ keys,
+                                                                 uchar4* __restrict__ image, float4* __restrict__ vertexConf,
+                                                                 float4* __restrict__ normalRadius,
+                                                                 unsigned short* __restrict__ time_out,
+                                                                 const float* __restrict__ depth_fil,
+                                                                 const uint8_t* __restrict__ rgb, int passthrough_geom,
+                                                                 int passthrough_rgb, float4* __restrict__ vertex_out,
+                                                                 float4* __restrict__ normal_out, uchar4* __restrict__ image_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.cols * a.rows) return;
+    const SplatTexel t = splat_resolve_px(i, s, a, keys);
+    image[i] = t.image;
+    vertexConf[i] = t.vertexConf, normalRadius[i] = t.normalRadius;
+    time_out[i] = t.time;
+    fill_in_px(i, t.vertexConf, t.normalRadius, t.image, depth_fil, rgb, a.cols, a.rows, a.c, passthrough_geom, passthrough_rgb,
+               vertex_out, normal_out, image_out);
 }
 
 // requiresFillIn: number of (cols/20 x rows/20) thumbnail samples with all three channels > 0
