@@ -417,6 +417,7 @@ extern "C" int mmf_rgb_step(mmf_ctx* c, const mmf_dataterm* corres_dev, float si
                                hipMemcpyHostToDevice, c->stream));
     RgbStepArgs a;
     a.next_level = 0;
+    a.final_step = 0;
     a.cols_magic = 0;
     a.residual_partials = nullptr;
     a.residual_records = 0;
@@ -1217,6 +1218,10 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
     b.icp_weight = icp_weight;
     b.so3_intr = level_intr(o->fx, o->fy, o->cx, o->cy, 2);
     b.so3_prefetched = (so3 && o->so3_prefetched) ? 1 : 0;
+    // nothing runs between the beginning and the first level's begin unless the SO3 loop does: one launch
+    const bool fold_first_level = !so3 || o->so3_prefetched;
+    b.fold_level_begin = fold_first_level ? 1 : 0;
+    b.first_intr = level_intr(o->fx, o->fy, o->cx, o->cy, MMF_NUM_PYRS - 1);
     hipLaunchKernelGGL(odom_begin_kernel, dim3(1), dim3(64), 0, c->stream, o->state, b);
     MMF_HIP_TRY(hipGetLastError());
 
@@ -1228,7 +1233,9 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
 
     const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};  // :312-314
     bool first_level = true;
-    bool begin_folded = false;  // this level's gn_level_begin ran in the last rgb_step of the level before
+    bool end_folded = false;  // odom_end ran in the finishing lane of the frame's last rgb_step
+    bool begin_folded = fold_first_level;  // this level's gn_level_begin already ran (in odom_begin_kernel, or in the
+                                           // last rgb_step of the level before)
     for (int i = MMF_NUM_PYRS - 1; i >= 0; --i) {
         const int cols = o->width >> i, rows = o->height >> i;
         const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, i);
@@ -1317,6 +1324,8 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
                 // the last step of a level also does the next level's gn_level_begin (one launch less per
                 // level).  Not with rgbOnly: its divergence `break` skips the finishing lane.
                 a.next_level = 0;
+                a.final_step = (last_l0 && !rgb_only) ? 1 : 0;  // odom_end in the finishing lane (which rgbOnly's `break` skips)
+                end_folded = a.final_step != 0;
                 if (j == iterations[i] - 1 && i > 0 && iterations[i - 1] > 0 && !rgb_only) {
                     a.next_level = 1;
                     a.intr = level_intr(o->fx, o->fy, o->cx, o->cy, i - 1);  // only read by the finishing lane's rgb_prepare
@@ -1334,8 +1343,10 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
         }
     }
 
-    hipLaunchKernelGGL(odom_end_kernel, dim3(1), dim3(64), 0, c->stream, o->state);
-    MMF_HIP_TRY(hipGetLastError());
+    if (!end_folded) {
+        hipLaunchKernelGGL(odom_end_kernel, dim3(1), dim3(64), 0, c->stream, o->state);
+        MMF_HIP_TRY(hipGetLastError());
+    }
     MMF_HIP_TRY(hipMemcpyAsync(o->host_result, o->state, sizeof(OdomState), hipMemcpyDeviceToHost, c->stream));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
 

@@ -530,7 +530,21 @@ struct RgbStepArgs {
     unsigned cols_magic;  // floor(2^32 / cols) + 1
     LevelIntr intr;       // intrinsics the finishing lane prepares the NEXT correspondence pass with
     int next_level;       // 1: that pass belongs to the next pyramid level (gn_level_begin_kernel folded in)
+    int final_step;       // 1: the very last step of the frame: the finishing lane also does odom_end
 };
+
+// RGBDOdometry.cpp:464-467, 475-476
+__device__ __forceinline__ void odom_end(OdomState* st) {
+    if (st->rgb) {
+        const float dx = st->tcurr[0] - st->tprev[0], dy = st->tcurr[1] - st->tprev[1], dz = st->tcurr[2] - st->tprev[2];
+        if (sqrtf(dx * dx + dy * dy + dz * dz) > 0.3) {
+            for (int k = 0; k < 9; ++k) st->Rcurr[k] = st->Rprev[k];
+            for (int k = 0; k < 3; ++k) st->tcurr[k] = st->tprev[k];
+        }
+    }
+    for (int k = 0; k < 3; ++k) st->trans_out[k] = st->tcurr[k];
+    for (int k = 0; k < 9; ++k) st->rot_out[k] = st->Rcurr[k];
+}
 
 // The two halves of one pass of rgbKernel (reduce.cu:504-535) over the PX records of a lane.
 // rgb_gather: every gather issued before any is consumed.  Records without a correspondence carry
@@ -691,6 +705,7 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
             st->st.lastRGBCount = (float)res_count;
 #ifndef MMF_SKIP_SOLVE
             solve_and_update(st, si, lds.total, icp ? lds.total2 : nullptr, a.intr);
+            if (a.final_step) odom_end(st);  // one launch less at the end of the frame
 #endif
 #ifdef MMF_STAMPS
             if (g_mmf_dbg) g_mmf_dbg[blockIdx.x * 16 + 7] = wall_clock64() + (st->Rcurr[0] == 1234.5f ? 1 : 0);
@@ -820,6 +835,8 @@ struct BeginArgs {
     float icp_weight;
     LevelIntr so3_intr;  // level 2
     int so3_prefetched;  // the SO3 pre-alignment of this frame already ran (so3_begin_kernel + the so3 launches)
+    int fold_level_begin;  // nothing runs between this kernel and the first gn_level_begin: do it here
+    LevelIntr first_intr;  // intrinsics of the first (coarsest) level
 };
 
 // the SO3 part of the beginning (RGBDOdometry.cpp:239-255): depends on the two images only, so the orchestrator
@@ -846,25 +863,8 @@ __global__ void so3_begin_kernel(OdomState* st, LevelIntr so3_intr) {
     so3_begin(st, so3_intr, 1);
 }
 
-// RGBDOdometry.cpp:221-228, 237, 252-255, 316-328
-__global__ void odom_begin_kernel(OdomState* st, BeginArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int k = 0; k < 9; ++k) st->Rprev[k] = st->Rcurr[k] = a.rot[k];
-    for (int k = 0; k < 3; ++k) st->tprev[k] = st->tcurr[k] = a.trans[k];
-    inverse3f(st->Rprev, st->Rprev_inv);
-    st->rgb_only = a.rgb_only;
-    st->icp = a.icp;
-    st->rgb = a.rgb;
-    st->so3 = a.so3;
-    st->icp_weight = a.icp_weight;
-    st->level_break = 0;
-    st->st.iterations_run = 0;
-    if (!a.so3_prefetched) so3_begin(st, a.so3_intr, a.so3);
-}
-
 // start of a pyramid level: RGBDOdometry.cpp:320-328 (first level only), :344, :348-358
-__global__ void gn_level_begin_kernel(OdomState* st, int first_level, LevelIntr intr) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void gn_level_begin(OdomState* st, int first_level, const LevelIntr& intr) {
     double resultRt[16];
     if (first_level) {
         for (int k = 0; k < 16; ++k) resultRt[k] = (k % 5 == 0) ? 1.0 : 0.0;
@@ -884,18 +884,31 @@ __global__ void gn_level_begin_kernel(OdomState* st, int first_level, LevelIntr 
     for (int k = 0; k < 3; ++k) st->kt[k] = kt[k];
 }
 
-// RGBDOdometry.cpp:464-467, 475-476
+// RGBDOdometry.cpp:221-228, 237, 252-255, 316-328
+__global__ void odom_begin_kernel(OdomState* st, BeginArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < 9; ++k) st->Rprev[k] = st->Rcurr[k] = a.rot[k];
+    for (int k = 0; k < 3; ++k) st->tprev[k] = st->tcurr[k] = a.trans[k];
+    inverse3f(st->Rprev, st->Rprev_inv);
+    st->rgb_only = a.rgb_only;
+    st->icp = a.icp;
+    st->rgb = a.rgb;
+    st->so3 = a.so3;
+    st->icp_weight = a.icp_weight;
+    st->level_break = 0;
+    st->st.iterations_run = 0;
+    if (!a.so3_prefetched) so3_begin(st, a.so3_intr, a.so3);
+    if (a.fold_level_begin) gn_level_begin(st, 1, a.first_intr);
+}
+
+__global__ void gn_level_begin_kernel(OdomState* st, int first_level, LevelIntr intr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    gn_level_begin(st, first_level, intr);
+}
+
 __global__ void odom_end_kernel(OdomState* st) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (st->rgb) {
-        const float dx = st->tcurr[0] - st->tprev[0], dy = st->tcurr[1] - st->tprev[1], dz = st->tcurr[2] - st->tprev[2];
-        if (sqrtf(dx * dx + dy * dy + dz * dz) > 0.3) {
-            for (int k = 0; k < 9; ++k) st->Rcurr[k] = st->Rprev[k];
-            for (int k = 0; k < 3; ++k) st->tcurr[k] = st->tprev[k];
-        }
-    }
-    for (int k = 0; k < 3; ++k) st->trans_out[k] = st->tcurr[k];
-    for (int k = 0; k < 9; ++k) st->rot_out[k] = st->Rcurr[k];
+    odom_end(st);
 }
 
 }  // namespace mmf
