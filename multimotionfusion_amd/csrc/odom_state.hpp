@@ -422,8 +422,36 @@ __device__ unsigned long long* g_mmf_dbg_solve = nullptr;
     } while (0)
 #endif
 
+// index of element (i, j), i <= j < 7, in the 29-sum record (the order unpack_se3 walks)
+__device__ __forceinline__ int se3_packed_index(int i, int j) { return i * 7 - (i * (i - 1)) / 2 + (j - i); }
+
+// Lane l < 42 of the finishing workgroup: element l of the combined system (l < 36: A[l], else b[l - 36]),
+// RGBDOdometry.cpp:431-435 -- the same expression per element as the serial combine.  Also stores it to
+// lastA / lastb, so the solving lane neither unpacks, combines nor issues those 42 stores.
+__device__ __forceinline__ double combine_element(OdomState* st, int l, double w, const float* tot_rgb, const float* tot_icp) {
+    int i, j;
+    if (l < 36) {
+        const int r = l / 6, c = l - r * 6;
+        i = r < c ? r : c, j = r < c ? c : r;
+    } else {
+        i = l - 36, j = 6;
+    }
+    const int idx = se3_packed_index(i, j);
+    double v;
+    if (tot_icp && tot_rgb)
+        v = l < 36 ? (double)tot_rgb[idx] + w * w * (double)tot_icp[idx] : (double)tot_rgb[idx] + w * (double)tot_icp[idx];
+    else
+        v = tot_icp ? (double)tot_icp[idx] : (double)tot_rgb[idx];
+    if (l < 36)
+        st->st.lastA[l] = v;
+    else
+        st->st.lastb[l - 36] = v;
+    return v;
+}
+
+// preA / preb (optional): the combined system, already stored to lastA / lastb (combine_element)
 __device__ inline void solve_and_update(OdomState* st, const SolveIn& si, const float* tot_rgb, const float* tot_icp,
-                                        const LevelIntr& in) {
+                                        const LevelIntr& in, const double* preA = nullptr, const double* preb = nullptr) {
     const double w = si.w;
     const int iters = si.iters;
     double resultRt[16];
@@ -434,9 +462,13 @@ __device__ inline void solve_and_update(OdomState* st, const SolveIn& si, const 
 
     float A_rgb[36], b_rgb[6], A_icp[36], b_icp[6];
     double A[36], b[6];
-    if (tot_rgb) unpack_se3(tot_rgb, A_rgb, b_rgb);
-    if (tot_icp) unpack_se3(tot_icp, A_icp, b_icp);
-    if (tot_icp && tot_rgb) {  // :431-435
+    if (preA) {
+        for (int k = 0; k < 36; ++k) A[k] = preA[k];
+        for (int k = 0; k < 6; ++k) b[k] = preb[k];
+    } else if (tot_rgb) unpack_se3(tot_rgb, A_rgb, b_rgb);
+    if (!preA && tot_icp) unpack_se3(tot_icp, A_icp, b_icp);
+    if (preA) {
+    } else if (tot_icp && tot_rgb) {  // :431-435
         for (int k = 0; k < 36; ++k) A[k] = (double)A_rgb[k] + w * w * (double)A_icp[k];
         for (int k = 0; k < 6; ++k) b[k] = (double)b_rgb[k] + w * (double)b_icp[k];
     } else if (tot_icp) {
@@ -491,8 +523,10 @@ __device__ inline void solve_and_update(OdomState* st, const SolveIn& si, const 
     MMF_SOLVE_STAMP(15);
     // exit stores
     st->st.iterations_run = iters + 1;
-    for (int k = 0; k < 36; ++k) st->st.lastA[k] = A[k];
-    for (int k = 0; k < 6; ++k) st->st.lastb[k] = b[k];
+    if (!preA) {
+        for (int k = 0; k < 36; ++k) st->st.lastA[k] = A[k];
+        for (int k = 0; k < 6; ++k) st->st.lastb[k] = b[k];
+    }
     for (int k = 0; k < 16; ++k) st->resultRt[k] = resultRt[k];
     for (int k = 0; k < 9; ++k) {
         st->Rcurr[k] = Rcurr[k];

@@ -695,6 +695,11 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
         // boundary => plain loads), all loads in flight together
         sum_partial_records2<kBlock>(partials, gridDim.x, a.icp_partials, icp ? a.icp_records : 0u, lds);
         MMF_STAMP(6);
+        // the 36 + 6 elements of the combined system by 42 lanes (and their lastA / lastb stores), so that the
+        // solving lane starts from the finished matrix
+        __shared__ double sol[42];
+        if (threadIdx.x < 42) sol[threadIdx.x] = combine_element(st, threadIdx.x, si.w, lds.total, icp ? lds.total2 : nullptr);
+        __syncthreads();
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < 2 * kResShards; ++k) st->res_acc[k] = 0u;
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
             st->st.lastRGBError = a.next_level ? FLT_MAX : dec.tmpError;  // RGBDOdometry.cpp:329 at a level start
             st->st.lastRGBCount = (float)res_count;
 #ifndef MMF_SKIP_SOLVE
-            solve_and_update(st, si, lds.total, icp ? lds.total2 : nullptr, a.intr);
+            solve_and_update(st, si, lds.total, icp ? lds.total2 : nullptr, a.intr, sol, sol + 36);
             if (a.final_step) odom_end(st);  // one launch less at the end of the frame
 #endif
 #ifdef MMF_STAMPS
