@@ -11,6 +11,7 @@
 #include "../../multimotionfusion_amd/cpp/MultiMotionFusion.h"
 #include "../../multimotionfusion_amd/cpp/RigidRANSAC.h"
 #include "../../multimotionfusion_amd/cpp/SuperPoint.h"
+#include "../../multimotionfusion_amd/cpp/cudafuncs.h"
 
 int main(int argc, char** argv) {
     if (argc < 2) {  // CPU containers: the check is that everything above compiles and links

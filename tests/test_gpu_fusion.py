@@ -329,3 +329,19 @@ def test_prefetch_with_frames_that_are_not_tracked(gpu_ctx):
     for i in range(n):
         assert np.array_equal(ref[i], got[i]), i
     assert np.array_equal(ref_map.view(np.uint32), got_map.view(np.uint32))
+
+
+def test_cpp_function_level_shim_on_the_device(tmp_path):
+    """cpp/cudafuncs.h: the reference's device entry points by their own names (icpStep, createVMap, pyrDownGaussF
+    ...) on DeviceArray / DeviceArray2D handles -- compiled with g++ against libmmf_hip.so and run with known
+    answers (tests/cpp/cudafuncs_check.cpp)."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(repo, "multimotionfusion_amd")
+    exe = tmp_path / "cudafuncs_check"
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-isystem", "/opt/rocm/include",
+                    os.path.join(repo, "tests", "cpp", "cudafuncs_check.cpp"), "-o", str(exe), f"-L{pkg}", "-lmmf_hip",
+                    "-lamdhip64", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "cudafuncs shim: ok" in r.stdout, (r.stdout, r.stderr)
