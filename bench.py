@@ -123,19 +123,25 @@ def main():
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     d_rgb = [up(f["rgb"]) for f in frames]
     d_depth = [up(f["depth"]) for f in frames]
-    # N > 1: two frame buffers, so that rank 0's broadcast of frame k + 1 (RCCL's own stream) overlaps the
-    # processing of frame k
-    rgb_in = [torch.empty_like(d_rgb[0]) for _ in range(2)]
-    depth_in = [torch.empty_like(d_depth[0]) for _ in range(2)]
-    mask_in = [torch.zeros(H, W, dtype=torch.uint8, device=dev) for _ in range(2)]
+    # N > 1: three frame buffers -- frame k is processed, frame k + 1 (already received) is prefetched on the
+    # side streams, frame k + 2 is being broadcast by rank 0 (RCCL's own stream)
+    NB = 3
+    rgb_in = [torch.empty_like(d_rgb[0]) for _ in range(NB)]
+    depth_in = [torch.empty_like(d_depth[0]) for _ in range(NB)]
+    mask_in = [torch.zeros(H, W, dtype=torch.uint8, device=dev) for _ in range(NB)]
     pending = {}
+    posted = set()
 
     ctx = Context(local_rank)
     from multimotionfusion_amd.fusion import MultiMotionFusion
     mmf = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], icp_weight=ICP_WEIGHT)
     odom = mmf.getFrameOdometry()
     state = {"frame": 0}
-    PREFETCH = os.environ.get("MMF_BENCH_PREFETCH", "1") != "0"
+    # next-frame prefetch on side streams: on at N = 1; at N > 1 only on request (MMF_BENCH_PREFETCH=2) -- the
+    # collective's own streams share the device with it there and that combination could not be measured on a
+    # one-GPU box (two ranks sharing one GPU time-slice pathologically with the extra streams)
+    _pf = os.environ.get("MMF_BENCH_PREFETCH", "1")
+    PREFETCH = _pf == "2" or (_pf != "0" and world == 1)
 
     def step(i):
         """One processFrame: bilateral filter, tracking (SO3 + 4/5/10 ICP+RGB GN iterations against
@@ -145,19 +151,30 @@ def main():
             mmf.reset()
         state["frame"] += 1
         if world > 1:  # rank 0's sensor frame reaches every model owner (RCCL broadcast over xGMI)
-            def post(n):  # start the broadcast of sequence frame n into buffer n % 2
-                b, kk = n % 2, n % len(frames)
+            def post(n):  # start the broadcast of sequence frame n into buffer n % NB (once)
+                if n in posted:
+                    return
+                posted.add(n)
+                b, kk = n % NB, n % len(frames)
                 if rank == 0:
                     rgb_in[b].copy_(d_rgb[kk])
                     depth_in[b].copy_(d_depth[kk])
                 pending[n] = shard.broadcast_frame_async(rgb_in[b], depth_in[b], mask_in[b], src=0)
+
+            def arrived(n):  # the compute stream waits for the collective; the host does not
+                for w in pending.pop(n, []):
+                    w.wait()
             n = state["frame"] - 1
-            if n not in pending:
-                post(n)
-            for w in pending.pop(n):
-                w.wait()  # the compute stream waits for the collective; the host does not
+            post(n)
             post(n + 1)
-            mmf.processFrame(rgb_in[n % 2], depth_in[n % 2], timestamp=i)
+            arrived(n)
+            if PREFETCH:  # the next frame has to be in place before this frame's tracking is enqueued: the side
+                arrived(n + 1)  # streams of the prefetch start right after it
+            post(n + 2)
+            posted.discard(n - 1)
+            mmf.processFrame(rgb_in[n % NB], depth_in[n % NB], timestamp=i)
+            if PREFETCH and (n + 1) % len(frames) != 0:
+                mmf.prefetchFrame(rgb_in[(n + 1) % NB], depth_in[(n + 1) % NB])
         else:  # inputs already resident in HBM
             mmf.processFrame(d_rgb[k], d_depth[k], timestamp=i)
             kn = state["frame"] % len(frames)
