@@ -203,3 +203,23 @@ def test_network_bit_exact_at_the_bench_size(gpu_ctx, orc):
     d = np.abs(xy[:, None, :].astype(np.int64) - xy[None, :, :]).max(axis=2) + np.eye(len(xy), dtype=np.int64) * 99
     assert d.min() > sp.nms_dist  # survivors are farther apart than the suppression radius
     sp.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_conv_layer_random_shapes_bit_exact(gpu_ctx, orc, seed):
+    """seeded random shapes: images smaller than a tile, single rows / columns, output channel counts that are
+    not multiples of 32, 1x1 and 3x3, pooled where both sides are even, every tile width"""
+    from multimotionfusion_amd.superpoint import conv
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(1, 41)), int(rng.integers(1, 51))
+    cin = int(rng.choice([32, 64, 96, 128]))
+    cout = int(rng.integers(1, 201))
+    k = int(rng.choice([1, 3]))
+    pool = bool(k == 3 and H % 2 == 0 and W % 2 == 0 and rng.integers(0, 2))
+    nt = int(rng.choice([0, 1, 2, 4]))
+    relu = bool(rng.integers(0, 2))
+    x = rng.normal(0, 1, (H, W, cin)).astype(np.float32)
+    w = rng.normal(0, np.sqrt(2.0 / (cin * k * k)), (cout, cin, k, k)).astype(np.float32)
+    b = rng.normal(0, 0.1, cout).astype(np.float32)
+    got = conv(gpu_ctx, dev(x), w, b, relu=relu, pool=pool, nt=nt).cpu().numpy()
+    assert_bit_equal(got, oracle_layer(orc, x, w, b, relu, pool), f"{H}x{W} {cin}->{cout} k{k} pool={pool} nt={nt} relu={relu}")
