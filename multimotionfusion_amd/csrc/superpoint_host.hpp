@@ -96,7 +96,6 @@ struct mmf_superpoint {
     // conv1b conv2a conv2b conv3a conv3b conv4a conv4b, {convPa | convDa} fused (512 outputs), convPb, convDb
     mmf::SpLayer L[10];
     float *act0 = nullptr, *act1 = nullptr, *head = nullptr, *semi = nullptr, *desc = nullptr, *heat = nullptr;
-    uint8_t* image = nullptr;  // staging for host images
     uint8_t* state = nullptr;
     unsigned *flags = nullptr, *prefix = nullptr, *block_sums = nullptr, *counters = nullptr;
     unsigned* host_counters = nullptr;  // pinned
@@ -183,7 +182,7 @@ extern "C" int mmf_superpoint_create(mmf_ctx* c, const float* const* weights, in
     };
     const size_t o_act0 = carve(npix * 64 * 4), o_act1 = carve(npix / 4 * 64 * 4);
     const size_t o_head = carve(ncell * 512 * 4), o_semi = carve(ncell * 65 * 4), o_desc = carve(ncell * 256 * 4);
-    const size_t o_heat = carve(npix * 4), o_image = carve(npix * 4), o_state = carve(npix);
+    const size_t o_heat = carve(npix * 4), o_state = carve(npix);
     const size_t o_flags = carve(npix * 4), o_prefix = carve(npix * 4);
     const size_t o_bsum = carve(((npix + mmf::kScanTile - 1) / mmf::kScanTile + 1) * 4), o_cnt = carve(64);
     const size_t o_xy = carve(npix * 8), o_conf = carve(npix * 4), o_kdesc = carve((size_t)max_keypoints * 256 * 4);
@@ -202,7 +201,7 @@ extern "C" int mmf_superpoint_create(mmf_ctx* c, const float* const* weights, in
     char* base = static_cast<char*>(sp->slab);
     sp->act0 = (float*)(base + o_act0), sp->act1 = (float*)(base + o_act1);
     sp->head = (float*)(base + o_head), sp->semi = (float*)(base + o_semi), sp->desc = (float*)(base + o_desc);
-    sp->heat = (float*)(base + o_heat), sp->image = (uint8_t*)(base + o_image), sp->state = (uint8_t*)(base + o_state);
+    sp->heat = (float*)(base + o_heat), sp->state = (uint8_t*)(base + o_state);
     sp->flags = (unsigned*)(base + o_flags), sp->prefix = (unsigned*)(base + o_prefix);
     sp->block_sums = (unsigned*)(base + o_bsum), sp->counters = (unsigned*)(base + o_cnt);
     sp->kp_xy = (int*)(base + o_xy), sp->kp_conf = (float*)(base + o_conf), sp->kp_desc = (float*)(base + o_kdesc);
