@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 1
+#define MMF_ABI_VERSION 2
 
 typedef enum {
     MMF_OK = 0,
@@ -271,12 +271,23 @@ int mmf_model_upload_map(mmf_model *m, const float *host_aos, unsigned count);
  *        image(rgba8) vertexConf normalRadius (float4) time(u16) -- splat prediction;
  *        fillVertex fillNormal (float4) fillImage (rgba8) -- fill-in */
 int mmf_model_texture(mmf_model *m, const char *name, void **dev_ptr, size_t *bytes);
+/* Model::setMaxDepth / setConfidenceThreshold / getConfidenceThreshold / getID (Model.h:222-230, 307) */
+int mmf_model_set_max_depth(mmf_model *m, float max_depth);
+int mmf_model_set_confidence_threshold(mmf_model *m, float conf_threshold);
+float mmf_model_confidence_threshold(mmf_model *m);
+int mmf_model_id(mmf_model *m);
 
 /* ---------------------------------------------------------------------------------------
  * Orchestrator: MultiMotionFusion::processFrame / predict (Core/MultiMotionFusion.h:78-86,
- * .cpp:207-854, 863-875) for the static-scene configuration (one global model, all-zero mask:
- * enableMultipleModels == false, :268-275).  Segmentation, model spawning, relocalisation and
- * loop closure stay in the reference's front-end.
+ * .cpp:207-854, 863-875): the global (camera) model plus the object models of the `models` list, each
+ * with its own RGBDOdometry, tracked / predicted / fused / cleaned per frame.  With
+ * enable_multiple_models == 0 this is the static-scene configuration (all-zero mask, :268-275).
+ * The segmentation proper (gSLICr + dense CRF, or the ground-truth id image of
+ * Segmentation.cpp:89-150), relocalisation and loop closure stay in the reference's front-end: the
+ * segmentation RESULT is handed in per frame (mmf_segmentation) or pulled through a callback at the point
+ * where the reference calls performSegmentation (:412).
+ * Every model runs on its own stream ("lane"); every public call returns with the fusion's own
+ * stream (the context's) ordered after all lanes.
  * ------------------------------------------------------------------------------------- */
 typedef struct mmf_fusion mmf_fusion;
 
@@ -290,7 +301,49 @@ typedef struct {
     float outlier_coeff;       /* GPUSetup::outlierCoefficient, GUI default 3 */
     int fill_in;               /* global model is created with fill-in enabled */
     int max_surfels;           /* 0 = Model::MAX_VERTICES */
+    float conf_object_init;    /* confObjectInit, GUI default 0.01 (-confO) */
+    int enable_multiple_models; /* setEnableMultipleModels (MultiMotionFusion.h:262) */
+    int preallocated_models;   /* preallocateModels(count) (:125-131; -a) */
+    int error_recording;       /* Model(..., enableErrorRecording): per-model ICP / RGB error images */
+    int pose_logging;          /* enablePoseLogging: Model::poseLog, exportPoses */
+    int max_object_surfels;    /* capacity of an object model's store, 0 = max_surfels */
 } mmf_fusion_config;
+
+/* SegmentationResult (Core/Segmentation/Segmentation.h:32-70) as far as processFrame consumes it */
+typedef struct {
+    unsigned id;                /* ModelData::id */
+    unsigned super_pixel_count; /* 0: the model was not seen in this frame (:607) */
+    float avg_confidence;       /* raises the object's confidence threshold, capped at 9 (:616-620) */
+    float depth_mean, depth_std; /* Model::setMaxDepth(depth_mean + 1.2 depth_std) (:409, :486, :586) */
+} mmf_segmentation_model;
+
+typedef struct {
+    const uint8_t *mask;  /* DEVICE, width*height u8: fullSegmentation = model id per pixel */
+    int has_new_label;    /* hasNewLabel: spawn an object model for the id mmf_fusion_next_model_id() (:469-487) */
+    int n_models;         /* entries of model_data: the active models in list order, then the new label's */
+    const mmf_segmentation_model *model_data; /* HOST; NULL: no max-depth / confidence / unseen updates */
+} mmf_segmentation;
+
+/* one processFrame call (MultiMotionFusion.h:78-80): FrameData + the optional arguments */
+typedef struct {
+    const uint8_t *rgb;  /* DEVICE u8 x 3 interleaved (FrameData::rgb) */
+    const float *depth;  /* DEVICE float32 metres (FrameData::depth) */
+    long long timestamp;
+    const float *in_pose; /* HOST 4x4 or NULL */
+    float weight_multiplier;
+    int bootstrap;
+    /* odom_cfg.init == "kp" (:312-384): one 4x4 (HOST) per active model in list order = the
+     * RigidRANSAC transformation of Model::getLastTrackTransform; NULL = no pose initialisation */
+    const float *init_transforms;
+    int n_init_transforms;
+    int icp_refine; /* odom_cfg.icp_refine */
+    /* enable_multiple_models: the result of performSegmentation(frame) for THIS frame; NULL = ask the callback */
+    const mmf_segmentation *segmentation;
+} mmf_frame;
+
+/* called where the reference calls performSegmentation (:412): every model of this frame has been tracked
+ * (poses, ICP / RGB error images and predictions of the previous fusion are readable); fill *out. */
+typedef int (*mmf_segmentation_fn)(void *user, mmf_fusion *f, const mmf_frame *frame, mmf_segmentation *out);
 
 int mmf_fusion_default_config(mmf_fusion_config *cfg);
 int mmf_fusion_create(mmf_ctx *ctx, int width, int height, float cx, float cy, float fx, float fy,
@@ -302,30 +355,74 @@ void mmf_fusion_destroy(mmf_fusion *f);
  * the reference returns false (:209-212). */
 int mmf_fusion_process_frame(mmf_fusion *f, const uint8_t *rgb, const float *depth, long long timestamp,
                              const float *in_pose, float weight_multiplier, int bootstrap);
+/* processFrame with every optional input (multiple models, pose initialisation of every model) */
+int mmf_fusion_process_frame_ex(mmf_fusion *f, const mmf_frame *frame);
+/* processFrame(const FrameData&) with the frame in HOST memory: rgb, depth and the optional id image
+ * (mask_host != NULL: FrameData::mask, already mapped to model ids) are staged through pinned double buffers
+ * and uploaded on the fusion's stream (:221, :261, :416). */
+int mmf_fusion_process_frame_host(mmf_fusion *f, const uint8_t *rgb_host, const float *depth_host,
+                                  const uint8_t *mask_host, int has_new_label, long long timestamp,
+                                  const float *in_pose, float weight_multiplier, int bootstrap);
 /* processFrame with the tracker initialised from keypoint tracks: odom_cfg.init == "kp"
  * (MultiMotionFusion.cpp:312-384).  init_transform = RigidRANSAC::Result::transformation of
  * Model::getLastTrackTransform (row-major 4x4, mmf_ransac_estimate): the camera model's pose becomes
- * pose * init_transform (:331), the map is predicted / fused / cleaned once at that pose with weight_multiplier
- * as the fusion weight (:352-366), then the dense tracker refines the pose when icp_refine != 0 (:377-381;
- * odom_cfg.icp_refine), else the initial pose is kept (:382-385).  On the first frame (tick 1) the
- * transformation is ignored, as in the reference.  Fails in frame-to-frame RGB mode (:370). */
+ * pose * init_transform (:331), the map is predicted / fused / cleaned once at that pose with
+ * Model::computeFusionWeight(weight_multiplier) (:352-366, Model.cpp:918), then the dense tracker refines the
+ * pose when icp_refine != 0 (:377-381; odom_cfg.icp_refine), else the initial pose is kept (:382-385).  On the
+ * first frame (tick 1) the transformation is ignored, as in the reference.  Fails in frame-to-frame RGB mode (:370). */
 int mmf_fusion_process_frame_init(mmf_fusion *f, const uint8_t *rgb, const float *depth, long long timestamp,
                                   const float *init_transform, int icp_refine, float weight_multiplier);
 /* Overlap across frames: enqueue the work of the NEXT frame that depends on the sensor frame only -- the depth
  * filter, vertex / normal maps and the depth pyramid on one side stream; the intensity pyramid, the gradients and
  * the SO3 pre-alignment (last frame's image against this one's) on another -- where they run while the current
  * frame is still being fused.  The following
- * mmf_fusion_process_frame(_init) call with the SAME rgb / depth pointers picks the results up instead of
+ * mmf_fusion_process_frame* call with the SAME rgb / depth pointers picks the results up instead of
  * recomputing them (same kernels, same bits); with other pointers the prefetch is discarded.  rgb / depth must
  * stay unchanged until that call.  Optional: without it every frame is processed on its own. */
 int mmf_fusion_prefetch_frame(mmf_fusion *f, const uint8_t *rgb, const float *depth);
-/* getCurrPose / getTick / getBackgroundModel (MultiMotionFusion.h:130-160) */
-int mmf_fusion_reset(mmf_fusion *f); /* empty map, identity pose, tick = 1 (a freshly constructed object) */
+/* predict() (MultiMotionFusion.h:86, .cpp:863-875): re-render every model's prediction at its current pose */
+int mmf_fusion_predict(mmf_fusion *f);
+/* getCurrPose / getTick / setTick / getBackgroundModel / getModels (MultiMotionFusion.h:100-216) */
+int mmf_fusion_reset(mmf_fusion *f); /* empty maps, identity poses, tick = 1, only the global model active */
 int mmf_fusion_get_pose(mmf_fusion *f, float pose[16]);
 int mmf_fusion_tick(mmf_fusion *f);
-mmf_model *mmf_fusion_model(mmf_fusion *f);
-mmf_odom *mmf_fusion_odometry(mmf_fusion *f);
+int mmf_fusion_set_tick(mmf_fusion *f, int tick);
+mmf_model *mmf_fusion_model(mmf_fusion *f);   /* getBackgroundModel(), = getIndexMap()'s owner */
+mmf_odom *mmf_fusion_odometry(mmf_fusion *f); /* its frameToModel */
+int mmf_fusion_num_models(mmf_fusion *f);     /* getModels().size() */
+mmf_model *mmf_fusion_model_at(mmf_fusion *f, int index);
+mmf_odom *mmf_fusion_odometry_at(mmf_fusion *f, int index);
+int mmf_fusion_num_inactive_models(mmf_fusion *f);
+mmf_model *mmf_fusion_inactive_model_at(mmf_fusion *f, int index);
+int mmf_fusion_next_model_id(mmf_fusion *f); /* getNextModelID(false): the id a new label must carry in the mask */
+int mmf_fusion_schedule_deactivation(mmf_fusion *f, int id); /* scheduleDeactivation: applied at the next frame */
+/* Model::getICPErrorTexture (which = 0) / getRGBErrorTexture (which = 1) of the index-th active model:
+ * width*height float32, written by the last level-0 iteration of its tracking */
+int mmf_fusion_error_texture(mmf_fusion *f, int index, int which, float **dev_ptr);
+/* getTextures() (MultiMotionFusion.h:124): "RGB" (u8 x 3), "DEPTH_METRIC", "DEPTH_METRIC_FILTERED" (float32),
+ * "MASK" (u8) of the current frame as device images */
+int mmf_fusion_texture(mmf_fusion *f, const char *name, const void **dev_ptr, size_t *bytes);
 const float *mmf_fusion_depth_filtered(mmf_fusion *f);
+/* the runtime setters the front-end pushes every GUI tick (MultiMotionFusion.cpp:1064-1116,
+ * GUI/MainController.cpp:641-670); they take effect at the next processFrame */
+int mmf_fusion_set_rgb_only(mmf_fusion *f, int val);
+int mmf_fusion_set_icp_weight(mmf_fusion *f, float val);
+int mmf_fusion_set_outlier_coefficient(mmf_fusion *f, float val);
+int mmf_fusion_set_pyramid(mmf_fusion *f, int val);
+int mmf_fusion_set_fast_odom(mmf_fusion *f, int val);
+int mmf_fusion_set_so3(mmf_fusion *f, int val);
+int mmf_fusion_set_frame_to_frame_rgb(mmf_fusion *f, int val);
+int mmf_fusion_set_depth_cutoff(mmf_fusion *f, float val);
+int mmf_fusion_set_confidence_threshold(mmf_fusion *f, float val);
+int mmf_fusion_set_enable_multiple_models(mmf_fusion *f, int val);
+int mmf_fusion_get_config(mmf_fusion *f, mmf_fusion_config *out);
+int mmf_fusion_set_segmentation_callback(mmf_fusion *f, mmf_segmentation_fn fn, void *user);
+/* exportPoses() (:1020-1045): `poses-<id>.txt` per pose-logging model under export_dir (which ends in '/') */
+int mmf_fusion_export_poses(mmf_fusion *f, const char *export_dir);
+/* Model::getPoseLog() of the index-th active model: ts[i], p7[7 i ..] = x y z qx qy qz qw */
+int mmf_fusion_pose_log(mmf_fusion *f, int index, long long *ts, float *p7, int max_entries, int *n_out);
+/* Model::computeFusionWeight (Model.cpp:876-891) for pose / lastPose (host 4x4), exported for tests */
+int mmf_compute_fusion_weight(const float pose[16], const float last_pose[16], float multiplier, float *out);
 
 /* ---- keypoint descriptor matching ------------------------------------
  * PointTracker::addKeypoints, Core/Utils/PointTracker.cpp:100-114:

@@ -40,7 +40,29 @@ class mmf_fusion_config(C.Structure):
     _fields_ = [("time_delta", C.c_int), ("conf_global_init", C.c_float), ("icp_weight", C.c_float),
                 ("depth_cutoff", C.c_float), ("max_depth_processed", C.c_float), ("rgb_only", C.c_int),
                 ("pyramid", C.c_int), ("fast_odom", C.c_int), ("so3", C.c_int), ("frame_to_frame_rgb", C.c_int),
-                ("outlier_coeff", C.c_float), ("fill_in", C.c_int), ("max_surfels", C.c_int)]
+                ("outlier_coeff", C.c_float), ("fill_in", C.c_int), ("max_surfels", C.c_int),
+                ("conf_object_init", C.c_float), ("enable_multiple_models", C.c_int), ("preallocated_models", C.c_int),
+                ("error_recording", C.c_int), ("pose_logging", C.c_int), ("max_object_surfels", C.c_int)]
+
+
+class mmf_segmentation_model(C.Structure):
+    _fields_ = [("id", C.c_uint), ("super_pixel_count", C.c_uint), ("avg_confidence", C.c_float),
+                ("depth_mean", C.c_float), ("depth_std", C.c_float)]
+
+
+class mmf_segmentation(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("has_new_label", C.c_int), ("n_models", C.c_int),
+                ("model_data", C.POINTER(mmf_segmentation_model))]
+
+
+class mmf_frame(C.Structure):
+    _fields_ = [("rgb", C.c_void_p), ("depth", C.c_void_p), ("timestamp", C.c_longlong),
+                ("in_pose", C.POINTER(C.c_float)), ("weight_multiplier", C.c_float), ("bootstrap", C.c_int),
+                ("init_transforms", C.POINTER(C.c_float)), ("n_init_transforms", C.c_int), ("icp_refine", C.c_int),
+                ("segmentation", C.POINTER(mmf_segmentation))]
+
+
+SEGMENTATION_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(mmf_frame), C.POINTER(mmf_segmentation))
 
 
 _vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
@@ -134,6 +156,38 @@ SIGNATURES = {
     "mmf_fusion_model": (_vp, [_vp]),
     "mmf_fusion_odometry": (_vp, [_vp]),
     "mmf_fusion_depth_filtered": (_vp, [_vp]),
+    "mmf_fusion_process_frame_ex": (_i, [_vp, C.POINTER(mmf_frame)]),
+    "mmf_fusion_process_frame_host": (_i, [_vp, _vp, _vp, _vp, _i, C.c_longlong, _fp, _f, _i]),
+    "mmf_fusion_predict": (_i, [_vp]),
+    "mmf_fusion_set_tick": (_i, [_vp, _i]),
+    "mmf_fusion_num_models": (_i, [_vp]),
+    "mmf_fusion_model_at": (_vp, [_vp, _i]),
+    "mmf_fusion_odometry_at": (_vp, [_vp, _i]),
+    "mmf_fusion_num_inactive_models": (_i, [_vp]),
+    "mmf_fusion_inactive_model_at": (_vp, [_vp, _i]),
+    "mmf_fusion_next_model_id": (_i, [_vp]),
+    "mmf_fusion_schedule_deactivation": (_i, [_vp, _i]),
+    "mmf_fusion_error_texture": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "mmf_fusion_texture": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_sz)]),
+    "mmf_fusion_set_rgb_only": (_i, [_vp, _i]),
+    "mmf_fusion_set_icp_weight": (_i, [_vp, _f]),
+    "mmf_fusion_set_outlier_coefficient": (_i, [_vp, _f]),
+    "mmf_fusion_set_pyramid": (_i, [_vp, _i]),
+    "mmf_fusion_set_fast_odom": (_i, [_vp, _i]),
+    "mmf_fusion_set_so3": (_i, [_vp, _i]),
+    "mmf_fusion_set_frame_to_frame_rgb": (_i, [_vp, _i]),
+    "mmf_fusion_set_depth_cutoff": (_i, [_vp, _f]),
+    "mmf_fusion_set_confidence_threshold": (_i, [_vp, _f]),
+    "mmf_fusion_set_enable_multiple_models": (_i, [_vp, _i]),
+    "mmf_fusion_get_config": (_i, [_vp, C.POINTER(mmf_fusion_config)]),
+    "mmf_fusion_set_segmentation_callback": (_i, [_vp, _vp, _vp]),
+    "mmf_fusion_export_poses": (_i, [_vp, C.c_char_p]),
+    "mmf_fusion_pose_log": (_i, [_vp, _i, C.POINTER(C.c_longlong), _fp, _i, _ip]),
+    "mmf_compute_fusion_weight": (_i, [_fp, _fp, _f, _fp]),
+    "mmf_model_set_max_depth": (_i, [_vp, _f]),
+    "mmf_model_set_confidence_threshold": (_i, [_vp, _f]),
+    "mmf_model_confidence_threshold": (_f, [_vp]),
+    "mmf_model_id": (_i, [_vp]),
 }
 
 _lib = None

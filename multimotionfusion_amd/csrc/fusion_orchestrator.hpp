@@ -1,0 +1,927 @@
+// fusion_orchestrator.hpp -- MultiMotionFusion::processFrame / predict (Core/MultiMotionFusion.cpp:207-854,
+// 863-875) for a list of rigid-body models: the global (camera) model plus the object models the segmentation
+// spawns.  Textually included at the end of mmf_hip.hip (it uses that file's static helpers).
+//
+// What stays with the caller: the segmentation itself (gSLICr + dense CRF, or a ground-truth id image) -- it is
+// handed in per frame (mmf_segmentation) or pulled through a callback at the point where the reference calls
+// performSegmentation (:412); relocalisation, ferns, deformation (closeLoops / reloc off).
+//
+// MI355X mapping: every model owns a LANE (a child context: its own stream + reduction scratch), so the
+// latency-bound Gauss-Newton chains of different models (19 x two small launches each) overlap on the device;
+// the chains of all models are enqueued before the first result is awaited.  What depends on the sensor frame
+// only (bilateral filter, depth / intensity pyramids, vertex / normal maps, gradients) is computed ONCE on the
+// fusion's own stream and aliased by every model's odometry -- the reference shares just the depth pyramid
+// (Model::GPUSetup::depth_tmp, Model.h:103) and recomputes the rest per model.
+#pragma once
+
+#include <vector>
+
+struct PoseLogItem {  // Model::PoseLogItem (Model.h:326-329)
+    long long ts;
+    float p[7];  // x y z qx qy qz qw
+};
+
+struct FusionModel {  // one ModelPointer of the reference's `models` list
+    mmf_ctx* lane = nullptr;  // stream + reduction scratch (models[0]: the fusion's own context)
+    bool own_lane = false;
+    mmf_model* model = nullptr;
+    mmf_odom* odom = nullptr;  // Model::frameToModel
+    float last_pose[16];       // Model::lastPose
+    int fill_in = 0;           // Model::allowsFillIn()
+    long long unseen = 0;      // Model::unseenCount
+    float* icp_error = nullptr;  // Model::icpError / rgbError (R32F, enableErrorRecording)
+    float* rgb_error = nullptr;
+    hipEvent_t ev_done = nullptr;
+    bool tracking = false;  // a tracking call is in flight on the lane
+    std::vector<PoseLogItem> pose_log;
+};
+
+struct mmf_fusion {
+    mmf_ctx* ctx = nullptr;
+    mmf_fusion_config cfg;
+    int width = 0, height = 0;
+    float cx = 0, cy = 0, fx = 0, fy = 0;
+    std::vector<FusionModel*> models;        // active; models[0] = globalModel
+    std::vector<FusionModel*> preallocated;  // preallocatedModels (MultiMotionFusion.h:349)
+    std::vector<FusionModel*> inactive;      // inactiveModels
+    std::vector<int> scheduled_deactivation;
+    int next_id = 0;                  // nextID (getNextModelID)
+    float* depth_filtered = nullptr;  // = filtered[cur]
+    uint8_t* mask = nullptr;          // textures[MASK]: all zeros unless enableMultipleModels
+    bool mask_is_zero = false;
+    int tick = 1;                     // MultiMotionFusion.cpp:36
+    int tracking_ok = 1;
+    const uint8_t* frame_rgb = nullptr;  // this frame's inputs (device), kept for predict()
+    const float* frame_depth = nullptr;
+    mmf_segmentation_fn seg_fn = nullptr;
+    void* seg_user = nullptr;
+    hipEvent_t ev_frame_ready = nullptr;  // fusion stream: the frame's shared inputs are complete
+    // next-frame prefetch (mmf_fusion_prefetch_frame): the filter and the input-side preparation of frame t+1 run
+    // on `side` while frame t is fused on the context's stream.  Two filtered-depth buffers: frame t's fuse /
+    // clean / fill-in read one while frame t+1's filter writes the other.
+    float* filtered[2] = {nullptr, nullptr};
+    int cur = 0;
+    hipStream_t side = nullptr;   // depth chain: filter, depth pyramid, vertex / normal maps
+    hipStream_t side2 = nullptr;  // image chain: intensity pyramid, gradients, SO3 pre-alignment
+    float* side_partials = nullptr;   // reduction scratch of the SO3 launches on side2 (never the context's: the
+    unsigned* side_ticket = nullptr;  // main stream may be inside a reduction of its own at the same time)
+    hipEvent_t ev_prefetch2_done = nullptr;
+    hipEvent_t ev_inputs_free = nullptr;    // fusion stream: enqueued work no longer reads the odometry's input-side
+                                            // buffers nor filtered[1 - cur]
+    hipEvent_t ev_prefetch_done = nullptr;  // side stream: the prefetch has been enqueued up to here
+    bool inputs_free_recorded = false;
+    bool pre_valid = false;
+    const uint8_t* pre_rgb = nullptr;
+    const float* pre_depth = nullptr;
+    // host FrameData hand-over (mmf_fusion_process_frame_host): pinned staging + device copies, double buffered
+    uint8_t* up_pin[2] = {nullptr, nullptr};
+    uint8_t* up_dev[2] = {nullptr, nullptr};
+    int up_cur = 0;
+};
+
+static void identity16(float* m) {
+    for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? 1.f : 0.f;
+}
+
+extern "C" int mmf_fusion_default_config(mmf_fusion_config* cfg) {
+    MMF_REQUIRE(cfg != nullptr, "mmf_fusion_default_config: null argument");
+    cfg->time_delta = 200;          // GUI/MainController.cpp:333 (timeDelta flag default)
+    cfg->conf_global_init = 10.0f;  // GUI default confGlobalInit
+    cfg->icp_weight = 10.0f;        // GUI default icpWeight
+    cfg->depth_cutoff = 15.0f;      // GUI default depthCutoff (bilateral filter maxD)
+    cfg->max_depth_processed = 20.0f;  // MultiMotionFusion.cpp:53
+    cfg->rgb_only = 0;
+    cfg->pyramid = 1;
+    cfg->fast_odom = 0;
+    cfg->so3 = 1;
+    cfg->frame_to_frame_rgb = 0;
+    cfg->outlier_coeff = 3.0f;      // GPUSetup::outlierCoefficient GUI default
+    cfg->fill_in = 1;               // the global model is created with fill-in enabled
+    cfg->max_surfels = 0;
+    cfg->conf_object_init = 0.01f;  // GUI/MainController.cpp:333 (-confO)
+    cfg->enable_multiple_models = 0;
+    cfg->preallocated_models = 0;   // GUI/MainController.cpp:339 (-a)
+    cfg->error_recording = 1;       // every Model is created with enableErrorRecording (MultiMotionFusion.cpp:70,128,944)
+    cfg->pose_logging = 0;          // enablePoseLogging
+    cfg->max_object_surfels = 0;
+    return MMF_OK;
+}
+
+static void fusion_model_destroy(FusionModel* fm) {
+    if (!fm) return;
+    mmf_model_destroy(fm->model);
+    mmf_odom_destroy(fm->odom);
+    (void)hipFree(fm->icp_error);
+    (void)hipFree(fm->rgb_error);
+    if (fm->ev_done) (void)hipEventDestroy(fm->ev_done);
+    if (fm->own_lane) mmf_ctx_destroy(fm->lane);
+    delete fm;
+}
+
+// std::make_shared<Model>(id, confidence, odom_cfg, enableFillIn, enableErrorRecording, ...) (Model.cpp:147-262)
+static int fusion_model_create(mmf_fusion* f, int id, float conf, int fill_in, bool own_lane, FusionModel** out) {
+    FusionModel* fm = new (std::nothrow) FusionModel();
+    MMF_REQUIRE(fm != nullptr, "mmf_fusion: out of host memory");
+    int rc = MMF_OK;
+    if (own_lane) {
+        rc = mmf_ctx_create(f->ctx->device, nullptr, 1, &fm->lane);
+        fm->own_lane = rc == MMF_OK;
+    } else {
+        fm->lane = f->ctx;
+    }
+    const int cap = id == 0 ? f->cfg.max_surfels : (f->cfg.max_object_surfels ? f->cfg.max_object_surfels : f->cfg.max_surfels);
+    if (rc == MMF_OK)
+        rc = mmf_model_create(fm->lane, f->width, f->height, f->cx, f->cy, f->fx, f->fy, (unsigned char)id, conf, cap, &fm->model);
+    if (rc == MMF_OK)
+        rc = mmf_odom_create(fm->lane, f->width, f->height, f->cx, f->cy, f->fx, f->fy, 0.10f,
+                             std::sin(20.f * 3.14159254f / 180.f), &fm->odom);
+    const size_t npix = (size_t)f->width * f->height;
+    if (rc == MMF_OK && f->cfg.error_recording) {
+        if (hipMalloc(&fm->icp_error, npix * 4) != hipSuccess || hipMalloc(&fm->rgb_error, npix * 4) != hipSuccess ||
+            hipMemsetAsync(fm->icp_error, 0, npix * 4, fm->lane->stream) != hipSuccess ||
+            hipMemsetAsync(fm->rgb_error, 0, npix * 4, fm->lane->stream) != hipSuccess)
+            rc = fail(MMF_ERR_HIP, "mmf_fusion: error textures: out of device memory");
+    }
+    if (rc == MMF_OK && hipEventCreateWithFlags(&fm->ev_done, hipEventDisableTiming) != hipSuccess)
+        rc = fail(MMF_ERR_HIP, "mmf_fusion: hipEventCreate failed");
+    if (rc != MMF_OK) {
+        const std::string keep = g_last_error;
+        fusion_model_destroy(fm);
+        return fail(rc, keep);
+    }
+    // the prediction images (model slab) and the filtered depth (the fusion's buffer) are not written
+    // between the init* calls of a frame and the end of its tracking
+    fm->odom->alias_inputs = true;
+    fm->fill_in = fill_in;
+    identity16(fm->last_pose);
+    if (f->cfg.pose_logging) fm->pose_log.reserve(1000);  // Model.cpp:177
+    *out = fm;
+    return MMF_OK;
+}
+
+// MultiMotionFusion::getNextModelID (MultiMotionFusion.cpp:983-999)
+static int fusion_next_model_id(mmf_fusion* f, bool assign) {
+    const int next = f->next_id;
+    if (assign) {
+        while (true) {
+            f->next_id = (f->next_id + 1) & 255;
+            bool occupied = false;
+            for (FusionModel* m : f->models)
+                if (f->next_id == (int)m->model->id) occupied = true;
+            if (!occupied) break;
+        }
+    }
+    return next;
+}
+
+extern "C" int mmf_fusion_create(mmf_ctx* c, int width, int height, float cx, float cy, float fx, float fy,
+                                 const mmf_fusion_config* cfg, mmf_fusion** out) {
+    MMF_REQUIRE(c && out, "mmf_fusion_create: null argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    mmf_fusion* f = new (std::nothrow) mmf_fusion();
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_create: out of host memory");
+    f->ctx = c;
+    if (cfg)
+        f->cfg = *cfg;
+    else
+        mmf_fusion_default_config(&f->cfg);
+    f->width = width, f->height = height;
+    f->cx = cx, f->cy = cy, f->fx = fx, f->fy = fy;
+    FusionModel* global = nullptr;
+    // globalModel (MultiMotionFusion.cpp:69-71): id 0, fill-in, on the fusion's own stream
+    int rc = fusion_model_create(f, fusion_next_model_id(f, true), f->cfg.conf_global_init, f->cfg.fill_in, false, &global);
+    if (rc != MMF_OK) {
+        delete f;
+        return rc;
+    }
+    f->models.push_back(global);
+    const size_t npix = (size_t)width * height;
+    MMF_HIP_TRY(hipMalloc(&f->filtered[0], npix * 4));
+    MMF_HIP_TRY(hipMalloc(&f->filtered[1], npix * 4));
+    f->depth_filtered = f->filtered[0];
+    // the side streams and events of the prefetch are created by its first call
+    MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_inputs_free, hipEventDisableTiming));
+    MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_frame_ready, hipEventDisableTiming));
+    MMF_HIP_TRY(hipMalloc(&f->mask, npix));
+    MMF_HIP_TRY(hipMemsetAsync(f->mask, 0, npix, c->stream));
+    f->mask_is_zero = true;
+    for (int i = 0; i < f->cfg.preallocated_models; ++i) {  // preallocateModels (:125-131)
+        FusionModel* fm = nullptr;
+        rc = fusion_model_create(f, fusion_next_model_id(f, true), f->cfg.conf_object_init, 0, true, &fm);
+        if (rc != MMF_OK) {
+            const std::string keep = g_last_error;
+            mmf_fusion_destroy(f);
+            return fail(rc, keep);
+        }
+        f->preallocated.push_back(fm);
+    }
+    *out = f;
+    return MMF_OK;
+}
+
+extern "C" void mmf_fusion_destroy(mmf_fusion* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->ctx->device);
+    (void)hipStreamSynchronize(f->ctx->stream);
+    if (f->side) (void)hipStreamSynchronize(f->side);
+    if (f->side2) (void)hipStreamSynchronize(f->side2);
+    for (auto* list : {&f->models, &f->preallocated, &f->inactive}) {
+        for (FusionModel* fm : *list) fusion_model_destroy(fm);
+        list->clear();
+    }
+    (void)hipFree(f->filtered[0]);
+    (void)hipFree(f->filtered[1]);
+    (void)hipFree(f->mask);
+    (void)hipFree(f->side_partials);
+    (void)hipFree(f->side_ticket);
+    for (int i = 0; i < 2; ++i) {
+        if (f->up_pin[i]) (void)hipHostFree(f->up_pin[i]);
+        (void)hipFree(f->up_dev[i]);
+    }
+    if (f->ev_inputs_free) (void)hipEventDestroy(f->ev_inputs_free);
+    if (f->ev_frame_ready) (void)hipEventDestroy(f->ev_frame_ready);
+    if (f->ev_prefetch_done) (void)hipEventDestroy(f->ev_prefetch_done);
+    if (f->side) (void)hipStreamDestroy(f->side);
+    if (f->ev_prefetch2_done) (void)hipEventDestroy(f->ev_prefetch2_done);
+    if (f->side2) (void)hipStreamDestroy(f->side2);
+    delete f;
+}
+
+extern "C" mmf_model* mmf_fusion_model(mmf_fusion* f) { return f ? f->models[0]->model : nullptr; }
+extern "C" mmf_odom* mmf_fusion_odometry(mmf_fusion* f) { return f ? f->models[0]->odom : nullptr; }
+extern "C" int mmf_fusion_tick(mmf_fusion* f) { return f ? f->tick : -1; }
+extern "C" const float* mmf_fusion_depth_filtered(mmf_fusion* f) { return f ? f->depth_filtered : nullptr; }
+
+// getModels() (MultiMotionFusion.h:107): the active list in its order, index 0 = the global model
+extern "C" int mmf_fusion_num_models(mmf_fusion* f) { return f ? (int)f->models.size() : -1; }
+extern "C" mmf_model* mmf_fusion_model_at(mmf_fusion* f, int index) {
+    return (f && index >= 0 && index < (int)f->models.size()) ? f->models[index]->model : nullptr;
+}
+extern "C" mmf_odom* mmf_fusion_odometry_at(mmf_fusion* f, int index) {
+    return (f && index >= 0 && index < (int)f->models.size()) ? f->models[index]->odom : nullptr;
+}
+extern "C" int mmf_fusion_num_inactive_models(mmf_fusion* f) { return f ? (int)f->inactive.size() : -1; }
+extern "C" mmf_model* mmf_fusion_inactive_model_at(mmf_fusion* f, int index) {
+    return (f && index >= 0 && index < (int)f->inactive.size()) ? f->inactive[index]->model : nullptr;
+}
+extern "C" int mmf_fusion_next_model_id(mmf_fusion* f) { return f ? f->next_id : -1; }
+
+static FusionModel* fusion_find(mmf_fusion* f, int id) {
+    for (FusionModel* m : f->models)
+        if ((int)m->model->id == id) return m;
+    return nullptr;
+}
+
+// Model::getICPErrorTexture / getRGBErrorTexture (Model.h:232-236): R32F images written by the last level-0
+// iteration of the model's tracking (reduce.cu:275,299; RGBDOdometry.cpp:369,408)
+extern "C" int mmf_fusion_error_texture(mmf_fusion* f, int index, int which, float** dev_ptr) {
+    MMF_REQUIRE(f && dev_ptr && index >= 0 && index < (int)f->models.size(), "mmf_fusion_error_texture: bad argument");
+    *dev_ptr = which == 0 ? f->models[index]->icp_error : f->models[index]->rgb_error;
+    MMF_REQUIRE(*dev_ptr != nullptr, "mmf_fusion_error_texture: error recording is off");
+    return MMF_OK;
+}
+
+// getTextures() (MultiMotionFusion.h:124): the raw input images of the current frame as device images
+extern "C" int mmf_fusion_texture(mmf_fusion* f, const char* name, const void** dev_ptr, size_t* bytes) {
+    MMF_REQUIRE(f && name && dev_ptr && bytes, "mmf_fusion_texture: null argument");
+    const size_t npix = (size_t)f->width * f->height;
+    const std::string s(name);
+    if (s == "RGB") *dev_ptr = f->frame_rgb, *bytes = npix * 3;                      // GPUTexture::RGB
+    else if (s == "DEPTH_METRIC") *dev_ptr = f->frame_depth, *bytes = npix * 4;      // GPUTexture::DEPTH_METRIC
+    else if (s == "DEPTH_METRIC_FILTERED") *dev_ptr = f->depth_filtered, *bytes = npix * 4;
+    else if (s == "MASK") *dev_ptr = f->mask, *bytes = npix;
+    else return fail(MMF_ERR_INVALID, "mmf_fusion_texture: unknown name '" + s + "'");
+    return MMF_OK;
+}
+
+// ---- runtime setters the front end pushes every GUI tick (MultiMotionFusion.cpp:1064-1116, GUI/MainController.cpp:641-670)
+#define MMF_FUSION_SETTER(name, field, type)                              \
+    extern "C" int mmf_fusion_set_##name(mmf_fusion* f, type val) {       \
+        MMF_REQUIRE(f != nullptr, "mmf_fusion_set_" #name ": null fusion object"); \
+        f->cfg.field = val;                                               \
+        return MMF_OK;                                                    \
+    }
+MMF_FUSION_SETTER(rgb_only, rgb_only, int)
+MMF_FUSION_SETTER(icp_weight, icp_weight, float)
+MMF_FUSION_SETTER(outlier_coefficient, outlier_coeff, float)
+MMF_FUSION_SETTER(pyramid, pyramid, int)
+MMF_FUSION_SETTER(fast_odom, fast_odom, int)
+MMF_FUSION_SETTER(so3, so3, int)
+MMF_FUSION_SETTER(frame_to_frame_rgb, frame_to_frame_rgb, int)
+MMF_FUSION_SETTER(depth_cutoff, depth_cutoff, float)
+MMF_FUSION_SETTER(enable_multiple_models, enable_multiple_models, int)
+#undef MMF_FUSION_SETTER
+// setConfidenceThreshold is declared by the reference (MultiMotionFusion.h:168) but has no definition: the
+// threshold lives in each Model (Model.h:222-224)
+extern "C" int mmf_fusion_set_confidence_threshold(mmf_fusion* f, float val) {
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_set_confidence_threshold: null fusion object");
+    f->models[0]->model->conf_threshold = val;
+    return MMF_OK;
+}
+extern "C" int mmf_fusion_set_tick(mmf_fusion* f, int val) {  // :1116
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_set_tick: null fusion object");
+    f->tick = val;
+    return MMF_OK;
+}
+extern "C" int mmf_fusion_get_config(mmf_fusion* f, mmf_fusion_config* out) {
+    MMF_REQUIRE(f && out, "mmf_fusion_get_config: null argument");
+    *out = f->cfg;
+    return MMF_OK;
+}
+extern "C" int mmf_fusion_set_segmentation_callback(mmf_fusion* f, mmf_segmentation_fn fn, void* user) {
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_set_segmentation_callback: null fusion object");
+    f->seg_fn = fn, f->seg_user = user;
+    return MMF_OK;
+}
+// scheduleDeactivation (MultiMotionFusion.cpp: scheduled_model_deactivation, applied at the next frame :279-283)
+extern "C" int mmf_fusion_schedule_deactivation(mmf_fusion* f, int id) {
+    MMF_REQUIRE(f != nullptr && id > 0, "mmf_fusion_schedule_deactivation: bad argument (the global model stays)");
+    f->scheduled_deactivation.push_back(id);
+    return MMF_OK;
+}
+
+// Model::computeFusionWeight (Model.cpp:876-891)
+static float fusion_weight(const float* pose, const float* last_pose, float multiplier) {
+    float inv[16];
+    inverse4f_host(pose, inv);  // getLastTransform() = getPose().inverse() * lastPose (Model.h:305)
+    return mmf::host::compute_fusion_weight(inv, last_pose, multiplier);
+}
+extern "C" int mmf_compute_fusion_weight(const float pose[16], const float last_pose[16], float multiplier, float* out) {
+    MMF_REQUIRE(pose && last_pose && out, "mmf_compute_fusion_weight: null argument");
+    *out = fusion_weight(pose, last_pose, multiplier);
+    return MMF_OK;
+}
+
+// Eigen::Quaternionf(rotation).coeffs() = (x, y, z, w), float32 (Eigen/src/Geometry/Quaternion.h,
+// quaternionbase_assign_impl: branch on the trace, else on the largest diagonal element)
+static void pose_to_log7(const float* T, float p[7]) {
+    p[0] = T[3], p[1] = T[7], p[2] = T[11];
+    const float R[3][3] = {{T[0], T[1], T[2]}, {T[4], T[5], T[6]}, {T[8], T[9], T[10]}};
+    float q[4];  // x y z w
+    float t = (R[0][0] + R[1][1]) + R[2][2];
+    if (t > 0.f) {
+        t = std::sqrt(t + 1.0f);
+        q[3] = 0.5f * t;
+        t = 0.5f / t;
+        q[0] = (R[2][1] - R[1][2]) * t;
+        q[1] = (R[0][2] - R[2][0]) * t;
+        q[2] = (R[1][0] - R[0][1]) * t;
+    } else {
+        int i = 0;
+        if (R[1][1] > R[0][0]) i = 1;
+        if (R[2][2] > R[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(((R[i][i] - R[j][j]) - R[k][k]) + 1.0f);
+        q[i] = 0.5f * t;
+        t = 0.5f / t;
+        q[3] = (R[k][j] - R[j][k]) * t;
+        q[j] = (R[j][i] + R[i][j]) * t;
+        q[k] = (R[k][i] + R[i][k]) * t;
+    }
+    p[3] = q[0], p[4] = q[1], p[5] = q[2], p[6] = q[3];
+}
+
+// every model's odometry reads the sensor-side images of the frame from the primary (global) odometry's buffers
+static void odom_alias_sensor_side(mmf_odom* o, const mmf_odom* primary) {
+    for (int i = 0; i < MMF_NUM_PYRS; ++i) {
+        o->vmaps_curr[i] = primary->vmaps_curr[i], o->nmaps_curr[i] = primary->nmaps_curr[i];
+        o->next_image[i] = primary->next_image[i], o->last_next_image[i] = primary->last_next_image[i];
+        o->dIdx[i] = primary->dIdx[i], o->dIdy[i] = primary->dIdy[i];
+        o->depth_pyr[i] = primary->depth_pyr[i];
+    }
+    o->depth_l0 = primary->depth_l0;
+}
+
+// Model::combinedPredict(ACTIVE) + Model::performFillIn of one model (the body of predict(), :863-875)
+static int fusion_predict_model(mmf_fusion* f, FusionModel* fm) {
+    const mmf_fusion_config& g = f->cfg;
+    if (fm->fill_in)  // combinedPredict + performFillIn in one pass
+        return model_combined_predict(fm->model, g.max_depth_processed, f->tick, f->tick, g.time_delta, f->frame_rgb,
+                                      f->depth_filtered, g.frame_to_frame_rgb, /*lost*/ 0);
+    return mmf_model_combined_predict(fm->model, g.max_depth_processed, f->tick, f->tick, g.time_delta);
+}
+
+// predictIndices -> fuse -> predictIndices -> clean of one model (:791-816 per model; models never read each
+// other's surfels, so running the four passes model by model on the model's own stream gives the same maps as
+// the reference's pass-by-pass loops over the list)
+static int fusion_fuse_clean_model(mmf_fusion* f, FusionModel* fm, float weighting) {
+    const mmf_fusion_config& g = f->cfg;
+    int rc = mmf_model_predict_indices(fm->model, f->tick, g.max_depth_processed, g.time_delta);
+    if (rc) return rc;
+    rc = mmf_model_fuse(fm->model, f->tick, f->frame_rgb, f->mask, f->frame_depth, f->depth_filtered, g.max_depth_processed,
+                        weighting);
+    if (rc) return rc;
+    rc = mmf_model_predict_indices(fm->model, f->tick, g.max_depth_processed, g.time_delta);
+    if (rc) return rc;
+    return mmf_model_clean(fm->model, f->tick, g.time_delta, g.max_depth_processed, f->depth_filtered, f->mask, g.outlier_coeff);
+}
+
+// getMaxDepth (:408): float operands, double arithmetic (1.2 is a double literal), returned as float
+static float seg_max_depth(const mmf_segmentation_model& d) { return (float)((double)d.depth_mean + (double)d.depth_std * 1.2); }
+
+static int lane_wait(FusionModel* fm, hipEvent_t ev) {
+    MMF_HIP_TRY(hipStreamWaitEvent(fm->lane->stream, ev, 0));
+    return MMF_OK;
+}
+
+// inactivateModel (:962-981) without the on-disk model database: the model leaves the active list and keeps its map
+static void fusion_inactivate(mmf_fusion* f, FusionModel* fm) {
+    f->models.erase(std::find(f->models.begin(), f->models.end(), fm));
+    f->inactive.push_back(fm);
+}
+
+// spawnObjectModel (:938-947)
+static int fusion_spawn(mmf_fusion* f, FusionModel** out) {
+    FusionModel* fm = nullptr;
+    if (!f->preallocated.empty()) {
+        fm = f->preallocated.front();
+        f->preallocated.erase(f->preallocated.begin());
+    } else {
+        int rc = fusion_model_create(f, fusion_next_model_id(f, true), f->cfg.conf_object_init, 0, true, &fm);
+        if (rc) return rc;
+    }
+    // frameToModel.initFirstRGB(textures[RGB]) (:946): with the shared sensor-side images, the "last" image the new
+    // model's SO3 pre-alignment reads next frame IS this frame's intensity pyramid (same kernels, same bits)
+    *out = fm;
+    return MMF_OK;
+}
+
+static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
+    MMF_REQUIRE(f != nullptr && fr != nullptr, "mmf_fusion_process_frame: null argument");
+    const uint8_t* rgb = fr->rgb;
+    const float* depth = fr->depth;
+    if (!rgb || !depth || fr->timestamp < 0)  // MultiMotionFusion.cpp:209-212
+        return fail(MMF_ERR_INVALID, "invalid image data");
+    mmf_ctx* c = f->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const mmf_fusion_config& g = f->cfg;
+    const float weight_multiplier = fr->weight_multiplier;
+    const bool have_init = fr->init_transforms != nullptr && fr->n_init_transforms > 0;  // odom_cfg.init == "kp"
+    FusionModel* global = f->models[0];
+    int rc = MMF_OK;
+    bool prefetched = false;
+    if (f->pre_valid) {  // whatever was prefetched has to be complete before this frame touches the same buffers
+        MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch_done, 0));
+        MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch2_done, 0));
+        prefetched = f->pre_rgb == rgb && f->pre_depth == depth;
+        f->pre_valid = false;
+    }
+    const bool track = f->tick > 1 && (fr->bootstrap || !fr->in_pose);  // :299 "regular execution"
+    // a prefetched SO3 pre-alignment only counts for the frame it was computed for, and only when that frame is tracked
+    if (!prefetched || !track || (have_init && !fr->icp_refine)) global->odom->so3_prefetched = false;
+    if (prefetched) {  // the filter (:262) and the input-side preparation already ran on the side stream
+        f->cur ^= 1;
+        f->depth_filtered = f->filtered[f->cur];
+    } else {
+        rc = mmf_filter_depth(c, depth, f->width, f->height, g.depth_cutoff, f->depth_filtered);  // :262
+        if (rc) return rc;
+    }
+    f->frame_rgb = rgb, f->frame_depth = depth;
+    if (!g.enable_multiple_models && !f->mask_is_zero) {  // :268-275: everything is background
+        MMF_HIP_TRY(hipMemsetAsync(f->mask, 0, (size_t)f->width * f->height, c->stream));
+        f->mask_is_zero = true;
+    }
+
+    for (int id : f->scheduled_deactivation)  // :279-283
+        if (FusionModel* fm = fusion_find(f, id)) fusion_inactivate(f, fm);
+    f->scheduled_deactivation.clear();
+
+    if (f->tick == 1) {  // :290-296
+        rc = mmf_model_initialise(global->model, rgb, depth, f->depth_filtered, f->tick, g.max_depth_processed);
+        if (rc) return rc;
+        rc = mmf_odom_init_first_rgb(global->odom, rgb, 0, 3);
+        if (rc) return rc;
+        MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
+        f->inputs_free_recorded = true;
+        MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
+    } else {
+        f->tracking_ok = 1;
+        const size_t n_models = f->models.size();
+        if (track) {
+            MMF_REQUIRE(!have_init || !g.frame_to_frame_rgb, "ICP initialisation not supported in frame-to-frame mode");  // :370
+            // generateCUDATextures (:302) + the sensor side of Model::initICP (Model.cpp:402-403: initICP, initRGB), once
+            // for all models.  One model without pose initialisation: sensor side and model side share four launches.
+            const bool one_pass = n_models == 1 && !have_init;
+            if (!prefetched && !one_pass) {
+                float identity[16];
+                identity16(identity);
+                rc = odom_prepare_batched(global->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, nullptr, nullptr,
+                                          nullptr, 4, identity, nullptr, nullptr, nullptr, nullptr,
+                                          PREP_INPUT_IMAGE | PREP_INPUT_DEPTH);
+                if (rc) return rc;
+            }
+            if (!one_pass) MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
+            for (size_t k = 0; k < n_models; ++k) {  // :312-387, enqueue only
+                FusionModel* fm = f->models[k];
+                fm->tracking = false;
+                if (k > 0) {
+                    rc = lane_wait(fm, f->ev_frame_ready);
+                    if (rc) return rc;
+                    odom_alias_sensor_side(fm->odom, global->odom);
+                }
+                bool do_icp = true;
+                if (have_init) {  // initialise by track transformation (:316-376)
+                    do_icp = fr->icp_refine != 0;
+                    float pose[16], tnew[16];
+                    mmf_model_get_pose(fm->model, pose);
+                    const float* T = fr->init_transforms + 16 * (k < (size_t)fr->n_init_transforms ? k : 0);
+                    if (k >= (size_t)fr->n_init_transforms) {
+                        std::memcpy(tnew, pose, sizeof(pose));  // no transformation for this model: keep its pose
+                    } else if (fm->model->id == 0) {
+                        mmf::host::matmul4(pose, T, tnew);  // Tnew = model->getPose() * T (:331)
+                    } else {
+                        mmf::host::matmul4(T, pose, tnew);  // Tnew = T * model->getPose() (:334)
+                    }
+                    mmf_model_set_pose(fm->model, tnew);  // overridePose: pose = lastPose = Tnew (:350, Model.h:301-304)
+                    std::memcpy(fm->last_pose, tnew, sizeof(tnew));
+                    rc = fusion_predict_model(f, fm);  // :353-355
+                    if (rc) return rc;
+                    // Model::fuse(..., weightMultiplier) applies computeFusionWeight(weightMultiplier) (:359-360, Model.cpp:918)
+                    rc = fusion_fuse_clean_model(f, fm, fusion_weight(tnew, fm->last_pose, weight_multiplier));  // :357-366
+                    if (rc) return rc;
+                }
+                if (!do_icp) continue;  // no refinement, use the initial pose directly (:382-385)
+                // Model::performTracking (Model.cpp:409-433) with Model::initICP (:390-407).  requiresFillIn (:380,
+                // :877-895) is decided on the device: the preparation jobs pick their sources from the flag
+                const mmf_model* m = fm->model;
+                int* fill_flag = reinterpret_cast<int*>(&m->totals[3]);
+                if (fm->fill_in) {
+                    hipLaunchKernelGGL(thumbnail_flag_kernel, dim3(1), dim3(256), 0, fm->lane->stream, m->image, m->width,
+                                       m->height, 0.75f, fill_flag);
+                    MMF_HIP_TRY(hipGetLastError());
+                }
+                float pose[16];
+                mmf_model_get_pose(fm->model, pose);
+                std::memcpy(fm->last_pose, pose, sizeof(pose));  // lastPose = pose (Model.cpp:412)
+                const uint8_t* pi = (const uint8_t*)((g.frame_to_frame_rgb && fm->fill_in) ? m->fill_image : m->image);
+                const int side = (k == 0 && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE;
+                rc = odom_prepare_batched(fm->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
+                                          (const float*)m->normalRadius, pi, 4, pose, fm->fill_in ? fill_flag : nullptr,
+                                          (const float*)m->fill_vertex, (const float*)m->fill_normal,
+                                          (const uint8_t*)m->fill_image, side);
+                if (rc) return rc;
+                const float trans[3] = {pose[3], pose[7], pose[11]};
+                const float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+                rc = odom_enqueue_tracking(fm->odom, trans, rot, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom, g.so3,
+                                           fm->icp_error, fm->rgb_error);
+                if (rc) return rc;
+                fm->tracking = true;
+            }
+            for (size_t k = 0; k < n_models; ++k) {  // the results, model by model
+                FusionModel* fm = f->models[k];
+                float pose[16];
+                mmf_model_get_pose(fm->model, pose);
+                if (fm->tracking) {
+                    float trans[3], rot[9];
+                    rc = odom_finish_tracking(fm->odom, trans, rot);
+                    if (rc) return rc;
+                    for (int r = 0; r < 3; ++r) {
+                        for (int q = 0; q < 3; ++q) pose[r * 4 + q] = rot[r * 3 + q];
+                        pose[r * 4 + 3] = trans[r];
+                    }
+                    mmf_model_set_pose(fm->model, pose);
+                    fm->tracking = false;
+                }
+            }
+            if (fr->bootstrap) {  // :397-400
+                MMF_REQUIRE(fr->in_pose != nullptr, "mmf_fusion_process_frame: bootstrap needs in_pose");
+                float pose[16], np[16];
+                mmf_model_get_pose(global->model, pose);
+                mmf::host::matmul4(pose, fr->in_pose, np);
+                mmf_model_set_pose(global->model, np);  // overridePose
+                std::memcpy(global->last_pose, np, sizeof(np));
+            }
+            // from here on nothing enqueued reads the odometries' sensor-side buffers or the other filtered-depth
+            // buffer (every lane's tracking has been awaited): the next frame's prefetch may start
+            MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
+            f->inputs_free_recorded = true;
+            if (one_pass) MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
+
+            if (g.enable_multiple_models) {  // :407-622
+                mmf_segmentation seg_cb;
+                const mmf_segmentation* seg = fr->segmentation;
+                if (!seg && f->seg_fn) {  // performSegmentation(frame) (:412)
+                    std::memset(&seg_cb, 0, sizeof(seg_cb));
+                    rc = f->seg_fn(f->seg_user, f, fr, &seg_cb);
+                    if (rc) return fail(MMF_ERR_STATE, "mmf_fusion_process_frame: the segmentation callback failed");
+                    seg = &seg_cb;
+                }
+                MMF_REQUIRE(seg && seg->mask, "mmf_fusion_process_frame: enableMultipleModels needs a segmentation "
+                                              "(mmf_frame::segmentation or mmf_fusion_set_segmentation_callback)");
+                // textures[MASK]->Upload(fullSegmentation) (:416)
+                MMF_HIP_TRY(hipMemcpyAsync(f->mask, seg->mask, (size_t)f->width * f->height, hipMemcpyDeviceToDevice, c->stream));
+                f->mask_is_zero = false;
+                MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
+                const int n_data = seg->model_data ? seg->n_models : 0;
+                FusionModel* fresh = nullptr;
+                if (seg->has_new_label) {  // :469-487
+                    rc = fusion_spawn(f, &fresh);
+                    if (rc) return rc;
+                    if (n_data > 0)
+                        fresh->model->max_depth = seg_max_depth(seg->model_data[n_data - 1]);
+                }
+                // Set max-depth (:585-586)
+                for (size_t i = 1; i < f->models.size() && (int)i < n_data; ++i)
+                    f->models[i]->model->max_depth = seg_max_depth(seg->model_data[i]);
+                if (fresh) {  // :588-601: the first surfels of the new model, then it joins the list
+                    rc = lane_wait(fresh, f->ev_frame_ready);
+                    if (rc) return rc;
+                    identity16(fresh->last_pose);
+                    float pose[16];
+                    mmf_model_get_pose(fresh->model, pose);
+                    rc = mmf_model_predict_indices(fresh->model, f->tick, g.max_depth_processed, g.time_delta);
+                    if (rc) return rc;
+                    rc = mmf_model_fuse(fresh->model, f->tick, rgb, f->mask, depth, f->depth_filtered, g.max_depth_processed,
+                                        fusion_weight(pose, fresh->last_pose, 100.f));  // fuse(..., 100) (:591-592)
+                    if (rc) return rc;
+                    // (the second predictIndices is commented out in the reference, :594)
+                    rc = mmf_model_clean(fresh->model, f->tick, g.time_delta, g.max_depth_processed, f->depth_filtered, f->mask,
+                                         g.outlier_coeff);
+                    if (rc) return rc;
+                    f->models.push_back(fresh);  // moveNewModelToList (:600)
+                }
+                // unseen models leave the list (:606-613); the confidence of object models rises (:616-620)
+                std::vector<FusionModel*> lost;
+                for (int i = 0; i < n_data; ++i) {
+                    FusionModel* fm = fusion_find(f, (int)seg->model_data[i].id);
+                    if (!fm || fm == fresh) continue;
+                    if (seg->model_data[i].super_pixel_count <= 0 && ++fm->unseen > 0 && fm->model->id != 0) lost.push_back(fm);
+                }
+                for (FusionModel* fm : lost) fusion_inactivate(f, fm);
+                for (size_t i = 1; i < f->models.size() && (int)i < n_data; ++i) {
+                    const float old_conf = f->models[i]->model->conf_threshold;
+                    const float avg = seg->model_data[i].avg_confidence;
+                    const float m1 = old_conf < avg ? avg : old_conf;
+                    f->models[i]->model->conf_threshold = 9.0f < m1 ? 9.0f : m1;
+                }
+            }
+        } else {
+            float pose[16];
+            std::memcpy(pose, fr->in_pose, sizeof(pose));
+            mmf_model_set_pose(global->model, pose);  // globalModel->overridePose(*inPose) (:670)
+            std::memcpy(global->last_pose, pose, sizeof(pose));
+            MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
+            f->inputs_free_recorded = true;
+            MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
+        }
+
+        for (size_t k = 0; k < f->models.size(); ++k) {  // predict() (:675), then :791-816, model by model
+            FusionModel* fm = f->models[k];
+            if (k > 0) {
+                rc = lane_wait(fm, f->ev_frame_ready);
+                if (rc) return rc;
+            }
+            rc = fusion_predict_model(f, fm);
+            if (rc) return rc;
+            if (!g.rgb_only && f->tracking_ok) {
+                float pose[16];
+                mmf_model_get_pose(fm->model, pose);
+                rc = fusion_fuse_clean_model(f, fm, fusion_weight(pose, fm->last_pose, weight_multiplier));
+                if (rc) return rc;
+            }
+        }
+    }
+    for (FusionModel* fm : f->models) {  // predict() (:821)
+        rc = fusion_predict_model(f, fm);
+        if (rc) return rc;
+    }
+    f->tick++;  // :825
+
+    // :829-846: pose log (camera->world for the first model, object->world for the others)
+    float global_pose[16];
+    mmf_model_get_pose(global->model, global_pose);
+    for (size_t k = 0; k < f->models.size(); ++k) {
+        FusionModel* fm = f->models[k];
+        if (fm->pose_log.capacity() == 0) continue;  // isLoggingPoses()
+        float T[16];
+        if (k == 0) {
+            std::memcpy(T, global_pose, sizeof(T));
+        } else {
+            float pose[16], inv[16];
+            mmf_model_get_pose(fm->model, pose);
+            inverse4f_host(pose, inv);
+            mmf::host::matmul4(global_pose, inv, T);
+        }
+        PoseLogItem item;
+        item.ts = fr->timestamp;
+        pose_to_log7(T, item.p);
+        fm->pose_log.push_back(item);
+    }
+
+    // the fusion's stream continues only after every lane: the next frame's filter, prefetch and mask upload
+    // overwrite what the lanes read
+    for (size_t k = 1; k < f->models.size(); ++k) {
+        FusionModel* fm = f->models[k];
+        MMF_HIP_TRY(hipEventRecord(fm->ev_done, fm->lane->stream));
+        MMF_HIP_TRY(hipStreamWaitEvent(c->stream, fm->ev_done, 0));
+    }
+    return MMF_OK;
+}
+
+extern "C" int mmf_fusion_process_frame_ex(mmf_fusion* f, const mmf_frame* frame) { return fusion_process_frame_impl(f, frame); }
+
+extern "C" int mmf_fusion_process_frame(mmf_fusion* f, const uint8_t* rgb, const float* depth, long long timestamp,
+                                        const float* in_pose, float weight_multiplier, int bootstrap) {
+    mmf_frame fr;
+    std::memset(&fr, 0, sizeof(fr));
+    fr.rgb = rgb, fr.depth = depth, fr.timestamp = timestamp;
+    fr.in_pose = in_pose, fr.weight_multiplier = weight_multiplier, fr.bootstrap = bootstrap;
+    fr.icp_refine = 1;
+    return fusion_process_frame_impl(f, &fr);
+}
+
+extern "C" int mmf_fusion_process_frame_init(mmf_fusion* f, const uint8_t* rgb, const float* depth, long long timestamp,
+                                             const float* init_transform, int icp_refine, float weight_multiplier) {
+    MMF_REQUIRE(init_transform != nullptr, "mmf_fusion_process_frame_init: null transformation");
+    mmf_frame fr;
+    std::memset(&fr, 0, sizeof(fr));
+    fr.rgb = rgb, fr.depth = depth, fr.timestamp = timestamp;
+    fr.weight_multiplier = weight_multiplier;
+    fr.init_transforms = init_transform, fr.n_init_transforms = 1, fr.icp_refine = icp_refine;
+    return fusion_process_frame_impl(f, &fr);
+}
+
+// processFrame(const FrameData&) with the frame still in host memory (the reference uploads FrameData::rgb / depth
+// to GL textures at :221, :261): rgb, depth and the optional id image go through pinned staging buffers into
+// device copies, double buffered so that frame t+1 can be staged while frame t's last passes still read theirs.
+extern "C" int mmf_fusion_process_frame_host(mmf_fusion* f, const uint8_t* rgb_host, const float* depth_host,
+                                             const uint8_t* mask_host, int has_new_label, long long timestamp,
+                                             const float* in_pose, float weight_multiplier, int bootstrap) {
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_process_frame_host: null fusion object");
+    if (!rgb_host || !depth_host || timestamp < 0) return fail(MMF_ERR_INVALID, "invalid image data");  // :209-212
+    mmf_ctx* c = f->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    const size_t npix = (size_t)f->width * f->height;
+    const size_t o_depth = 0, o_rgb = npix * 4, o_mask = npix * 7, total = npix * 8;  // 8 B/px
+    if (!f->up_pin[0])
+        for (int i = 0; i < 2; ++i) {
+            MMF_HIP_TRY(hipHostMalloc((void**)&f->up_pin[i], total, hipHostMallocDefault));
+            MMF_HIP_TRY(hipMalloc((void**)&f->up_dev[i], total));
+        }
+    const int b = f->up_cur;
+    f->up_cur ^= 1;
+    std::memcpy(f->up_pin[b] + o_depth, depth_host, npix * 4);
+    std::memcpy(f->up_pin[b] + o_rgb, rgb_host, npix * 3);
+    size_t bytes = npix * 7;
+    if (mask_host) {
+        std::memcpy(f->up_pin[b] + o_mask, mask_host, npix);
+        bytes = total;
+    }
+    MMF_HIP_TRY(hipMemcpyAsync(f->up_dev[b], f->up_pin[b], bytes, hipMemcpyHostToDevice, c->stream));
+    mmf_frame fr;
+    std::memset(&fr, 0, sizeof(fr));
+    fr.rgb = f->up_dev[b] + o_rgb, fr.depth = (const float*)(f->up_dev[b] + o_depth), fr.timestamp = timestamp;
+    fr.in_pose = in_pose, fr.weight_multiplier = weight_multiplier, fr.bootstrap = bootstrap;
+    fr.icp_refine = 1;
+    mmf_segmentation seg;
+    std::memset(&seg, 0, sizeof(seg));
+    if (mask_host) {
+        seg.mask = f->up_dev[b] + o_mask, seg.has_new_label = has_new_label;
+        fr.segmentation = &seg;
+    }
+    return fusion_process_frame_impl(f, &fr);
+}
+
+// MultiMotionFusion::predict (:863-875) as a public call (the GUI re-predicts when a view changes)
+extern "C" int mmf_fusion_predict(mmf_fusion* f) {
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_predict: null fusion object");
+    MMF_REQUIRE(f->frame_rgb != nullptr, "mmf_fusion_predict: no frame has been processed yet");
+    MMF_HIP_TRY(hipSetDevice(f->ctx->device));
+    for (size_t k = 0; k < f->models.size(); ++k) {
+        FusionModel* fm = f->models[k];
+        int rc = fusion_predict_model(f, fm);
+        if (rc) return rc;
+        if (k > 0) {
+            MMF_HIP_TRY(hipEventRecord(fm->ev_done, fm->lane->stream));
+            MMF_HIP_TRY(hipStreamWaitEvent(f->ctx->stream, fm->ev_done, 0));
+        }
+    }
+    return MMF_OK;
+}
+
+// The filter and the input-side preparation (vertex / normal maps, depth and intensity pyramids, gradients) of the
+// NEXT frame, enqueued on a second stream so that they run while the current frame is still being fused.
+// rgb / depth must stay unchanged until the mmf_fusion_process_frame call that consumes them (same pointers).
+extern "C" int mmf_fusion_prefetch_frame(mmf_fusion* f, const uint8_t* rgb, const float* depth) {
+    MMF_REQUIRE(f && rgb && depth, "mmf_fusion_prefetch_frame: null argument");
+    mmf_ctx* c = f->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    mmf_odom* odom = f->models[0]->odom;
+    if (f->side == nullptr) {  // first use
+        MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+        MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking));
+        MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch_done, hipEventDisableTiming));
+        MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch2_done, hipEventDisableTiming));
+        MMF_HIP_TRY(hipMalloc(&f->side_partials, sizeof(float) * kMaxGrid * kPartialStride));
+        MMF_HIP_TRY(hipMalloc(&f->side_ticket, sizeof(unsigned) * kTicketWords));
+        MMF_HIP_TRY(hipMemsetAsync(f->side_ticket, 0, sizeof(unsigned) * kTicketWords, f->side2));
+    }
+    f->pre_valid = false;  // an earlier prefetch is simply overwritten: same streams, same order
+    if (f->inputs_free_recorded) {
+        MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_inputs_free, 0));
+        MMF_HIP_TRY(hipStreamWaitEvent(f->side2, f->ev_inputs_free, 0));
+    }
+    const mmf_fusion_config& g = f->cfg;
+    float identity[16];
+    identity16(identity);
+    hipStream_t img_stream = f->side2;
+    // image chain (second side stream): intensity pyramid + gradients, then the SO3 pre-alignment, which needs
+    // nothing but this frame's and the last frame's level-2 images
+    int rc = odom_prepare_batched(odom, nullptr, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity,
+                                  nullptr, nullptr, nullptr, nullptr, PREP_INPUT_IMAGE, img_stream);
+    if (rc) return rc;
+    odom->so3_prefetched = false;
+    if (g.so3 && f->tick > 1) {  // a model exists: the frame will be tracked, SO3 first
+        rc = odom_prefetch_so3(odom, img_stream, f->side_partials, f->side_ticket);
+        if (rc) return rc;
+    }
+    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch2_done, img_stream));
+    // depth chain (first side stream): filter, depth pyramid, vertex and normal maps
+    float* target = f->filtered[1 - f->cur];
+    rc = filter_depth_on(c, f->side, depth, f->width, f->height, g.depth_cutoff, target);
+    if (rc) return rc;
+    rc = odom_prepare_batched(odom, target, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity, nullptr,
+                              nullptr, nullptr, nullptr, PREP_INPUT_DEPTH, f->side);
+    if (rc) return rc;
+    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch_done, f->side));
+    f->pre_valid = true, f->pre_rgb = rgb, f->pre_depth = depth;
+    return MMF_OK;
+}
+
+extern "C" int mmf_fusion_get_pose(mmf_fusion* f, float pose[16]) {
+    MMF_REQUIRE(f && pose, "mmf_fusion_get_pose: null argument");
+    return mmf_model_get_pose(f->models[0]->model, pose);
+}
+
+static int model_reset_store(mmf_model* m) {
+    if (int rc = model_resolve_count(m)) return rc;  // lets an in-flight count land before it is dropped
+    m->count = 0, m->count_pending = false, m->count_bound = 0;
+    MMF_HIP_TRY(hipMemsetAsync(m->totals, 0, 16, m->ctx->stream));
+    identity16(m->pose);
+    m->max_depth = FLT_MAX;
+    return MMF_OK;
+}
+
+// start a new map: empty surfel stores, identity poses, tick = 1, only the global model active (what
+// constructing a fresh MultiMotionFusion does, MultiMotionFusion.cpp:21-97); object models return to the
+// preallocated pool
+extern "C" int mmf_fusion_reset(mmf_fusion* f) {
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_reset: null fusion object");
+    MMF_HIP_TRY(hipSetDevice(f->ctx->device));
+    if (f->pre_valid) {  // a prefetched frame belongs to the sequence that ends here
+        MMF_HIP_TRY(hipStreamWaitEvent(f->ctx->stream, f->ev_prefetch_done, 0));
+        MMF_HIP_TRY(hipStreamWaitEvent(f->ctx->stream, f->ev_prefetch2_done, 0));
+        f->pre_valid = false;
+    }
+    for (auto* list : {&f->models, &f->inactive})
+        for (size_t k = (list == &f->models ? 1 : 0); k < list->size(); ++k) f->preallocated.push_back((*list)[k]);
+    f->models.resize(1);
+    f->inactive.clear();
+    f->scheduled_deactivation.clear();
+    std::vector<FusionModel*> all(f->preallocated);
+    all.push_back(f->models[0]);
+    for (FusionModel* fm : all) {
+        int rc = model_reset_store(fm->model);
+        if (rc) return rc;
+        fm->model->conf_threshold = fm->model->id == 0 ? f->cfg.conf_global_init : f->cfg.conf_object_init;
+        identity16(fm->last_pose);
+        fm->odom->so3_prefetched = false;
+        fm->odom->have_tmp = false;
+        fm->unseen = 0;
+        fm->pose_log.clear();
+    }
+    f->tick = 1;
+    return MMF_OK;
+}
+
+// MultiMotionFusion::exportPoses (:1020-1045): one file per pose-logging model, `poses-<id>.txt` in export_dir,
+// lines `ts x y z qx qy qz qw` (operator<< formatting: 6 significant digits)
+extern "C" int mmf_fusion_export_poses(mmf_fusion* f, const char* export_dir) {
+    MMF_REQUIRE(f && export_dir, "mmf_fusion_export_poses: null argument");
+    for (auto* list : {&f->models, &f->inactive})
+        for (FusionModel* fm : *list) {
+            if (fm->pose_log.capacity() == 0) continue;
+            const std::string name = std::string(export_dir) + "poses-" + std::to_string((int)fm->model->id) + ".txt";
+            FILE* fp = std::fopen(name.c_str(), "w");
+            if (!fp) return fail(MMF_ERR_INVALID, "mmf_fusion_export_poses: cannot open " + name);
+            for (const PoseLogItem& it : fm->pose_log) {
+                std::fprintf(fp, "%lld", it.ts);
+                for (int i = 0; i < 7; ++i) std::fprintf(fp, " %g", (double)it.p[i]);
+                std::fprintf(fp, "\n");
+            }
+            std::fclose(fp);
+        }
+    return MMF_OK;
+}
+
+// the pose log of one active model (Model::getPoseLog): n entries of {ts, x y z qx qy qz qw}
+extern "C" int mmf_fusion_pose_log(mmf_fusion* f, int index, long long* ts, float* p7, int max_entries, int* n_out) {
+    MMF_REQUIRE(f && n_out && index >= 0 && index < (int)f->models.size(), "mmf_fusion_pose_log: bad argument");
+    const std::vector<PoseLogItem>& log = f->models[index]->pose_log;
+    *n_out = (int)log.size();
+    for (int i = 0; i < (int)log.size() && i < max_entries; ++i) {
+        if (ts) ts[i] = log[i].ts;
+        if (p7) std::memcpy(p7 + 7 * i, log[i].p, sizeof(float) * 7);
+    }
+    return MMF_OK;
+}

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -16,6 +17,7 @@
 
 #include "map_kernels.hpp"
 #include "prep_batch.hpp"
+#include "pose_algebra.hpp"
 #include "track_kernels.hpp"
 
 using namespace mmf;
@@ -732,6 +734,7 @@ struct mmf_odom {
     // last_depth (both come from the same prediction, RGBDOdometry.cpp:179 -- see odom_populate_rgbd)
     bool prep_batched = false;
     bool so3_prefetched = false;  // this frame's SO3 pre-alignment already ran (odom_prefetch_so3)
+    bool pending_icp = false, pending_so3 = false;  // mode of the tracking call that is in flight (enqueue -> finish)
     mmf_odom_stats stats;
 };
 
@@ -1157,8 +1160,9 @@ static IcpArgs odom_icp_args(mmf_odom* o, int level, float* err_map) {
 
 // the ten launches of the SO3 pre-alignment (RGBDOdometry.cpp:239-310): last frame's image against this frame's
 // at level 2 -- no model, no pose
-static int odom_enqueue_so3(mmf_odom* o, hipStream_t stream) {
+static int odom_enqueue_so3(mmf_odom* o, hipStream_t stream, float* partials = nullptr, unsigned* ticket = nullptr) {
     mmf_ctx* c = o->ctx;
+    if (!partials) partials = c->partials_f, ticket = c->ticket;
     const int lvl = 2, cols = o->width >> lvl, rows = o->height >> lvl;
     So3Args a;
     a.last_image = o->last_next_image[lvl];
@@ -1170,8 +1174,7 @@ static int odom_enqueue_so3(mmf_odom* o, hipStream_t stream) {
     a.cols_magic = (unsigned)((1ull << 32) / (unsigned)cols) + 1u;
     const int grid = reduce_grid(cols * rows, kBlock);
     for (int i = 0; i < 10; ++i) {
-        hipLaunchKernelGGL((so3_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), 0, stream, o->state, a, c->partials_f,
-                           c->ticket);
+        hipLaunchKernelGGL((so3_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), 0, stream, o->state, a, partials, ticket);
         MMF_HIP_TRY(hipGetLastError());
     }
     return MMF_OK;
@@ -1179,10 +1182,10 @@ static int odom_enqueue_so3(mmf_odom* o, hipStream_t stream) {
 
 // the SO3 pre-alignment of the NEXT frame ahead of its tracking, on `stream` (after that frame's intensity
 // pyramid): its begin part, then the ten launches; getIncrementalTransformation then skips both
-static int odom_prefetch_so3(mmf_odom* o, hipStream_t stream) {
+static int odom_prefetch_so3(mmf_odom* o, hipStream_t stream, float* partials, unsigned* ticket) {
     hipLaunchKernelGGL(so3_begin_kernel, dim3(1), dim3(64), 0, stream, o->state, level_intr(o->fx, o->fy, o->cx, o->cy, 2));
     MMF_HIP_TRY(hipGetLastError());
-    int rc = odom_enqueue_so3(o, stream);
+    int rc = odom_enqueue_so3(o, stream, partials, ticket);
     if (rc) return rc;
     o->so3_prefetched = true;
     return MMF_OK;
@@ -1192,10 +1195,11 @@ static int odom_prefetch_so3(mmf_odom* o, hipStream_t stream) {
 // every kernel below is enqueued back to back on the context's stream; the data-dependent
 // `break`s of the reference (:285-292, :376-378) become flags in the device state that make the
 // remaining launches of that loop return immediately.
-extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[3], float rot[9], int rgb_only,
-                                                       float icp_weight, int pyramid, int fast_odom, int so3,
-                                                       float* icp_err_dev, float* rgb_err_dev) {
-    MMF_REQUIRE(o && trans && rot, "mmf_odom_get_incremental_transformation: null argument");
+// first half: everything up to and including the copy of the result towards the host is enqueued on the
+// context's stream, nothing waits.  The orchestrator enqueues the chains of all its models (one stream each)
+// before it waits for the first result.
+static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float rot[9], int rgb_only, float icp_weight,
+                                 int pyramid, int fast_odom, int so3, float* icp_err_dev, float* rgb_err_dev) {
     mmf_ctx* c = o->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     const bool icp = !rgb_only && icp_weight > 0;  // :221-222
@@ -1348,7 +1352,16 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
         MMF_HIP_TRY(hipGetLastError());
     }
     MMF_HIP_TRY(hipMemcpyAsync(o->host_result, o->state, sizeof(OdomState), hipMemcpyDeviceToHost, c->stream));
+    o->pending_icp = icp, o->pending_so3 = so3 != 0;
+    return MMF_OK;
+}
+
+// second half: wait for the stream, hand the result out
+static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
+    mmf_ctx* c = o->ctx;
+    MMF_HIP_TRY(hipSetDevice(c->device));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    const bool icp = o->pending_icp, so3 = o->pending_so3;
 
     if (so3)  // :469-473
         for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(o->last_next_image[i], o->next_image[i]);
@@ -1374,6 +1387,15 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
     o->stats.iterations_run = r->st.iterations_run;
     o->stats.so3_iterations_run = r->st.so3_iterations_run;
     return MMF_OK;
+}
+
+extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[3], float rot[9], int rgb_only,
+                                                       float icp_weight, int pyramid, int fast_odom, int so3,
+                                                       float* icp_err_dev, float* rgb_err_dev) {
+    MMF_REQUIRE(o && trans && rot, "mmf_odom_get_incremental_transformation: null argument");
+    int rc = odom_enqueue_tracking(o, trans, rot, rgb_only, icp_weight, pyramid, fast_odom, so3, icp_err_dev, rgb_err_dev);
+    if (rc) return rc;
+    return odom_finish_tracking(o, trans, rot);
 }
 
 extern "C" int mmf_odom_get_stats(mmf_odom* o, mmf_odom_stats* out) {
@@ -1478,6 +1500,7 @@ struct mmf_model {
     float cx = 0, cy = 0, fx = 0, fy = 0;
     unsigned char id = 0;
     float conf_threshold = 10.f;
+    float max_depth = FLT_MAX;  // Model::maxDepth (Model.h:129, set per object from the segmentation: MultiMotionFusion.cpp:486,586)
     int capacity = 0;
     float pose[16];
     unsigned count = 0;  // host copy of the number of surfels in set[cur]
@@ -1652,6 +1675,19 @@ extern "C" int mmf_model_get_pose(mmf_model* m, float pose[16]) {
     std::memcpy(pose, m->pose, sizeof(m->pose));
     return MMF_OK;
 }
+// Model::setMaxDepth / setConfidenceThreshold (Model.h:224-230)
+extern "C" int mmf_model_set_max_depth(mmf_model* m, float max_depth) {
+    MMF_REQUIRE(m != nullptr, "mmf_model_set_max_depth: null model");
+    m->max_depth = max_depth;
+    return MMF_OK;
+}
+extern "C" int mmf_model_set_confidence_threshold(mmf_model* m, float conf_threshold) {
+    MMF_REQUIRE(m != nullptr, "mmf_model_set_confidence_threshold: null model");
+    m->conf_threshold = conf_threshold;
+    return MMF_OK;
+}
+extern "C" float mmf_model_confidence_threshold(mmf_model* m) { return m ? m->conf_threshold : 0.f; }
+extern "C" int mmf_model_id(mmf_model* m) { return m ? (int)m->id : -1; }
 // makes m->count exact again (after the stream has passed the clean pass that produced it)
 static int model_resolve_count(mmf_model* m) {
     if (!m->count_pending) return MMF_OK;
@@ -1827,7 +1863,7 @@ extern "C" int mmf_model_fuse(mmf_model* m, int time, const uint8_t* rgb, const 
     a.time = time;
     a.weighting = weighting;
     a.maskID = m->id;
-    a.maxDepth = depth_cutoff;  // std::min(depthCutoff, maxDepth) with maxDepth = FLT_MAX by default (Model.h:129)
+    a.maxDepth = depth_cutoff < m->max_depth ? depth_cutoff : m->max_depth;  // std::min(depthCutoff, maxDepth) (Model.cpp:928)
     a.count = (int)m->count;
     hipLaunchKernelGGL(fuse_data_kernel, grid1d(npix), dim3(256), 0, c->stream, rgb, depth_raw, depth_filtered, mask,
                        m->index, m->vertConf, m->normRad, a, m->meas, m->flags_b, m->winner);
@@ -2190,357 +2226,6 @@ extern "C" int mmf_debug_set_stamps(void* dev_buf) {
 #endif
 
 // =============================================================================================
-// Orchestrator: MultiMotionFusion::processFrame / predict (Core/MultiMotionFusion.cpp:207-854,
-// 863-875) for one rigid-body model per object (the static-scene configuration,
-// enableMultipleModels == false; segmentation, model spawning and loop closure are out of scope).
+// Orchestrator: MultiMotionFusion::processFrame / predict (Core/MultiMotionFusion.cpp:207-854, 863-875)
 // =============================================================================================
-struct mmf_fusion {
-    mmf_ctx* ctx = nullptr;
-    mmf_fusion_config cfg;
-    int width = 0, height = 0;
-    mmf_model* model = nullptr;   // globalModel
-    mmf_odom* odom = nullptr;     // its frameToModel
-    float* depth_filtered = nullptr;  // = filtered[cur]
-    uint8_t* mask = nullptr;      // all zeros: static scene (MultiMotionFusion.cpp:268-275)
-    int tick = 1;                 // MultiMotionFusion.cpp:36
-    float last_pose[16];
-    int tracking_ok = 1;
-    // next-frame prefetch (mmf_fusion_prefetch_frame): the filter and the input-side preparation of frame t+1 run
-    // on `side` while frame t is fused on the context's stream.  Two filtered-depth buffers: frame t's fuse /
-    // clean / fill-in read one while frame t+1's filter writes the other.
-    float* filtered[2] = {nullptr, nullptr};
-    int cur = 0;
-    hipStream_t side = nullptr;   // depth chain: filter, depth pyramid, vertex / normal maps
-    hipStream_t side2 = nullptr;  // image chain: intensity pyramid, gradients, SO3 pre-alignment
-    hipEvent_t ev_prefetch2_done = nullptr;
-    hipEvent_t ev_inputs_free = nullptr;    // context stream: enqueued work no longer reads the odometry's input-side
-                                            // buffers nor filtered[1 - cur]
-    hipEvent_t ev_prefetch_done = nullptr;  // side stream: the prefetch has been enqueued up to here
-    bool inputs_free_recorded = false;
-    bool pre_valid = false;
-    const uint8_t* pre_rgb = nullptr;
-    const float* pre_depth = nullptr;
-};
-
-extern "C" int mmf_fusion_default_config(mmf_fusion_config* cfg) {
-    MMF_REQUIRE(cfg != nullptr, "mmf_fusion_default_config: null argument");
-    cfg->time_delta = 200;          // GUI/MainController.cpp:333 (timeDelta flag default)
-    cfg->conf_global_init = 10.0f;  // GUI default confGlobalInit
-    cfg->icp_weight = 10.0f;        // GUI default icpWeight
-    cfg->depth_cutoff = 15.0f;      // GUI default depthCutoff (bilateral filter maxD)
-    cfg->max_depth_processed = 20.0f;  // MultiMotionFusion.cpp:53
-    cfg->rgb_only = 0;
-    cfg->pyramid = 1;
-    cfg->fast_odom = 0;
-    cfg->so3 = 1;
-    cfg->frame_to_frame_rgb = 0;
-    cfg->outlier_coeff = 3.0f;      // GPUSetup::outlierCoefficient GUI default
-    cfg->fill_in = 1;               // the global model is created with fill-in enabled
-    cfg->max_surfels = 0;
-    return MMF_OK;
-}
-
-extern "C" int mmf_fusion_create(mmf_ctx* c, int width, int height, float cx, float cy, float fx, float fy,
-                                 const mmf_fusion_config* cfg, mmf_fusion** out) {
-    MMF_REQUIRE(c && out, "mmf_fusion_create: null argument");
-    MMF_HIP_TRY(hipSetDevice(c->device));
-    mmf_fusion* f = new (std::nothrow) mmf_fusion();
-    MMF_REQUIRE(f != nullptr, "mmf_fusion_create: out of host memory");
-    f->ctx = c;
-    if (cfg)
-        f->cfg = *cfg;
-    else
-        mmf_fusion_default_config(&f->cfg);
-    f->width = width, f->height = height;
-    int rc = mmf_model_create(c, width, height, cx, cy, fx, fy, 0, f->cfg.conf_global_init, f->cfg.max_surfels, &f->model);
-    if (rc == MMF_OK)
-        rc = mmf_odom_create(c, width, height, cx, cy, fx, fy, 0.10f, std::sin(20.f * 3.14159254f / 180.f), &f->odom);
-    if (rc != MMF_OK) {
-        mmf_model_destroy(f->model);
-        mmf_odom_destroy(f->odom);
-        delete f;
-        return rc;
-    }
-    // the prediction images (model slab) and the filtered depth (this object's buffer) are not written
-    // between the init* calls of a frame and the end of its tracking
-    f->odom->alias_inputs = true;
-    const size_t npix = (size_t)width * height;
-    MMF_HIP_TRY(hipMalloc(&f->filtered[0], npix * 4));
-    MMF_HIP_TRY(hipMalloc(&f->filtered[1], npix * 4));
-    f->depth_filtered = f->filtered[0];
-    // the side streams and events of the prefetch are created by its first call
-    MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_inputs_free, hipEventDisableTiming));
-    MMF_HIP_TRY(hipMalloc(&f->mask, npix));
-    MMF_HIP_TRY(hipMemsetAsync(f->mask, 0, npix, c->stream));
-    for (int i = 0; i < 16; ++i) f->last_pose[i] = (i % 5 == 0) ? 1.f : 0.f;
-    *out = f;
-    return MMF_OK;
-}
-
-extern "C" void mmf_fusion_destroy(mmf_fusion* f) {
-    if (!f) return;
-    (void)hipSetDevice(f->ctx->device);
-    (void)hipStreamSynchronize(f->ctx->stream);
-    if (f->side) (void)hipStreamSynchronize(f->side);
-    if (f->side2) (void)hipStreamSynchronize(f->side2);
-    mmf_model_destroy(f->model);
-    mmf_odom_destroy(f->odom);
-    (void)hipFree(f->filtered[0]);
-    (void)hipFree(f->filtered[1]);
-    (void)hipFree(f->mask);
-    if (f->ev_inputs_free) (void)hipEventDestroy(f->ev_inputs_free);
-    if (f->ev_prefetch_done) (void)hipEventDestroy(f->ev_prefetch_done);
-    if (f->side) (void)hipStreamDestroy(f->side);
-    if (f->ev_prefetch2_done) (void)hipEventDestroy(f->ev_prefetch2_done);
-    if (f->side2) (void)hipStreamDestroy(f->side2);
-    delete f;
-}
-
-extern "C" mmf_model* mmf_fusion_model(mmf_fusion* f) { return f ? f->model : nullptr; }
-extern "C" mmf_odom* mmf_fusion_odometry(mmf_fusion* f) { return f ? f->odom : nullptr; }
-extern "C" int mmf_fusion_tick(mmf_fusion* f) { return f ? f->tick : -1; }
-extern "C" const float* mmf_fusion_depth_filtered(mmf_fusion* f) { return f ? f->depth_filtered : nullptr; }
-
-// MultiMotionFusion::predict (MultiMotionFusion.cpp:863-875)
-static int fusion_predict(mmf_fusion* f, const uint8_t* rgb) {
-    if (f->cfg.fill_in)  // combinedPredict + performFillIn in one pass
-        return model_combined_predict(f->model, f->cfg.max_depth_processed, f->tick, f->tick, f->cfg.time_delta, rgb,
-                                      f->depth_filtered, f->cfg.frame_to_frame_rgb, /*lost*/ 0);
-    return mmf_model_combined_predict(f->model, f->cfg.max_depth_processed, f->tick, f->tick, f->cfg.time_delta);
-}
-
-// Model::computeFusionWeight (Model.cpp:876-891): the norm of rodrigues2(R) is the rotation angle
-static float fusion_weight(const float* pose, const float* last_pose, float multiplier) {
-    float inv[16], d[16];
-    inverse4f_host(pose, inv);  // getLastTransform() = getPose().inverse() * lastPose (Model.h:305)
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) {
-            float s = 0;
-            for (int k = 0; k < 4; ++k) s += inv[r * 4 + k] * last_pose[k * 4 + c];
-            d[r * 4 + c] = s;
-        }
-    const float tn = std::sqrt(d[3] * d[3] + d[7] * d[7] + d[11] * d[11]);
-    const double rx = d[9] - d[6], ry = d[2] - d[8], rz = d[4] - d[1];
-    const double s = std::sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
-    double cth = ((double)(d[0] + d[5] + d[10]) - 1) * 0.5;
-    cth = cth > 1. ? 1. : cth < -1. ? -1. : cth;
-    const double theta = std::acos(cth);
-    const float rn = (s < 1e-5) ? (cth > 0 ? 0.f : (float)theta) : (float)theta;
-    float weighting = tn > rn ? tn : rn;
-    const float largest = 0.01f, minWeight = 0.5f;
-    if (weighting > largest) weighting = largest;
-    const float w = 1.0f - (weighting / largest);
-    return (w > minWeight ? w : minWeight) * multiplier;
-}
-
-// init_transform (optional): odom_cfg.init == "kp" -- the tracker starts from pose * init_transform
-// (MultiMotionFusion.cpp:312-384); icp_refine = odom_cfg.icp_refine
-static int fusion_process_frame_impl(mmf_fusion* f, const uint8_t* rgb, const float* depth, long long timestamp,
-                                     const float* in_pose, float weight_multiplier, int bootstrap,
-                                     const float* init_transform, int icp_refine) {
-    MMF_REQUIRE(f != nullptr, "mmf_fusion_process_frame: null fusion object");
-    if (!rgb || !depth || timestamp < 0)  // MultiMotionFusion.cpp:209-212
-        return fail(MMF_ERR_INVALID, "invalid image data");
-    mmf_ctx* c = f->ctx;
-    MMF_HIP_TRY(hipSetDevice(c->device));
-    const mmf_fusion_config& g = f->cfg;
-    int rc = MMF_OK;
-    bool prefetched = false;
-    if (f->pre_valid) {  // whatever was prefetched has to be complete before this frame touches the same buffers
-        MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch_done, 0));
-        MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch2_done, 0));
-        prefetched = f->pre_rgb == rgb && f->pre_depth == depth;
-        f->pre_valid = false;
-    }
-    // a prefetched SO3 pre-alignment only counts for the frame it was computed for, and only when that frame is tracked
-    if (!prefetched || f->tick == 1 || (in_pose && !bootstrap) || (init_transform && !icp_refine)) f->odom->so3_prefetched = false;
-    if (prefetched) {  // the filter (:262) and the input-side preparation already ran on the side stream
-        f->cur ^= 1;
-        f->depth_filtered = f->filtered[f->cur];
-    } else {
-        rc = mmf_filter_depth(c, depth, f->width, f->height, g.depth_cutoff, f->depth_filtered);  // :262
-        if (rc) return rc;
-    }
-
-    if (f->tick == 1) {  // :290-296
-        rc = mmf_model_initialise(f->model, rgb, depth, f->depth_filtered, f->tick, g.max_depth_processed);
-        if (rc) return rc;
-        rc = mmf_odom_init_first_rgb(f->odom, rgb, 0, 3);
-        if (rc) return rc;
-        MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
-        f->inputs_free_recorded = true;
-    } else {
-        f->tracking_ok = 1;
-        if ((bootstrap || !in_pose) && init_transform) {
-            // initialise by track transformation (:312-376): Tnew = pose * T for the camera model (:331), then one
-            // predict / fuse / clean round at that pose with weightMultiplier as the fusion weight (:352-366)
-            MMF_REQUIRE(!g.frame_to_frame_rgb, "ICP initialisation not supported in frame-to-frame mode");  // :370
-            float pose[16], tnew[16];
-            mmf_model_get_pose(f->model, pose);
-            for (int r = 0; r < 4; ++r)
-                for (int k = 0; k < 4; ++k) {
-                    float acc = 0.f;
-                    for (int q = 0; q < 4; ++q) acc = acc + pose[r * 4 + q] * init_transform[q * 4 + k];
-                    tnew[r * 4 + k] = acc;
-                }
-            mmf_model_set_pose(f->model, tnew);  // model->overridePose(Tnew) (:350)
-            rc = fusion_predict(f, rgb);
-            if (rc) return rc;
-            rc = mmf_model_predict_indices(f->model, f->tick, g.max_depth_processed, g.time_delta);
-            if (rc) return rc;
-            rc = mmf_model_fuse(f->model, f->tick, rgb, f->mask, depth, f->depth_filtered, g.max_depth_processed,
-                                weight_multiplier);
-            if (rc) return rc;
-            rc = mmf_model_predict_indices(f->model, f->tick, g.max_depth_processed, g.time_delta);
-            if (rc) return rc;
-            rc = mmf_model_clean(f->model, f->tick, g.time_delta, g.max_depth_processed, f->depth_filtered, f->mask,
-                                 g.outlier_coeff);
-            if (rc) return rc;
-        }
-        if ((bootstrap || !in_pose) && init_transform && !icp_refine) {
-            // no refinement, use the initial pose directly (:382-385)
-        } else if (bootstrap || !in_pose) {
-            // Model::performTracking (Model.cpp:409-433) with Model::initICP (:390-407)
-            // requiresFillIn (:380, :877-895) decided on the device: the preparation jobs pick their
-            // sources from the flag, no host round trip
-            const mmf_model* mm = f->model;
-            int* fill_flag = reinterpret_cast<int*>(&mm->totals[3]);
-            if (g.fill_in) {
-                hipLaunchKernelGGL(thumbnail_flag_kernel, dim3(1), dim3(256), 0, c->stream, mm->image, mm->width, mm->height,
-                                   0.75f, fill_flag);
-                MMF_HIP_TRY(hipGetLastError());
-            }
-            float pose[16];
-            mmf_model_get_pose(f->model, pose);
-            std::memcpy(f->last_pose, pose, sizeof(pose));  // lastPose = pose (Model.cpp:412)
-            // generateCUDATextures (:302) + Model::initICP (Model.cpp:390-407): initICPModel, initRGBModel,
-            // initICP, initRGB -- here as the four launches of odom_prepare_batched
-            const mmf_model* m = f->model;
-            const uint8_t* pi = (const uint8_t*)((g.frame_to_frame_rgb && g.fill_in) ? m->fill_image : m->image);
-            rc = odom_prepare_batched(f->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
-                                      (const float*)m->normalRadius, pi, 4, pose, g.fill_in ? fill_flag : nullptr,
-                                      (const float*)m->fill_vertex, (const float*)m->fill_normal,
-                                      (const uint8_t*)m->fill_image, prefetched ? PREP_MODEL_SIDE : PREP_ALL);
-            if (rc) return rc;
-            float trans[3] = {pose[3], pose[7], pose[11]};
-            float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
-            rc = mmf_odom_get_incremental_transformation(f->odom, trans, rot, g.rgb_only, g.icp_weight, g.pyramid,
-                                                         g.fast_odom, g.so3, nullptr, nullptr);
-            if (rc) return rc;
-            for (int r = 0; r < 3; ++r) {
-                for (int k = 0; k < 3; ++k) pose[r * 4 + k] = rot[r * 3 + k];
-                pose[r * 4 + 3] = trans[r];
-            }
-            mmf_model_set_pose(f->model, pose);
-        } else {
-            float pose[16];
-            mmf_model_get_pose(f->model, pose);
-            std::memcpy(f->last_pose, pose, sizeof(pose));
-            mmf_model_set_pose(f->model, in_pose);  // globalModel->overridePose(*inPose) (:670)
-        }
-
-        // from here on nothing enqueued reads the odometry's input-side buffers or the other filtered-depth
-        // buffer: the next frame's prefetch may start
-        MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
-        f->inputs_free_recorded = true;
-
-        rc = fusion_predict(f, rgb);  // :675
-        if (rc) return rc;
-
-        if (!g.rgb_only && f->tracking_ok) {  // :791-817
-            float pose[16];
-            mmf_model_get_pose(f->model, pose);
-            rc = mmf_model_predict_indices(f->model, f->tick, g.max_depth_processed, g.time_delta);
-            if (rc) return rc;
-            rc = mmf_model_fuse(f->model, f->tick, rgb, f->mask, depth, f->depth_filtered, g.max_depth_processed,
-                                fusion_weight(pose, f->last_pose, weight_multiplier));
-            if (rc) return rc;
-            rc = mmf_model_predict_indices(f->model, f->tick, g.max_depth_processed, g.time_delta);
-            if (rc) return rc;
-            rc = mmf_model_clean(f->model, f->tick, g.time_delta, g.max_depth_processed, f->depth_filtered, f->mask,
-                                 g.outlier_coeff);
-            if (rc) return rc;
-        }
-    }
-    rc = fusion_predict(f, rgb);  // :821
-    if (rc) return rc;
-    f->tick++;  // :825
-    return MMF_OK;
-}
-
-extern "C" int mmf_fusion_process_frame(mmf_fusion* f, const uint8_t* rgb, const float* depth, long long timestamp,
-                                        const float* in_pose, float weight_multiplier, int bootstrap) {
-    return fusion_process_frame_impl(f, rgb, depth, timestamp, in_pose, weight_multiplier, bootstrap, nullptr, 1);
-}
-
-extern "C" int mmf_fusion_process_frame_init(mmf_fusion* f, const uint8_t* rgb, const float* depth, long long timestamp,
-                                             const float* init_transform, int icp_refine, float weight_multiplier) {
-    MMF_REQUIRE(init_transform != nullptr, "mmf_fusion_process_frame_init: null transformation");
-    return fusion_process_frame_impl(f, rgb, depth, timestamp, nullptr, weight_multiplier, 0, init_transform, icp_refine);
-}
-
-// The filter and the input-side preparation (vertex / normal maps, depth and intensity pyramids, gradients) of the
-// NEXT frame, enqueued on a second stream so that they run while the current frame is still being fused.
-// rgb / depth must stay unchanged until the mmf_fusion_process_frame call that consumes them (same pointers).
-extern "C" int mmf_fusion_prefetch_frame(mmf_fusion* f, const uint8_t* rgb, const float* depth) {
-    MMF_REQUIRE(f && rgb && depth, "mmf_fusion_prefetch_frame: null argument");
-    mmf_ctx* c = f->ctx;
-    MMF_HIP_TRY(hipSetDevice(c->device));
-    if (f->side == nullptr) {  // first use
-        MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
-        MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking));
-        MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch_done, hipEventDisableTiming));
-        MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch2_done, hipEventDisableTiming));
-    }
-    f->pre_valid = false;  // an earlier prefetch is simply overwritten: same streams, same order
-    if (f->inputs_free_recorded) {
-        MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_inputs_free, 0));
-        MMF_HIP_TRY(hipStreamWaitEvent(f->side2, f->ev_inputs_free, 0));
-    }
-    const mmf_fusion_config& g = f->cfg;
-    const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    hipStream_t img_stream = f->side2;
-    // image chain (second side stream): intensity pyramid + gradients, then the SO3 pre-alignment, which needs
-    // nothing but this frame's and the last frame's level-2 images
-    int rc = odom_prepare_batched(f->odom, nullptr, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity,
-                                  nullptr, nullptr, nullptr, nullptr, PREP_INPUT_IMAGE, img_stream);
-    if (rc) return rc;
-    f->odom->so3_prefetched = false;
-    if (g.so3 && f->tick > 1) {  // a model exists: the frame will be tracked, SO3 first
-        rc = odom_prefetch_so3(f->odom, img_stream);
-        if (rc) return rc;
-    }
-    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch2_done, img_stream));
-    // depth chain (first side stream): filter, depth pyramid, vertex and normal maps
-    float* target = f->filtered[1 - f->cur];
-    rc = filter_depth_on(c, f->side, depth, f->width, f->height, g.depth_cutoff, target);
-    if (rc) return rc;
-    rc = odom_prepare_batched(f->odom, target, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity, nullptr,
-                              nullptr, nullptr, nullptr, PREP_INPUT_DEPTH, f->side);
-    if (rc) return rc;
-    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch_done, f->side));
-    f->pre_valid = true, f->pre_rgb = rgb, f->pre_depth = depth;
-    return MMF_OK;
-}
-
-extern "C" int mmf_fusion_get_pose(mmf_fusion* f, float pose[16]) {
-    MMF_REQUIRE(f && pose, "mmf_fusion_get_pose: null argument");
-    return mmf_model_get_pose(f->model, pose);
-}
-
-// start a new map: empty surfel store, identity pose, tick = 1 (what constructing a fresh
-// MultiMotionFusion does, MultiMotionFusion.cpp:21-97)
-extern "C" int mmf_fusion_reset(mmf_fusion* f) {
-    MMF_REQUIRE(f != nullptr, "mmf_fusion_reset: null fusion object");
-    if (f->pre_valid) {  // a prefetched frame belongs to the sequence that ends here
-        MMF_HIP_TRY(hipStreamWaitEvent(f->ctx->stream, f->ev_prefetch_done, 0));
-        MMF_HIP_TRY(hipStreamWaitEvent(f->ctx->stream, f->ev_prefetch2_done, 0));
-        f->pre_valid = false;
-    }
-    f->odom->so3_prefetched = false;
-    f->tick = 1;
-    f->model->count = 0;
-    for (int i = 0; i < 16; ++i) f->model->pose[i] = f->last_pose[i] = (i % 5 == 0) ? 1.f : 0.f;
-    f->odom->have_tmp = false;
-    return MMF_OK;
-}
+#include "fusion_orchestrator.hpp"

@@ -1,12 +1,12 @@
-"""Host-side mirror of class MultiMotionFusion (Core/MultiMotionFusion.h:78-160) for the
-static-scene configuration: processFrame / getCurrPose / getTick / getBackgroundModel.
+"""Host-side mirror of class MultiMotionFusion (Core/MultiMotionFusion.h:78-300): processFrame (one or many
+rigid-body models), predict, getModels / getBackgroundModel / getTextures, the runtime setters, exportPoses.
 The orchestration itself is native code inside libmmf_hip.so (mmf_fusion_*)."""
 import ctypes as C
 import weakref
 
 import numpy as np
 
-from ._capi import check, fptr, mmf_fusion_config
+from ._capi import check, fptr, mmf_frame, mmf_fusion_config, mmf_segmentation, mmf_segmentation_model
 from .cudafuncs import Context, _p
 from .model import Model
 from .odometry import RGBDOdometry
@@ -27,20 +27,60 @@ class MultiMotionFusion:
         self.handle = h
         ctx._children.append(weakref.ref(self))
         # borrowed views of the objects the fusion owns
-        self._model = Model.__new__(Model)
-        self._model.ctx, self._model.width, self._model.height, self._model.id = ctx, width, height, 0
-        self._model.handle = C.c_void_p(ctx.lib.mmf_fusion_model(h))
-        self._model.close = lambda: None
-        self._odom = RGBDOdometry.__new__(RGBDOdometry)
-        self._odom.ctx, self._odom.width, self._odom.height = ctx, width, height
-        self._odom.handle = C.c_void_p(ctx.lib.mmf_fusion_odometry(h))
-        self._odom.close = lambda: None
+        self._model = self._borrow_model(ctx.lib.mmf_fusion_model(h))
+        self._odom = self._borrow_odom(ctx.lib.mmf_fusion_odometry(h))
+
+    def _borrow_model(self, handle):
+        m = Model.__new__(Model)
+        m.ctx, m.width, m.height = self.ctx, self.width, self.height
+        m.handle = C.c_void_p(handle)
+        m.id = self.ctx.lib.mmf_model_id(m.handle)
+        m.close = lambda: None
+        return m
+
+    def _borrow_odom(self, handle):
+        o = RGBDOdometry.__new__(RGBDOdometry)
+        o.ctx, o.width, o.height = self.ctx, self.width, self.height
+        o.handle = C.c_void_p(handle)
+        o.close = lambda: None
+        return o
 
     def processFrame(self, rgb, depth, timestamp=0, inPose=None, weightMultiplier=1.0, bootstrap=False, initTransform=None,
-                     icpRefine=True):
+                     icpRefine=True, mask=None, hasNewLabel=False, modelData=None, initTransforms=None):
         """MultiMotionFusion::processFrame: rgb [H,W,3] uint8, depth [H,W] float32 (CUDA tensors).
         initTransform: `-init kp` (MultiMotionFusion.cpp:312-384) -- the 4x4 of Model::getLastTrackTransform, applied
-        to the pose before the dense tracker (which then refines it when icpRefine, `-icp_refine`)."""
+        to the pose before the dense tracker (which then refines it when icpRefine, `-icp_refine`).
+        mask / hasNewLabel / modelData: the SegmentationResult of this frame when enable_multiple_models is set
+        (fullSegmentation as a CUDA uint8 [H,W] tensor of model ids; modelData: dicts with id, super_pixel_count,
+        avg_confidence, depth_mean, depth_std in list order).  initTransforms: one 4x4 per active model."""
+        if mask is not None or initTransforms is not None:
+            fr = mmf_frame()
+            fr.rgb, fr.depth, fr.timestamp = _p(rgb), _p(depth), int(timestamp)
+            fr.weight_multiplier, fr.bootstrap, fr.icp_refine = float(weightMultiplier), int(bool(bootstrap)), int(bool(icpRefine))
+            keep = []
+            if inPose is not None:
+                pose = np.ascontiguousarray(np.asarray(inPose, np.float32).reshape(16))
+                keep.append(pose)
+                fr.in_pose = fptr(pose)
+            if initTransforms is not None:
+                T = np.ascontiguousarray(np.asarray(initTransforms, np.float32).reshape(-1, 16))
+                keep.append(T)
+                fr.init_transforms, fr.n_init_transforms = fptr(T), T.shape[0]
+            if mask is not None:
+                seg = mmf_segmentation()
+                seg.mask, seg.has_new_label = _p(mask), int(bool(hasNewLabel))
+                if modelData:
+                    arr = (mmf_segmentation_model * len(modelData))()
+                    for i, d in enumerate(modelData):
+                        arr[i].id, arr[i].super_pixel_count = int(d["id"]), int(d["super_pixel_count"])
+                        arr[i].avg_confidence = float(d["avg_confidence"])
+                        arr[i].depth_mean, arr[i].depth_std = float(d["depth_mean"]), float(d["depth_std"])
+                    seg.n_models, seg.model_data = len(modelData), arr
+                    keep.append(arr)
+                keep.append(seg)
+                fr.segmentation = C.pointer(seg)
+            check(self.ctx.lib.mmf_fusion_process_frame_ex(self.handle, C.byref(fr)))
+            return
         if initTransform is not None:
             assert inPose is None and not bootstrap
             T = np.ascontiguousarray(np.asarray(initTransform, np.float32).reshape(16))
@@ -72,6 +112,95 @@ class MultiMotionFusion:
 
     def getBackgroundModel(self):
         return self._model
+
+    def getModels(self):
+        """std::list<std::shared_ptr<Model>>& getModels(): the active models in list order (index 0 = global)."""
+        lib = self.ctx.lib
+        return [self._borrow_model(lib.mmf_fusion_model_at(self.handle, i)) for i in range(lib.mmf_fusion_num_models(self.handle))]
+
+    def getInactiveModels(self):
+        lib = self.ctx.lib
+        return [self._borrow_model(lib.mmf_fusion_inactive_model_at(self.handle, i))
+                for i in range(lib.mmf_fusion_num_inactive_models(self.handle))]
+
+    def getModelOdometry(self, index):
+        o = self._borrow_odom(self.ctx.lib.mmf_fusion_odometry_at(self.handle, index))
+        o._refresh_stats()
+        return o
+
+    def getNextModelID(self):
+        return self.ctx.lib.mmf_fusion_next_model_id(self.handle)
+
+    def scheduleDeactivation(self, model_id):
+        check(self.ctx.lib.mmf_fusion_schedule_deactivation(self.handle, int(model_id)))
+
+    def processFrameHost(self, rgb, depth, timestamp=0, mask=None, hasNewLabel=False, inPose=None, weightMultiplier=1.0,
+                         bootstrap=False):
+        """processFrame(const FrameData&) with HOST numpy arrays: staged through pinned buffers and uploaded inside."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.float32)
+        m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
+        pose = np.ascontiguousarray(np.asarray(inPose, np.float32).reshape(16)) if inPose is not None else None
+        check(self.ctx.lib.mmf_fusion_process_frame_host(self.handle, rgb.ctypes.data, depth.ctypes.data,
+                                                         m.ctypes.data if m is not None else None, int(bool(hasNewLabel)),
+                                                         int(timestamp), fptr(pose) if pose is not None else None,
+                                                         float(weightMultiplier), int(bool(bootstrap))))
+
+    def predict(self):
+        check(self.ctx.lib.mmf_fusion_predict(self.handle))
+
+    def setTick(self, val):
+        check(self.ctx.lib.mmf_fusion_set_tick(self.handle, int(val)))
+
+    def _set(self, name, val):
+        check(getattr(self.ctx.lib, "mmf_fusion_set_" + name)(self.handle, val))
+
+    def setRgbOnly(self, v): self._set("rgb_only", int(bool(v)))
+    def setIcpWeight(self, v): self._set("icp_weight", float(v))
+    def setOutlierCoefficient(self, v): self._set("outlier_coefficient", float(v))
+    def setPyramid(self, v): self._set("pyramid", int(bool(v)))
+    def setFastOdom(self, v): self._set("fast_odom", int(bool(v)))
+    def setSo3(self, v): self._set("so3", int(bool(v)))
+    def setFrameToFrameRGB(self, v): self._set("frame_to_frame_rgb", int(bool(v)))
+    def setDepthCutoff(self, v): self._set("depth_cutoff", float(v))
+    def setConfidenceThreshold(self, v): self._set("confidence_threshold", float(v))
+    def setEnableMultipleModels(self, v): self._set("enable_multiple_models", int(bool(v)))
+
+    def getConfig(self):
+        cfg = mmf_fusion_config()
+        check(self.ctx.lib.mmf_fusion_get_config(self.handle, C.byref(cfg)))
+        return cfg
+
+    def getTexture(self, name):
+        """getTextures()[name]: "RGB", "DEPTH_METRIC", "DEPTH_METRIC_FILTERED", "MASK" as a CUDA tensor view."""
+        import torch
+        from .model import _as_tensor
+        p, b = C.c_void_p(), C.c_size_t()
+        check(self.ctx.lib.mmf_fusion_texture(self.handle, name.encode(), C.byref(p), C.byref(b)))
+        dt = torch.uint8 if name in ("RGB", "MASK") else torch.float32
+        shape = (self.height, self.width, 3) if name == "RGB" else (self.height, self.width)
+        return _as_tensor(p.value, b.value, dt, shape, self.ctx.device, self)
+
+    def getErrorTexture(self, index, which="icp"):
+        """Model::getICPErrorTexture / getRGBErrorTexture of the index-th active model (CUDA float32 [H,W] view)."""
+        import torch
+        from .model import _as_tensor
+        p = C.c_void_p()
+        check(self.ctx.lib.mmf_fusion_error_texture(self.handle, int(index), 0 if which == "icp" else 1, C.byref(p)))
+        return _as_tensor(p.value, self.width * self.height * 4, torch.float32, (self.height, self.width), self.ctx.device, self)
+
+    def exportPoses(self, export_dir):
+        check(self.ctx.lib.mmf_fusion_export_poses(self.handle, export_dir.encode()))
+
+    def getPoseLog(self, index=0):
+        n = C.c_int()
+        check(self.ctx.lib.mmf_fusion_pose_log(self.handle, index, None, None, 0, C.byref(n)))
+        ts = np.zeros(n.value, np.int64)
+        p7 = np.zeros((n.value, 7), np.float32)
+        if n.value:
+            check(self.ctx.lib.mmf_fusion_pose_log(self.handle, index, ts.ctypes.data_as(C.POINTER(C.c_longlong)), fptr(p7),
+                                                   n.value, C.byref(n)))
+        return ts, p7
 
     def getFrameOdometry(self):
         self._odom._refresh_stats()

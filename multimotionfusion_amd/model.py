@@ -49,6 +49,15 @@ class Model:
         check(self.ctx.lib.mmf_model_get_pose(self.handle, fptr(p)))
         return p.reshape(4, 4)
 
+    def confidenceThreshold(self):
+        return float(self.ctx.lib.mmf_model_confidence_threshold(self.handle))
+
+    def setConfidenceThreshold(self, v):
+        check(self.ctx.lib.mmf_model_set_confidence_threshold(self.handle, float(v)))
+
+    def setMaxDepth(self, v):
+        check(self.ctx.lib.mmf_model_set_max_depth(self.handle, float(v)))
+
     def lastCount(self):
         n = C.c_uint(0)
         check(self.ctx.lib.mmf_model_count(self.handle, C.byref(n)))

@@ -140,6 +140,11 @@ typedef struct {
 } orc_surfel;
 
 void orc_inverse4f(const float m[16], float inv[16]);
+/* host pose algebra of the surfel passes (mmf_oracle_pose.c; Model.cpp:876-891, 1301-1342, Eigen JacobiSVD) */
+void orc_jacobi_svd3f(const float a[9], float U[9], float sv[3], float V[9]);
+void orc_rodrigues2(const float matrix[9], float out[3]);
+void orc_matmul4f(const float a[16], const float b[16], float out[16]);
+float orc_compute_fusion_weight(const float pose[16], const float last_pose[16], float weight_multiplier);
 void orc_bilateral_filter(const float *depth, int cols, int rows, float maxD, float *out);
 int orc_surfel_initialise(const uint8_t *rgb, const float *depth_raw, const float *depth_filtered, int cols,
                           int rows, float cx, float cy, float fx, float fy, int time, float maxDepth,

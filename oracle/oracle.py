@@ -18,7 +18,7 @@ def build(force=False, march=None, out=None):
     target = out or "liboracle.so"
     path = os.path.join(_DIR, target)
     src_m = max(os.path.getmtime(os.path.join(_DIR, f))
-                for f in ("mmf_oracle.c", "mmf_oracle_surfel.c", "mmf_oracle_match.c", "mmf_oracle_superpoint.c", "mmf_oracle_slic.c", "mmf_oracle.h",
+                for f in ("mmf_oracle.c", "mmf_oracle_surfel.c", "mmf_oracle_match.c", "mmf_oracle_superpoint.c", "mmf_oracle_slic.c", "mmf_oracle_pose.c", "mmf_oracle.h",
                           "Makefile"))
     if not force and os.path.exists(path) and os.path.getmtime(path) >= src_m:
         return path
@@ -349,6 +349,38 @@ def inverse4f(m):
     out = np.zeros(16, np.float32)
     lib().orc_inverse4f(_pf(m), _pf(out))
     return out.reshape(4, 4)
+
+
+def matmul4f(a, b):
+    """Eigen Matrix4f product, float32, terms summed in k order."""
+    a, b = _f(np.reshape(a, 16)), _f(np.reshape(b, 16))
+    out = np.zeros(16, np.float32)
+    lib().orc_matmul4f(_pf(a), _pf(b), _pf(out))
+    return out.reshape(4, 4)
+
+
+def jacobi_svd3f(a):
+    """Eigen::JacobiSVD<Matrix3f>(a, ComputeFullU | ComputeFullV) -> U, singular values, V."""
+    a = _f(np.reshape(a, 9))
+    U, sv, V = np.zeros(9, np.float32), np.zeros(3, np.float32), np.zeros(9, np.float32)
+    lib().orc_jacobi_svd3f(_pf(a), _pf(U), _pf(sv), _pf(V))
+    return U.reshape(3, 3), sv, V.reshape(3, 3)
+
+
+def rodrigues2(R):
+    """Model::rodrigues2 (Model.cpp:1301-1342)."""
+    R = _f(np.reshape(R, 9))
+    out = np.zeros(3, np.float32)
+    lib().orc_rodrigues2(_pf(R), _pf(out))
+    return out
+
+
+def compute_fusion_weight(pose, last_pose, weight_multiplier):
+    """Model::computeFusionWeight (Model.cpp:876-891)."""
+    pose, last_pose = _f(np.reshape(pose, 16)), _f(np.reshape(last_pose, 16))
+    f = lib().orc_compute_fusion_weight
+    f.restype = C.c_float
+    return float(f(_pf(pose), _pf(last_pose), _cf(weight_multiplier)))
 
 
 def bilateral_filter(depth, maxD):

@@ -51,101 +51,10 @@ def se3_sum_tolerance(out29, rel=2e-5):
     return tol
 
 
-class OracleFusion:
-    """processFrame (Core/MultiMotionFusion.cpp:207-854, static-scene path) restated on top of the
-    oracle's functions -- the checker for mmf_fusion_process_frame."""
-
-    def __init__(self, orc, w, h, K, time_delta=200, conf=10.0, icp_weight=10.0, depth_cutoff=15.0, max_depth=20.0,
-                 outlier_coeff=3.0):
-        self.orc, self.w, self.h, self.K = orc, w, h, K
-        self.time_delta, self.conf, self.icp_weight = time_delta, conf, icp_weight
-        self.depth_cutoff, self.max_depth, self.outlier_coeff = depth_cutoff, max_depth, outlier_coeff
-        self.odom = orc.Odometry(w, h, K["cx"], K["cy"], K["fx"], K["fy"])
-        self.tick = 1
-        self.pose = np.eye(4, dtype=np.float32)
-        self.last_pose = np.eye(4, dtype=np.float32)
-        self.surfels = np.zeros((0, 12), np.float32)
-        self.mask = np.zeros((h, w), np.uint8)
-
-    def predict(self, rgb, fil):
-        o = self.orc
-        self.image, self.vertexConf, self.normalRadius, self.time_tex = o.combined_predict(
-            self.surfels, self.pose, self.K, self.w, self.h, self.max_depth, self.conf, self.tick, self.tick,
-            self.time_delta)
-        self.fillVertex, self.fillNormal, self.fillImage = o.fill_in(self.vertexConf, self.normalRadius, self.image,
-                                                                     fil, rgb, self.K, 0, 0)
-
-    def fusion_weight(self, multiplier):
-        d = (o4 := self.orc.inverse4f(self.pose)) @ self.last_pose  # float32 product, row by row like the C code
-        d = np.zeros((4, 4), np.float32)
-        for r in range(4):
-            for c in range(4):
-                s = np.float32(0)
-                for k in range(4):
-                    s = np.float32(s + np.float32(o4[r, k] * self.last_pose[k, c]))
-                d[r, c] = s
-        tn = np.float32(np.sqrt(np.float32(d[0, 3] * d[0, 3] + d[1, 3] * d[1, 3]) + d[2, 3] * d[2, 3]))
-        rx, ry, rz = float(d[2, 1] - d[1, 2]), float(d[0, 2] - d[2, 0]), float(d[1, 0] - d[0, 1])
-        s = np.sqrt((rx * rx + ry * ry + rz * rz) * 0.25)
-        c = min(1.0, max(-1.0, (float(np.float32(d[0, 0] + d[1, 1]) + d[2, 2]) - 1) * 0.5))
-        theta = np.arccos(c)
-        rn = np.float32(0.0 if (s < 1e-5 and c > 0) else theta)
-        weighting = np.float32(max(tn, rn))
-        weighting = min(weighting, np.float32(0.01))
-        wv = np.float32(1.0) - np.float32(weighting / np.float32(0.01))
-        return float(np.float32(max(wv, np.float32(0.5)) * np.float32(multiplier)))
-
-    def fuse_and_clean(self, rgb, depth, fil, weight):
-        o = self.orc
-        index, vc, ct, nr = o.predict_indices(self.surfels, self.pose, self.K, self.w, self.h, self.max_depth,
-                                              self.tick, self.time_delta)
-        s_upd, new = o.fuse(self.surfels, rgb, depth, fil, self.mask, index, vc, nr, self.pose, self.K, self.tick,
-                            weight, 0, self.max_depth)
-        index, vc, ct, nr = o.predict_indices(s_upd, self.pose, self.K, self.w, self.h, self.max_depth, self.tick,
-                                              self.time_delta)
-        self.surfels = o.clean(s_upd, new, self.pose, self.K, self.w, self.h, self.tick, self.time_delta, self.conf,
-                               self.outlier_coeff, 0, index, vc, ct, fil, self.mask)
-
-    def process_frame(self, rgb, depth, weight_multiplier=1.0, init_transform=None, icp_refine=True):
-        o = self.orc
-        fil = o.bilateral_filter(depth, self.depth_cutoff)
-        if self.tick == 1:
-            self.surfels = o.surfel_initialise(rgb, depth, fil, self.K, self.tick, self.max_depth)
-            self.odom.initFirstRGB(rgb)
-        else:
-            if init_transform is not None:  # MultiMotionFusion.cpp:312-376
-                T = np.asarray(init_transform, np.float32)
-                tnew = np.zeros((4, 4), np.float32)
-                for r in range(4):
-                    for c in range(4):
-                        acc = np.float32(0)
-                        for k in range(4):
-                            acc = np.float32(acc + np.float32(self.pose[r, k] * T[k, c]))
-                        tnew[r, c] = acc
-                self.pose = tnew
-                self.predict(rgb, fil)
-                self.fuse_and_clean(rgb, depth, fil, float(np.float32(weight_multiplier)))
-        if self.tick > 1 and (init_transform is None or icp_refine):
-            do_fill = o.requires_fill_in(self.image, 0.75)
-            self.fill_in_taken = bool(do_fill)
-            self.last_pose = self.pose.copy()
-            if do_fill:
-                self.odom.initICPModel(self.fillVertex, self.fillNormal, self.pose)
-                self.odom.initRGBModel(self.fillImage)
-            else:
-                self.odom.initICPModel(self.vertexConf, self.normalRadius, self.pose)
-                self.odom.initRGBModel(self.image)
-            self.odom.initICP(fil, self.max_depth)
-            self.odom.initRGB(rgb)
-            t, R = self.odom.getIncrementalTransformation(self.pose[:3, 3], self.pose[:3, :3], False, self.icp_weight,
-                                                          True, False, True)
-            self.pose = np.eye(4, dtype=np.float32)
-            self.pose[:3, :3], self.pose[:3, 3] = R, t
-        if self.tick > 1:
-            self.predict(rgb, fil)
-            self.fuse_and_clean(rgb, depth, fil, self.fusion_weight(weight_multiplier))
-        self.predict(rgb, fil)
-        self.tick += 1
+def OracleFusion(orc, w, h, K, **kw):
+    """The processFrame checker: oracle/fusion.py (cited restatement of MultiMotionFusion.cpp:207-854)."""
+    from oracle.fusion import OracleFusion as _OracleFusion
+    return _OracleFusion(w, h, K, **kw)
 
 
 def slic_like_labels(W, H, S, seed=0, empty_every=0):

@@ -1,0 +1,102 @@
+"""-m gpu: multi-model MultiMotionFusion::processFrame (Core/MultiMotionFusion.cpp:312-387, 407-622, 791-816, 863-875) --
+the global model plus object models spawned from a ground-truth id image (configs 4 / 5 of BASELINE.json), each on
+its own stream -- against the oracle orchestration (oracle/fusion.py).
+
+What is bit-exact: everything that does not pass through the tracker's float32 sums -- the first surfels of a model in
+the frame it is spawned (identity pose), Model::computeFusionWeight, the pose log's quaternion.  Poses agree within
+1e-5 (north_star: 1e-4 rel. translation / 1e-3 rad); surfel counts after tracked frames within max(8, 0.2 %)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import OracleFusion
+from multimotionfusion_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def scene(w, h, n_frames, n_objects, seed=21):
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n_frames, seed=seed)
+    objs = synth.make_objects(n_objects, seed=seed)
+    traj = synth.object_trajectories(objs, n_frames, seed=seed)
+    frames = [synth.render(p, w, h, seed=i, objects=objs, object_poses=[t[i] for t in traj]) for i, p in enumerate(poses)]
+    return K, poses, traj, frames, objs
+
+
+def gt_mask(ids, known):
+    """Segmentation.cpp:89-150 for a ground-truth id image whose ids already are model ids: ids of models that do not
+    exist (yet) read as background."""
+    return np.where(np.isin(ids, list(known)), ids, 0).astype(np.uint8)
+
+
+def model_data(mask, depth, ids):
+    """SegmentationResult::modelData of the pre-masked path (Segmentation.cpp:121-147): pixel count / 256 as the
+    super-pixel count, avgConfidence 0.4, mean and mean absolute deviation of the depth per id."""
+    out = []
+    for i in ids:
+        sel = mask == i
+        n = int(sel.sum())
+        mean = float(depth[sel].mean()) if n else 0.0
+        std = float(np.abs(depth[sel] - mean).mean()) if n else 0.0
+        out.append(dict(id=i, super_pixel_count=n // 256, avg_confidence=0.4, depth_mean=mean, depth_std=std))
+    return out
+
+
+@pytest.mark.parametrize("w,h,with_data", [(320, 240, False), (320, 240, True)])
+def test_three_objects_spawned_one_per_frame(gpu_ctx, orc, w, h, with_data):
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    n_frames, n_obj = 6, 3
+    K, poses, traj, frames, objs = scene(w, h, n_frames, n_obj)
+    g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1, preallocated_models=1,
+                          pose_logging=1)
+    o = OracleFusion(orc, w, h, K, enable_multiple_models=True, pose_logging=True)
+    known = [0]
+    for i, f in enumerate(frames):
+        spawn = 1 <= i <= n_obj  # one new label per frame (Segmentation.cpp:113-118: allowNew && !hasNewLabel)
+        if spawn:
+            assert g.getNextModelID() == i
+            known.append(i)
+        mask = gt_mask(f["ids"], known)
+        assert (mask == known[-1]).sum() > 200, "the object must be visible"
+        data = model_data(mask, f["depth"], known) if with_data and i > 0 else None
+        g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=1000 + i, mask=dev(mask), hasNewLabel=spawn, modelData=data)
+        o.process_frame(f["rgb"], f["depth"], timestamp=1000 + i, mask=mask, has_new_label=spawn, model_data=data)
+        gm = g.getModels()
+        assert [m.id for m in gm] == [m.id for m in o.models] == known[:len(gm)], (i, [m.id for m in gm])
+        for k, (a, b) in enumerate(zip(gm, o.models)):
+            pa = a.getPose()
+            assert np.abs(pa - b.pose).max() <= 1e-5, (i, k, pa, b.pose)
+            na, nb = a.lastCount(), b.surfels.shape[0]
+            assert abs(na - nb) <= max(8, 0.002 * nb), (i, k, na, nb)
+            if k > 0:
+                assert abs(a.confidenceThreshold() - b.conf) < 1e-7 and a.id == k
+        if spawn:  # the new model was created at the identity pose: nothing of it went through the tracker
+            fresh_g, fresh_o = gm[-1].downloadMap(), o.models[-1].surfels
+            assert fresh_o.shape[0] > 50
+            assert np.array_equal(fresh_g.view(np.uint32), fresh_o.view(np.uint32)), (i, fresh_g.shape, fresh_o.shape)
+    # pose log (MultiMotionFusion.cpp:829-846): one entry per frame the model was in the list, object->world
+    from multimotionfusion_amd.klg import pose_7d
+    gm = g.getModels()
+    for k in range(0, n_obj + 1):
+        ts, p7 = g.getPoseLog(k)
+        lo = o.models[k].pose_log
+        assert len(ts) == len(lo) == n_frames - k and ts[-1] == 1000 + n_frames - 1
+        assert np.abs(p7[-1] - pose_7d(lo[-1][1])).max() < 2e-5
+    # the object models follow their objects.  Model frame = camera frame at the spawn frame s (the model is created at
+    # the identity pose), so X_cam(t) = P(t)^-1 X_model with P_gt(t) = C_s^-1 T(s) T(t)^-1 C_t
+    t = n_frames - 1
+    for k in range(1, n_obj + 1):
+        s = k
+        p_gt = np.linalg.inv(poses[s]) @ traj[k - 1][s] @ np.linalg.inv(traj[k - 1][t]) @ poses[t]
+        p_est = gm[k].getPose().astype(np.float64)
+        # measured where the object is (a rotation error of the small object turns into centimetres at the camera origin)
+        c = np.linalg.inv(poses[s]) @ np.append(traj[k - 1][s][:3, :3] @ objs[k - 1]["centre"] + traj[k - 1][s][:3, 3], 1.0)
+        err = np.linalg.norm((np.linalg.inv(p_est) @ c - np.linalg.inv(p_gt) @ c)[:3])
+        assert err < 0.01, (k, err)
+        assert synth.rotation_angle(p_est[:3, :3], p_gt[:3, :3]) < 0.04
+    g.close()
