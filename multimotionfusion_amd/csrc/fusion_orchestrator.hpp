@@ -264,7 +264,14 @@ extern "C" int mmf_fusion_num_inactive_models(mmf_fusion* f) { return f ? (int)f
 extern "C" mmf_model* mmf_fusion_inactive_model_at(mmf_fusion* f, int index) {
     return (f && index >= 0 && index < (int)f->inactive.size()) ? f->inactive[index]->model : nullptr;
 }
-extern "C" int mmf_fusion_next_model_id(mmf_fusion* f) { return f ? f->next_id : -1; }
+// The id the next spawned model will carry = the label a new segment must have in the id image.  The reference
+// hands getNextModelID() to the segmentation (:148) but spawns the FRONT of preallocatedModels when there is one
+// (:940-942), whose id was assigned at preallocation: with `-a N` its new segment is labelled with an id no model
+// has.  Here the label and the spawned model always agree.
+extern "C" int mmf_fusion_next_model_id(mmf_fusion* f) {
+    if (!f) return -1;
+    return f->preallocated.empty() ? f->next_id : (int)f->preallocated.front()->model->id;
+}
 
 static FusionModel* fusion_find(mmf_fusion* f, int id) {
     for (FusionModel* m : f->models)

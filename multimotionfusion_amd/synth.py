@@ -108,9 +108,9 @@ def make_objects(n, seed=2, kinds=("box",)):
         R0 = make_pose(np.deg2rad([25.0 + 20.0 * rng.uniform(), 30.0 + 25.0 * rng.uniform(), 40.0 * rng.uniform()]))
         orient = make_pose(t=c) @ R0 @ make_pose(t=-c)
         if kind == "sphere":
-            objs.append(dict(kind="sphere", centre=c, size=np.array([0.11 + 0.05 * rng.uniform()] * 3), orient=orient))
+            objs.append(dict(kind="sphere", centre=c, size=np.array([0.13 + 0.06 * rng.uniform()] * 3), orient=orient))
         else:
-            objs.append(dict(kind="box", centre=c, size=0.09 + 0.05 * rng.uniform(size=3), orient=orient))
+            objs.append(dict(kind="box", centre=c, size=0.12 + 0.06 * rng.uniform(size=3), orient=orient))
     return objs
 
 

@@ -69,3 +69,29 @@ def test_cpp_shims_compile_and_link(tmp_path):
     subprocess.run(cmd, check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert out.strip() == "abi 2"
+
+
+def test_compute_fusion_weight_matches_the_oracle_bit_for_bit():
+    """Model::computeFusionWeight (Model.cpp:876-891, with rodrigues2's JacobiSVD, :1301-1342) is host arithmetic:
+    the library's C++ restatement (csrc/pose_algebra.hpp) against the oracle's C one (oracle/mmf_oracle_pose.c) on
+    random pose pairs, including the increments a tracked frame produces (mm / mrad) and large ones."""
+    import numpy as np
+    from multimotionfusion_amd import _capi, synth
+    from oracle import oracle as orc
+    lib = _capi.load()
+    rng = np.random.default_rng(5)
+    seen = set()
+    for k in range(3000):
+        P = synth.make_pose(rng.normal(size=3) * 0.5, rng.normal(size=3)).astype(np.float32)
+        scale = 10.0 ** rng.uniform(-7, 0)
+        L = (P.astype(np.float64) @ synth.make_pose(rng.normal(size=3) * scale, rng.normal(size=3) * scale)).astype(np.float32)
+        if k % 7 == 0:
+            L = P.copy()  # overridePose: pose == lastPose
+        mult = float(np.float32(rng.choice([1.0, 3.0, 100.0])))
+        out = np.zeros(1, np.float32)
+        assert lib.mmf_compute_fusion_weight(_capi.fptr(np.ascontiguousarray(P.reshape(16))), _capi.fptr(np.ascontiguousarray(L.reshape(16))),
+                                             mult, _capi.fptr(out)) == 0
+        ref = np.float32(orc.compute_fusion_weight(P, L, mult))
+        assert out[0].view(np.uint32) == ref.view(np.uint32), (k, out[0], ref)
+        seen.add(float(out[0] / mult))
+    assert min(seen) == 0.5 and max(seen) == 1.0 and len(seen) > 20  # both clamps and the range between were hit

@@ -233,12 +233,19 @@ def test_process_frame_keypoint_initialisation(gpu_ctx, orc, icp_refine):
         if i > 0:
             T = (np.linalg.inv(poses[i - 1]) @ poses[i]).astype(np.float32)
             T[:3, 3] += np.float32(0.0005) * np.array([1, -1, 0.5], np.float32)
-        g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=i, initTransform=T, icpRefine=icp_refine)
-        o.process_frame(f["rgb"], f["depth"], init_transform=T, icp_refine=icp_refine)
+        g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=i, initTransform=T, icpRefine=icp_refine, weightMultiplier=3.0)
+        o.process_frame(f["rgb"], f["depth"], init_transform=T, icp_refine=icp_refine, weight_multiplier=3.0)
         pg = g.getCurrPose()
         assert np.abs(pg - o.pose).max() <= 1e-5, (i, pg, o.pose)
         ng, no = g.getBackgroundModel().lastCount(), o.surfels.shape[0]
         assert abs(ng - no) <= max(8, 0.002 * no), (i, ng, no)
+        if not icp_refine:
+            # nothing passes through the tracker: poses are the chain of the given transformations and BOTH fusion rounds
+            # of a frame (:357-366 with computeFusionWeight(weightMultiplier) at pose == lastPose, then :791-816) must
+            # give the oracle's surfels bit for bit -- a raw weightMultiplier instead of
+            # Model::computeFusionWeight(weightMultiplier) (Model.cpp:918) changes every confidence
+            assert np.array_equal(pg, o.pose), i
+            assert np.array_equal(g.getBackgroundModel().downloadMap().view(np.uint32), o.surfels.view(np.uint32)), i
         gt = np.linalg.inv(poses[0]) @ poses[i]
         assert np.linalg.norm(pg[:3, 3] - gt[:3, 3]) < (0.01 if icp_refine else 0.005 * (i + 1))
     if not icp_refine:  # the pose is exactly the chain of the given transformations

@@ -3,8 +3,16 @@ the global model plus object models spawned from a ground-truth id image (config
 its own stream -- against the oracle orchestration (oracle/fusion.py).
 
 What is bit-exact: everything that does not pass through the tracker's float32 sums -- the first surfels of a model in
-the frame it is spawned (identity pose), Model::computeFusionWeight, the pose log's quaternion.  Poses agree within
-1e-5 (north_star: 1e-4 rel. translation / 1e-3 rad); surfel counts after tracked frames within max(8, 0.2 %)."""
+the frame it is spawned (identity pose), Model::computeFusionWeight, the pose log's quaternion.
+Poses: the tracker differs from the oracle only in float32 summation order (~1e-7 in a pose).  For the global model
+that stays below 1e-5 over a sequence.  An object model is a few thousand pixels of a map full of silhouette
+artefacts: its 19 fixed Gauss-Newton iterations with hard-gated projective association are NOT stable against
+one-ulp input noise -- the ORACLE ITSELF moves an object pose by 1e-4 .. 1e-3 when the depth image is perturbed by
+1e-7 relative (tests/test_oracle_fusion.py::test_object_tracking_is_sensitive_to_one_ulp_noise), while the global
+pose moves by < 1e-6.  Object poses are therefore compared (a) in a RE-SYNCHRONISED run, where every frame starts
+from the oracle's maps and poses so that each frame's tracking is compared on identical inputs: north_star's tolerance
+(1e-4 translation, 1e-3 rad) for every frame and a median <= 1e-5 over all (frame, object) pairs; (b) free running:
+the object models stay on their objects (ground truth) and their surfel counts stay within 2 %."""
 import numpy as np
 import pytest
 import torch
@@ -47,8 +55,8 @@ def model_data(mask, depth, ids):
     return out
 
 
-@pytest.mark.parametrize("w,h,with_data", [(320, 240, False), (320, 240, True)])
-def test_three_objects_spawned_one_per_frame(gpu_ctx, orc, w, h, with_data):
+@pytest.mark.parametrize("w,h,with_data,sync", [(320, 240, False, False), (320, 240, True, True)])
+def test_three_objects_spawned_one_per_frame(gpu_ctx, orc, w, h, with_data, sync):
     from multimotionfusion_amd.fusion import MultiMotionFusion
     n_frames, n_obj = 6, 3
     K, poses, traj, frames, objs = scene(w, h, n_frames, n_obj)
@@ -56,6 +64,7 @@ def test_three_objects_spawned_one_per_frame(gpu_ctx, orc, w, h, with_data):
                           pose_logging=1)
     o = OracleFusion(orc, w, h, K, enable_multiple_models=True, pose_logging=True)
     known = [0]
+    object_diffs, keep = [], []
     for i, f in enumerate(frames):
         spawn = 1 <= i <= n_obj  # one new label per frame (Segmentation.cpp:113-118: allowNew && !hasNewLabel)
         if spawn:
@@ -64,21 +73,35 @@ def test_three_objects_spawned_one_per_frame(gpu_ctx, orc, w, h, with_data):
         mask = gt_mask(f["ids"], known)
         assert (mask == known[-1]).sum() > 200, "the object must be visible"
         data = model_data(mask, f["depth"], known) if with_data and i > 0 else None
-        g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=1000 + i, mask=dev(mask), hasNewLabel=spawn, modelData=data)
+        keep.append((dev(f["rgb"]), dev(f["depth"]), dev(mask)))  # predict() re-reads the frame: keep it alive
+        g.processFrame(*keep[-1][:2], timestamp=1000 + i, mask=keep[-1][2], hasNewLabel=spawn, modelData=data)
         o.process_frame(f["rgb"], f["depth"], timestamp=1000 + i, mask=mask, has_new_label=spawn, model_data=data)
         gm = g.getModels()
         assert [m.id for m in gm] == [m.id for m in o.models] == known[:len(gm)], (i, [m.id for m in gm])
         for k, (a, b) in enumerate(zip(gm, o.models)):
             pa = a.getPose()
-            assert np.abs(pa - b.pose).max() <= 1e-5, (i, k, pa, b.pose)
+            if k == 0:
+                assert np.abs(pa - b.pose).max() <= 1e-5, (i, k, pa, b.pose)
+            elif sync:
+                assert np.abs(pa[:3, 3] - b.pose[:3, 3]).max() <= 1e-4, (i, k, pa, b.pose)
+                assert synth.rotation_angle(pa[:3, :3].astype(np.float64), b.pose[:3, :3]) <= 1e-3
+                if k < len(gm) - 1 or not spawn:  # tracked this frame
+                    object_diffs.append(float(np.abs(pa - b.pose).max()))
             na, nb = a.lastCount(), b.surfels.shape[0]
-            assert abs(na - nb) <= max(8, 0.002 * nb), (i, k, na, nb)
+            assert abs(na - nb) <= max(8, 0.002 * nb if k == 0 or sync else 0.02 * nb), (i, k, na, nb)
             if k > 0:
                 assert abs(a.confidenceThreshold() - b.conf) < 1e-7 and a.id == k
         if spawn:  # the new model was created at the identity pose: nothing of it went through the tracker
             fresh_g, fresh_o = gm[-1].downloadMap(), o.models[-1].surfels
             assert fresh_o.shape[0] > 50
             assert np.array_equal(fresh_g.view(np.uint32), fresh_o.view(np.uint32)), (i, fresh_g.shape, fresh_o.shape)
+        if sync:  # the next frame starts from the oracle's state: maps, poses, and the predictions rendered from them
+            for a, b in zip(gm, o.models):
+                a.uploadMap(b.surfels)
+                a.overridePose(b.pose)
+            g.predict()
+    if sync:
+        assert len(object_diffs) >= 6 and np.median(object_diffs) <= 1e-5, object_diffs
     # pose log (MultiMotionFusion.cpp:829-846): one entry per frame the model was in the list, object->world
     from multimotionfusion_amd.klg import pose_7d
     gm = g.getModels()
@@ -86,11 +109,12 @@ def test_three_objects_spawned_one_per_frame(gpu_ctx, orc, w, h, with_data):
         ts, p7 = g.getPoseLog(k)
         lo = o.models[k].pose_log
         assert len(ts) == len(lo) == n_frames - k and ts[-1] == 1000 + n_frames - 1
-        assert np.abs(p7[-1] - pose_7d(lo[-1][1])).max() < 2e-5
+        if k == 0 or sync:
+            assert np.abs(p7[-1] - pose_7d(lo[-1][1])).max() < (2e-5 if k == 0 else 2e-3)
     # the object models follow their objects.  Model frame = camera frame at the spawn frame s (the model is created at
     # the identity pose), so X_cam(t) = P(t)^-1 X_model with P_gt(t) = C_s^-1 T(s) T(t)^-1 C_t
     t = n_frames - 1
-    for k in range(1, n_obj + 1):
+    for k in range(1, n_obj + 1 if not sync else 0):
         s = k
         p_gt = np.linalg.inv(poses[s]) @ traj[k - 1][s] @ np.linalg.inv(traj[k - 1][t]) @ poses[t]
         p_est = gm[k].getPose().astype(np.float64)
