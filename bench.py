@@ -1,20 +1,26 @@
 #!/usr/bin/env python
-"""bench.py -- frames/sec at 640x480 of the dense-tracking hot path on MI355X, plus the ICP
-JtJ-reduce roofline figure and a CPU baseline (BASELINE.json metric).
+"""bench.py -- frames/sec of MultiMotionFusion::processFrame on MI355X, the roofline figure of the dominant
+Gauss-Newton kernel and a CPU baseline (BASELINE.json metric).
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N ...            (starts its N ranks itself through torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one MultiMotionFusion::processFrame for one rigid-body model (static scene):
-bilateral depth filter, dense tracking (pyramids, SO3 pre-alignment, 4/5/10 ICP+RGB Gauss-Newton
-iterations against the splat prediction), splat, index map, fuse, index map, clean, splat and
-fill-in -- all inputs already resident in HBM.  With N GPUs every rank tracks its own model
-on the same broadcast frame (per-object shard, weak scaling); value = model-frames/s over all
-ranks.  Prints ONE JSON line on rank 0.
+N = 1 (BASELINE.json configs[1]): a "step" is one processFrame of the 640x480 synthetic sequence, static scene, one
+rigid-body model: bilateral depth filter, dense tracking (pyramids, SO3 pre-alignment, 4/5/10 ICP+RGB Gauss-Newton
+iterations against the splat prediction), splat, index map, fuse, index map, clean, splat and fill-in -- all inputs
+already resident in HBM.
+N > 1 (configs[4]): 1280x960, moving rigid objects, mask = ground-truth ids, one rigid-body model per GPU (rank 0 the
+static scene, rank r object r): rank 0 broadcasts the frame (RCCL), every rank prepares the sensor side and runs
+processFrame for the model it owns (mmf_fusion_set_shard), poses are all-gathered; value = model-frames/s over all
+ranks (weak scaling).  MMF_BENCH_WORKLOAD=config5 runs that workload at N = 1 too (the like-for-like base of the curve).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,59 +30,121 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-W, H = 640, 480  # BASELINE.json configs[1]; MMF_BENCH_SIZE=1280x960 rehearses config 5's frame size
-if os.environ.get("MMF_BENCH_SIZE"):
-    W, H = (int(v) for v in os.environ["MMF_BENCH_SIZE"].lower().split("x"))
 ICP_WEIGHT = 10.0  # GUI default (GUI/MainController.cpp:333-345)
 DEPTH_CUTOFF = 15.0
-N_FRAMES = 30  # frames of the synthetic sequence; the map is reset when the sequence wraps
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
+N_FRAMES = 30  # frames of the static sequence; the map is reset when the sequence wraps
+N_FRAMES_OBJECTS = 10  # frames of the moving-object sequences (played forwards and backwards: no reset)
+SCHEDULE = (10, 5, 4)  # Gauss-Newton iterations at pyramid levels 0, 1, 2 (RGBDOdometry.cpp:312-314)
 
 
 def icp_step_bytes(n_px):
     return 48 * n_px + 116  # 12 floats per pixel + one JtJJtrSE3
 
 
-def cpu_baseline(frames, K, poses):
-    """Naive OpenMP CPU run of the same ICP reduction (oracle = "port"), bounded sample."""
+def producer_bytes(n_px):
+    """Algorithmic bytes of one level's producer launch (ICP reduction + photometric correspondence pass of one
+    Gauss-Newton iteration): ICP 48 B/px + correspondence pass 14 B/px read (2 x i16 gradients, f32 depth,
+    u8 intensity, gathered f32 depth + u8 intensity) + the 8-byte record it writes per pixel."""
+    return 70 * n_px
+
+
+def gn_chain_bytes(w, h):
+    """One getIncrementalTransformation: (48 + 30 + 32) B/px (icpStep, computeRgbResidual, rgbStep) over the
+    10/5/4 iteration schedule."""
+    return 110 * sum(it * (w >> l) * (h >> l) for l, it in enumerate(SCHEDULE))
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here.  Nothing has touched the GPU yet (no
+    torch import), so starting children is safe; this process only relays their output and exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps",
+           str(args.steps), "--warmup", str(args.warmup), "--roofline-frames", str(args.roofline_frames)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    return subprocess.call(cmd)
+
+
+def cpu_baseline(frames, K, W, H):
+    """The oracle (the CPU restatement = "port") on the GPU box's host cores, a bounded sample of the SAME workload:
+    whole processFrame calls on the first frames of the sequence (single thread), and -- what north_star asks to stand
+    beside the ICP roofline figure -- the naive OpenMP run of the ICP reduction on all host cores."""
     from oracle import oracle as orc
+    from oracle.fusion import OracleFusion
+    o = OracleFusion(W, H, K, icp_weight=ICP_WEIGHT, depth_cutoff=DEPTH_CUTOFF)
+    o.process_frame(frames[0]["rgb"], frames[0]["depth"])  # first frame: initialise only
+    n_timed, t0 = 0, time.perf_counter()
+    for f in frames[1:]:
+        o.process_frame(f["rgb"], f["depth"])
+        n_timed += 1
+        if time.perf_counter() - t0 > 12.0:
+            break
+    frame_s = (time.perf_counter() - t0) / n_timed
     try:
         libpath = orc.build(march="native", out="liboracle_native.so")
     except Exception:
         libpath = orc.build()
-    prev, cur = poses[0], poses[1]
-    o = orc.Odometry(W, H, K["cx"], K["cy"], K["fx"], K["fy"])
-    o.initICPModel(frames[0]["vertex"], frames[0]["normal"], prev.astype(np.float32))
-    o.initICP(frames[1]["depth"], DEPTH_CUTOFF)
-    Rp = prev[:3, :3].astype(np.float32)
-    tp = prev[:3, 3].astype(np.float32)
+    od = o.models[0].odom
+    pose = o.models[0].pose
+    Rp, tp = pose[:3, :3].astype(np.float32), pose[:3, 3].astype(np.float32)
     Rpi = np.linalg.inv(Rp).astype(np.float32)
     per_level = []
-    reps_by_level = (4000, 8000, 16000)  # ~2 s of wall time on all host cores (a few hundred core-seconds)
-    for lvl in range(3):
+    for lvl, reps in enumerate((600, 1200, 2400)):
         d = 1 << lvl
-        args = (Rp, tp, o.buffer("vmaps_curr", lvl), o.buffer("nmaps_curr", lvl), Rpi, tp, K["fx"] / d, K["fy"] / d,
-                K["cx"] / d, K["cy"] / d, o.buffer("vmaps_g_prev", lvl), o.buffer("nmaps_g_prev", lvl), 0.10,
-                float(np.sin(20.0 * 3.14159254 / 180.0)))
+        a = (Rp, tp, od.buffer("vmaps_curr", lvl), od.buffer("nmaps_curr", lvl), Rpi, tp, K["fx"] / d, K["fy"] / d, K["cx"] / d,
+             K["cy"] / d, od.buffer("vmaps_g_prev", lvl), od.buffer("nmaps_g_prev", lvl), 0.10, float(np.sin(20.0 * 3.14159254 / 180.0)))
         for _ in range(3):
-            orc.icp_step_omp_f32(*args, libpath=libpath)
+            orc.icp_step_omp_f32(*a, libpath=libpath)
         ts = []
-        for _ in range(reps_by_level[lvl]):
-            t0 = time.perf_counter()
-            orc.icp_step_omp_f32(*args, libpath=libpath)
-            ts.append(time.perf_counter() - t0)
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            orc.icp_step_omp_f32(*a, libpath=libpath)
+            ts.append(time.perf_counter() - t1)
         per_level.append(float(np.median(ts)))
-    schedule_s = 10 * per_level[0] + 5 * per_level[1] + 4 * per_level[2]
+    schedule_s = sum(it * t for it, t in zip(SCHEDULE, per_level))
     return {
-        "value": 1.0 / schedule_s,
-        "unit": "frames/s",
-        "cores": orc.omp_threads(libpath),
-        "kind": "port",
-        "sample": ("oracle icp_step (OpenMP, f32 accumulators) on the same 640x480 synthetic frame pair: median of "
-                   "4000/8000/16000 reps at L0/L1/L2 (~2 s of wall time on every host core); value = 1/(10*t0+5*t1+4*t2), the ICP reduction schedule of one frame "
-                   "only (no RGB term, no pyramids)"),
-        "ms_per_step_l0": per_level[0] * 1e3,
-        "gbps_l0": icp_step_bytes(W * H) / per_level[0] / 1e9,
+        "value": 1.0 / frame_s, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": (f"oracle/fusion.py processFrame (the whole step the GPU value measures: filter, tracking, splat, index map, fuse, "
+                   f"clean) on frames 1..{n_timed} of the same {W}x{H} sequence, one host thread, {frame_s * n_timed:.1f} s of CPU work"),
+        "icp_reduce_openmp": {"frames_per_s_schedule_only": 1.0 / schedule_s, "cores": orc.omp_threads(libpath),
+                              "ms_per_step_l0": per_level[0] * 1e3, "gbps_l0": icp_step_bytes(W * H) / per_level[0] / 1e9,
+                              "sample": "oracle icp_step (OpenMP, f32 accumulators), median of 600/1200/2400 reps at L0/L1/L2; "
+                                        "1/(10 t0 + 5 t1 + 4 t2) = the ICP reduction schedule of one frame only"},
     }
+
+
+def pmc_traffic(kernel_substr, W, H):
+    """HBM traffic per launch of the roofline kernel from the committed rocprofv3 --pmc summary (separate FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 corrections applied by tools/pmc_summary.py); None when there is no summary for this
+    kernel and frame size."""
+    path = os.path.join(REPO, "profiles", "r02_pmc_summary.json")
+    try:
+        with open(path) as fp:
+            for rec in json.load(fp)["kernels"]:
+                if kernel_substr in rec["kernel"] and rec["width"] == W and rec["height"] == H and rec["level"] == 0:
+                    return float(rec["traffic_bytes_per_launch"]), "profiles/r02_pmc_summary.json"
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
+def object_sequence(synth, W, H, n_objects, n_frames=N_FRAMES_OBJECTS):
+    K = synth.intrinsics(W, H)
+    poses = synth.trajectory(n_frames, seed=1)
+    objs = synth.make_objects(n_objects, seed=2)
+    traj = synth.object_trajectories(objs, n_frames, seed=2)
+    frames = [synth.render(p, W, H, seed=i, objects=objs, object_poses=[t[i] for t in traj]) for i, p in enumerate(poses)]
+    return K, poses, frames
+
+
+def pingpong(i, n):
+    """frame index of step i when a sequence of n frames is played forwards and backwards: 0..n-1, n-2..1, 0.."""
+    p = i % (2 * n - 2)
+    return p if p < n else 2 * n - 2 - p
 
 
 def main():
@@ -85,8 +153,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--roofline-reps", type=int, default=200)
+    ap.add_argument("--roofline-frames", type=int, default=40)
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -100,6 +170,7 @@ def main():
     ndev = max(1, torch.cuda.device_count())
     if backend != "nccl":
         local_rank %= ndev
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -107,91 +178,136 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    config5 = world > 1 or os.environ.get("MMF_BENCH_WORKLOAD", "") == "config5"
+    W, H = (1280, 960) if config5 else (640, 480)
+    if os.environ.get("MMF_BENCH_SIZE"):  # rehearsals at other frame sizes
+        W, H = (int(v) for v in os.environ["MMF_BENCH_SIZE"].lower().split("x"))
 
     from multimotionfusion_amd import shard, synth
-    from multimotionfusion_amd.cudafuncs import Context
-    from multimotionfusion_amd.odometry import RGBDOdometry
+    from multimotionfusion_amd.cudafuncs import Context, _p
+    from multimotionfusion_amd.fusion import MultiMotionFusion
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    K = synth.intrinsics(W, H)
-    # every rank tracks one rigid-body model against the SAME sensor frames (broadcast by rank 0)
-    poses = synth.trajectory(N_FRAMES, seed=1)
-    frames = [synth.render(p, W, H, seed=i) for i, p in enumerate(poses)]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    d_rgb = [up(f["rgb"]) for f in frames]
-    d_depth = [up(f["depth"]) for f in frames]
-    # N > 1: three frame buffers -- frame k is processed, frame k + 1 (already received) is prefetched on the
-    # side streams, frame k + 2 is being broadcast by rank 0 (RCCL's own stream)
-    NB = 3
-    rgb_in = [torch.empty_like(d_rgb[0]) for _ in range(NB)]
-    depth_in = [torch.empty_like(d_depth[0]) for _ in range(NB)]
-    mask_in = [torch.zeros(H, W, dtype=torch.uint8, device=dev) for _ in range(NB)]
-    pending = {}
-    posted = set()
-
     ctx = Context(local_rank)
-    from multimotionfusion_amd.fusion import MultiMotionFusion
-    mmf = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], icp_weight=ICP_WEIGHT)
-    odom = mmf.getFrameOdometry()
-    state = {"frame": 0}
-    # next-frame prefetch on side streams: on at N = 1; at N > 1 only on request (MMF_BENCH_PREFETCH=2) -- the
-    # collective's own streams share the device with it there and that combination could not be measured on a
-    # one-GPU box (two ranks sharing one GPU time-slice pathologically with the extra streams)
-    _pf = os.environ.get("MMF_BENCH_PREFETCH", "1")
-    PREFETCH = _pf == "2" or (_pf != "0" and world == 1)
+    ranks_seen = world
+    if world > 1:
+        seen = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(seen)
+        ranks_seen = int(seen.item())
 
-    def step(i):
-        """One processFrame: bilateral filter, tracking (SO3 + 4/5/10 ICP+RGB GN iterations against
-        the splat prediction), splat, index map, fuse, index map, clean, splat + fill-in."""
-        k = state["frame"] % len(frames)
-        if state["frame"] and k == 0:  # sequence wrapped: start a fresh map (the trajectory jumps back)
-            mmf.reset()
-        state["frame"] += 1
-        if world > 1:  # rank 0's sensor frame reaches every model owner (RCCL broadcast over xGMI)
-            def post(n):  # start the broadcast of sequence frame n into buffer n % NB (once)
-                if n in posted:
-                    return
-                posted.add(n)
-                b, kk = n % NB, n % len(frames)
-                if rank == 0:
-                    rgb_in[b].copy_(d_rgb[kk])
-                    depth_in[b].copy_(d_depth[kk])
-                pending[n] = shard.broadcast_frame_async(rgb_in[b], depth_in[b], mask_in[b], src=0)
+    # ------------------------------------------------------------------------------------------------------------
+    if not config5:
+        K = synth.intrinsics(W, H)
+        poses = synth.trajectory(N_FRAMES, seed=1)
+        frames = [synth.render(p, W, H, seed=i) for i, p in enumerate(poses)]
+        d_rgb = [up(f["rgb"]) for f in frames]
+        d_depth = [up(f["depth"]) for f in frames]
+        mmf = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], icp_weight=ICP_WEIGHT)
+        PREFETCH = os.environ.get("MMF_BENCH_PREFETCH", "1") != "0"
+        state = {"frame": 0}
 
-            def arrived(n):  # the compute stream waits for the collective; the host does not
-                for w in pending.pop(n, []):
-                    w.wait()
-            n = state["frame"] - 1
-            post(n)
-            post(n + 1)
-            arrived(n)
-            if PREFETCH:  # the next frame has to be in place before this frame's tracking is enqueued: the side
-                arrived(n + 1)  # streams of the prefetch start right after it
-            post(n + 2)
-            posted.discard(n - 1)
-            mmf.processFrame(rgb_in[n % NB], depth_in[n % NB], timestamp=i)
-            if PREFETCH and (n + 1) % len(frames) != 0:
-                mmf.prefetchFrame(rgb_in[(n + 1) % NB], depth_in[(n + 1) % NB])
-        else:  # inputs already resident in HBM
+        def step(i):
+            k = state["frame"] % len(frames)
+            if state["frame"] and k == 0:  # sequence wrapped: start a fresh map (the trajectory jumps back)
+                mmf.reset()
+            state["frame"] += 1
             mmf.processFrame(d_rgb[k], d_depth[k], timestamp=i)
             kn = state["frame"] % len(frames)
             if PREFETCH and kn != 0:  # the next frame's filter, pyramids and SO3 pre-alignment overlap this frame's fusion
                 mmf.prefetchFrame(d_rgb[kn], d_depth[kn])
-        pose = mmf.getCurrPose()
-        if world > 1:  # every rank learns every model's pose (18 floats per rank), without a host round trip
-            od = mmf.getFrameOdometry()
-            state["poses"] = shard.gather_poses_async(pose, od.lastICPError, od.lastICPCount, dev)
-        return pose
+            return mmf.getCurrPose()
 
-    def fence():
-        if world > 1:
-            if state.get("poses") is not None:
-                state["poses"][0].wait()
-            dist.barrier()
-        torch.cuda.synchronize()
+        def fence():
+            torch.cuda.synchronize()
+
+        models_per_gpu = 1
+        workload = (f"{W}x{H} synthetic RGB-D sequence through MultiMotionFusion::processFrame, static scene (no segmentation): "
+                    "bilateral filter, dense ICP+RGB odometry (SO3 + 4/5/10 Gauss-Newton iterations, icpWeight 10) against the "
+                    "surfel splat, index map, fuse, clean, splat + fill-in; one rigid-body model; the next frame's depth filter, "
+                    "input pyramids and SO3 pre-alignment run on two side streams during the current frame's fusion")
+    else:
+        # configs[4]: moving rigid objects, mask = ground-truth ids, one rigid-body model per rank
+        n_obj = 8
+        K = synth.intrinsics(W, H)
+        frames = poses = None
+        if rank == 0:
+            K, poses, frames = object_sequence(synth, W, H, n_obj)
+            for f in frames:  # ids of objects no rank owns read as background (Segmentation.cpp:104-118)
+                f["mask"] = np.where(f["ids"] < world, f["ids"], 0).astype(np.uint8)
+            d_rgb = [up(f["rgb"]) for f in frames]
+            d_depth = [up(f["depth"]) for f in frames]
+            d_mask = [up(f["mask"]) for f in frames]
+        NB = 3  # frame k is processed, k + 1 already received, k + 2 being broadcast (RCCL's own stream)
+        rgb_in = [torch.empty((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(NB)]
+        depth_in = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(NB)]
+        mask_in = [torch.zeros((H, W), dtype=torch.uint8, device=dev) for _ in range(NB)]
+        mmf = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], icp_weight=ICP_WEIGHT, enable_multiple_models=1,
+                                preallocated_models=0)
+        mmf.setShard(rank, world)
+        pending, posted = {}, set()
+        state = {"frame": 0, "poses": None}
+
+        def step(i):
+            n = state["frame"]
+            state["frame"] += 1
+
+            def post(m):  # start the broadcast of step m's frame into buffer m % NB (once)
+                if m in posted:
+                    return
+                posted.add(m)
+                b, kk = m % NB, pingpong(m, N_FRAMES_OBJECTS)
+                if world == 1:
+                    return
+                if rank == 0:
+                    rgb_in[b].copy_(d_rgb[kk])
+                    depth_in[b].copy_(d_depth[kk])
+                    mask_in[b].copy_(d_mask[kk])
+                pending[m] = shard.broadcast_frame_async(rgb_in[b], depth_in[b], mask_in[b], src=0)
+
+            post(n)
+            post(n + 1)
+            for w_ in pending.pop(n, []):  # the compute stream waits for the collective; the host does not
+                w_.wait()
+            post(n + 2)
+            posted.discard(n - 1)
+            if state["poses"] is not None:  # last step's all-gather: the poses of the models other ranks own
+                work, recs = state["poses"]
+                work.wait()
+                got = torch.stack(recs).cpu().numpy()
+                for r in range(min(world, len(mmf.getModels()))):
+                    if r != rank:
+                        mmf.setModelPose(r, got[r, :16].reshape(4, 4))
+                state["poses"] = None
+            spawn = 1 <= n < world  # object id n appears in the mask of step n: a new label (one per frame)
+            if world == 1:
+                kk = pingpong(n, N_FRAMES_OBJECTS)
+                mmf.processFrame(d_rgb[kk], d_depth[kk], timestamp=i, mask=d_mask[kk], hasNewLabel=False)
+            else:
+                b = n % NB
+                mmf.processFrame(rgb_in[b], depth_in[b], timestamp=i, mask=mask_in[b], hasNewLabel=spawn)
+            models = mmf.getModels()
+            pose = models[rank].getPose() if rank < len(models) else np.eye(4, dtype=np.float32)
+            if world > 1:  # every rank learns every model's pose (18 floats per rank), without a host round trip
+                od = mmf.getModelOdometry(rank) if rank < len(models) else None
+                state["poses"] = shard.gather_poses_async(pose, od.lastICPError if od else 0.0, od.lastICPCount if od else 0.0, dev)
+            return pose
+
+        def fence():
+            if world > 1:
+                if state["poses"] is not None:
+                    state["poses"][0].wait()
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        models_per_gpu = 1
+        workload = (f"{W}x{H} synthetic RGB-D, moving rigid objects, mask = ground-truth ids (BASELINE.json configs[4]): {world} "
+                    f"rigid-body models (the static scene + {world - 1} objects), ONE PER GPU (mmf_fusion_set_shard): rank 0 broadcasts "
+                    "the frame (8 B/px, RCCL), every rank runs the sensor-side preparation and processFrame for the model it owns "
+                    "(bilateral filter, dense ICP+RGB odometry, splat, index map, fuse, clean), poses are all-gathered (72 B per rank); "
+                    "the sequence is played forwards and backwards (no reset)")
 
     for i in range(args.warmup):
         step(i)
@@ -207,35 +323,59 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # accuracy sanity of the last tracked frame against the known trajectory (relative to frame 0)
-    k = (state["frame"] - 1) % len(frames)
-    gt = np.linalg.inv(poses[0]) @ poses[k]
-    t_err = float(np.linalg.norm(last_pose[:3, 3] - gt[:3, 3]))
-    odom = mmf.getFrameOdometry()
-    n_surfels = mmf.getBackgroundModel().lastCount()
+    # ---- roofline of the dominant kernel of the frame: the level-0 producer launch of the Gauss-Newton loop
+    # (track_producer_kernel: ICP J^T J reduction + photometric correspondence pass), timed INSIDE processFrame by
+    # start / stop HIP events on each launch (the dispatch's own timestamps, on the stream it is launched on).
+    # Every rank runs these extra frames (they contain the collectives); rank 0 reports its own model's kernels.
+    own = rank if config5 else 0
+    odom = mmf.getModelOdometry(own) if own < len(mmf.getModels()) else None
+    if odom is not None:
+        odom.enableTiming(True)
+    for i in range(args.roofline_frames):
+        step(args.warmup + args.steps + i)
+    fence()
+    tm = odom.getTiming() if odom is not None else None
+    if odom is not None:
+        odom.enableTiming(False)
 
     result = None
     if rank == 0:
-        # roofline of the dominant kernel: level-0 ICP JtJ reduction, HIP events on the launch stream
         n0 = W * H
-        us = odom.timeIcpKernel(0, args.roofline_reps)
-        achieved = icp_step_bytes(n0) / (us * 1e-6) / 1e9
-        # traffic: memory-side bytes per level-0 launch from the separate rocprofv3 --pmc passes kept in
-        # profiles/r01_pmc_icp_{fetch,write}_size.csv (this kernel, tools/pmc_icp.py): FETCH_SIZE
-        # 7348.5 KiB, doubled because gfx950 tallies 128-byte read requests at 64 bytes (guide, HBM
-        # section; calibrated there for 16-B-per-lane streams -- the 16-B-per-lane build of this kernel,
-        # profiles/r01_pmc_icp_px4_*.csv, reads 7305.25 KiB, so the same factor is applied here) +
-        # WRITE_SIZE 75 KiB (600 partial records).  Algorithmic bytes are 14.75 MB: no wasted re-reads.
-        traffic = (2 * 7348.5 + 75.0) * 1024
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": traffic, "kernel": f"icp_kernel2<2,1,256,packed> level 0 ({W}x{H})", "us_per_launch": us,
-                    "bytes_per_launch": icp_step_bytes(n0),
-                    "us_per_launch_l1": odom.timeIcpKernel(1, args.roofline_reps),
-                    "us_per_launch_l2": odom.timeIcpKernel(2, args.roofline_reps)}
-        # the two surfel projections named in the north star, timed the same way (HIP events on the stream,
-        # back to back; both are idempotent on the current map): achieved = algorithmic bytes of
-        # SURVEY.md 8(d) / launch-pair time.  Reported beside the contract's roofline object, not in it.
         model = mmf.getBackgroundModel()
+        n_surfels = model.lastCount()
+        t_err = None
+        if not config5:  # accuracy sanity of the last tracked frame against the known trajectory (relative to frame 0)
+            k = (state["frame"] - 1) % len(frames)
+            gt = np.linalg.inv(poses[0]) @ poses[k]
+            t_err = float(np.linalg.norm(last_pose[:3, 3] - gt[:3, 3]))
+
+        us = tm["producer_l0"]["mean_us"]
+        achieved = producer_bytes(n0) / (us * 1e-6) / 1e9
+        traffic, traffic_src = pmc_traffic("track_producer_kernel", W, H)
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": f"track_producer_kernel<2,true> level 0 ({W}x{H}): ICP JtJ reduction + photometric correspondence pass",
+                    "us_per_launch": us, "us_per_launch_min": tm["producer_l0"]["min_us"], "launches_timed": tm["producer_l0"]["launches"],
+                    "bytes_per_launch": producer_bytes(n0), "bytes_formula": "48 N (ICP) + 14 N read + 8 N written (correspondence pass)",
+                    "timing": "hipExtLaunchKernelGGL start/stop events per launch inside processFrame"}
+        per_level = {f"l{l}": {"producer_us": tm[f"producer_l{l}"]["mean_us"], "rgb_step_us": tm[f"rgb_step_l{l}"]["mean_us"],
+                               "producer_min_us": tm[f"producer_l{l}"]["min_us"], "rgb_step_min_us": tm[f"rgb_step_l{l}"]["min_us"],
+                               "producer_GBps": producer_bytes(n0 >> (2 * l)) / max(tm[f"producer_l{l}"]["mean_us"], 1e-9) / 1e3}
+                     for l in range(3)}
+        chain_b = gn_chain_bytes(W, H)
+        gn_chain = {"bytes": chain_b, "us": tm["chain_us"], "GBps": chain_b / max(tm["chain_us"], 1e-9) / 1e3,
+                    "frac": chain_b / max(tm["chain_us"], 1e-9) / 1e3 / HBM_PEAK_GBPS, "per_level": per_level,
+                    "what": "one getIncrementalTransformation of one model on the device (odom_begin .. last step): SO3 pre-alignment "
+                            "(unless prefetched) + 19 x (producer + photometric step / solve); bytes = 110 B/px x (10 N0 + 5 N1 + 4 N2)"}
+        # the stand-alone ICP reduction kernel (the function-level icpStep entry point), back-to-back launches
+        us_icp = odom.timeIcpKernel(0, 200)
+        icp_standalone = {"kernel": "icp_kernel2<2,1,256,packed> level 0", "us_per_launch_back_to_back": us_icp,
+                          "bytes_per_launch": icp_step_bytes(n0), "GBps": icp_step_bytes(n0) / us_icp / 1e3,
+                          "frac": icp_step_bytes(n0) / us_icp / 1e3 / HBM_PEAK_GBPS,
+                          "note": "launch throughput of 200 dependent launches between two HIP events, not a kernel duration"}
+
+        # the two surfel projections named in the north star (HIP events on the stream, back to back; both are idempotent on
+        # the current map): achieved = algorithmic bytes of SURVEY.md 8(d) / launch-pair time
         tick = mmf.getTick()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
@@ -253,65 +393,17 @@ def main():
         us_spl = timed(lambda: model.combinedPredict(20.0, tick, tick, 200))
         b_idx, b_spl = 48 * n_surfels + 52 * n0, 48 * n_surfels + 38 * n0
         surfel_passes = {
-            "predictIndices": {"us": us_idx, "bytes": b_idx, "GBps": b_idx / us_idx / 1e3, "frac": b_idx / us_idx / 1e3 / 8000.0,
+            "predictIndices": {"us": us_idx, "bytes": b_idx, "GBps": b_idx / us_idx / 1e3, "frac": b_idx / us_idx / 1e3 / HBM_PEAK_GBPS,
                                "kernels": "index_map_kernel + index_resolve_kernel"},
-            "combinedPredict": {"us": us_spl, "bytes": b_spl, "GBps": b_spl / us_spl / 1e3, "frac": b_spl / us_spl / 1e3 / 8000.0,
+            "combinedPredict": {"us": us_spl, "bytes": b_spl, "GBps": b_spl / us_spl / 1e3, "frac": b_spl / us_spl / 1e3 / HBM_PEAK_GBPS,
                                 "kernels": "splat_kernel + splat_resolve_kernel"},
         }
-        # the keypoint descriptor matcher, the one MFMA kernel beside the path:
-        # 1024 x 1024 descriptors of 256 floats, 2 * nq * nt * dim flops on v_mfma_f32_32x32x2_f32
-        from multimotionfusion_amd.matcher import matchDescriptors
-        gen = torch.Generator(device="cpu").manual_seed(0)
-        dq = torch.nn.functional.normalize(torch.randn(1024, 256, generator=gen), dim=1).to(dev)
-        dt = torch.nn.functional.normalize(torch.randn(1024, 256, generator=gen), dim=1).to(dev)
-        matchDescriptors(ctx, dq, dt, 0.7)  # sizes the workspace
-        m_idx = torch.empty(1024, dtype=torch.int32, device=dev)
-        m_dist = torch.empty(1024, dtype=torch.float32, device=dev)
-        from multimotionfusion_amd.cudafuncs import _p
-
-        def match_raw():  # the C entry point with preallocated outputs: the Python wrapper's allocations would dominate
-            ctx.lib.mmf_match_descriptors(ctx.handle, _p(dq), 1024, _p(dt), 1024, 256, 0.7, _p(m_idx), _p(m_dist))
-
-        us_match = timed(match_raw, reps=100)
-        flops = 2.0 * 1024 * 1024 * 256
-        matcher = {"us": us_match, "nq": 1024, "nt": 1024, "dim": 256, "TFLOPs": flops / us_match / 1e6,
-                   "frac_f32_mfma_peak": flops / us_match / 1e6 / 157.3, "launches": 3,
-                   "kernels": "row_norms_kernel (MFMA; also resets the arg-min keys) + match_tile64_kernel (MFMA, LDS-shared 64x64 tiles) + match_cross_check_kernel"}
-        # the SuperPoint keypoint network (north star: "the only true dense contractions ... on MFMA"): one
-        # forward pass (12 convolutions + normalisation + heat map) on an image of the bench size, random-init
-        # weights, f32 operands on v_mfma_f32_32x32x2_f32; flops = convolution multiply-adds * 2
-        from multimotionfusion_amd.superpoint import SuperPoint, forward_flops, random_weights
-        kp = SuperPoint(ctx, random_weights(0), max_width=W, max_height=H)
-        us_sp = timed(lambda: kp.enqueue(d_rgb[0]), reps=30)
-        fl_sp = float(forward_flops(W, H))
-        superpoint = {"us": us_sp, "GFLOP": fl_sp / 1e9, "TFLOPs": fl_sp / us_sp / 1e6,
-                      "frac_f32_mfma_peak": fl_sp / us_sp / 1e6 / 157.3, "launches": 13, "dtype": "f32",
-                      "kernels": "sp_conv1a (grey + 1->64, VALU) + 8 x sp_conv_mfma_kernel + 1 x sp_conv_mfma_pair_kernel (implicit GEMM, fused ReLU / "
-                                 "2x2 max pool) + sp_l2_normalize + sp_heatmap",
-                      "weights": "random-init SuperPointNet architecture"}
-        kp.close()
-        # super-pixel resampling of a per-model map for the segmentation: the ICP-error
-        # map of the frame into 16-pixel super-pixels (a regular grid stands in for gSLICr's mask)
-        from multimotionfusion_amd import slic
-        S = 16
-        yy, xx = np.mgrid[0:H, 0:W]
-        labels = torch.from_numpy(((yy // S).clip(0, H // S - 1) * (W // S) + (xx // S).clip(0, W // S - 1)).astype(np.int32)).to(dev)
-        err_map = torch.rand((H, W), device=dev)
-        slic_out = torch.empty((H // S, W // S), dtype=torch.float32, device=dev)
-
-        def slic_raw():
-            ctx.lib.mmf_slic_downsample(ctx.handle, _p(labels), W, H, S, _p(err_map), 1, 0, 0, 0.0, _p(slic_out), None)
-
-        slic_raw()
-        us_slic = timed(slic_raw, reps=50)
-        slic_info = {"us": us_slic, "superpixels": (H // S) * (W // S), "bytes_in": 8 * n0, "bytes_out": 4 * (H // S) * (W // S),
-                     "kernels": "slic_reset + slic_census (atomics) + slic_sum (wave per super-pixel, pixel-order sums) + "
-                                "slic_finish", "replaces": "two 4.9 MB / 1.2 MB texture downloads per model + CPU loops"}
         result = {
-            "metric": f"frames/sec @ {W}x{H} (dense ICP+RGB tracking); ICP JtJ-reduce achieved HBM GB/s vs peak",
+            "metric": f"frames/sec @ {W}x{H} (dense ICP+RGB tracking + surfel fusion); GN producer (ICP JtJ-reduce) achieved HBM GB/s vs peak",
             "value": world * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -320,28 +412,78 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{W}x{H} synthetic RGB-D sequence through MultiMotionFusion::processFrame, static "
-                                   "scene (no segmentation): bilateral filter, dense ICP+RGB odometry (SO3 + 4/5/10 "
-                                   "Gauss-Newton iterations, icpWeight 10) against the surfel splat, index map, fuse, "
-                                   "clean, splat + fill-in; one rigid-body model per GPU; the next frame's depth filter, input "
-                                   "pyramids and SO3 pre-alignment run on two side streams during the current frame's fusion",
-                       "width": W, "height": H, "models_per_gpu": 1, "parallelism": f"model-shard x{world}"},
+            "config": {"workload": workload, "width": W, "height": H, "models_per_gpu": models_per_gpu,
+                       "parallelism": f"model-shard x{world}"},
             "roofline": roofline,
+            "gn_chain": gn_chain,
+            "icp_kernel_standalone": icp_standalone,
             "surfel_passes": surfel_passes,
-            "matcher": matcher,
-            "superpoint": superpoint,
-            "slic_downsample": slic_info,
             "device": ctx.device_name(),
-            "last_frame_translation_error_m": t_err,
-            "icp_inliers_last": odom.lastICPCount,
             "surfels": n_surfels,
+            "icp_inliers_last": mmf.getFrameOdometry().lastICPCount,
         }
-        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
-            result["cpu_baseline"] = cpu_baseline(frames, K, poses)
+        if t_err is not None:
+            result["last_frame_translation_error_m"] = t_err
+        if config5 and world > 1:
+            result["config"]["scaling_note"] = ("N = 1 of the driver's curve is the 640x480 static-scene metric of BASELINE.json; the same "
+                                                "1280x960 workload at N = 1 is `MMF_BENCH_WORKLOAD=config5 python bench.py` (profiles/)")
+
+    if rank == 0 and world == 1 and not config5:
+        # ---- several rigid-body models on ONE GPU, each on its own stream (configs[3]): 640x480, moving objects, mask = GT ids
+        mmf.close()
+        Ko, _, oframes = object_sequence(synth, W, H, 7)
+        o_rgb = [up(f["rgb"]) for f in oframes]
+        o_depth = [up(f["depth"]) for f in oframes]
+        sweep = []
+        for m in (1, 2, 4, 8):
+            o_mask = [up(np.where(f["ids"] < m, f["ids"], 0).astype(np.uint8)) for f in oframes]
+            g = MultiMotionFusion(ctx, W, H, Ko["cx"], Ko["cy"], Ko["fx"], Ko["fy"], icp_weight=ICP_WEIGHT, enable_multiple_models=1,
+                                  preallocated_models=m - 1)
+            n_steps, track_s = 60, 0.0
+            for i in range(m + 10 + n_steps):
+                if i == m + 10:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                kk = pingpong(i, N_FRAMES_OBJECTS)
+                g.processFrame(o_rgb[kk], o_depth[kk], timestamp=i, mask=o_mask[kk], hasNewLabel=1 <= i < m)
+                if i >= m + 10:
+                    track_s += g.lastTimings()[0]
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / n_steps
+            assert len(g.getModels()) == m
+            sweep.append({"models_per_gpu": m, "ms_per_frame": dt * 1e3, "model_frames_per_s": m / dt,
+                          "tracking_phase_ms": track_s / n_steps * 1e3,
+                          "gn_chain_aggregate_GBps": m * gn_chain_bytes(W, H) / (track_s / n_steps) / 1e9,
+                          "gn_chain_aggregate_frac": m * gn_chain_bytes(W, H) / (track_s / n_steps) / 1e9 / HBM_PEAK_GBPS,
+                          "surfels": [mm.lastCount() for mm in g.getModels()]})
+            g.close()
+        result["multi_model"] = {"what": f"{W}x{H}, static scene + (m - 1) moving objects, mask = ground-truth ids, every model on its own "
+                                         "stream with its own reduction scratch, sensor-side preparation shared; tracking_phase = host wall "
+                                         "clock from the first enqueue to the last pose; aggregate = m x 388.6 MB / tracking_phase",
+                                 "sweep": sweep}
+        # ---- host FrameData hand-over: the same static sequence with the upload inside processFrame (pinned double buffers)
+        g = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], icp_weight=ICP_WEIGHT)
+        n_steps = 60
+        for i in range(10 + n_steps):
+            if i == 10:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            k = i % (N_FRAMES - 1)
+            g.processFrameHost(frames[k]["rgb"], frames[k]["depth"], timestamp=i)
+        torch.cuda.synchronize()
+        result["with_host_upload"] = {"frames_per_s": n_steps / (time.perf_counter() - t1), "bytes_per_frame": 7 * n0,
+                                      "what": "mmf_fusion_process_frame_host: rgb + depth copied into pinned staging and uploaded on the "
+                                              "fusion's stream inside processFrame (no prefetch); never part of `value`"}
+        g.close()
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(frames, K, W, H)
     fence()
     if rank == 0:
         print(json.dumps(result), flush=True)
-    mmf.close()
+    try:
+        mmf.close()
+    except Exception:
+        pass
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -214,6 +214,20 @@ int mmf_odom_download(mmf_odom *o, const char *name, int level, void *host_dst, 
  * between), bracketed by HIP events on the context's stream; returns the mean time per launch.
  * variant: 0 = the shipped launch geometry, else PX * 10000 + BLOCK (tuning sweeps). */
 int mmf_odom_time_icp_kernel(mmf_odom *o, int level, int reps, int variant, float *mean_us_out);
+/* Measurement mode for bench.py: while on, every launch of the Gauss-Newton loop's two kernels -- the producer
+ * (ICP J^T J reduction + photometric correspondence pass of one iteration) and the photometric Jacobian /
+ * solve step -- carries its own start / stop HIP events (the dispatch's begin / end timestamps, the same
+ * ones a kernel trace reports), and the whole chain of a getIncrementalTransformation two more.  Sums, minima and
+ * launch counts accumulate per pyramid level until the mode is switched (which also clears them). */
+typedef struct {
+    double producer_us_sum[MMF_NUM_PYRS], producer_us_min[MMF_NUM_PYRS];
+    double rgb_step_us_sum[MMF_NUM_PYRS], rgb_step_us_min[MMF_NUM_PYRS];
+    int producer_launches[MMF_NUM_PYRS], rgb_step_launches[MMF_NUM_PYRS];
+    double chain_us_sum; /* odom_begin .. last step of one tracking call, on the device */
+    int chains;
+} mmf_odom_timing;
+int mmf_odom_enable_timing(mmf_odom *o, int on);
+int mmf_odom_get_timing(mmf_odom *o, mmf_odom_timing *out);
 
 /* ---------------------------------------------------------------------------------------
  * Surfel model: Core/Model/Model.{h,cpp} (store, fuse, clean, initialise) and
@@ -416,6 +430,15 @@ int mmf_fusion_set_depth_cutoff(mmf_fusion *f, float val);
 int mmf_fusion_set_confidence_threshold(mmf_fusion *f, float val);
 int mmf_fusion_set_enable_multiple_models(mmf_fusion *f, int val);
 int mmf_fusion_get_config(mmf_fusion *f, mmf_fusion_config *out);
+/* Per-rigid-body shard (one process per GPU): this process runs the GPU work of the models whose list index k has
+ * k % world == rank; the other models exist as bookkeeping only (ids, thresholds, poses).  The sensor-side
+ * preparation of a frame runs on every rank.  Poses of remote models are handed in by the caller (the all-gather
+ * of mmf_shard_* or of the host framework). */
+int mmf_fusion_set_shard(mmf_fusion *f, int rank, int world);
+int mmf_fusion_owns_model(mmf_fusion *f, int index);
+int mmf_fusion_set_model_pose(mmf_fusion *f, int index, const float pose[16]);
+/* host wall clock of the last processFrame call: the tracking phase (first enqueue .. last result) and the whole call */
+int mmf_fusion_last_timings(mmf_fusion *f, double *tracking_s, double *frame_s);
 int mmf_fusion_set_segmentation_callback(mmf_fusion *f, mmf_segmentation_fn fn, void *user);
 /* exportPoses() (:1020-1045): `poses-<id>.txt` per pose-logging model under export_dir (which ends in '/') */
 int mmf_fusion_export_poses(mmf_fusion *f, const char *export_dir);

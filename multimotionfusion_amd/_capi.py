@@ -45,6 +45,12 @@ class mmf_fusion_config(C.Structure):
                 ("error_recording", C.c_int), ("pose_logging", C.c_int), ("max_object_surfels", C.c_int)]
 
 
+class mmf_odom_timing(C.Structure):
+    _fields_ = [("producer_us_sum", C.c_double * 3), ("producer_us_min", C.c_double * 3), ("rgb_step_us_sum", C.c_double * 3),
+                ("rgb_step_us_min", C.c_double * 3), ("producer_launches", C.c_int * 3), ("rgb_step_launches", C.c_int * 3),
+                ("chain_us_sum", C.c_double), ("chains", C.c_int)]
+
+
 class mmf_segmentation_model(C.Structure):
     _fields_ = [("id", C.c_uint), ("super_pixel_count", C.c_uint), ("avg_confidence", C.c_float),
                 ("depth_mean", C.c_float), ("depth_std", C.c_float)]
@@ -184,6 +190,12 @@ SIGNATURES = {
     "mmf_fusion_export_poses": (_i, [_vp, C.c_char_p]),
     "mmf_fusion_pose_log": (_i, [_vp, _i, C.POINTER(C.c_longlong), _fp, _i, _ip]),
     "mmf_compute_fusion_weight": (_i, [_fp, _fp, _f, _fp]),
+    "mmf_fusion_set_shard": (_i, [_vp, _i, _i]),
+    "mmf_fusion_owns_model": (_i, [_vp, _i]),
+    "mmf_fusion_set_model_pose": (_i, [_vp, _i, _fp]),
+    "mmf_fusion_last_timings": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mmf_odom_enable_timing": (_i, [_vp, _i]),
+    "mmf_odom_get_timing": (_i, [_vp, C.POINTER(mmf_odom_timing)]),
     "mmf_model_set_max_depth": (_i, [_vp, _f]),
     "mmf_model_set_confidence_threshold": (_i, [_vp, _f]),
     "mmf_model_confidence_threshold": (_f, [_vp]),

@@ -14,6 +14,7 @@
 // (Model::GPUSetup::depth_tmp, Model.h:103) and recomputes the rest per model.
 #pragma once
 
+#include <chrono>
 #include <vector>
 
 struct PoseLogItem {  // Model::PoseLogItem (Model.h:326-329)
@@ -46,6 +47,11 @@ struct mmf_fusion {
     std::vector<FusionModel*> inactive;      // inactiveModels
     std::vector<int> scheduled_deactivation;
     int next_id = 0;                  // nextID (getNextModelID)
+    // per-rigid-body shard: this process owns the models whose list index k has k % shard_world ==
+    // shard_rank and runs their track / predict / fuse / clean; the others only exist as bookkeeping here (ids,
+    // thresholds, poses handed in through mmf_fusion_set_model_pose) -- their owners run on other GPUs
+    int shard_rank = 0, shard_world = 1;
+    double t_tracking_s = 0, t_frame_s = 0;  // host wall clock of the last processFrame: tracking phase, whole call
     float* depth_filtered = nullptr;  // = filtered[cur]
     uint8_t* mask = nullptr;          // textures[MASK]: all zeros unless enableMultipleModels
     bool mask_is_zero = false;
@@ -273,6 +279,30 @@ extern "C" int mmf_fusion_next_model_id(mmf_fusion* f) {
     return f->preallocated.empty() ? f->next_id : (int)f->preallocated.front()->model->id;
 }
 
+static inline bool fusion_owns(const mmf_fusion* f, size_t index) { return (int)(index % (size_t)f->shard_world) == f->shard_rank; }
+
+extern "C" int mmf_fusion_set_shard(mmf_fusion* f, int rank, int world) {
+    MMF_REQUIRE(f && world >= 1 && rank >= 0 && rank < world, "mmf_fusion_set_shard: bad argument");
+    f->shard_rank = rank, f->shard_world = world;
+    return MMF_OK;
+}
+extern "C" int mmf_fusion_owns_model(mmf_fusion* f, int index) {
+    return (f && index >= 0 && fusion_owns(f, (size_t)index)) ? 1 : 0;
+}
+// the pose of a model another rank owns, as gathered from its owner (Model::overridePose semantics)
+extern "C" int mmf_fusion_set_model_pose(mmf_fusion* f, int index, const float pose[16]) {
+    MMF_REQUIRE(f && pose && index >= 0 && index < (int)f->models.size(), "mmf_fusion_set_model_pose: bad argument");
+    std::memcpy(f->models[index]->model->pose, pose, sizeof(float) * 16);
+    std::memcpy(f->models[index]->last_pose, pose, sizeof(float) * 16);
+    return MMF_OK;
+}
+extern "C" int mmf_fusion_last_timings(mmf_fusion* f, double* tracking_s, double* frame_s) {
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_last_timings: null fusion object");
+    if (tracking_s) *tracking_s = f->t_tracking_s;
+    if (frame_s) *frame_s = f->t_frame_s;
+    return MMF_OK;
+}
+
 static FusionModel* fusion_find(mmf_fusion* f, int id) {
     for (FusionModel* m : f->models)
         if ((int)m->model->id == id) return m;
@@ -461,6 +491,8 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
         return fail(MMF_ERR_INVALID, "invalid image data");
     mmf_ctx* c = f->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    f->t_tracking_s = 0;
     const mmf_fusion_config& g = f->cfg;
     const float weight_multiplier = fr->weight_multiplier;
     const bool have_init = fr->init_transforms != nullptr && fr->n_init_transforms > 0;  // odom_cfg.init == "kp"
@@ -494,9 +526,11 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     f->scheduled_deactivation.clear();
 
     if (f->tick == 1) {  // :290-296
-        rc = mmf_model_initialise(global->model, rgb, depth, f->depth_filtered, f->tick, g.max_depth_processed);
-        if (rc) return rc;
-        rc = mmf_odom_init_first_rgb(global->odom, rgb, 0, 3);
+        if (fusion_owns(f, 0)) {
+            rc = mmf_model_initialise(global->model, rgb, depth, f->depth_filtered, f->tick, g.max_depth_processed);
+            if (rc) return rc;
+        }
+        rc = mmf_odom_init_first_rgb(global->odom, rgb, 0, 3);  // sensor side: every rank
         if (rc) return rc;
         MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
         f->inputs_free_recorded = true;
@@ -508,7 +542,8 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             MMF_REQUIRE(!have_init || !g.frame_to_frame_rgb, "ICP initialisation not supported in frame-to-frame mode");  // :370
             // generateCUDATextures (:302) + the sensor side of Model::initICP (Model.cpp:402-403: initICP, initRGB), once
             // for all models.  One model without pose initialisation: sensor side and model side share four launches.
-            const bool one_pass = n_models == 1 && !have_init;
+            const auto t_track = std::chrono::steady_clock::now();
+            const bool one_pass = n_models == 1 && !have_init && fusion_owns(f, 0);
             if (!prefetched && !one_pass) {
                 float identity[16];
                 identity16(identity);
@@ -521,6 +556,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             for (size_t k = 0; k < n_models; ++k) {  // :312-387, enqueue only
                 FusionModel* fm = f->models[k];
                 fm->tracking = false;
+                if (!fusion_owns(f, k)) continue;
                 if (k > 0) {
                     rc = lane_wait(fm, f->ev_frame_ready);
                     if (rc) return rc;
@@ -574,8 +610,11 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 if (rc) return rc;
                 fm->tracking = true;
             }
+            bool any_tracked = false;
+            const bool global_tracked = global->tracking;
             for (size_t k = 0; k < n_models; ++k) {  // the results, model by model
                 FusionModel* fm = f->models[k];
+                any_tracked = any_tracked || fm->tracking;
                 float pose[16];
                 mmf_model_get_pose(fm->model, pose);
                 if (fm->tracking) {
@@ -590,6 +629,11 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     fm->tracking = false;
                 }
             }
+            // the sensor-side image ring (this frame's / last frame's intensity pyramid, RGBDOdometry.cpp:469-473) lives in
+            // the global odometry: when its owner is another rank, the swap its tracking would have done happens here
+            if (g.so3 && any_tracked && !global_tracked)
+                for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(global->odom->last_next_image[i], global->odom->next_image[i]);
+            f->t_tracking_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_track).count();
             if (fr->bootstrap) {  // :397-400
                 MMF_REQUIRE(fr->in_pose != nullptr, "mmf_fusion_process_frame: bootstrap needs in_pose");
                 float pose[16], np[16];
@@ -630,7 +674,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 // Set max-depth (:585-586)
                 for (size_t i = 1; i < f->models.size() && (int)i < n_data; ++i)
                     f->models[i]->model->max_depth = seg_max_depth(seg->model_data[i]);
-                if (fresh) {  // :588-601: the first surfels of the new model, then it joins the list
+                if (fresh && !fusion_owns(f, f->models.size())) {
+                    f->models.push_back(fresh);  // another rank's model: bookkeeping only
+                } else if (fresh) {  // :588-601: the first surfels of the new model, then it joins the list
                     rc = lane_wait(fresh, f->ev_frame_ready);
                     if (rc) return rc;
                     identity16(fresh->last_pose);
@@ -674,6 +720,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
 
         for (size_t k = 0; k < f->models.size(); ++k) {  // predict() (:675), then :791-816, model by model
             FusionModel* fm = f->models[k];
+            if (!fusion_owns(f, k)) continue;
             if (k > 0) {
                 rc = lane_wait(fm, f->ev_frame_ready);
                 if (rc) return rc;
@@ -688,8 +735,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             }
         }
     }
-    for (FusionModel* fm : f->models) {  // predict() (:821)
-        rc = fusion_predict_model(f, fm);
+    for (size_t k = 0; k < f->models.size(); ++k) {  // predict() (:821)
+        if (!fusion_owns(f, k)) continue;
+        rc = fusion_predict_model(f, f->models[k]);
         if (rc) return rc;
     }
     f->tick++;  // :825
@@ -719,9 +767,11 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     // overwrite what the lanes read
     for (size_t k = 1; k < f->models.size(); ++k) {
         FusionModel* fm = f->models[k];
+        if (!fusion_owns(f, k)) continue;
         MMF_HIP_TRY(hipEventRecord(fm->ev_done, fm->lane->stream));
         MMF_HIP_TRY(hipStreamWaitEvent(c->stream, fm->ev_done, 0));
     }
+    f->t_frame_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return MMF_OK;
 }
 
@@ -796,6 +846,7 @@ extern "C" int mmf_fusion_predict(mmf_fusion* f) {
     MMF_HIP_TRY(hipSetDevice(f->ctx->device));
     for (size_t k = 0; k < f->models.size(); ++k) {
         FusionModel* fm = f->models[k];
+        if (!fusion_owns(f, k)) continue;
         int rc = fusion_predict_model(f, fm);
         if (rc) return rc;
         if (k > 0) {

@@ -3,6 +3,7 @@
 #include "../../include/mmf_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -698,6 +699,8 @@ extern "C" int mmf_compute_derivative_images(mmf_ctx* c, const uint8_t* src, siz
 // ---------------------------------------------------------------------------------------------
 // RGBDOdometry object
 // ---------------------------------------------------------------------------------------------
+constexpr int kMaxTimedLaunches = 48;  // 19 iterations x (producer + step)
+
 struct mmf_odom {
     mmf_ctx* ctx = nullptr;
     int width = 0, height = 0;
@@ -735,6 +738,14 @@ struct mmf_odom {
     bool prep_batched = false;
     bool so3_prefetched = false;  // this frame's SO3 pre-alignment already ran (odom_prefetch_so3)
     bool pending_icp = false, pending_so3 = false;  // mode of the tracking call that is in flight (enqueue -> finish)
+    // measurement mode (mmf_odom_enable_timing): every producer / rgb_step launch of a tracking call carries its own
+    // start / stop events (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps), the whole chain two more
+    bool timing = false;
+    hipEvent_t ev_kernel[2 * kMaxTimedLaunches] = {};
+    int timed_kind[kMaxTimedLaunches] = {};  // level * 2 + (0 producer | 1 rgb_step)
+    int n_timed = 0;
+    hipEvent_t ev_chain[2] = {};
+    mmf_odom_timing timing_acc;
     mmf_odom_stats stats;
 };
 
@@ -758,6 +769,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     o->dist_thres = dist_thresh;
     o->angle_thres = angle_thresh;
     std::memset(&o->stats, 0, sizeof(o->stats));
+    std::memset(&o->timing_acc, 0, sizeof(o->timing_acc));
     o->stats.lastICPCount = o->stats.lastRGBCount = o->stats.lastSO3Count = (float)(width * height);  // :24-28
 
     // carve every pyramid buffer out of one allocation, each 256-byte aligned
@@ -830,6 +842,10 @@ extern "C" void mmf_odom_destroy(mmf_odom* o) {
     (void)hipStreamSynchronize(o->ctx->stream);
     (void)hipFree(o->slab);
     (void)hipHostFree(o->host_result);
+    for (hipEvent_t e : o->ev_kernel)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : o->ev_chain)
+        if (e) (void)hipEventDestroy(e);
     delete o;
 }
 
@@ -1226,6 +1242,8 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     const bool fold_first_level = !so3 || o->so3_prefetched;
     b.fold_level_begin = fold_first_level ? 1 : 0;
     b.first_intr = level_intr(o->fx, o->fy, o->cx, o->cy, MMF_NUM_PYRS - 1);
+    o->n_timed = 0;
+    if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[0], c->stream));
     hipLaunchKernelGGL(odom_begin_kernel, dim3(1), dim3(64), 0, c->stream, o->state, b);
     MMF_HIP_TRY(hipGetLastError());
 
@@ -1279,14 +1297,19 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                                         icp_default_variant(cols * rows) / 1000000 != 1;
             if (fuse_producers) {  // ICP reduction + correspondence pass side by side in one launch
                 icp_records = (cols * rows + kBlock * ipx - 1) / (kBlock * ipx);
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (o->timing && o->n_timed < kMaxTimedLaunches) {
+                    e0 = o->ev_kernel[2 * o->n_timed], e1 = o->ev_kernel[2 * o->n_timed + 1];
+                    o->timed_kind[o->n_timed++] = i * 2;
+                }
                 if (ipx == 2)
-                    hipLaunchKernelGGL((track_producer_kernel<2, true>), dim3(icp_records + res_records), dim3(kBlock), 0,
-                                       c->stream, o->state, ia, (unsigned)icp_records, ra, c->partials_icp,
-                                       c->partials_res);
+                    hipExtLaunchKernelGGL((track_producer_kernel<2, true>), dim3(icp_records + res_records), dim3(kBlock), 0,
+                                          c->stream, e0, e1, 0, o->state, ia, (unsigned)icp_records, ra, c->partials_icp,
+                                          c->partials_res);
                 else
-                    hipLaunchKernelGGL((track_producer_kernel<1, true>), dim3(icp_records + res_records), dim3(kBlock), 0,
-                                       c->stream, o->state, ia, (unsigned)icp_records, ra, c->partials_icp,
-                                       c->partials_res);
+                    hipExtLaunchKernelGGL((track_producer_kernel<1, true>), dim3(icp_records + res_records), dim3(kBlock), 0,
+                                          c->stream, e0, e1, 0, o->state, ia, (unsigned)icp_records, ra, c->partials_icp,
+                                          c->partials_res);
                 MMF_HIP_TRY(hipGetLastError());
             } else {
                 if (rgb) {
@@ -1336,12 +1359,17 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                     begin_folded = true;
                 }
                 const int grid = reduce_grid(cols * rows, kBlock * 4);  // width, height are multiples of 4
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (o->timing && o->n_timed < kMaxTimedLaunches) {
+                    e0 = o->ev_kernel[2 * o->n_timed], e1 = o->ev_kernel[2 * o->n_timed + 1];
+                    o->timed_kind[o->n_timed++] = i * 2 + 1;
+                }
                 if (res_vec4)  // the 4-pixel correspondence pass wrote compact records
-                    hipLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, true>), dim3(grid), dim3(kBlock), 0, c->stream,
-                                       o->state, a, c->partials_f, c->ticket);
+                    hipExtLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, true>), dim3(grid), dim3(kBlock), 0, c->stream, e0, e1,
+                                          0, o->state, a, c->partials_f, c->ticket);
                 else
-                    hipLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, false>), dim3(grid), dim3(kBlock), 0, c->stream,
-                                       o->state, a, c->partials_f, c->ticket);
+                    hipExtLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, false>), dim3(grid), dim3(kBlock), 0, c->stream, e0,
+                                          e1, 0, o->state, a, c->partials_f, c->ticket);
                 MMF_HIP_TRY(hipGetLastError());
             }
         }
@@ -1351,6 +1379,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         hipLaunchKernelGGL(odom_end_kernel, dim3(1), dim3(64), 0, c->stream, o->state);
         MMF_HIP_TRY(hipGetLastError());
     }
+    if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[1], c->stream));
     MMF_HIP_TRY(hipMemcpyAsync(o->host_result, o->state, sizeof(OdomState), hipMemcpyDeviceToHost, c->stream));
     o->pending_icp = icp, o->pending_so3 = so3 != 0;
     return MMF_OK;
@@ -1362,6 +1391,24 @@ static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
     MMF_HIP_TRY(hipSetDevice(c->device));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
     const bool icp = o->pending_icp, so3 = o->pending_so3;
+    if (o->timing) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, o->ev_chain[0], o->ev_chain[1]) == hipSuccess) {
+            o->timing_acc.chain_us_sum += ms * 1e3;
+            o->timing_acc.chains += 1;
+        }
+        for (int k = 0; k < o->n_timed; ++k)
+            if (hipEventElapsedTime(&ms, o->ev_kernel[2 * k], o->ev_kernel[2 * k + 1]) == hipSuccess) {
+                const int lvl = o->timed_kind[k] >> 1, step = o->timed_kind[k] & 1;
+                double* sum = step ? o->timing_acc.rgb_step_us_sum : o->timing_acc.producer_us_sum;
+                double* mn = step ? o->timing_acc.rgb_step_us_min : o->timing_acc.producer_us_min;
+                int* n = step ? o->timing_acc.rgb_step_launches : o->timing_acc.producer_launches;
+                sum[lvl] += ms * 1e3;
+                if (n[lvl] == 0 || ms * 1e3 < mn[lvl]) mn[lvl] = ms * 1e3;
+                n[lvl] += 1;
+            }
+        o->n_timed = 0;
+    }
 
     if (so3)  // :469-473
         for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(o->last_next_image[i], o->next_image[i]);
@@ -1396,6 +1443,24 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
     int rc = odom_enqueue_tracking(o, trans, rot, rgb_only, icp_weight, pyramid, fast_odom, so3, icp_err_dev, rgb_err_dev);
     if (rc) return rc;
     return odom_finish_tracking(o, trans, rot);
+}
+
+// measurement mode: per-launch durations of the Gauss-Newton kernels from the dispatches' own timestamps
+extern "C" int mmf_odom_enable_timing(mmf_odom* o, int on) {
+    MMF_REQUIRE(o != nullptr, "mmf_odom_enable_timing: null odometry");
+    MMF_HIP_TRY(hipSetDevice(o->ctx->device));
+    if (on && !o->ev_chain[0]) {
+        for (hipEvent_t& e : o->ev_kernel) MMF_HIP_TRY(hipEventCreate(&e));
+        for (hipEvent_t& e : o->ev_chain) MMF_HIP_TRY(hipEventCreate(&e));
+    }
+    o->timing = on != 0;
+    std::memset(&o->timing_acc, 0, sizeof(o->timing_acc));
+    return MMF_OK;
+}
+extern "C" int mmf_odom_get_timing(mmf_odom* o, mmf_odom_timing* out) {
+    MMF_REQUIRE(o && out, "mmf_odom_get_timing: null argument");
+    *out = o->timing_acc;
+    return MMF_OK;
 }
 
 extern "C" int mmf_odom_get_stats(mmf_odom* o, mmf_odom_stats* out) {

@@ -149,6 +149,22 @@ class MultiMotionFusion:
     def predict(self):
         check(self.ctx.lib.mmf_fusion_predict(self.handle))
 
+    def setShard(self, rank, world):
+        """Per-rigid-body shard: this process runs the models whose list index k has k % world == rank."""
+        check(self.ctx.lib.mmf_fusion_set_shard(self.handle, int(rank), int(world)))
+
+    def ownsModel(self, index):
+        return bool(self.ctx.lib.mmf_fusion_owns_model(self.handle, int(index)))
+
+    def setModelPose(self, index, pose):
+        p = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+        check(self.ctx.lib.mmf_fusion_set_model_pose(self.handle, int(index), fptr(p)))
+
+    def lastTimings(self):
+        a, b = C.c_double(), C.c_double()
+        check(self.ctx.lib.mmf_fusion_last_timings(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def setTick(self, val):
         check(self.ctx.lib.mmf_fusion_set_tick(self.handle, int(val)))
 

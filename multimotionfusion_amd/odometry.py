@@ -113,6 +113,22 @@ class RGBDOdometry:
         npdt = {torch.float32: np.float32, torch.uint8: np.uint8, torch.int16: np.int16}[dt]
         return host.view(npdt).reshape(planes * rows, cols)
 
+    def enableTiming(self, on=True):
+        """Measurement mode: per-launch durations of the Gauss-Newton kernels (dispatch timestamps via HIP events)."""
+        check(self.ctx.lib.mmf_odom_enable_timing(self.handle, int(bool(on))))
+
+    def getTiming(self):
+        from ._capi import mmf_odom_timing
+        t = mmf_odom_timing()
+        check(self.ctx.lib.mmf_odom_get_timing(self.handle, C.byref(t)))
+        out = {"chain_us": t.chain_us_sum / max(t.chains, 1), "chains": t.chains}
+        for lvl in range(3):
+            for name in ("producer", "rgb_step"):
+                n = getattr(t, name + "_launches")[lvl]
+                out[f"{name}_l{lvl}"] = {"launches": n, "mean_us": getattr(t, name + "_us_sum")[lvl] / max(n, 1),
+                                         "min_us": getattr(t, name + "_us_min")[lvl]}
+        return out
+
     def timeIcpKernel(self, level, reps, variant=0):
         us = C.c_float(0)
         check(self.ctx.lib.mmf_odom_time_icp_kernel(self.handle, level, reps, variant, C.byref(us)))
