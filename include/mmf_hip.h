@@ -226,7 +226,7 @@ typedef struct {
     double chain_us_sum; /* odom_begin .. last step of one tracking call, on the device */
     int chains;
 } mmf_odom_timing;
-int mmf_odom_enable_timing(mmf_odom *o, int on);
+int mmf_odom_enable_timing(mmf_odom *o, int mode); /* 0 off, 1 the chain only (two events per call), 2 every kernel too */
 int mmf_odom_get_timing(mmf_odom *o, mmf_odom_timing *out);
 
 /* ---------------------------------------------------------------------------------------

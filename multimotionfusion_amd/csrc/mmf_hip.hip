@@ -740,7 +740,7 @@ struct mmf_odom {
     bool pending_icp = false, pending_so3 = false;  // mode of the tracking call that is in flight (enqueue -> finish)
     // measurement mode (mmf_odom_enable_timing): every producer / rgb_step launch of a tracking call carries its own
     // start / stop events (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps), the whole chain two more
-    bool timing = false;
+    int timing = 0;  // 1: chain events only; 2: also every kernel of the chain
     hipEvent_t ev_kernel[2 * kMaxTimedLaunches] = {};
     int timed_kind[kMaxTimedLaunches] = {};  // level * 2 + (0 producer | 1 rgb_step)
     int n_timed = 0;
@@ -1298,7 +1298,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
             if (fuse_producers) {  // ICP reduction + correspondence pass side by side in one launch
                 icp_records = (cols * rows + kBlock * ipx - 1) / (kBlock * ipx);
                 hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (o->timing && o->n_timed < kMaxTimedLaunches) {
+                if (o->timing >= 2 && o->n_timed < kMaxTimedLaunches) {
                     e0 = o->ev_kernel[2 * o->n_timed], e1 = o->ev_kernel[2 * o->n_timed + 1];
                     o->timed_kind[o->n_timed++] = i * 2;
                 }
@@ -1360,7 +1360,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 }
                 const int grid = reduce_grid(cols * rows, kBlock * 4);  // width, height are multiples of 4
                 hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (o->timing && o->n_timed < kMaxTimedLaunches) {
+                if (o->timing >= 2 && o->n_timed < kMaxTimedLaunches) {
                     e0 = o->ev_kernel[2 * o->n_timed], e1 = o->ev_kernel[2 * o->n_timed + 1];
                     o->timed_kind[o->n_timed++] = i * 2 + 1;
                 }
@@ -1453,7 +1453,7 @@ extern "C" int mmf_odom_enable_timing(mmf_odom* o, int on) {
         for (hipEvent_t& e : o->ev_kernel) MMF_HIP_TRY(hipEventCreate(&e));
         for (hipEvent_t& e : o->ev_chain) MMF_HIP_TRY(hipEventCreate(&e));
     }
-    o->timing = on != 0;
+    o->timing = on < 0 ? 0 : (on > 2 ? 2 : on);
     std::memset(&o->timing_acc, 0, sizeof(o->timing_acc));
     return MMF_OK;
 }

@@ -113,9 +113,10 @@ class RGBDOdometry:
         npdt = {torch.float32: np.float32, torch.uint8: np.uint8, torch.int16: np.int16}[dt]
         return host.view(npdt).reshape(planes * rows, cols)
 
-    def enableTiming(self, on=True):
-        """Measurement mode: per-launch durations of the Gauss-Newton kernels (dispatch timestamps via HIP events)."""
-        check(self.ctx.lib.mmf_odom_enable_timing(self.handle, int(bool(on))))
+    def enableTiming(self, mode=2):
+        """Measurement mode: 0 off, 1 the duration of the whole Gauss-Newton chain, 2 also of each of its kernels
+        (dispatch timestamps via HIP events; mode 2 perturbs the chain it sits in)."""
+        check(self.ctx.lib.mmf_odom_enable_timing(self.handle, int(mode)))
 
     def getTiming(self):
         from ._capi import mmf_odom_timing
