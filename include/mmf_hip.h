@@ -363,6 +363,7 @@ int mmf_fusion_default_config(mmf_fusion_config *cfg);
 int mmf_fusion_create(mmf_ctx *ctx, int width, int height, float cx, float cy, float fx, float fy,
                       const mmf_fusion_config *cfg, mmf_fusion **out);
 void mmf_fusion_destroy(mmf_fusion *f);
+int mmf_fusion_preallocate_models(mmf_fusion *f, unsigned count); /* preallocateModels (:125-131) */
 /* processFrame(frame, inPose, weightMultiplier, gt_pose, bootstrap): rgb = u8 x 3 interleaved and
  * depth = float32 metres, both already in HBM (the reference uploads FrameData to GL textures
  * here, :221,261); in_pose may be NULL.  Returns MMF_ERR_INVALID with "invalid image data" where

@@ -1,21 +1,42 @@
-// MultiMotionFusion.h -- C++ shims with the reference's class and method names for the surfel
-// model (Core/Model/Model.h:120-300 + Core/Model/ModelProjection.h:37-77) and the orchestrator
-// (Core/MultiMotionFusion.h:78-160), forwarding to the C ABI of include/mmf_hip.h.
+// MultiMotionFusion.h -- C++ shims with the reference's class and method names for the surfel model
+// (Core/Model/Model.h:120-360 + Core/Model/ModelProjection.h:37-77) and the orchestrator
+// (Core/MultiMotionFusion.h:50-300), forwarding to the C ABI of include/mmf_hip.h.
 //
-// GPUTexture* arguments / getters of the reference become device pointers to dense images
-// (see mmf_model_texture for names and formats); there is no OpenGL object behind them.
+// GPUTexture* arguments / getters keep their place in the signatures (GPUTexture.h: a view of a dense device image
+// instead of an OpenGL texture).  Eigen / OpenCV types of the reference become plain arrays: poses are row-major
+// float[16], FrameData carries raw pointers.  What the front-end pushes per GUI tick (GUI/MainController.cpp:641-670)
+// and per frame (:588) compiles against this header; setters of subsystems that stay in the reference (CRF, model
+// spawning policy, redetection) are kept as recorded no-ops so those call sites need no #ifdef.
 #pragma once
 #include <cstdint>
+#include <cstring>
+#include <list>
+#include <map>
+#include <memory>
+#include <string>
 #include <vector>
 
+#include "GPUTexture.h"
 #include "RGBDOdometry.h"
 
-// FrameData (Core/FrameData.h:25-43) without OpenCV: device-resident colour / depth of one frame.
+// FrameData (Core/FrameData.h:25-43) without OpenCV: one frame in HOST memory, as the log readers deliver it
+struct FrameData {
+    int64_t timestamp = 0;
+    const uint8_t* rgb = nullptr;   // CV_8UC3, width x height
+    const float* depth = nullptr;   // CV_32FC1 metres, 0 = invalid
+    const uint8_t* mask = nullptr;  // optional CV_8UC1 id image, already mapped to model ids (Segmentation.cpp:89-150)
+    bool hasNewLabel = false;       // SegmentationResult::hasNewLabel of that id image
+};
+// the same frame already resident in HBM (no upload inside processFrame)
 struct FrameDataDevice {
     long long timestamp = 0;
     const uint8_t* rgb = nullptr;  // u8 x 3, interleaved, width x height
     const float* depth = nullptr;  // float32 metres, 0 = invalid
+    const uint8_t* mask = nullptr;
+    bool hasNewLabel = false;
 };
+
+class ModelProjection;
 
 class Model {
    public:
@@ -27,57 +48,139 @@ class Model {
         float normal[3], radius;
     };
 
+    // Model(id, confidenceThresh, odom_cfg, enableFillIn, ...) (Model.cpp:147-262): a stand-alone model with its own
+    // frame-to-model odometry
     Model(mmf::Context& ctx, int width, int height, float cx, float cy, float fx, float fy, unsigned char id,
-          float confidenceThresh, int maxSurfels = MAX_VERTICES) {
+          float confidenceThresh, bool enableFillIn = true, int maxSurfels = MAX_VERTICES)
+        : width_(width), height_(height), fill_in_(enableFillIn) {
         mmf::check(mmf_model_create(ctx.get(), width, height, cx, cy, fx, fy, id, confidenceThresh, maxSurfels, &m_),
                    "mmf_model_create");
+        mmf::check(mmf_odom_create(ctx.get(), width, height, cx, cy, fx, fy, 0.10f, std::sin(20.f * 3.14159254f / 180.f), &o_),
+                   "mmf_odom_create");
         owned_ = true;
+        identity(lastPose_);
     }
-    explicit Model(mmf_model* borrowed) : m_(borrowed), owned_(false) {}
+    // a model (and its odometry) owned by a MultiMotionFusion object
+    Model(mmf_model* borrowed, mmf_odom* odom, int width, int height, bool fillIn)
+        : m_(borrowed), o_(odom), owned_(false), width_(width), height_(height), fill_in_(fillIn) {
+        identity(lastPose_);
+    }
     ~Model() {
-        if (owned_) mmf_model_destroy(m_);
+        if (owned_) {
+            mmf_model_destroy(m_);
+            mmf_odom_destroy(o_);
+        }
     }
     Model(const Model&) = delete;
     Model& operator=(const Model&) = delete;
 
-    void initialise(const uint8_t* rgb, const float* depthRaw, const float* depthFiltered, int time, float maxDepth) {
-        mmf::check(mmf_model_initialise(m_, rgb, depthRaw, depthFiltered, time, maxDepth), "mmf_model_initialise");
+    // ----- first frame
+    void initialise(GPUTexture* rgb, GPUTexture* depthRaw, GPUTexture* depthFiltered, int time, float maxDepth) {
+        mmf::check(mmf_model_initialise(m_, rgb->ptr<uint8_t>(), depthRaw->ptr<float>(), depthFiltered->ptr<float>(), time, maxDepth),
+                   "mmf_model_initialise");
+    }
+
+    // ----- tracking (Model.h:150-157, Model.cpp:359-433)
+    // generateCUDATextures(depth, mask): the filtered depth every model's initICP builds its pyramid from
+    // (Model::GPUSetup::depth_tmp; the mask pyramid is never read by the tracker)
+    static void generateCUDATextures(GPUTexture* depth, GPUTexture* /*mask*/) { shared_depth() = depth->ptr<float>(); }
+
+    void initICP(bool doFillIn, bool frameToFrameRGB, float depthCutoff, GPUTexture* rgb) {
+        float pose[16];
+        getPose(pose);
+        const bool fill = doFillIn;
+        mmf::check(mmf_odom_init_icp_model(o_, (const float*)texture(fill ? "fillVertex" : "vertexConf"),
+                                           (const float*)texture(fill ? "fillNormal" : "normalRadius"), depthCutoff, pose),
+                   "mmf_odom_init_icp_model");
+        const bool fillImage = fill || (frameToFrameRGB && allowsFillIn());
+        mmf::check(mmf_odom_init_rgb_model(o_, (const uint8_t*)texture(fillImage ? "fillImage" : "image"), 0, 4),
+                   "mmf_odom_init_rgb_model");
+        mmf::check(mmf_odom_build_depth_pyramid(o_, shared_depth(), 0), "mmf_odom_build_depth_pyramid");
+        mmf::check(mmf_odom_init_icp(o_, nullptr, nullptr, depthCutoff), "mmf_odom_init_icp");
+        mmf::check(mmf_odom_init_rgb(o_, rgb->ptr<uint8_t>(), 0, 3), "mmf_odom_init_rgb");
+    }
+
+    void performTracking(bool frameToFrameRGB, bool rgbOnly, float icpWeight, bool pyramid, bool fastOdom, bool so3,
+                         float maxDepthProcessed, GPUTexture* rgb, int64_t logTimestamp, bool tryFillIn = false) {
+        float pose[16];
+        getPose(pose);
+        std::memcpy(lastPose_, pose, sizeof(pose));  // lastPose = pose (Model.cpp:412)
+        initICP(tryFillIn, frameToFrameRGB, maxDepthProcessed, rgb);
+        float trans[3] = {pose[3], pose[7], pose[11]};
+        float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+        mmf::check(mmf_odom_get_incremental_transformation(o_, trans, rot, rgbOnly, icpWeight, pyramid, fastOdom, so3, nullptr, nullptr),
+                   "mmf_odom_get_incremental_transformation");
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) pose[4 * r + c] = rot[3 * r + c];
+            pose[4 * r + 3] = trans[r];
+        }
+        mmf::check(mmf_model_set_pose(m_, pose), "mmf_model_set_pose");
+        timestamp_ns_.push_back(logTimestamp);
+    }
+
+    // ----- fusion (Model.h:196-207)
+    float computeFusionWeight(float weightMultiplier) const {
+        float pose[16], w = 0.f;
+        getPose(pose);
+        mmf::check(mmf_compute_fusion_weight(pose, lastPose_, weightMultiplier, &w), "mmf_compute_fusion_weight");
+        return w;
+    }
+    void fuse(const int& time, GPUTexture* rgb, GPUTexture* mask, GPUTexture* depthRaw, GPUTexture* depthFiltered,
+              const float depthCutoff, const float weightMultiplier) {
+        mmf::check(mmf_model_fuse(m_, time, rgb->ptr<uint8_t>(), mask->ptr<uint8_t>(), depthRaw->ptr<float>(),
+                                  depthFiltered->ptr<float>(), depthCutoff, computeFusionWeight(weightMultiplier)),
+                   "mmf_model_fuse");
+    }
+    void clean(const int& time, std::vector<float>& graph, const int timeDelta, const float depthCutoff, const bool /*isFern*/,
+               GPUTexture* depthFiltered, GPUTexture* mask, float outlierCoefficient = 3.0f) {
+        if (!graph.empty()) {  // deformation graph: loop closure stays in the reference
+            std::fprintf(stderr, "Model::clean: deformation graphs are not supported on this path\n");
+            std::exit(-1);
+        }
+        mmf::check(mmf_model_clean(m_, time, timeDelta, depthCutoff, depthFiltered->ptr<float>(), mask->ptr<uint8_t>(), outlierCoefficient),
+                   "mmf_model_clean");
+    }
+
+    // ----- prediction and fill-in (Model.h:208-220)
+    bool allowsFillIn() const { return fill_in_; }
+    void performFillIn(GPUTexture* rawRGB, GPUTexture* rawDepth, bool frameToFrameRGB, bool lost) {
+        if (!fill_in_) return;
+        mmf::check(mmf_model_perform_fill_in(m_, rawRGB->ptr<uint8_t>(), rawDepth->ptr<float>(), frameToFrameRGB, lost),
+                   "mmf_model_perform_fill_in");
+    }
+    void combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta, int /*ModelProjection::Prediction*/ = 0) {
+        mmf::check(mmf_model_combined_predict(m_, depthCutoff, time, maxTime, timeDelta), "mmf_model_combined_predict");
     }
     void predictIndices(int time, float depthCutoff, int timeDelta) {
         mmf::check(mmf_model_predict_indices(m_, time, depthCutoff, timeDelta), "mmf_model_predict_indices");
     }
-    void combinedPredict(float depthCutoff, int time, int maxTime, int timeDelta) {
-        mmf::check(mmf_model_combined_predict(m_, depthCutoff, time, maxTime, timeDelta), "mmf_model_combined_predict");
-    }
     // ModelProjection::synthesizeDepth (ModelProjection.h:49-50); result: texture("depth")
     void synthesizeDepth(float depthCutoff, float confThreshold, int time, int maxTime, int timeDelta) {
-        mmf::check(mmf_model_synthesize_depth(m_, depthCutoff, confThreshold, time, maxTime, timeDelta),
-                   "mmf_model_synthesize_depth");
+        mmf::check(mmf_model_synthesize_depth(m_, depthCutoff, confThreshold, time, maxTime, timeDelta), "mmf_model_synthesize_depth");
     }
-    void fuse(const int& time, const uint8_t* rgb, const uint8_t* mask, const float* depthRaw,
-              const float* depthFiltered, const float depthCutoff, const float weighting) {
-        mmf::check(mmf_model_fuse(m_, time, rgb, mask, depthRaw, depthFiltered, depthCutoff, weighting), "mmf_model_fuse");
-    }
-    void clean(const int& time, const int timeDelta, const float depthCutoff, const float* depthFiltered,
-               const uint8_t* mask, float outlierCoefficient = 3.0f) {
-        mmf::check(mmf_model_clean(m_, time, timeDelta, depthCutoff, depthFiltered, mask, outlierCoefficient),
-                   "mmf_model_clean");
-    }
-    void performFillIn(const uint8_t* rawRGB, const float* rawDepth, bool frameToFrameRGB, bool lost) {
-        mmf::check(mmf_model_perform_fill_in(m_, rawRGB, rawDepth, frameToFrameRGB, lost), "mmf_model_perform_fill_in");
-    }
-    bool requiresFillIn(float ratio = 0.75f) {
+    bool requiresFillIn(float ratio = 0.75f) {  // MultiMotionFusion::requiresFillIn(model, ratio)
+        if (!fill_in_) return false;
         int r = 0;
         mmf::check(mmf_model_requires_fill_in(m_, ratio, &r), "mmf_model_requires_fill_in");
         return r != 0;
     }
+
+    // ----- getters (Model.h:222-312)
+    float getConfidenceThreshold() const { return mmf_model_confidence_threshold(m_); }
+    void setConfidenceThreshold(float confThresh) { mmf::check(mmf_model_set_confidence_threshold(m_, confThresh), "setConfidenceThreshold"); }
+    void setMaxDepth(float d) { mmf::check(mmf_model_set_max_depth(m_, d), "setMaxDepth"); }
+    unsigned int getID() const { return (unsigned)mmf_model_id(m_); }
     unsigned lastCount() const {
         unsigned n = 0;
         mmf::check(mmf_model_count(m_, &n), "mmf_model_count");
         return n;
     }
-    void overridePose(const float pose[16]) { mmf::check(mmf_model_set_pose(m_, pose), "mmf_model_set_pose"); }
+    void overridePose(const float pose[16]) {  // pose = lastPose = p (Model.h:301-304)
+        mmf::check(mmf_model_set_pose(m_, pose), "mmf_model_set_pose");
+        std::memcpy(lastPose_, pose, sizeof(lastPose_));
+    }
     void getPose(float pose[16]) const { mmf::check(mmf_model_get_pose(m_, pose), "mmf_model_get_pose"); }
+    const float* getLastPose() const { return lastPose_; }
     std::vector<surfel_t> downloadMap() const {  // Model.cpp:1353-1384
         std::vector<surfel_t> out(lastCount());
         unsigned got = 0;
@@ -87,7 +190,13 @@ class Model {
         out.resize(got);
         return out;
     }
-    // getVertexConfProjection() etc.: device image behind the reference's GPUTexture getter
+    RGBDOdometry::Stats getFrameOdometryStats() const {
+        RGBDOdometry::Stats s;
+        mmf::check(mmf_odom_get_stats(o_, &s), "mmf_odom_get_stats");
+        return s;
+    }
+    // the GPUTexture getters of Model / ModelProjection (Model.h:232-244, ModelProjection.h:52-77) by name:
+    // index vertConf colorTime normRad | image vertexConf normalRadius time | depth | fillVertex fillNormal fillImage
     const void* texture(const char* name, size_t* bytes = nullptr) const {
         void* p = nullptr;
         size_t b = 0;
@@ -95,65 +204,210 @@ class Model {
         if (bytes) *bytes = b;
         return p;
     }
+    size_t getSplatVertexConfTexBytes() const {
+        size_t b = 0;
+        (void)texture("vertexConf", &b);
+        return b;
+    }
+    GPUTexture getRGBProjection() const { return GPUTexture(texture("image"), width_, height_, GPUTexture::RGBA8, "image"); }
+    GPUTexture getVertexConfProjection() const { return GPUTexture(texture("vertexConf"), width_, height_, GPUTexture::RGBA32F, "vertexConf"); }
+    GPUTexture getNormalProjection() const { return GPUTexture(texture("normalRadius"), width_, height_, GPUTexture::RGBA32F, "normalRadius"); }
+    GPUTexture getTimeProjection() const { return GPUTexture(texture("time"), width_, height_, GPUTexture::R16UI, "time"); }
+    GPUTexture getFillInImageTexture() const { return GPUTexture(texture("fillImage"), width_, height_, GPUTexture::RGBA8, "fillImage"); }
+    GPUTexture getFillInVertexTexture() const { return GPUTexture(texture("fillVertex"), width_, height_, GPUTexture::RGBA32F, "fillVertex"); }
+    GPUTexture getFillInNormalTexture() const { return GPUTexture(texture("fillNormal"), width_, height_, GPUTexture::RGBA32F, "fillNormal"); }
+    GPUTexture getSparseIndexTex() const { return GPUTexture(texture("index"), width_, height_, GPUTexture::R32UI, "index"); }
+    GPUTexture getSparseVertConfTex() const { return GPUTexture(texture("vertConf"), width_, height_, GPUTexture::RGBA32F, "vertConf"); }
+    GPUTexture getSparseColorTimeTex() const { return GPUTexture(texture("colorTime"), width_, height_, GPUTexture::RGBA32F, "colorTime"); }
+    GPUTexture getSparseNormalRadTex() const { return GPUTexture(texture("normRad"), width_, height_, GPUTexture::RGBA32F, "normRad"); }
     mmf_model* handle() const { return m_; }
+    mmf_odom* odometryHandle() const { return o_; }
 
    private:
+    static const float*& shared_depth() {
+        static const float* d = nullptr;
+        return d;
+    }
+    static void identity(float* m) {
+        for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? 1.f : 0.f;
+    }
     mmf_model* m_ = nullptr;
+    mmf_odom* o_ = nullptr;
     bool owned_ = false;
+    int width_ = 0, height_ = 0;
+    bool fill_in_ = false;
+    float lastPose_[16];
+    std::vector<int64_t> timestamp_ns_;
 };
+
+typedef std::shared_ptr<Model> ModelPointer;
+typedef std::list<ModelPointer> ModelList;
 
 class MultiMotionFusion {
    public:
     // MultiMotionFusion::MultiMotionFusion (MultiMotionFusion.cpp:21-97); unset options keep the
     // GUI defaults of GUI/MainController.cpp:333-345, 514-517
     MultiMotionFusion(mmf::Context& ctx, int width, int height, float cx, float cy, float fx, float fy,
-                      const mmf_fusion_config* cfg = nullptr) {
+                      const mmf_fusion_config* cfg = nullptr)
+        : width_(width), height_(height) {
         mmf::check(mmf_fusion_create(ctx.get(), width, height, cx, cy, fx, fy, cfg, &f_), "mmf_fusion_create");
+        mmf::check(mmf_fusion_get_config(f_, &cfg_), "mmf_fusion_get_config");
     }
-    ~MultiMotionFusion() { mmf_fusion_destroy(f_); }
+    virtual ~MultiMotionFusion() {
+        for (auto& kv : textures_) delete kv.second;
+        models_.clear();
+        mmf_fusion_destroy(f_);
+    }
     MultiMotionFusion(const MultiMotionFusion&) = delete;
     MultiMotionFusion& operator=(const MultiMotionFusion&) = delete;
+
+    void preallocateModels(unsigned count) { mmf::check(mmf_fusion_preallocate_models(f_, count), "mmf_fusion_preallocate_models"); }
 
     // bool processFrame(const FrameData&, const Eigen::Matrix4f* inPose = 0, float weightMultiplier = 1,
     //                   GroundTruthOdometryInterface* = nullptr, bool bootstrap = false)  (MultiMotionFusion.h:78-80).
     // Like the reference it prints "invalid image data" and returns false for a bad frame and
-    // returns false after a regular frame (MultiMotionFusion.cpp:209-212, 853).
+    // returns false after a regular frame (MultiMotionFusion.cpp:209-212, 853).  The frame is uploaded inside (:221, :261).
+    bool processFrame(const FrameData& frame, const float* inPose = nullptr, const float weightMultiplier = 1.f,
+                      void* /*GroundTruthOdometryInterface*/ = nullptr, const bool bootstrap = false) {
+        return finish(mmf_fusion_process_frame_host(f_, frame.rgb, frame.depth, frame.mask, frame.hasNewLabel, frame.timestamp, inPose,
+                                                    weightMultiplier, bootstrap),
+                      "mmf_fusion_process_frame_host");
+    }
     bool processFrame(const FrameDataDevice& frame, const float* inPose = nullptr, const float weightMultiplier = 1.f,
                       const bool bootstrap = false) {
-        const int rc = mmf_fusion_process_frame(f_, frame.rgb, frame.depth, frame.timestamp, inPose, weightMultiplier,
-                                                bootstrap);
-        if (rc == MMF_ERR_INVALID) {
-            std::fprintf(stderr, "%s\n", mmf_last_error());
-            return false;
-        }
-        mmf::check(rc, "mmf_fusion_process_frame");
-        return false;
+        if (!frame.mask)
+            return finish(mmf_fusion_process_frame(f_, frame.rgb, frame.depth, frame.timestamp, inPose, weightMultiplier, bootstrap),
+                          "mmf_fusion_process_frame");
+        mmf_segmentation seg;
+        std::memset(&seg, 0, sizeof(seg));
+        seg.mask = frame.mask, seg.has_new_label = frame.hasNewLabel;
+        mmf_frame fr;
+        std::memset(&fr, 0, sizeof(fr));
+        fr.rgb = frame.rgb, fr.depth = frame.depth, fr.timestamp = frame.timestamp;
+        fr.in_pose = inPose, fr.weight_multiplier = weightMultiplier, fr.bootstrap = bootstrap, fr.icp_refine = 1;
+        fr.segmentation = &seg;
+        return finish(mmf_fusion_process_frame_ex(f_, &fr), "mmf_fusion_process_frame_ex");
     }
     // the same frame step with odom_cfg.init == "kp" (MultiMotionFusion.cpp:312-384): trackTransform is
     // RigidRANSAC::Result::transformation of Model::getLastTrackTransform (row-major 4x4), icpRefine is
     // odom_cfg.icp_refine.  In the reference this is selected by the OdometryConfig passed to the constructor.
     bool processFrame(const FrameDataDevice& frame, const float trackTransform[16], const bool icpRefine,
                       const float weightMultiplier = 1.f) {
-        const int rc = mmf_fusion_process_frame_init(f_, frame.rgb, frame.depth, frame.timestamp, trackTransform, icpRefine,
-                                                     weightMultiplier);
-        if (rc == MMF_ERR_INVALID) {
-            std::fprintf(stderr, "%s\n", mmf_last_error());
-            return false;
-        }
-        mmf::check(rc, "mmf_fusion_process_frame_init");
-        return false;
+        return finish(mmf_fusion_process_frame_init(f_, frame.rgb, frame.depth, frame.timestamp, trackTransform, icpRefine, weightMultiplier),
+                      "mmf_fusion_process_frame_init");
     }
     // not in the reference: start the next frame's input-side work (filter, pyramids, gradients) on a second
     // stream while the current frame is still being fused; pass the same frame to processFrame afterwards
     void prefetchFrame(const FrameDataDevice& next) {
         mmf::check(mmf_fusion_prefetch_frame(f_, next.rgb, next.depth), "mmf_fusion_prefetch_frame");
     }
-    void getCurrPose(float pose[16]) const { mmf::check(mmf_fusion_get_pose(f_, pose), "mmf_fusion_get_pose"); }
+
+    void predict() { mmf::check(mmf_fusion_predict(f_), "mmf_fusion_predict"); }  // MultiMotionFusion.h:86
+
+    // getIndexMap() (:92): the global model's projections (ModelProjection's getters live on Model here)
+    Model& getIndexMap() { return *getBackgroundModel(); }
+    ModelPointer getBackgroundModel() { return getModels().front(); }
+    ModelList& getModels() {  // :107 -- rebuilt from the native list when it changed
+        const int n = mmf_fusion_num_models(f_);
+        bool same = (int)models_.size() == n;
+        int i = 0;
+        for (auto it = models_.begin(); same && it != models_.end(); ++it, ++i) same = (*it)->handle() == mmf_fusion_model_at(f_, i);
+        if (!same) {
+            models_.clear();
+            for (int k = 0; k < n; ++k)
+                models_.push_back(std::make_shared<Model>(mmf_fusion_model_at(f_, k), mmf_fusion_odometry_at(f_, k), width_, height_,
+                                                          k == 0 && cfg_.fill_in));
+        }
+        return models_;
+    }
+    // getTextures() (:124): the raw input images of the current frame
+    std::map<std::string, GPUTexture*>& getTextures() {
+        struct Spec { const std::string* name; GPUTexture::Format fmt; };
+        const Spec specs[] = {{&GPUTexture::RGB, GPUTexture::RGB8}, {&GPUTexture::DEPTH_METRIC, GPUTexture::R32F},
+                              {&GPUTexture::DEPTH_METRIC_FILTERED, GPUTexture::R32F}, {&GPUTexture::MASK, GPUTexture::R8UI}};
+        for (const Spec& s : specs) {
+            const void* p = nullptr;
+            size_t b = 0;
+            mmf::check(mmf_fusion_texture(f_, s.name->c_str(), &p, &b), "mmf_fusion_texture");
+            auto it = textures_.find(*s.name);
+            if (it == textures_.end())
+                textures_[*s.name] = new GPUTexture(p, width_, height_, s.fmt, *s.name);
+            else
+                it->second->rebind(p);
+        }
+        return textures_;
+    }
+    // getModelToModel() (:136): the front-end only reads lastICPError / lastICPCount of it for its plots
+    // (GUI/MainController.cpp:627-640); here they are the global model's frame-to-model statistics
+    RGBDOdometry::Stats getModelToModel() {
+        RGBDOdometry::Stats s;
+        mmf::check(mmf_odom_get_stats(mmf_fusion_odometry(f_), &s), "mmf_odom_get_stats");
+        return s;
+    }
+    float getConfidenceThreshold() { return mmf_model_confidence_threshold(mmf_fusion_model(f_)); }
+
+    // ----- the setters of GUI/MainController.cpp:641-670
+    void setRgbOnly(const bool& v) { mmf::check(mmf_fusion_set_rgb_only(f_, v), "setRgbOnly"); }
+    void setIcpWeight(const float& v) { mmf::check(mmf_fusion_set_icp_weight(f_, v), "setIcpWeight"); }
+    void setOutlierCoefficient(const float& v) { mmf::check(mmf_fusion_set_outlier_coefficient(f_, v), "setOutlierCoefficient"); }
+    void setPyramid(const bool& v) { mmf::check(mmf_fusion_set_pyramid(f_, v), "setPyramid"); }
+    void setFastOdom(const bool& v) { mmf::check(mmf_fusion_set_fast_odom(f_, v), "setFastOdom"); }
+    void setSo3(const bool& v) { mmf::check(mmf_fusion_set_so3(f_, v), "setSo3"); }
+    void setFrameToFrameRGB(const bool& v) { mmf::check(mmf_fusion_set_frame_to_frame_rgb(f_, v), "setFrameToFrameRGB"); }
+    void setConfidenceThreshold(const float& v) { mmf::check(mmf_fusion_set_confidence_threshold(f_, v), "setConfidenceThreshold"); }
+    void setDepthCutoff(const float& v) { mmf::check(mmf_fusion_set_depth_cutoff(f_, v), "setDepthCutoff"); }
+    void setEnableMultipleModels(bool v) { mmf::check(mmf_fusion_set_enable_multiple_models(f_, v), "setEnableMultipleModels"); }
+    void setTick(const int& v) { mmf::check(mmf_fusion_set_tick(f_, v), "setTick"); }
+    void scheduleDeactivation(const ModelPointer& m) { mmf::check(mmf_fusion_schedule_deactivation(f_, (int)m->getID()), "scheduleDeactivation"); }
+    // settings of subsystems that stay in the reference's front-end (segmentation / CRF, spawning policy, redetection,
+    // ferns): recorded, not interpreted here
+    void setFernThresh(const float& v) { other_["fernThresh"] = v; }
+    void setModelSpawnOffset(const unsigned& v) { other_["modelSpawnOffset"] = (float)v; }
+    void setModelDeactivateCount(const unsigned& v) { other_["modelDeactivateCount"] = (float)v; }
+    void setCrfPairwiseSigmaRGB(const float& v) { other_["crfPairwiseSigmaRGB"] = v; }
+    void setCrfPairwiseSigmaPosition(const float& v) { other_["crfPairwiseSigmaPosition"] = v; }
+    void setCrfPairwiseSigmaDepth(const float& v) { other_["crfPairwiseSigmaDepth"] = v; }
+    void setCrfPairwiseWeightAppearance(const float& v) { other_["crfPairwiseWeightAppearance"] = v; }
+    void setCrfPairwiseWeightSmoothness(const float& v) { other_["crfPairwiseWeightSmoothness"] = v; }
+    void setCrfThresholdNew(const float& v) { other_["crfThresholdNew"] = v; }
+    void setCrfUnaryWeightError(const float& v) { other_["crfUnaryWeightError"] = v; }
+    void setCrfIteration(const unsigned& v) { other_["crfIteration"] = (float)v; }
+    void setCrfUnaryKError(const float& v) { other_["crfUnaryKError"] = v; }
+    void setNewModelMinRelativeSize(const float& v) { other_["newModelMinRelativeSize"] = v; }
+    void setNewModelMaxRelativeSize(const float& v) { other_["newModelMaxRelativeSize"] = v; }
+    void setEnableRedetection(bool v) { other_["enableRedetection"] = v; }
+    void setSetInhibit(bool v) { other_["inhibitModels"] = v; }
+    void setEnableSmartModelDelete(bool v) { other_["enableSmartModelDelete"] = v; }
+    const std::map<std::string, float>& frontEndSettings() const { return other_; }
+
+    // ----- getters (:186-216)
+    const bool& getLost() { return lost_; }  // relocalisation stays in the reference: never lost here
     int getTick() const { return mmf_fusion_tick(f_); }
-    Model getBackgroundModel() { return Model(mmf_fusion_model(f_)); }
+    int getTimeDelta() { return refresh().time_delta; }
+    float getMaxDepthProcessed() { return refresh().max_depth_processed; }
+    void getCurrPose(float pose[16]) const { mmf::check(mmf_fusion_get_pose(f_, pose), "mmf_fusion_get_pose"); }
+    void exportPoses(const std::string& exportDir = "") { mmf::check(mmf_fusion_export_poses(f_, exportDir.c_str()), "mmf_fusion_export_poses"); }
     mmf_odom* getFrameOdometryHandle() { return mmf_fusion_odometry(f_); }
     mmf_fusion* handle() const { return f_; }
 
    private:
+    bool finish(int rc, const char* what) {
+        if (rc == MMF_ERR_INVALID) {
+            std::fprintf(stderr, "%s\n", mmf_last_error());
+            return false;
+        }
+        mmf::check(rc, what);
+        return false;
+    }
+    const mmf_fusion_config& refresh() {
+        mmf::check(mmf_fusion_get_config(f_, &cfg_), "mmf_fusion_get_config");
+        return cfg_;
+    }
     mmf_fusion* f_ = nullptr;
+    mmf_fusion_config cfg_;
+    int width_, height_;
+    ModelList models_;
+    std::map<std::string, GPUTexture*> textures_;
+    std::map<std::string, float> other_;
+    bool lost_ = false;
 };

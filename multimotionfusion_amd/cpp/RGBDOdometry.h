@@ -52,6 +52,7 @@ class Context {
 class RGBDOdometry {
    public:
     static const int NUM_PYRS = MMF_NUM_PYRS;  // RGBDOdometry.h:72
+    typedef mmf_odom_stats Stats;  // the public result members (RGBDOdometry.h:62-67) as a value
 
     RGBDOdometry(mmf::Context& ctx, int width, int height, float cx, float cy, float fx, float fy,
                  unsigned char maskID = 0, float distThresh = 0.10f,

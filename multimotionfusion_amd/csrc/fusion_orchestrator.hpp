@@ -211,17 +211,26 @@ extern "C" int mmf_fusion_create(mmf_ctx* c, int width, int height, float cx, fl
     MMF_HIP_TRY(hipMalloc(&f->mask, npix));
     MMF_HIP_TRY(hipMemsetAsync(f->mask, 0, npix, c->stream));
     f->mask_is_zero = true;
-    for (int i = 0; i < f->cfg.preallocated_models; ++i) {  // preallocateModels (:125-131)
-        FusionModel* fm = nullptr;
-        rc = fusion_model_create(f, fusion_next_model_id(f, true), f->cfg.conf_object_init, 0, true, &fm);
-        if (rc != MMF_OK) {
-            const std::string keep = g_last_error;
-            mmf_fusion_destroy(f);
-            return fail(rc, keep);
-        }
-        f->preallocated.push_back(fm);
+    rc = mmf_fusion_preallocate_models(f, (unsigned)(f->cfg.preallocated_models > 0 ? f->cfg.preallocated_models : 0));
+    if (rc != MMF_OK) {
+        const std::string keep = g_last_error;
+        mmf_fusion_destroy(f);
+        return fail(rc, keep);
     }
     *out = f;
+    return MMF_OK;
+}
+
+// preallocateModels(count) (MultiMotionFusion.cpp:125-131): object models created ahead of their first use
+extern "C" int mmf_fusion_preallocate_models(mmf_fusion* f, unsigned count) {
+    MMF_REQUIRE(f != nullptr, "mmf_fusion_preallocate_models: null fusion object");
+    MMF_HIP_TRY(hipSetDevice(f->ctx->device));
+    for (unsigned i = 0; i < count; ++i) {
+        FusionModel* fm = nullptr;
+        int rc = fusion_model_create(f, fusion_next_model_id(f, true), f->cfg.conf_object_init, 0, true, &fm);
+        if (rc) return rc;
+        f->preallocated.push_back(fm);
+    }
     return MMF_OK;
 }
 

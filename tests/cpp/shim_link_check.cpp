@@ -33,7 +33,8 @@ int main(int argc, char** argv) {
     const bool r = mmf.processFrame(bad);
     float pose[16];
     mmf.getCurrPose(pose);
-    Model bg = mmf.getBackgroundModel();
+    ModelPointer bgp = mmf.getBackgroundModel();
+    Model& bg = *bgp;
     std::printf("processFrame(bad)=%d tick=%d surfels=%u pose00=%g icpCount=%g\n", (int)r, mmf.getTick(), bg.lastCount(),
                 pose[0], odom.lastICPCount);
     // SuperPoint with all-zero weights: every heat value is 1/65 >= 0.015, so the greedy suppression leaves a
