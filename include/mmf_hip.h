@@ -445,6 +445,9 @@ int mmf_fusion_set_segmentation_callback(mmf_fusion *f, mmf_segmentation_fn fn, 
 int mmf_fusion_export_poses(mmf_fusion *f, const char *export_dir);
 /* Model::getPoseLog() of the index-th active model: ts[i], p7[7 i ..] = x y z qx qy qz qw */
 int mmf_fusion_pose_log(mmf_fusion *f, int index, long long *ts, float *p7, int max_entries, int *n_out);
+/* test hook: the device build's mmf_expf and the packed exponential of the two-pixel bilateral filter on n arguments
+ * (the packed one is defined for x <= 0 or NaN only) */
+int mmf_debug_expf(mmf_ctx *ctx, const float *x_dev, int n, float *out_mmf_dev, float *out_packed_dev);
 /* Model::computeFusionWeight (Model.cpp:876-891) for pose / lastPose (host 4x4), exported for tests */
 int mmf_compute_fusion_weight(const float pose[16], const float last_pose[16], float multiplier, float *out);
 

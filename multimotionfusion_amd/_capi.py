@@ -191,6 +191,7 @@ SIGNATURES = {
     "mmf_fusion_pose_log": (_i, [_vp, _i, C.POINTER(C.c_longlong), _fp, _i, _ip]),
     "mmf_compute_fusion_weight": (_i, [_fp, _fp, _f, _fp]),
     "mmf_fusion_preallocate_models": (_i, [_vp, C.c_uint]),
+    "mmf_debug_expf": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mmf_fusion_set_shard": (_i, [_vp, _i, _i]),
     "mmf_fusion_owns_model": (_i, [_vp, _i]),
     "mmf_fusion_set_model_pose": (_i, [_vp, _i, _fp]),

@@ -2280,6 +2280,30 @@ extern "C" int mmf_slic_upsample_u8(mmf_ctx* c, const int* labels, int width, in
     return MMF_OK;
 }
 
+// the two exponentials of the surfel path as the gfx950 build evaluates them -- mmf_expf (include/mmf_math.h: surfel
+// confidence, SuperPoint softmax, scalar bilateral filter) and the packed expf_nonpositive2 of the two-pixel bilateral
+// filter -- on caller-supplied arguments, so that a test can hold BOTH against a float64 exp instead of against the
+// oracle that shares their source
+__global__ void debug_expf_kernel(const float* __restrict__ x, int n, float* __restrict__ out_mmf, float* __restrict__ out_pk) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= n) return;
+    const float a = x[i], b = i + 1 < n ? x[i + 1] : 0.f;
+    out_mmf[i] = mmf_expf(a);
+    if (i + 1 < n) out_mmf[i + 1] = mmf_expf(b);
+    const v2fs arg[1] = {v2fs{a, b}};
+    v2fs e[1];
+    expf_nonpositive2<1>(arg, e);
+    out_pk[i] = e[0].x;
+    if (i + 1 < n) out_pk[i + 1] = e[0].y;
+}
+extern "C" int mmf_debug_expf(mmf_ctx* c, const float* x_dev, int n, float* out_mmf_dev, float* out_packed_dev) {
+    MMF_REQUIRE(c && x_dev && out_mmf_dev && out_packed_dev && n > 0, "mmf_debug_expf: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(debug_expf_kernel, grid1d(((size_t)n + 1) / 2), dim3(256), 0, c->stream, x_dev, n, out_mmf_dev, out_packed_dev);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
 #ifdef MMF_STAMPS
 // diagnostic builds only (tools/rgb_step_probe.py): phase-stamp buffer of the instrumented kernels
 extern "C" int mmf_debug_set_stamps(void* dev_buf) {

@@ -345,15 +345,18 @@ __device__ inline void so3_finish(OdomState* st, const float* tot, const LevelIn
 // The reference evaluates this with a general 4x4 inverse and two dense 3x3 products in double,
 // then casts to float.  This runs on ONE lane on the critical path of every Gauss-Newton
 // iteration (double-precision issue is ~8 cycles per op there), so the same quantities are
-// formed from the structure of the operands: resultRt is a product of rigid transforms
-// (inverse = [R^T | -R^T t], exact to ~1e-16) and K = [fx 0 cx; 0 fy cy; 0 0 1].  The results
-// differ from the literal formulas by O(1e-16) relative before the cast to float -- far inside
-// the parity tolerance, and ~8x fewer double operations.
+// formed from the structure of the operands: resultRt = [A t; 0 1], so its inverse is
+// [A^-1 | -A^-1 t] with the exact 3x3 inverse of A (NOT A^T: with SO3 seeding A is a product of
+// float-cast rotations and orthogonal only to ~1e-7, which the reference's general inverse does
+// not assume either), and K = [fx 0 cx; 0 fy cy; 0 0 1].  The results differ from the literal
+// 4x4 formulas by O(1e-16) relative before the cast to float, with ~5x fewer double operations.
 __device__ inline void rgb_prepare(const double* resultRt, const LevelIntr& in, float* krkinv, float* kt) {
     const double fx = in.fx, fy = in.fy, cx = in.cx, cy = in.cy;
     // Rt = resultRt^-1
-    const double R[9] = {resultRt[0], resultRt[4], resultRt[8], resultRt[1], resultRt[5],
-                         resultRt[9], resultRt[2], resultRt[6], resultRt[10]};
+    const double A3[9] = {resultRt[0], resultRt[1], resultRt[2], resultRt[4], resultRt[5],
+                          resultRt[6], resultRt[8], resultRt[9], resultRt[10]};
+    double R[9];
+    inverse3d(A3, R);
     const double tx = resultRt[3], ty = resultRt[7], tz = resultRt[11];
     const double t3[3] = {-(R[0] * tx + R[1] * ty + R[2] * tz), -(R[3] * tx + R[4] * ty + R[5] * tz),
                           -(R[6] * tx + R[7] * ty + R[8] * tz)};

@@ -29,6 +29,14 @@
 #include "mmf_oracle.h"
 #include "../include/mmf_math.h" /* shared bit-exact expf (see its header) */
 
+/* -DORC_LIBM_EXP builds the checker with the C library's expf instead: the independent measure of how much the
+ * shared definition matters (tests/test_oracle_surfel.py::test_libm_exp_variant) */
+#ifdef ORC_LIBM_EXP
+#define ORC_EXPF expf
+#else
+#define ORC_EXPF mmf_expf
+#endif
+
 typedef struct {
     float x, y, z;
 } v3;
@@ -111,7 +119,7 @@ static inline float confidence(float x, float y, float cx, float cy, float weigh
     const float maxRadDist = 400, twoSigmaSquared = 0.72f;
     const float px = x - cx, py = y - cy;
     const float radialDist = sqrtf(px * px + py * py) / maxRadDist;
-    return mmf_expf((-(radialDist * radialDist) / twoSigmaSquared)) * weighting;
+    return ORC_EXPF((-(radialDist * radialDist) / twoSigmaSquared)) * weighting;
 }
 /* 24-bit depth key (A2) */
 static inline uint32_t depth24(float zw) {
@@ -163,7 +171,7 @@ void orc_bilateral_filter(const float *depth, int cols, int rows, float maxD, fl
                     const float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) +
                                          ((float)y - (float)cy) * ((float)y - (float)cy);
                     const float color2 = (value - tmp) * (value - tmp);
-                    const float weight = mmf_expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+                    const float weight = ORC_EXPF(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
                     sum1 += tmp * weight;
                     sum2 += weight;
                 }

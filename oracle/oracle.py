@@ -13,8 +13,9 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_DIR, "liboracle.so")
 
 
-def build(force=False, march=None, out=None):
-    """make the oracle library (gcc).  `march`/`out` let bench.py build a -march=native copy."""
+def build(force=False, march=None, out=None, extra=None):
+    """make the oracle library (gcc).  `march`/`out` let bench.py build a -march=native copy; `extra` adds compiler
+    flags (-DORC_LIBM_EXP: the C library's expf instead of the shared mmf_expf)."""
     target = out or "liboracle.so"
     path = os.path.join(_DIR, target)
     src_m = max(os.path.getmtime(os.path.join(_DIR, f))
@@ -25,6 +26,8 @@ def build(force=False, march=None, out=None):
     cmd = ["make", "-C", _DIR, f"OUT={target}", "-B"]
     if march:
         cmd.append(f"MARCH={march}")
+    if extra:
+        cmd.append(f"EXTRA={extra}")
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
     return path
 

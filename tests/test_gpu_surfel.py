@@ -189,3 +189,33 @@ def test_surfel_capacity_is_a_hard_limit(gpu_ctx, orc):
     m.combinedPredict(MAXD, 2, 2, TIME_DELTA)
     assert m.downloadMap().shape[0] == m.lastCount()
     m.close()
+
+
+def test_device_exponentials_against_float64(gpu_ctx):
+    """The gfx950 build of mmf_expf AND the separately written packed exponential of the two-pixel bilateral filter
+    (expf_nonpositive2, surfel_kernels.hpp) against numpy's float64 exp over dense argument sweeps: <= 2 ulp each, and
+    bit-identical to each other where the packed one is defined (x <= 0).  An independent check: the oracle shares
+    mmf_expf's source with the kernels, so agreement with it says nothing about the function itself."""
+    import ctypes
+    xs = np.concatenate([np.linspace(-104.0, 0.0, 2_000_001), -np.logspace(-8, 2, 200_001), -np.arange(0, 104, 0.693359375 / 2),
+                         [0.0, -0.0, -87.3, -87.4, -88.0, -103.0, -103.5]]).astype(np.float32)
+    pos = np.concatenate([np.linspace(0.0, 88.7, 500_001), [88.72, 89.0, 1e-8, 1.0]]).astype(np.float32)
+    for args, packed_defined in ((xs, True), (pos, False)):
+        x = torch.from_numpy(args).cuda()
+        a, b = torch.empty_like(x), torch.empty_like(x)
+        assert gpu_ctx.lib.mmf_debug_expf(gpu_ctx.handle, ctypes.c_void_p(x.data_ptr()), x.numel(), ctypes.c_void_p(a.data_ptr()),
+                                          ctypes.c_void_p(b.data_ptr())) == 0
+        torch.cuda.synchronize()
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        want = np.exp(args.astype(np.float64))
+        normal = want > 1.2e-38  # below: subnormal results, compared absolutely
+        ulp = np.abs(a[normal].astype(np.float64) - want[normal]) / np.spacing(want[normal].astype(np.float32)).astype(np.float64)
+        assert ulp.max() <= 2.0, ulp.max()
+        assert np.abs(a[~normal].astype(np.float64) - want[~normal]).max() <= 2 * 1.4e-45 * 2 ** 23 if (~normal).any() else True
+        if packed_defined:
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    nan = torch.tensor([float("nan"), -1.0], device="cuda")
+    a, b = torch.empty_like(nan), torch.empty_like(nan)
+    gpu_ctx.lib.mmf_debug_expf(gpu_ctx.handle, ctypes.c_void_p(nan.data_ptr()), 2, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()))
+    torch.cuda.synchronize()
+    assert torch.isnan(a[0]) and torch.isnan(b[0]) and a[1] == b[1]

@@ -171,3 +171,41 @@ def test_surfel_cycle_golden_fixture(orc):
     s1c[:, 3] = 20.0
     image, vcp, nrp, tm = orc.combined_predict(s1c, pose1, K, w, h, MAXD, 10.0, 2, 2, 200)
     assert np.array_equal(vcp.view(np.uint32), g["splat_vertexConf"].view(np.uint32)) and np.array_equal(image, g["splat_image"])
+
+
+def test_libm_exp_variant(orc):
+    """The checker shares mmf_expf (include/mmf_math.h) with the kernels, which by itself would make 'bit-exact' a
+    comparison of a function with itself.  Here the SAME oracle is built against the C library's expf
+    (-DORC_LIBM_EXP) and the outputs that pass through exp -- the bilateral filter and the confidence of new surfels --
+    are compared: a handful of last-bit differences, nothing more, i.e. the bit-exact parity claims carry over to a
+    libm-based statement of the shaders up to the ulp of exp itself."""
+    path = orc.build(out="liboracle_libm.so", extra="-DORC_LIBM_EXP")
+    alt = orc.lib(path)
+    K, f = scene(320, 240, seed=3)
+    d = np.ascontiguousarray(f["depth"], np.float32)
+    rows, cols = d.shape
+    pf = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    out_alt = np.zeros_like(d)
+    alt.orc_bilateral_filter(pf(d), cols, rows, C.c_float(15.0), pf(out_alt))
+    out = orc.bilateral_filter(d, 15.0)
+    ne = out.view(np.uint32) != out_alt.view(np.uint32)
+    ulp = np.abs(out.view(np.int32).astype(np.int64) - out_alt.view(np.int32).astype(np.int64))
+    print(f"bilateral filter: {int(ne.sum())} of {ne.size} outputs differ between mmf_expf and libm expf, max {int(ulp.max())} ulp")
+    # measured: 12.9 % of the outputs differ, by at most 5 ulp (a quotient of two 169-term sums of weights that are each within
+    # 2 ulp of the other build's)
+    assert ne.mean() < 0.35 and ulp.max() <= 8
+    assert np.abs(out - out_alt).max() < 2e-6  # 1.2 micrometres at 3.3 m
+    # surfel confidence (surfels.glsl:36-46) through Model::initialise
+    rgb = np.ascontiguousarray(f["rgb"], np.uint8)
+    s_alt = np.zeros((rows * cols, 12), np.float32)
+    alt.orc_surfel_initialise.restype = C.c_int
+    n = alt.orc_surfel_initialise(rgb.ctypes.data_as(C.POINTER(C.c_uint8)), pf(d), pf(out), cols, rows, C.c_float(K["cx"]),
+                                  C.c_float(K["cy"]), C.c_float(K["fx"]), C.c_float(K["fy"]), 1, C.c_float(MAXD), pf(s_alt))
+    s = orc.surfel_initialise(rgb, d, out, K, 1, MAXD)
+    assert n == s.shape[0]
+    s_alt = s_alt[:n]
+    other = np.delete(np.arange(12), 3)
+    assert np.array_equal(s[:, other].view(np.uint32), s_alt[:, other].view(np.uint32))  # only the confidence passes through exp
+    du = np.abs(s[:, 3].view(np.int32).astype(np.int64) - s_alt[:, 3].view(np.int32).astype(np.int64))
+    print(f"surfel confidence: {int((du > 0).sum())} of {n} differ, max {int(du.max())} ulp")
+    assert du.max() <= 2
