@@ -639,8 +639,11 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 }
             }
             // the sensor-side image ring (this frame's / last frame's intensity pyramid, RGBDOdometry.cpp:469-473) lives in
-            // the global odometry: when its owner is another rank, the swap its tracking would have done happens here
-            if (g.so3 && any_tracked && !global_tracked)
+            // the global odometry: when its owner is another rank, the swap its tracking does there happens here, whether
+            // or not this rank tracked anything (every rank's ring must advance with the global model's)
+            (void)any_tracked;
+            const bool global_tracks_somewhere = !(have_init && !fr->icp_refine);
+            if (g.so3 && global_tracks_somewhere && !global_tracked)
                 for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(global->odom->last_next_image[i], global->odom->next_image[i]);
             f->t_tracking_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_track).count();
             if (fr->bootstrap) {  // :397-400

@@ -1,0 +1,152 @@
+"""-m gpu: config 5's frame size (BASELINE.json configs[4]: 1280x960) -- one ICP step, one surfel cycle and the
+capacity limit against the oracle, and properties of a processFrame sequence with moving objects and ground-truth ids
+that hold at any size (the oracle orchestration takes ~10 s per frame here, so the sequence is checked through
+invariants: tracking accuracy against the known trajectory, repeatability, surfel bookkeeping)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ANGLE_THRESH, DIST_THRESH, assert_bit_equal, se3_sum_tolerance
+from multimotionfusion_amd import synth
+
+pytestmark = pytest.mark.gpu
+W, H = 1280, 960
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_icp_step_1280x960(gpu_ctx, orc):
+    from multimotionfusion_amd.cudafuncs import CameraModel, createNMap, createVMap, icpStep, tranformMaps
+    K = synth.intrinsics(W, H)
+    poses = synth.trajectory(2, seed=3)
+    fp, fc = synth.render(poses[0], W, H, seed=0), synth.render(poses[1], W, H, seed=1)
+    intr = CameraModel(K["fx"], K["fy"], K["cx"], K["cy"])
+    maps = []
+    for f in (fp, fc):
+        v = torch.empty((3 * H, W), dtype=torch.float32, device="cuda")
+        n = torch.empty_like(v)
+        createVMap(gpu_ctx, intr, dev(f["depth"]), v, 15.0)
+        createNMap(gpu_ctx, v, n)
+        maps.append((v, n))
+    (vp, npv), (vc, nc) = maps
+    Rp, tp = poses[0][:3, :3].astype(np.float32), poses[0][:3, 3].astype(np.float32)
+    vg, ng = torch.empty_like(vp), torch.empty_like(npv)
+    tranformMaps(gpu_ctx, vp, npv, Rp, tp, vg, ng)
+    Rpi = np.linalg.inv(Rp.astype(np.float64)).astype(np.float32)
+    err = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+    A, b, res = icpStep(gpu_ctx, Rp, tp, vc, nc, Rpi, tp, intr, vg, ng, DIST_THRESH, ANGLE_THRESH, err)
+    out, err_o = orc.icp_step(Rp, tp, vc.cpu().numpy(), nc.cpu().numpy(), Rpi, tp, K["fx"], K["fy"], K["cx"], K["cy"],
+                              vg.cpu().numpy(), ng.cpu().numpy(), DIST_THRESH, ANGLE_THRESH, want_err=True)
+    Ao, bo, ro = orc.unpack_se3(out)
+    assert res[1] == ro[1] > 0.4 * W * H  # inlier count: exact
+    tol = se3_sum_tolerance(out)
+    k = 0
+    for i in range(6):
+        for j in range(i, 7):
+            got = A[i, j] if j < 6 else b[i]
+            want = Ao[i, j] if j < 6 else bo[i]
+            assert abs(float(got) - float(want)) <= tol[k] + 1e-6 * abs(float(want)), (i, j, got, want)
+            k += 1
+    assert_bit_equal(err.cpu().numpy(), err_o, "ICP error map")
+
+
+def test_surfel_cycle_and_capacity_1280x960(gpu_ctx, orc):
+    """A frame has 1 228 800 pixels, more than Model::MAX_VERTICES = 1024^2: initialise is capped (the first 1 048 576 of
+    the draw order), then one predictIndices / fuse / predictIndices / clean / combinedPredict cycle, all bit-exact."""
+    from multimotionfusion_amd.model import MAX_VERTICES, Model, filterDepth
+    K = synth.intrinsics(W, H)
+    poses = synth.trajectory(2, seed=5)
+    f0, f1 = synth.render(poses[0], W, H, seed=0, dropout=0.0), synth.render(poses[1], W, H, seed=1)
+    m = Model(gpu_ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], 0, 10.0)
+    mask = np.zeros((H, W), np.uint8)
+    d_mask = dev(mask)
+    fil0 = orc.bilateral_filter(f0["depth"], 15.0)
+    d0 = dev(f0["depth"])
+    d_fil0 = filterDepth(gpu_ctx, d0, 15.0)
+    assert_bit_equal(d_fil0.cpu().numpy(), fil0, "bilateral filter")
+    m.overridePose(poses[0])
+    m.initialise(dev(f0["rgb"]), d0, d_fil0, 1, 20.0)
+    s = orc.surfel_initialise(f0["rgb"], f0["depth"], fil0, K, 1, 20.0)
+    assert s.shape[0] > MAX_VERTICES and m.lastCount() == MAX_VERTICES
+    s = s[:MAX_VERTICES]
+    assert_bit_equal(m.downloadMap(), s, "initialise, capped")
+    pose = poses[1].astype(np.float32)
+    fil1 = orc.bilateral_filter(f1["depth"], 15.0)
+    d1 = dev(f1["depth"])
+    d_fil1 = filterDepth(gpu_ctx, d1, 15.0)
+    m.overridePose(pose)
+    m.predictIndices(2, 20.0, 200)
+    index, vc, ct, nr = orc.predict_indices(s, pose, K, W, H, 20.0, 2, 200)
+    assert_bit_equal(m.texture("index").cpu().numpy().view(np.uint32), index, "index map")
+    m.fuse(2, dev(f1["rgb"]), d_mask, d1, d_fil1, 20.0, 1.0)
+    s_upd, new = orc.fuse(s, f1["rgb"], f1["depth"], fil1, mask, index, vc, nr, pose, K, 2, 1.0, 0, 20.0)
+    assert_bit_equal(m.downloadMap(), s_upd, "fused surfels")
+    m.predictIndices(2, 20.0, 200)
+    index, vc, ct, nr = orc.predict_indices(s_upd, pose, K, W, H, 20.0, 2, 200)
+    m.clean(2, 200, 20.0, d_fil1, d_mask, 3.0)
+    s2 = orc.clean(s_upd, new, pose, K, W, H, 2, 200, 10.0, 3.0, 0, index, vc, ct, fil1, mask)
+    s2 = s2[:MAX_VERTICES]
+    assert m.lastCount() == s2.shape[0]
+    assert_bit_equal(m.downloadMap(), s2, "cleaned surfels")
+    m.combinedPredict(20.0, 2, 2, 200)
+    image, vcp, nrp, tm = orc.combined_predict(s2, pose, K, W, H, 20.0, 10.0, 2, 2, 200)
+    assert_bit_equal(m.texture("vertexConf").cpu().numpy(), vcp, "splat vertexConf")
+    assert_bit_equal(m.texture("image").cpu().numpy(), image, "splat image")
+    m.close()
+
+
+def test_process_frame_objects_1280x960(gpu_ctx):
+    """Three frames + of config 5's workload on one GPU: the static scene and two moving objects with a ground-truth id
+    image, every model on its own stream.  Properties: the camera pose follows the known trajectory, the object models
+    exist with the right ids / thresholds and hold surfels of their objects only, the run repeats bit for bit (the
+    per-model streams do not race), and a sharded run (this process owning only model 1) gives that model the very
+    same poses and surfels."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    n = 5
+    K = synth.intrinsics(W, H)
+    poses = synth.trajectory(n, seed=1)
+    objs = synth.make_objects(8, seed=2)
+    traj = synth.object_trajectories(objs, n, seed=2)
+    frames = [synth.render(p, W, H, seed=i, objects=objs, object_poses=[t[i] for t in traj]) for i, p in enumerate(poses)]
+    rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+    mask = [dev(np.where(f["ids"] < 3, f["ids"], 0).astype(np.uint8)) for f in frames]
+
+    def run(shard=None):
+        g = MultiMotionFusion(gpu_ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1, preallocated_models=2)
+        if shard is not None:
+            g.setShard(*shard)
+        out = []
+        for i in range(n):
+            g.processFrame(rgb[i], depth[i], timestamp=i, mask=mask[i], hasNewLabel=1 <= i <= 2)
+            out.append([m.getPose() for m in g.getModels()])
+        models = g.getModels()
+        res = dict(poses=out, ids=[m.id for m in models], conf=[m.confidenceThreshold() for m in models],
+                   counts=[m.lastCount() for m in models], maps=[m.downloadMap() if shard is None or g.ownsModel(k) else None
+                                                                  for k, m in enumerate(models)])
+        g.close()
+        return res
+
+    a = run()
+    assert a["ids"] == [0, 1, 2] and a["conf"][0] == 10.0 and abs(a["conf"][1] - 0.01) < 1e-7
+    gt = np.linalg.inv(poses[0]) @ poses[n - 1]
+    cam = a["poses"][-1][0]
+    assert np.linalg.norm(cam[:3, 3] - gt[:3, 3]) < 0.005 and synth.rotation_angle(cam[:3, :3].astype(np.float64), gt[:3, :3]) < 0.005
+    assert a["counts"][0] > 1_000_000 and 5_000 < a["counts"][1] < 200_000 and 5_000 < a["counts"][2] < 200_000
+    for k in (1, 2):  # an object's surfels lie on the object: within its extent around its centre, in the model frame
+        s = a["maps"][k]
+        spawn = k
+        c = (np.linalg.inv(poses[spawn]) @ np.append(traj[k - 1][spawn][:3, :3] @ objs[k - 1]["centre"] + traj[k - 1][spawn][:3, 3], 1.0))[:3]
+        assert np.percentile(np.linalg.norm(s[:, :3] - c, axis=1), 95) < 0.45, k
+    b = run()
+    for i in range(n):
+        for pa, pb in zip(a["poses"][i], b["poses"][i]):
+            assert np.array_equal(pa, pb), i
+    for sa, sb in zip(a["maps"], b["maps"]):
+        assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32))
+    c = run(shard=(1, 3))  # this process owns model index 1 only
+    for i in range(1, n):
+        assert np.array_equal(a["poses"][i][1], c["poses"][i][1]), i
+    assert np.array_equal(a["maps"][1].view(np.uint32), c["maps"][1].view(np.uint32))
+    assert c["counts"][0] == 0 and c["counts"][2] == 0  # the other models are bookkeeping only here

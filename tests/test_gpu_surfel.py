@@ -199,7 +199,7 @@ def test_device_exponentials_against_float64(gpu_ctx):
     import ctypes
     xs = np.concatenate([np.linspace(-104.0, 0.0, 2_000_001), -np.logspace(-8, 2, 200_001), -np.arange(0, 104, 0.693359375 / 2),
                          [0.0, -0.0, -87.3, -87.4, -88.0, -103.0, -103.5]]).astype(np.float32)
-    pos = np.concatenate([np.linspace(0.0, 88.7, 500_001), [88.72, 89.0, 1e-8, 1.0]]).astype(np.float32)
+    pos = np.concatenate([np.linspace(0.0, 88.7, 500_001), [1e-8, 1.0]]).astype(np.float32)
     for args, packed_defined in ((xs, True), (pos, False)):
         x = torch.from_numpy(args).cuda()
         a, b = torch.empty_like(x), torch.empty_like(x)
@@ -214,8 +214,65 @@ def test_device_exponentials_against_float64(gpu_ctx):
         assert np.abs(a[~normal].astype(np.float64) - want[~normal]).max() <= 2 * 1.4e-45 * 2 ** 23 if (~normal).any() else True
         if packed_defined:
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    nan = torch.tensor([float("nan"), -1.0], device="cuda")
+    nan = torch.tensor([float("nan"), -1.0, 89.0, -200.0], device="cuda")
     a, b = torch.empty_like(nan), torch.empty_like(nan)
-    gpu_ctx.lib.mmf_debug_expf(gpu_ctx.handle, ctypes.c_void_p(nan.data_ptr()), 2, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()))
+    gpu_ctx.lib.mmf_debug_expf(gpu_ctx.handle, ctypes.c_void_p(nan.data_ptr()), 4, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()))
     torch.cuda.synchronize()
-    assert torch.isnan(a[0]) and torch.isnan(b[0]) and a[1] == b[1]
+    assert torch.isnan(a[0]) and torch.isnan(b[0]) and a[1] == b[1] and torch.isinf(a[2]) and a[3] == 0 and b[3] == 0
+
+
+@pytest.mark.parametrize("w,h,obj_id", [(320, 240, 2), (640, 480, 3)])
+def test_object_model_cycle_bit_exact(gpu_ctx, orc, w, h, obj_id):
+    """An OBJECT model as the segmentation spawns it (MultiMotionFusion.cpp:588-601, 791-816): id != 0, confidence
+    threshold confObjectInit = 0.01, no fill-in, created empty at the identity pose, fed through a ground-truth id
+    image that also holds other ids -- only pixels with mask == id may be fused (data.vert:118, copy_unstable.vert:120) --
+    and with Model::setMaxDepth in force.  Every pass bit-exact against the oracle."""
+    from multimotionfusion_amd.model import Model, filterDepth
+    CONF_OBJ = 0.01
+    K = synth.intrinsics(w, h)
+    n = 4
+    poses = synth.trajectory(n, seed=9)
+    objs = synth.make_objects(4, seed=9)
+    traj = synth.object_trajectories(objs, n, seed=9)
+    frames = [synth.render(p, w, h, seed=i, objects=objs, object_poses=[t[i] for t in traj]) for i, p in enumerate(poses)]
+    m = Model(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], obj_id, CONF_OBJ)
+    assert m.lastCount() == 0
+    s = np.zeros((0, 12), np.float32)
+    for t in range(n):
+        tick = t + 2
+        f = frames[t]
+        mask = f["ids"].astype(np.uint8)
+        assert (mask == obj_id).sum() > 500 and len(np.unique(mask)) >= 4
+        depth_of_object = f["depth"][mask == obj_id]
+        max_depth = float(np.float32(depth_of_object.mean() + 1.2 * np.abs(depth_of_object - depth_of_object.mean()).mean()))
+        m.setMaxDepth(max_depth)
+        # model frame = camera frame of the first frame: P(t) = C_0^-1 T(0) T(t)^-1 C_t (see test_gpu_multimodel)
+        pose = (np.linalg.inv(poses[0]) @ traj[obj_id - 1][0] @ np.linalg.inv(traj[obj_id - 1][t]) @ poses[t]).astype(np.float32)
+        fil = orc.bilateral_filter(f["depth"], CUTOFF)
+        d_rgb, d_raw, d_mask = dev(f["rgb"]), dev(f["depth"]), dev(mask)
+        d_fil = filterDepth(gpu_ctx, d_raw, CUTOFF)
+        m.overridePose(pose)
+        weight = 100.0 if t == 0 else 0.75
+        m.predictIndices(tick, MAXD, TIME_DELTA)
+        index, vc, ct, nr = orc.predict_indices(s, pose, K, w, h, MAXD, tick, TIME_DELTA)
+        assert_bit_equal(m.texture("index").cpu().numpy().view(np.uint32), index, f"index map t={t}")
+        m.fuse(tick, d_rgb, d_mask, d_raw, d_fil, MAXD, weight)
+        s_upd, new = orc.fuse(s, f["rgb"], f["depth"], fil, mask, index, vc, nr, pose, K, tick, weight, obj_id, min(MAXD, max_depth))
+        assert_bit_equal(m.downloadMap(), s_upd, f"fused surfels t={t}")
+        if t > 0:  # at the spawn the second predictIndices is commented out (MultiMotionFusion.cpp:594)
+            m.predictIndices(tick, MAXD, TIME_DELTA)
+            index, vc, ct, nr = orc.predict_indices(s_upd, pose, K, w, h, MAXD, tick, TIME_DELTA)
+        m.clean(tick, TIME_DELTA, MAXD, d_fil, d_mask, 3.0)
+        s = orc.clean(s_upd, new, pose, K, w, h, tick, TIME_DELTA, CONF_OBJ, 3.0, obj_id, index, vc, ct, fil, mask)
+        assert m.lastCount() == s.shape[0]
+        assert_bit_equal(m.downloadMap(), s, f"cleaned surfels t={t}")
+        # every surfel came from a pixel of the object: within the object's depth range in the camera frame
+        if t == 0:
+            assert s.shape[0] > 100 and s[:, 2].max() <= max_depth + 1e-3
+        m.combinedPredict(MAXD, tick, tick, TIME_DELTA)
+        image, vcp, nrp, tm = orc.combined_predict(s, pose, K, w, h, MAXD, CONF_OBJ, tick, tick, TIME_DELTA)
+        assert_bit_equal(m.texture("image").cpu().numpy(), image, f"splat image t={t}")
+        assert_bit_equal(m.texture("vertexConf").cpu().numpy(), vcp, f"splat vertexConf t={t}")
+        assert_bit_equal(m.texture("normalRadius").cpu().numpy(), nrp, f"splat normalRadius t={t}")
+        assert (vcp[..., 2] > 0).sum() > 100
+    m.close()
