@@ -438,6 +438,23 @@ int mmf_fusion_get_config(mmf_fusion *f, mmf_fusion_config *out);
 int mmf_fusion_set_shard(mmf_fusion *f, int rank, int world);
 int mmf_fusion_owns_model(mmf_fusion *f, int index);
 int mmf_fusion_set_model_pose(mmf_fusion *f, int index, const float pose[16]);
+/* The shard's two exchanges over RCCL, for a front-end that runs one process per GPU (the reference is
+ * single GPU and walks its Model list serially, MultiMotionFusion.cpp:312, 793-816).  RCCL is bound at run time
+ * (dlopen of librccl.so.1); all collectives run on the context's stream.
+ *   mmf_shard_unique_id  rank 0: ncclGetUniqueId; ship the 128 bytes to the other ranks by any means
+ *   mmf_shard_create     ncclCommInitRank(world, id, rank) on the context's device
+ *   mmf_shard_attach     use the caller's ncclComm_t instead (not destroyed by mmf_shard_destroy)
+ *   mmf_shard_broadcast_frame  the root's rgb (u8 x 3) / depth (f32) / id image (u8, may be NULL) into the same
+ *                        buffers of every rank: 8 B/px, asynchronous on the stream -- call before processFrame
+ *   mmf_shard_gather_poses     after processFrame: all-gather of {pose, lastICPError, lastICPCount} (18 floats per
+ *                        model slot); the poses of models other ranks own land in this rank's bookkeeping */
+typedef struct mmf_shard mmf_shard;
+int mmf_shard_unique_id(char id[128]);
+int mmf_shard_create(mmf_ctx *ctx, int rank, int world, const char id[128], mmf_shard **out);
+int mmf_shard_attach(mmf_ctx *ctx, int rank, int world, void *nccl_comm, mmf_shard **out);
+void mmf_shard_destroy(mmf_shard *s);
+int mmf_shard_broadcast_frame(mmf_shard *s, uint8_t *rgb, float *depth, uint8_t *mask, int width, int height, int root);
+int mmf_shard_gather_poses(mmf_shard *s, mmf_fusion *f);
 /* host wall clock of the last processFrame call: the tracking phase (first enqueue .. last result) and the whole call */
 int mmf_fusion_last_timings(mmf_fusion *f, double *tracking_s, double *frame_s);
 int mmf_fusion_set_segmentation_callback(mmf_fusion *f, mmf_segmentation_fn fn, void *user);

@@ -191,6 +191,12 @@ SIGNATURES = {
     "mmf_fusion_pose_log": (_i, [_vp, _i, C.POINTER(C.c_longlong), _fp, _i, _ip]),
     "mmf_compute_fusion_weight": (_i, [_fp, _fp, _f, _fp]),
     "mmf_fusion_preallocate_models": (_i, [_vp, C.c_uint]),
+    "mmf_shard_unique_id": (_i, [C.c_char_p]),
+    "mmf_shard_create": (_i, [_vp, _i, _i, C.c_char_p, C.POINTER(_vp)]),
+    "mmf_shard_attach": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "mmf_shard_destroy": (None, [_vp]),
+    "mmf_shard_broadcast_frame": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
+    "mmf_shard_gather_poses": (_i, [_vp, _vp]),
     "mmf_debug_expf": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mmf_fusion_set_shard": (_i, [_vp, _i, _i]),
     "mmf_fusion_owns_model": (_i, [_vp, _i]),

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libmmf_hip.so")
 # -ffp-contract=off: the per-pixel arithmetic must round exactly like the CPU oracle's
 # (no fused multiply-add), see csrc/device_math.hpp.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
-               "-Wall", "-Wextra"]
+               "-Wall", "-Wextra", "-I/opt/rocm/include", "-ldl"]
 SOURCES = ["mmf_hip.hip"]
 
 

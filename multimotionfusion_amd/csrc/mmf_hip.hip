@@ -2318,3 +2318,8 @@ extern "C" int mmf_debug_set_stamps(void* dev_buf) {
 // Orchestrator: MultiMotionFusion::processFrame / predict (Core/MultiMotionFusion.cpp:207-854, 863-875)
 // =============================================================================================
 #include "fusion_orchestrator.hpp"
+
+// =============================================================================================
+// Per-rigid-body shard across GPUs: frame broadcast + pose all-gather over RCCL
+// =============================================================================================
+#include "shard_rccl.hpp"

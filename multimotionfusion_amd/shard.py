@@ -62,3 +62,40 @@ def gather_poses(pose: np.ndarray, icp_error: float, icp_count: float, device) -
     out = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
     dist.all_gather(out, rec)
     return torch.stack(out).cpu().numpy()
+
+
+class Shard:
+    """The C-level shard (mmf_shard_*): the same two exchanges -- frame broadcast, pose all-gather -- run by
+    libmmf_hip.so on the context's stream over RCCL, for front-ends that are not PyTorch programs.  `unique_id` is the
+    128-byte ncclUniqueId rank 0 made with Shard.unique_id(); ship it to the other ranks by any means."""
+
+    @staticmethod
+    def unique_id(lib):
+        import ctypes as C
+        from ._capi import check
+        buf = C.create_string_buffer(128)
+        check(lib.mmf_shard_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx, rank, world, unique_id):
+        import ctypes as C
+        from ._capi import check
+        self.ctx, self.rank, self.world = ctx, rank, world
+        h = C.c_void_p()
+        check(ctx.lib.mmf_shard_create(ctx.handle, int(rank), int(world), unique_id, C.byref(h)))
+        self.handle = h
+
+    def broadcast_frame(self, rgb, depth, mask=None, root=0):
+        from ._capi import check
+        from .cudafuncs import _p
+        h, w = depth.shape
+        check(self.ctx.lib.mmf_shard_broadcast_frame(self.handle, _p(rgb), _p(depth), _p(mask), w, h, int(root)))
+
+    def gather_poses(self, fusion):
+        from ._capi import check
+        check(self.ctx.lib.mmf_shard_gather_poses(self.handle, fusion.handle))
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.mmf_shard_destroy(self.handle)
+        self.handle = None
