@@ -321,6 +321,8 @@ typedef struct {
     int error_recording;       /* Model(..., enableErrorRecording): per-model ICP / RGB error images */
     int pose_logging;          /* enablePoseLogging: Model::poseLog, exportPoses */
     int max_object_surfels;    /* capacity of an object model's store, 0 = max_surfels */
+    int batch_tracking;        /* 1: the Gauss-Newton chains of all models of a frame run as ONE chain of launches with
+                                  gridDim.y = model (default); 0: one chain per model on the model's own stream */
 } mmf_fusion_config;
 
 /* SegmentationResult (Core/Segmentation/Segmentation.h:32-70) as far as processFrame consumes it */

@@ -42,7 +42,7 @@ class mmf_fusion_config(C.Structure):
                 ("pyramid", C.c_int), ("fast_odom", C.c_int), ("so3", C.c_int), ("frame_to_frame_rgb", C.c_int),
                 ("outlier_coeff", C.c_float), ("fill_in", C.c_int), ("max_surfels", C.c_int),
                 ("conf_object_init", C.c_float), ("enable_multiple_models", C.c_int), ("preallocated_models", C.c_int),
-                ("error_recording", C.c_int), ("pose_logging", C.c_int), ("max_object_surfels", C.c_int)]
+                ("error_recording", C.c_int), ("pose_logging", C.c_int), ("max_object_surfels", C.c_int), ("batch_tracking", C.c_int)]
 
 
 class mmf_odom_timing(C.Structure):

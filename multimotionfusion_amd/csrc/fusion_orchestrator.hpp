@@ -110,6 +110,7 @@ extern "C" int mmf_fusion_default_config(mmf_fusion_config* cfg) {
     cfg->error_recording = 1;       // every Model is created with enableErrorRecording (MultiMotionFusion.cpp:70,128,944)
     cfg->pose_logging = 0;          // enablePoseLogging
     cfg->max_object_surfels = 0;
+    cfg->batch_tracking = 1;
     return MMF_OK;
 }
 
@@ -117,8 +118,6 @@ static void fusion_model_destroy(FusionModel* fm) {
     if (!fm) return;
     mmf_model_destroy(fm->model);
     mmf_odom_destroy(fm->odom);
-    (void)hipFree(fm->icp_error);
-    (void)hipFree(fm->rgb_error);
     if (fm->ev_done) (void)hipEventDestroy(fm->ev_done);
     if (fm->own_lane) mmf_ctx_destroy(fm->lane);
     delete fm;
@@ -141,13 +140,8 @@ static int fusion_model_create(mmf_fusion* f, int id, float conf, int fill_in, b
     if (rc == MMF_OK)
         rc = mmf_odom_create(fm->lane, f->width, f->height, f->cx, f->cy, f->fx, f->fy, 0.10f,
                              std::sin(20.f * 3.14159254f / 180.f), &fm->odom);
-    const size_t npix = (size_t)f->width * f->height;
-    if (rc == MMF_OK && f->cfg.error_recording) {
-        if (hipMalloc(&fm->icp_error, npix * 4) != hipSuccess || hipMalloc(&fm->rgb_error, npix * 4) != hipSuccess ||
-            hipMemsetAsync(fm->icp_error, 0, npix * 4, fm->lane->stream) != hipSuccess ||
-            hipMemsetAsync(fm->rgb_error, 0, npix * 4, fm->lane->stream) != hipSuccess)
-            rc = fail(MMF_ERR_HIP, "mmf_fusion: error textures: out of device memory");
-    }
+    if (rc == MMF_OK && f->cfg.error_recording)  // Model::icpError / rgbError: images inside the odometry's slab
+        fm->icp_error = fm->odom->icp_err, fm->rgb_error = fm->odom->rgb_err;
     if (rc == MMF_OK && hipEventCreateWithFlags(&fm->ev_done, hipEventDisableTiming) != hipSuccess)
         rc = fail(MMF_ERR_HIP, "mmf_fusion: hipEventCreate failed");
     if (rc != MMF_OK) {
@@ -562,6 +556,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 if (rc) return rc;
             }
             if (!one_pass) MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
+            std::vector<FusionModel*> tracked;
             for (size_t k = 0; k < n_models; ++k) {  // :312-387, enqueue only
                 FusionModel* fm = f->models[k];
                 fm->tracking = false;
@@ -596,28 +591,86 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 // Model::performTracking (Model.cpp:409-433) with Model::initICP (:390-407).  requiresFillIn (:380,
                 // :877-895) is decided on the device: the preparation jobs pick their sources from the flag
                 const mmf_model* m = fm->model;
-                int* fill_flag = reinterpret_cast<int*>(&m->totals[3]);
                 if (fm->fill_in) {
                     hipLaunchKernelGGL(thumbnail_flag_kernel, dim3(1), dim3(256), 0, fm->lane->stream, m->image, m->width,
-                                       m->height, 0.75f, fill_flag);
+                                       m->height, 0.75f, reinterpret_cast<int*>(&m->totals[3]));
                     MMF_HIP_TRY(hipGetLastError());
                 }
                 float pose[16];
                 mmf_model_get_pose(fm->model, pose);
                 std::memcpy(fm->last_pose, pose, sizeof(pose));  // lastPose = pose (Model.cpp:412)
+                fm->tracking = true;
+                tracked.push_back(fm);
+            }
+            // ONE chain of launches for all tracked models (gridDim.y = model) when every level runs on the fused
+            // producer path and no model went through a pose-initialisation round on its own stream; else one chain
+            // per model on the model's stream.  Either way nothing waits here.
+            const bool batched = tracked.size() > 1 && tracked.size() <= (size_t)kMaxBatch && !have_init && g.batch_tracking;
+            auto collect_prep = [&](PrepStages& stages, FusionModel* fm, int side) {
+                const mmf_model* m = fm->model;
                 const uint8_t* pi = (const uint8_t*)((g.frame_to_frame_rgb && fm->fill_in) ? m->fill_image : m->image);
-                const int side = (k == 0 && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE;
-                rc = odom_prepare_batched(fm->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
-                                          (const float*)m->normalRadius, pi, 4, pose, fm->fill_in ? fill_flag : nullptr,
-                                          (const float*)m->fill_vertex, (const float*)m->fill_normal,
-                                          (const uint8_t*)m->fill_image, side);
+                float pose[16];
+                mmf_model_get_pose(fm->model, pose);
+                odom_prepare_collect(stages, fm->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
+                                     (const float*)m->normalRadius, pi, 4, pose,
+                                     fm->fill_in ? reinterpret_cast<const int*>(&m->totals[3]) : nullptr, (const float*)m->fill_vertex,
+                                     (const float*)m->fill_normal, (const uint8_t*)m->fill_image, side);
+            };
+            bool batch_ok = batched;
+            if (batched) {
+                FusionModel* lead = tracked[0];
+                hipStream_t st = lead->lane->stream;
+                for (size_t k = 1; k < tracked.size(); ++k) {  // the other models' last work (previous frame's predict) precedes
+                    MMF_HIP_TRY(hipEventRecord(tracked[k]->ev_done, tracked[k]->lane->stream));
+                    MMF_HIP_TRY(hipStreamWaitEvent(st, tracked[k]->ev_done, 0));
+                }
+                PrepStages stages;
+                for (size_t k = 0; k < tracked.size(); ++k)
+                    collect_prep(stages, tracked[k], (k == 0 && tracked[k] == global && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE);
+                rc = stages.launch(st);
                 if (rc) return rc;
+                batch_ok = odom_batchable(lead->odom, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom);
+                if (batch_ok) {
+                    TrackBatch tb;
+                    tb.n = (int)tracked.size();
+                    std::memset(&tb.bd, 0, sizeof(tb.bd));
+                    for (int k = 0; k < tb.n; ++k) {
+                        tb.o[k] = tracked[k]->odom;
+                        tb.bd.d[k] = (long long)(reinterpret_cast<char*>(tracked[k]->odom->slab) - reinterpret_cast<char*>(lead->odom->slab));
+                        float pose[16];
+                        mmf_model_get_pose(tracked[k]->model, pose);
+                        for (int r = 0; r < 3; ++r) {
+                            for (int q = 0; q < 3; ++q) tb.poses.rot[k][r * 3 + q] = pose[r * 4 + q];
+                            tb.poses.trans[k][r] = pose[r * 4 + 3];
+                        }
+                    }
+                    rc = odom_enqueue_tracking(lead->odom, tb.poses.trans[0], tb.poses.rot[0], g.rgb_only, g.icp_weight, g.pyramid,
+                                               g.fast_odom, g.so3, lead->icp_error, lead->rgb_error, &tb);
+                    if (rc) return rc;
+                    for (size_t k = 1; k < tracked.size(); ++k) {  // the lanes continue after the chain
+                        MMF_HIP_TRY(hipEventRecord(tracked[k]->ev_done, st));
+                        MMF_HIP_TRY(hipStreamWaitEvent(tracked[k]->lane->stream, tracked[k]->ev_done, 0));
+                    }
+                }
+            }
+            for (size_t k = 0; k < tracked.size() && !batch_ok; ++k) {
+                FusionModel* fm = tracked[k];
+                if (!batched) {  // (a failed batch has prepared every model already)
+                    PrepStages stages;
+                    collect_prep(stages, fm, (fm == global && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE);
+                    rc = stages.launch(fm->lane->stream);
+                    if (rc) return rc;
+                } else if (k > 0) {  // prepared on the leader's stream
+                    MMF_HIP_TRY(hipEventRecord(fm->ev_done, tracked[0]->lane->stream));
+                    MMF_HIP_TRY(hipStreamWaitEvent(fm->lane->stream, fm->ev_done, 0));
+                }
+                float pose[16];
+                mmf_model_get_pose(fm->model, pose);
                 const float trans[3] = {pose[3], pose[7], pose[11]};
                 const float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
                 rc = odom_enqueue_tracking(fm->odom, trans, rot, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom, g.so3,
                                            fm->icp_error, fm->rgb_error);
                 if (rc) return rc;
-                fm->tracking = true;
             }
             bool any_tracked = false;
             const bool global_tracked = global->tracking;

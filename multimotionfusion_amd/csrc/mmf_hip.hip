@@ -15,6 +15,7 @@
 #include <new>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "map_kernels.hpp"
 #include "prep_batch.hpp"
@@ -185,10 +186,10 @@ static int icp_default_variant(int /*npix*/) {
 }
 
 template <int W, int NV, int BLOCK, bool PACKED, int MODE>
-static int launch_icp2_variant(mmf_ctx* c, OdomState* st, const IcpArgs& a) {
+static int launch_icp2_variant(mmf_ctx* c, OdomState* st, const IcpArgs& a, float* partials) {
     const int grid = (a.cols * a.rows + BLOCK * W * NV - 1) / (BLOCK * W * NV);  // <= kMaxIcpGrid, checked by the caller
     hipLaunchKernelGGL((icp_kernel2<W, NV, BLOCK, PACKED, MODE>), dim3(grid), dim3(BLOCK), 0, c->stream, st, a,
-                       c->partials_icp);
+                       partials);
     return grid;
 }
 
@@ -232,7 +233,9 @@ static bool icp2_fits(const IcpArgs& a, int block, int px) {
 
 // launches the ICP producer; *records_out = number of partial records it writes to c->partials_icp
 template <int MODE>
-static hipError_t launch_icp(mmf_ctx* c, OdomState* st, IcpArgs a, int variant = 0, int* records_out = nullptr) {
+static hipError_t launch_icp(mmf_ctx* c, OdomState* st, IcpArgs a, int variant = 0, int* records_out = nullptr,
+                             float* partials = nullptr) {
+    if (!partials) partials = c->partials_icp;
     if (variant == 0) variant = icp_default_variant(a.cols * a.rows);
     icp_args_derive(a);
     const int gen = variant / 1000000;
@@ -243,7 +246,7 @@ static hipError_t launch_icp(mmf_ctx* c, OdomState* st, IcpArgs a, int variant =
     if (icp2_fits(a, block, px)) {
         const bool packed = gen != 1 && a.prev_packed != nullptr;
 #define MMF_ICP2(W, NV, B)                                                                 \
-    grid = packed ? launch_icp2_variant<W, NV, B, true, MODE>(c, st, a) : launch_icp2_variant<W, NV, B, false, MODE>(c, st, a)
+    grid = packed ? launch_icp2_variant<W, NV, B, true, MODE>(c, st, a, partials) : launch_icp2_variant<W, NV, B, false, MODE>(c, st, a, partials)
         switch (px * 10000 + block) {
             case 40256: MMF_ICP2(2, 2, 256); break;
             case 40128: MMF_ICP2(2, 2, 128); break;
@@ -257,7 +260,7 @@ static hipError_t launch_icp(mmf_ctx* c, OdomState* st, IcpArgs a, int variant =
 #undef MMF_ICP2
     } else {  // very large images: the grid-stride first-generation kernel
         grid = reduce_grid(a.cols * a.rows, 256);
-        hipLaunchKernelGGL((icp_kernel<1, 256, MODE>), dim3(grid), dim3(256), 0, c->stream, st, a, c->partials_icp);
+        hipLaunchKernelGGL((icp_kernel<1, 256, MODE>), dim3(grid), dim3(256), 0, c->stream, st, a, partials);
     }
     if (records_out) *records_out = grid;
     return hipGetLastError();
@@ -440,11 +443,11 @@ extern "C" int mmf_rgb_step(mmf_ctx* c, const mmf_dataterm* corres_dev, float si
     if ((cols * rows) % 4 == 0) {
         const int grid = reduce_grid(cols * rows, kBlock * 4);
         hipLaunchKernelGGL((rgb_step_kernel<FINISH_RAW, 4>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state,
-                           a, c->partials_f, c->ticket);
+                           a, c->partials_f, c->ticket, BatchDelta{});
     } else {
         const int grid = reduce_grid(cols * rows, kBlock);
         hipLaunchKernelGGL((rgb_step_kernel<FINISH_RAW, 1>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state,
-                           a, c->partials_f, c->ticket);
+                           a, c->partials_f, c->ticket, BatchDelta{});
     }
     MMF_HIP_TRY(hipGetLastError());
     float tot[32];
@@ -723,6 +726,13 @@ struct mmf_odom {
     float* cloud[MMF_NUM_PYRS];
     mmf_dataterm* corres[MMF_NUM_PYRS];
     float* prev_packed[MMF_NUM_PYRS];  // model vertex + normal, pixel interleaved 24-byte records (the ICP gather side)
+    // reduction scratch of the Gauss-Newton loop and the two error images, inside the slab: every odometry object has
+    // its own (concurrent chains on different streams, or one batched chain addressing model m at slab(m) - slab(0))
+    float* gn_partials_f = nullptr;
+    float* gn_partials_icp = nullptr;
+    int2* gn_partials_res = nullptr;
+    unsigned* gn_ticket = nullptr;
+    float *icp_err = nullptr, *rgb_err = nullptr;  // Model::icpError / rgbError (R32F), written on the last level-0 iteration
     OdomState* state = nullptr;  // device
     OdomState* host_result = nullptr;  // pinned
     bool have_tmp = false;  // vmaps_tmp filled by an initICP* call (ordering contract)
@@ -738,6 +748,7 @@ struct mmf_odom {
     bool prep_batched = false;
     bool so3_prefetched = false;  // this frame's SO3 pre-alignment already ran (odom_prefetch_so3)
     bool pending_icp = false, pending_so3 = false;  // mode of the tracking call that is in flight (enqueue -> finish)
+    hipStream_t track_stream = nullptr;             // the stream that call's chain runs on (the batch leader's)
     // measurement mode (mmf_odom_enable_timing): every producer / rgb_step launch of a tracking call carries its own
     // start / stop events (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps), the whole chain two more
     int timing = 0;  // 1: chain events only; 2: also every kernel of the chain
@@ -802,6 +813,9 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
         o_pp[i] = carve(n * 6 * sizeof(float));
     }
     size_t o_state = carve(sizeof(OdomState));
+    const size_t o_pf = carve(sizeof(float) * kMaxGrid * kPartialStride), o_pi = carve(sizeof(float) * kMaxIcpGrid * kPartialStride),
+                 o_pr = carve(sizeof(int2) * kMaxGrid), o_tk = carve(sizeof(unsigned) * kTicketWords), o_ei = carve(n0 * 4),
+                 o_er = carve(n0 * 4);
     o->slab_bytes = off;
     hipError_t e = hipMalloc(&o->slab, o->slab_bytes);
     if (e != hipSuccess) {
@@ -830,6 +844,9 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
         o->prev_packed[i] = (float*)(base + o_pp[i]);
     }
     o->state = (OdomState*)(base + o_state);
+    o->gn_partials_f = (float*)(base + o_pf), o->gn_partials_icp = (float*)(base + o_pi);
+    o->gn_partials_res = (int2*)(base + o_pr), o->gn_ticket = (unsigned*)(base + o_tk);
+    o->icp_err = (float*)(base + o_ei), o->rgb_err = (float*)(base + o_er);
     MMF_HIP_TRY(hipHostMalloc(&o->host_result, sizeof(OdomState), hipHostMallocDefault));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
     *out = o;
@@ -1000,24 +1017,41 @@ extern "C" int mmf_odom_init_first_rgb(mmf_odom* o, const uint8_t* rgb, size_t s
 }
 
 // ---- the whole per-frame preparation in four launches (prep_batch.hpp) -------------------------
-struct PrepBuilder {
-    PrepBatch b;
-    int blocks = 0;
-    PrepBuilder() { b.njobs = 0; }
+struct PrepBuilder {  // the jobs of one stage (possibly of several models); launched kMaxPrepJobs at a time
+    std::vector<PrepJob> jobs;
     PrepJob& add(int op, int cols, int rows) {
-        PrepJob& j = b.job[b.njobs++];
+        if (jobs.capacity() < 96) jobs.reserve(96);  // references handed out stay valid while a stage is being filled
+        jobs.emplace_back();
+        PrepJob& j = jobs.back();
         std::memset(&j, 0, sizeof(j));
         j.op = op;
         j.cols = cols, j.rows = rows;
         j.gx = (cols + kTileX - 1) / kTileX;
-        j.first_block = blocks;
-        blocks += j.gx * ((rows + kTileY - 1) / kTileY);
         return j;
     }
     int launch(hipStream_t stream) {
-        if (!b.njobs) return MMF_OK;
-        hipLaunchKernelGGL(prep_batch_kernel, dim3(blocks), tile_block(), 0, stream, b);
-        MMF_HIP_TRY(hipGetLastError());
+        for (size_t first = 0; first < jobs.size(); first += kMaxPrepJobs) {
+            PrepBatch b;
+            b.njobs = 0;
+            int blocks = 0;
+            for (size_t k = first; k < jobs.size() && b.njobs < kMaxPrepJobs; ++k) {
+                PrepJob& j = b.job[b.njobs++];
+                j = jobs[k];
+                j.first_block = blocks;
+                blocks += j.gx * ((j.rows + kTileY - 1) / kTileY);
+            }
+            hipLaunchKernelGGL(prep_batch_kernel, dim3(blocks), tile_block(), 0, stream, b);
+            MMF_HIP_TRY(hipGetLastError());
+        }
+        jobs.clear();
+        return MMF_OK;
+    }
+};
+struct PrepStages {  // the four dependent launches of a frame's preparation
+    PrepBuilder stage[4];
+    int launch(hipStream_t stream) {
+        for (PrepBuilder& pb : stage)
+            if (int rc = pb.launch(stream)) return rc;
         return MMF_OK;
     }
 };
@@ -1032,14 +1066,12 @@ struct PrepBuilder {
 // (mmf_fusion_prefetch_frame); PREP_ALL is both groups in the same four launches.
 enum PrepSide { PREP_INPUT_IMAGE = 1, PREP_INPUT_DEPTH = 2, PREP_MODEL_SIDE = 4, PREP_ALL = 7 };
 
-static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float depth_cutoff, const uint8_t* rgb,
-                                int rgb_channels, const float* pred_vertex, const float* pred_normal,
-                                const uint8_t* pred_image, int pred_channels, const float pose[16],
-                                const int* sel = nullptr, const float* alt_vertex = nullptr,
-                                const float* alt_normal = nullptr, const uint8_t* alt_image = nullptr,
-                                int side = PREP_ALL, hipStream_t stream = nullptr) {
-    mmf_ctx* c = o->ctx;
-    if (stream == nullptr) stream = c->stream;
+static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* depth_filtered, float depth_cutoff, const uint8_t* rgb,
+                                 int rgb_channels, const float* pred_vertex, const float* pred_normal,
+                                 const uint8_t* pred_image, int pred_channels, const float pose[16],
+                                 const int* sel = nullptr, const float* alt_vertex = nullptr,
+                                 const float* alt_normal = nullptr, const uint8_t* alt_image = nullptr,
+                                 int side = PREP_ALL) {
     const bool in_img = (side & PREP_INPUT_IMAGE) != 0, in_depth = (side & PREP_INPUT_DEPTH) != 0;
     const bool model_side = (side & PREP_MODEL_SIDE) != 0;
     const int W = o->width, H = o->height;
@@ -1103,7 +1135,7 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
     }
 
     {   // stage 1: inputs -> level 0 (and level 1 of the depth pyramid)
-        PrepBuilder pb;
+        PrepBuilder& pb = stages.stage[0];
         if (in_depth) {
             pyr(pb, PREP_PYRDOWN_F, depth_filtered, o->depth_pyr[1], 1);
             vmap_job(pb, 0, depth_filtered);
@@ -1123,36 +1155,39 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
             cm.src0 = pred_vertex, cm.src1 = pred_normal, cm.dst0 = uv[0], cm.dst1 = un[0];
             cm.sel = sel, cm.alt0 = alt_vertex, cm.alt1 = alt_normal;
         }
-        int rc = pb.launch(stream);
-        if (rc) return rc;
     }
     {   // stage 2: level 0 -> level 1 (and level 2 of the depth pyramid)
-        PrepBuilder pb;
+        PrepBuilder& pb = stages.stage[1];
         if (in_depth) {
             pyr(pb, PREP_PYRDOWN_F, o->depth_pyr[1], o->depth_pyr[2], 2);
             vmap_job(pb, 1, o->depth_pyr[1]);
         }
         level_jobs(pb, 0);
         down_jobs(pb, 1, nullptr);
-        int rc = pb.launch(stream);
-        if (rc) return rc;
     }
     {   // stage 3: level 1 -> level 2
-        PrepBuilder pb;
+        PrepBuilder& pb = stages.stage[2];
         if (in_depth) vmap_job(pb, 2, o->depth_pyr[2]);
         level_jobs(pb, 1);
         down_jobs(pb, 2, nullptr);
-        int rc = pb.launch(stream);
-        if (rc) return rc;
     }
     {   // stage 4: level 2
-        PrepBuilder pb;
+        PrepBuilder& pb = stages.stage[3];
         level_jobs(pb, 2);
-        int rc = pb.launch(stream);
-        if (rc) return rc;
     }
     if (model_side) o->prep_batched = true;
-    return MMF_OK;
+}
+
+static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float depth_cutoff, const uint8_t* rgb,
+                                int rgb_channels, const float* pred_vertex, const float* pred_normal,
+                                const uint8_t* pred_image, int pred_channels, const float pose[16],
+                                const int* sel = nullptr, const float* alt_vertex = nullptr,
+                                const float* alt_normal = nullptr, const uint8_t* alt_image = nullptr,
+                                int side = PREP_ALL, hipStream_t stream = nullptr) {
+    PrepStages stages;
+    odom_prepare_collect(stages, o, depth_filtered, depth_cutoff, rgb, rgb_channels, pred_vertex, pred_normal, pred_image,
+                         pred_channels, pose, sel, alt_vertex, alt_normal, alt_image, side);
+    return stages.launch(stream ? stream : o->ctx->stream);
 }
 
 static IcpArgs odom_icp_args(mmf_odom* o, int level, float* err_map) {
@@ -1178,7 +1213,8 @@ static IcpArgs odom_icp_args(mmf_odom* o, int level, float* err_map) {
 // at level 2 -- no model, no pose
 static int odom_enqueue_so3(mmf_odom* o, hipStream_t stream, float* partials = nullptr, unsigned* ticket = nullptr) {
     mmf_ctx* c = o->ctx;
-    if (!partials) partials = c->partials_f, ticket = c->ticket;
+    (void)c;
+    if (!partials) partials = o->gn_partials_f, ticket = o->gn_ticket;
     const int lvl = 2, cols = o->width >> lvl, rows = o->height >> lvl;
     So3Args a;
     a.last_image = o->last_next_image[lvl];
@@ -1214,12 +1250,31 @@ static int odom_prefetch_so3(mmf_odom* o, hipStream_t stream, float* partials, u
 // first half: everything up to and including the copy of the result towards the host is enqueued on the
 // context's stream, nothing waits.  The orchestrator enqueues the chains of all its models (one stream each)
 // before it waits for the first result.
+// The models one chain of launches tracks: o[0] leads (its stream, its launch arguments), the others ride at their
+// slab offsets (BatchDelta).  All share the sensor-side images (fusion_orchestrator.hpp) and the configuration.
+struct TrackBatch {
+    int n = 1;
+    mmf_odom* o[kMaxBatch];
+    BatchDelta bd;
+    BeginPoses poses;
+};
+
+static bool odom_batchable(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom);
+
 static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float rot[9], int rgb_only, float icp_weight,
-                                 int pyramid, int fast_odom, int so3, float* icp_err_dev, float* rgb_err_dev) {
+                                 int pyramid, int fast_odom, int so3, float* icp_err_dev, float* rgb_err_dev,
+                                 const TrackBatch* batch = nullptr) {
     mmf_ctx* c = o->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     const bool icp = !rgb_only && icp_weight > 0;  // :221-222
     const bool rgb = rgb_only || icp_weight < 100;
+    const unsigned ny = batch ? (unsigned)batch->n : 1u;
+    BatchDelta bd;
+    BeginPoses poses;
+    std::memset(&bd, 0, sizeof(bd));
+    std::memset(&poses, 0, sizeof(poses));
+    if (batch) bd = batch->bd, poses = batch->poses;
+    MMF_REQUIRE(ny == 1 || odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom), "odom_enqueue_tracking: not batchable");
 
     if (rgb && !o->prep_batched)
         for (int i = 0; i < MMF_NUM_PYRS; ++i) {  // :230-235
@@ -1244,9 +1299,10 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     b.first_intr = level_intr(o->fx, o->fy, o->cx, o->cy, MMF_NUM_PYRS - 1);
     o->n_timed = 0;
     if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[0], c->stream));
-    hipLaunchKernelGGL(odom_begin_kernel, dim3(1), dim3(64), 0, c->stream, o->state, b);
+    hipLaunchKernelGGL(odom_begin_kernel, dim3(ny), dim3(64), 0, c->stream, o->state, b, bd, poses);
     MMF_HIP_TRY(hipGetLastError());
 
+    const bool so3_ran_here = so3 && !o->so3_prefetched;  // in the leader's state: shared with the others at the first level begin
     if (so3 && !o->so3_prefetched) {  // :239-310
         int rc = odom_enqueue_so3(o, c->stream);
         if (rc) return rc;
@@ -1266,7 +1322,8 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
             if (rc) return rc;
         }
         if (!begin_folded) {
-            hipLaunchKernelGGL(gn_level_begin_kernel, dim3(1), dim3(64), 0, c->stream, o->state, first_level ? 1 : 0, in);
+            hipLaunchKernelGGL(gn_level_begin_kernel, dim3(ny), dim3(64), 0, c->stream, o->state, first_level ? 1 : 0, in, bd,
+                               (first_level && so3_ran_here) ? 1 : 0);
             MMF_HIP_TRY(hipGetLastError());
         }
         first_level = false;
@@ -1303,38 +1360,39 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                     o->timed_kind[o->n_timed++] = i * 2;
                 }
                 if (ipx == 2)
-                    hipExtLaunchKernelGGL((track_producer_kernel<2, true>), dim3(icp_records + res_records), dim3(kBlock), 0,
-                                          c->stream, e0, e1, 0, o->state, ia, (unsigned)icp_records, ra, c->partials_icp,
-                                          c->partials_res);
+                    hipExtLaunchKernelGGL((track_producer_kernel<2, true>), dim3(icp_records + res_records, ny), dim3(kBlock), 0,
+                                          c->stream, e0, e1, 0, o->state, ia, (unsigned)icp_records, ra, o->gn_partials_icp,
+                                          o->gn_partials_res, bd);
                 else
-                    hipExtLaunchKernelGGL((track_producer_kernel<1, true>), dim3(icp_records + res_records), dim3(kBlock), 0,
-                                          c->stream, e0, e1, 0, o->state, ia, (unsigned)icp_records, ra, c->partials_icp,
-                                          c->partials_res);
+                    hipExtLaunchKernelGGL((track_producer_kernel<1, true>), dim3(icp_records + res_records, ny), dim3(kBlock), 0,
+                                          c->stream, e0, e1, 0, o->state, ia, (unsigned)icp_records, ra, o->gn_partials_icp,
+                                          o->gn_partials_res, bd);
                 MMF_HIP_TRY(hipGetLastError());
             } else {
+                MMF_REQUIRE(ny == 1, "odom_enqueue_tracking: this level cannot be batched");
                 if (rgb) {
                     if (res_vec4)
                         hipLaunchKernelGGL((rgb_residual_kernel<FINISH_GN, 4>), dim3(res_records), dim3(kBlock), 0,
-                                           c->stream, o->state, ra, c->partials_res);
+                                           c->stream, o->state, ra, o->gn_partials_res);
                     else
                         hipLaunchKernelGGL((rgb_residual_kernel<FINISH_GN, 1>), dim3(res_records), dim3(kBlock), 0,
-                                           c->stream, o->state, ra, c->partials_res);
+                                           c->stream, o->state, ra, o->gn_partials_res);
                     MMF_HIP_TRY(hipGetLastError());
                 }
                 if (icp) {  // :403-410
-                    MMF_HIP_TRY(launch_icp<FINISH_GN>(c, o->state, ia, 0, &icp_records));
+                    MMF_HIP_TRY(launch_icp<FINISH_GN>(c, o->state, ia, 0, &icp_records, o->gn_partials_icp));
                     if (!rgb) {  // ICP-only tracking: one workgroup sums the records, solves, updates the pose
                         hipLaunchKernelGGL((icp_finish_kernel<FINISH_GN>), dim3(1), dim3(256), 0, c->stream, o->state,
-                                           c->partials_icp, (unsigned)icp_records, in);
+                                           o->gn_partials_icp, (unsigned)icp_records, in);
                         MMF_HIP_TRY(hipGetLastError());
                     }
                 }
             }
             if (rgb) {  // :418-423, then :425-460 in the finishing workgroup
                 RgbStepArgs a;
-                a.residual_partials = c->partials_res;
+                a.residual_partials = o->gn_partials_res;
                 a.residual_records = (unsigned)res_records;
-                a.icp_partials = c->partials_icp;
+                a.icp_partials = o->gn_partials_icp;
                 a.icp_records = (unsigned)icp_records;
                 a.corres = o->corres[i];
                 a.cloud = o->cloud[i];
@@ -1365,31 +1423,54 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                     o->timed_kind[o->n_timed++] = i * 2 + 1;
                 }
                 if (res_vec4)  // the 4-pixel correspondence pass wrote compact records
-                    hipExtLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, true>), dim3(grid), dim3(kBlock), 0, c->stream, e0, e1,
-                                          0, o->state, a, c->partials_f, c->ticket);
+                    hipExtLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, true>), dim3(grid, ny), dim3(kBlock), 0, c->stream, e0, e1,
+                                          0, o->state, a, o->gn_partials_f, o->gn_ticket, bd);
                 else
-                    hipExtLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, false>), dim3(grid), dim3(kBlock), 0, c->stream, e0,
-                                          e1, 0, o->state, a, c->partials_f, c->ticket);
+                    hipExtLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, false>), dim3(grid, ny), dim3(kBlock), 0, c->stream, e0,
+                                          e1, 0, o->state, a, o->gn_partials_f, o->gn_ticket, bd);
                 MMF_HIP_TRY(hipGetLastError());
             }
         }
     }
 
     if (!end_folded) {
-        hipLaunchKernelGGL(odom_end_kernel, dim3(1), dim3(64), 0, c->stream, o->state);
+        hipLaunchKernelGGL(odom_end_kernel, dim3(ny), dim3(64), 0, c->stream, o->state, bd);
         MMF_HIP_TRY(hipGetLastError());
     }
     if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[1], c->stream));
-    MMF_HIP_TRY(hipMemcpyAsync(o->host_result, o->state, sizeof(OdomState), hipMemcpyDeviceToHost, c->stream));
-    o->pending_icp = icp, o->pending_so3 = so3 != 0;
+    for (unsigned m = 0; m < ny; ++m) {  // every model's result towards the host, on the chain's stream
+        mmf_odom* om = batch ? batch->o[m] : o;
+        MMF_HIP_TRY(hipMemcpyAsync(om->host_result, om->state, sizeof(OdomState), hipMemcpyDeviceToHost, c->stream));
+        om->pending_icp = icp, om->pending_so3 = so3 != 0;
+        om->track_stream = c->stream;
+        if (om != o) om->so3_prefetched = false;
+    }
     return MMF_OK;
+}
+
+// can several models ride one chain (every level on the fused producer path)?  Same tests as the loop above.
+static bool odom_batchable(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom) {
+    const bool icp = !rgb_only && icp_weight > 0, rgb = rgb_only || icp_weight < 100;
+    if (!icp || !rgb || rgb_only || !o->prep_batched || icp_default_variant(0) / 1000000 == 1) return false;
+    const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};
+    for (int i = 0; i < MMF_NUM_PYRS; ++i) {
+        if (!iterations[i]) continue;
+        const int cols = o->width >> i, rows = o->height >> i;
+        RgbResidualArgs ra = make_residual_args(1.f, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0, o->last_depth[i], 0,
+                                                o->last_image[i], 0, o->next_image[i], 0, o->corres[i], o->max_depth_delta_rgb,
+                                                cols, rows, nullptr, 0);
+        IcpArgs ia = odom_icp_args(o, i, nullptr);
+        if (!residual_vec4_ok(ra) || !icp2_fits(ia, kBlock, std::min(2, icp_max_px(ia, 2)))) return false;
+    }
+    return true;
 }
 
 // second half: wait for the stream, hand the result out
 static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
     mmf_ctx* c = o->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
-    MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    MMF_HIP_TRY(hipStreamSynchronize(o->track_stream ? o->track_stream : c->stream));  // the chain it rode on
+    o->track_stream = nullptr;
     const bool icp = o->pending_icp, so3 = o->pending_so3;
     if (o->timing) {
         float ms = 0.f;

@@ -44,7 +44,7 @@ struct PrepJob {
     float f[12];
 };
 
-constexpr int kMaxPrepJobs = 12;
+constexpr int kMaxPrepJobs = 24;  // 24 x 144 B of kernel arguments; longer job lists go out as several launches
 struct PrepBatch {
     int njobs;
     PrepJob job[kMaxPrepJobs];

@@ -462,6 +462,22 @@ __global__ __launch_bounds__(kBlock) void rgb_residual_kernel(const OdomState* _
         residual_block<MODE == FINISH_GN>(st, a, partials, lds, blockIdx.x, gridDim.x);
 }
 
+// ---- several rigid-body models in ONE launch ----------------------------------------------------------------
+// The Gauss-Newton chains of the models of a frame (MultiMotionFusion.cpp:312-387: one performTracking per model)
+// are independent and have the same fixed schedule, so the orchestrator runs them as ONE chain of launches with
+// gridDim.y = number of models instead of one chain per model (the launches are latency bound: ~20 us per
+// iteration whatever the work).  Every RGBDOdometry keeps all its buffers -- state, model-side pyramids, records,
+// reduction scratch, error images -- in one slab with the same layout, so model m's pointers are model 0's plus
+// the byte distance between the two slabs; the sensor-side images are shared and take no offset.
+constexpr int kMaxBatch = 8;
+struct BatchDelta {
+    long long d[kMaxBatch];  // slab(m) - slab(0) in bytes; d[0] = 0
+};
+template <typename T>
+__device__ __forceinline__ T* batch_shift(T* p, long long d) {
+    return p ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + d) : p;
+}
+
 // Both producers of one Gauss-Newton iteration in ONE launch: workgroups [0, icp_blocks) run the
 // ICP reduction, the rest the photometric correspondence pass.  The two passes are independent
 // (RGBDOdometry.cpp:363-410), so running them side by side removes a launch boundary and lets
@@ -470,8 +486,18 @@ template <int W, bool PACKED>
 __global__ __launch_bounds__(kBlock) void track_producer_kernel(const OdomState* __restrict__ st, IcpArgs ia,
                                                                 unsigned icp_blocks, RgbResidualArgs ra,
                                                                 float* __restrict__ icp_partials,
-                                                                int2* __restrict__ res_partials) {
+                                                                int2* __restrict__ res_partials, BatchDelta bd) {
     __shared__ GridReduceLds<float, kBlock> lds;
+    if (gridDim.y > 1) {  // model blockIdx.y: its state, model-side maps, records and error images (wave uniform)
+        const long long d = bd.d[blockIdx.y];
+        st = batch_shift(st, d);
+        ia.vmap_g_prev.base = batch_shift(ia.vmap_g_prev.base, d), ia.nmap_g_prev.base = batch_shift(ia.nmap_g_prev.base, d);
+        ia.prev_packed = batch_shift(ia.prev_packed, d), ia.err_map = batch_shift(ia.err_map, d);
+        ra.last_depth = batch_shift(ra.last_depth, d), ra.next_depth = batch_shift(ra.next_depth, d);
+        ra.last_image = batch_shift(ra.last_image, d), ra.corres = batch_shift(ra.corres, d);
+        ra.err_map = batch_shift(ra.err_map, d);
+        icp_partials = batch_shift(icp_partials, d), res_partials = batch_shift(res_partials, d);
+    }
     // st->level_break is checked inside the blocks, after their state-independent loads are in flight
     using T = typename std::conditional<W == 2, v2f, float>::type;
     // the correspondence workgroups are the long pole of the launch (phase stamps): they take the
@@ -616,8 +642,15 @@ __device__ __forceinline__ void rgb_rows(const RgbStepArgs& a, float sigma, bool
 template <int MODE, int PX, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict__ st, RgbStepArgs a,
                                                           float* __restrict__ partials,
-                                                          unsigned* __restrict__ ticket) {
+                                                          unsigned* __restrict__ ticket, BatchDelta bd) {
     __shared__ GridReduceLds<float, kBlock> lds;
+    if (gridDim.y > 1) {  // model blockIdx.y (see BatchDelta)
+        const long long d = bd.d[blockIdx.y];
+        st = batch_shift(st, d);
+        a.corres = batch_shift(a.corres, d), a.cloud = batch_shift(a.cloud, d);
+        a.icp_partials = batch_shift(a.icp_partials, d), a.residual_partials = batch_shift(a.residual_partials, d);
+        partials = batch_shift(partials, d), ticket = batch_shift(ticket, d);
+    }
     MMF_STAMP(0);
     const int N = a.cols * a.rows;
     int i0 = (blockIdx.x * kBlock + threadIdx.x) * PX;
@@ -834,6 +867,9 @@ __global__ __launch_bounds__(kBlock) void so3_kernel(OdomState* __restrict__ st,
 }
 
 // ---- single-lane bookkeeping of the device-resident loop ----------------------------------
+struct BeginPoses {  // the pose each model's tracking starts from (batched launches)
+    float trans[kMaxBatch][3], rot[kMaxBatch][9];
+};
 struct BeginArgs {
     float trans[3], rot[9];
     int rgb_only, icp, rgb, so3;
@@ -889,9 +925,22 @@ __device__ __forceinline__ void gn_level_begin(OdomState* st, int first_level, c
     for (int k = 0; k < 3; ++k) st->kt[k] = kt[k];
 }
 
-// RGBDOdometry.cpp:221-228, 237, 252-255, 316-328
-__global__ void odom_begin_kernel(OdomState* st, BeginArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// the SO3 pre-alignment depends on the two sensor images only (RGBDOdometry.cpp:239-310): with the sensor side
+// shared by all models of a frame it is computed once, in the leader's state, and copied to the others
+__device__ __forceinline__ void so3_share(OdomState* dst, const OdomState* src) {
+    const So3State s = so3_load(src);
+    so3_store(dst, s);
+}
+
+// RGBDOdometry.cpp:221-228, 237, 252-255, 316-328.  Batched: block m = model m, poses from `poses`.
+__global__ void odom_begin_kernel(OdomState* st, BeginArgs a, BatchDelta bd, BeginPoses poses) {
+    if (threadIdx.x != 0) return;
+    const OdomState* leader = st;
+    if (gridDim.x > 1) {
+        st = batch_shift(st, bd.d[blockIdx.x]);
+        for (int k = 0; k < 9; ++k) a.rot[k] = poses.rot[blockIdx.x][k];
+        for (int k = 0; k < 3; ++k) a.trans[k] = poses.trans[blockIdx.x][k];
+    }
     for (int k = 0; k < 9; ++k) st->Rprev[k] = st->Rcurr[k] = a.rot[k];
     for (int k = 0; k < 3; ++k) st->tprev[k] = st->tcurr[k] = a.trans[k];
     inverse3f(st->Rprev, st->Rprev_inv);
@@ -902,17 +951,25 @@ __global__ void odom_begin_kernel(OdomState* st, BeginArgs a) {
     st->icp_weight = a.icp_weight;
     st->level_break = 0;
     st->st.iterations_run = 0;
-    if (!a.so3_prefetched) so3_begin(st, a.so3_intr, a.so3);
+    if (!a.so3_prefetched)
+        so3_begin(st, a.so3_intr, a.so3);
+    else if (blockIdx.x > 0)
+        so3_share(st, leader);  // the prefetched pre-alignment sits complete in the leader's state (nobody writes it here)
     if (a.fold_level_begin) gn_level_begin(st, 1, a.first_intr);
 }
 
-__global__ void gn_level_begin_kernel(OdomState* st, int first_level, LevelIntr intr) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// share_so3: the SO3 loop has just run in the leader's state (block 0's)
+__global__ void gn_level_begin_kernel(OdomState* st, int first_level, LevelIntr intr, BatchDelta bd, int share_so3) {
+    if (threadIdx.x != 0) return;
+    const OdomState* leader = st;
+    if (gridDim.x > 1) st = batch_shift(st, bd.d[blockIdx.x]);
+    if (share_so3 && blockIdx.x > 0) so3_share(st, leader);
     gn_level_begin(st, first_level, intr);
 }
 
-__global__ void odom_end_kernel(OdomState* st) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void odom_end_kernel(OdomState* st, BatchDelta bd) {
+    if (threadIdx.x != 0) return;
+    if (gridDim.x > 1) st = batch_shift(st, bd.d[blockIdx.x]);
     odom_end(st);
 }
 

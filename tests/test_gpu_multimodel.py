@@ -124,3 +124,40 @@ def test_three_objects_spawned_one_per_frame(gpu_ctx, orc, w, h, with_data, sync
         assert err < 0.01, (k, err)
         assert synth.rotation_angle(p_est[:3, :3], p_gt[:3, :3]) < 0.04
     g.close()
+
+
+def test_batched_chain_equals_one_chain_per_model(gpu_ctx):
+    """The Gauss-Newton chains of all models of a frame run as ONE chain of launches (gridDim.y = model, every model's
+    buffers at its slab offset, the SO3 pre-alignment computed once and shared); batch_tracking = 0 runs one chain per
+    model on the model's own stream.  Same kernels on the same data: poses and maps must agree bit for bit."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h, n_frames, n_obj = 320, 240, 7, 4
+    K, poses, traj, frames, objs = scene(w, h, n_frames, n_obj, seed=31)
+    rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+
+    def run(batch):
+        g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1, preallocated_models=n_obj,
+                              batch_tracking=batch)
+        known, out, keep = [0], [], []
+        for i, f in enumerate(frames):
+            spawn = 1 <= i <= n_obj
+            if spawn:
+                known.append(i)
+            keep.append(dev(gt_mask(f["ids"], known)))
+            g.processFrame(rgb[i], depth[i], timestamp=i, mask=keep[-1], hasNewLabel=spawn)
+            out.append([m.getPose() for m in g.getModels()])
+        maps = [m.downloadMap() for m in g.getModels()]
+        stats = [(g.getModelOdometry(k).lastICPCount, g.getModelOdometry(k).lastRGBCount, g.getModelOdometry(k).iterations_run) for k in range(len(maps))]
+        err = g.getErrorTexture(1, "icp").cpu().numpy().copy()
+        g.close()
+        return out, maps, stats, err
+
+    a, b = run(1), run(0)
+    for i in range(n_frames):
+        assert len(a[0][i]) == len(b[0][i]) == min(i, n_obj) + 1
+        for k, (pa, pb) in enumerate(zip(a[0][i], b[0][i])):
+            assert np.array_equal(pa, pb), (i, k, np.abs(pa - pb).max())
+    for sa, sb in zip(a[1], b[1]):
+        assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32))
+    assert a[2] == b[2] and all(s[2] == 19 for s in a[2])
+    assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)) and (a[3] > 0).sum() > 100  # every model's own error image
