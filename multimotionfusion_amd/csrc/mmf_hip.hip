@@ -1440,7 +1440,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[1], c->stream));
     for (unsigned m = 0; m < ny; ++m) {  // every model's result towards the host, on the chain's stream
         mmf_odom* om = batch ? batch->o[m] : o;
-        MMF_HIP_TRY(hipMemcpyAsync(om->host_result, om->state, sizeof(OdomState), hipMemcpyDeviceToHost, c->stream));
+        MMF_HIP_TRY(hipMemcpyAsync(om->host_result, om->state, offsetof(OdomState, res_acc), hipMemcpyDeviceToHost, c->stream));
         om->pending_icp = icp, om->pending_so3 = so3 != 0;
         om->track_stream = c->stream;
         if (om != o) om->so3_prefetched = false;

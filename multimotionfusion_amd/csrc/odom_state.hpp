@@ -57,9 +57,15 @@ struct OdomState {
     // {count, sum diff^2} of the photometric correspondence pass of the current Gauss-Newton step,
     // accumulated with integer atomics (exact, order independent) over kResShards address pairs;
     // zeroed by gn_level_begin_kernel and by the finishing lane of every step
-    unsigned res_acc[16];
+    // over kResShards address pairs, each pair on ITS OWN 128-byte line: device-scope atomics on one line serialise
+    // (~12 ns per arrival); with all 16 counters in one line the 600 atomics of a 640x480 correspondence pass
+    // cost ~7 us -- more than the pass itself (and 4x that at 1280x960)
+    // Count and sum travel in ONE 64-bit atomic: count << 40 | sum (sum < 2^40 per shard: 255^2 x 16 M pixels).
+    alignas(128) unsigned long long res_acc[16 * 16];
 };
-constexpr int kResShards = 8;
+constexpr int kResShards = 16;
+constexpr int kResStride = 16;  // 64-bit words between two shards (128 B)
+constexpr int kResCountShift = 40;
 
 // ---- small dense algebra (double unless suffixed f) -----------------------------------------
 

@@ -227,9 +227,9 @@ __device__ __forceinline__ void residual_publish(const OdomState* st, int2* __re
                                                  int sigma) {
     if (threadIdx.x != 0) return;
     if (ACC) {
-        unsigned* acc = const_cast<unsigned*>(st->res_acc) + 2 * (bid % kResShards);
-        (void)__hip_atomic_fetch_add(acc, (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (void)__hip_atomic_fetch_add(acc + 1, (unsigned)sigma, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* acc = const_cast<unsigned long long*>(st->res_acc) + kResStride * (bid % kResShards);
+        const unsigned long long packed = ((unsigned long long)(unsigned)count << kResCountShift) | (unsigned long long)(unsigned)sigma;
+        (void)__hip_atomic_fetch_add(acc, packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         partials[bid] = make_int2(count, sigma);
     }
@@ -671,8 +671,10 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     unsigned cnt = 0, sg = 0;
     if (MODE == FINISH_GN) {
         si = load_solve_in(st);
+        unsigned long long acc = 0;
 #pragma unroll
-        for (int k = 0; k < kResShards; ++k) cnt += st->res_acc[2 * k], sg += st->res_acc[2 * k + 1];
+        for (int k = 0; k < kResShards; ++k) acc += st->res_acc[kResStride * k];
+        cnt = (unsigned)(acc >> kResCountShift), sg = (unsigned)(acc & ((1ull << kResCountShift) - 1ull));  // the sum wraps at 2^32 like the reference's int
     }
     __builtin_amdgcn_sched_barrier(0);
     RgbLane<PX> lane;
@@ -732,10 +734,10 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
         // solving lane starts from the finished matrix
         __shared__ double sol[42];
         if (threadIdx.x < 42) sol[threadIdx.x] = combine_element(st, threadIdx.x, si.w, lds.total, icp ? lds.total2 : nullptr);
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + kResShards)  // the next correspondence pass starts from zero totals
+            st->res_acc[kResStride * (threadIdx.x - 64)] = 0ull;
         __syncthreads();
         if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < 2 * kResShards; ++k) st->res_acc[k] = 0u;
             st->sigma = res_sigma;
             st->rgbCount = res_count;
             st->sigmaVal = dec.sigmaVal;
@@ -920,7 +922,7 @@ __device__ __forceinline__ void gn_level_begin(OdomState* st, int first_level, c
     rgb_prepare(resultRt, intr, krkinv, kt);
     st->st.lastRGBError = FLT_MAX;
     st->level_break = 0;
-    for (int k = 0; k < 2 * kResShards; ++k) st->res_acc[k] = 0u;
+    for (int k = 0; k < kResShards; ++k) st->res_acc[kResStride * k] = 0ull;
     for (int k = 0; k < 9; ++k) st->krkinv[k] = krkinv[k];
     for (int k = 0; k < 3; ++k) st->kt[k] = kt[k];
 }
