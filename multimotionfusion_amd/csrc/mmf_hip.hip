@@ -1940,7 +1940,6 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     MMF_REQUIRE(m != nullptr, "mmf_model_combined_predict: null model");
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
-    const size_t npix = (size_t)m->width * m->height;
     SplatArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
     a.c = make_cam(m, false);
@@ -1955,11 +1954,11 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
         hipLaunchKernelGGL(splat_kernel, grid1d(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
                            m->keys, m->count_pending ? m->totals : nullptr);
     if (fill_rgb && fill_depth)
-        hipLaunchKernelGGL(splat_resolve_fill_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys,
+        hipLaunchKernelGGL(splat_resolve_fill_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys,
                            m->image, m->vertexConf, m->normalRadius, m->time_tex, fill_depth, fill_rgb, lost ? 1 : 0,
                            (lost || frame_to_frame_rgb) ? 1 : 0, m->fill_vertex, m->fill_normal, m->fill_image);
     else
-        hipLaunchKernelGGL(splat_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->image,
+        hipLaunchKernelGGL(splat_resolve_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->image,
                            m->vertexConf, m->normalRadius, m->time_tex);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
@@ -1976,7 +1975,6 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
     MMF_REQUIRE(m != nullptr, "mmf_model_synthesize_depth: null model");
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
-    const size_t npix = (size_t)m->width * m->height;
     SplatArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
     a.c = make_cam(m, false);
@@ -1988,7 +1986,7 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
     if (m->count)
         hipLaunchKernelGGL(splat_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
                            m->keys, nullptr);
-    hipLaunchKernelGGL(splat_depth_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys,
+    hipLaunchKernelGGL(splat_depth_resolve_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys,
                        m->synth_depth);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
