@@ -47,6 +47,24 @@ static int fail(int code, const std::string& msg) {
         if (!(cond)) return fail(MMF_ERR_INVALID, (msg));       \
     } while (0)
 
+// Waiting for a short dependent chain: hipStreamSynchronize / hipEventSynchronize park the thread and wake it ~20-30 us
+// after the work is done (measured as idle gaps in the kernel trace); the frame has two such waits on its critical path.
+// Poll first (the waits are a few hundred microseconds at most), park only when the work takes unusually long.
+static hipError_t wait_stream(hipStream_t s) {
+    for (int i = 0; i < 200000; ++i) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+    }
+    return hipStreamSynchronize(s);
+}
+static hipError_t wait_event(hipEvent_t ev) {
+    for (int i = 0; i < 200000; ++i) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+    }
+    return hipEventSynchronize(ev);
+}
+
 extern "C" int mmf_abi_version(void) { return MMF_ABI_VERSION; }
 extern "C" const char* mmf_last_error(void) { return g_last_error.c_str(); }
 
@@ -1469,7 +1487,7 @@ static bool odom_batchable(mmf_odom* o, int rgb_only, float icp_weight, int pyra
 static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
     mmf_ctx* c = o->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
-    MMF_HIP_TRY(hipStreamSynchronize(o->track_stream ? o->track_stream : c->stream));  // the chain it rode on
+    MMF_HIP_TRY(wait_stream(o->track_stream ? o->track_stream : c->stream));  // the chain it rode on
     o->track_stream = nullptr;
     const bool icp = o->pending_icp, so3 = o->pending_so3;
     if (o->timing) {
@@ -1683,6 +1701,7 @@ struct mmf_model {
     float4 *fill_vertex = nullptr, *fill_normal = nullptr;
     uchar4* fill_image = nullptr;
     unsigned* host_totals = nullptr;  // pinned
+    hipEvent_t ev_count = nullptr;    // the copy of the count towards host_totals has landed
 };
 
 static Cam make_cam(const mmf_model* m, bool double_reciprocal) {
@@ -1797,6 +1816,7 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     hipLaunchKernelGGL(fill_u64_kernel, grid1d(npix), dim3(256), 0, c->stream, m->keys, npix, kEmptyKey);
     MMF_HIP_TRY(hipGetLastError());
     MMF_HIP_TRY(hipHostMalloc(&m->host_totals, 64, hipHostMallocDefault));
+    MMF_HIP_TRY(hipEventCreateWithFlags(&m->ev_count, hipEventDisableTiming));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
     *out = m;
     return MMF_OK;
@@ -1808,6 +1828,7 @@ extern "C" void mmf_model_destroy(mmf_model* m) {
     (void)hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(m->slab);
     (void)hipHostFree(m->host_totals);
+    if (m->ev_count) (void)hipEventDestroy(m->ev_count);
     delete m;
 }
 
@@ -1837,7 +1858,9 @@ extern "C" int mmf_model_id(mmf_model* m) { return m ? (int)m->id : -1; }
 // makes m->count exact again (after the stream has passed the clean pass that produced it)
 static int model_resolve_count(mmf_model* m) {
     if (!m->count_pending) return MMF_OK;
-    MMF_HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    // only the copy that follows the clean pass is awaited, not whatever has been enqueued since (a stream
+    // synchronisation here idled the GPU for ~45 us per frame: the splat of the frame was already in the queue)
+    MMF_HIP_TRY(wait_event(m->ev_count));
     m->count = m->host_totals[0] < (unsigned)m->capacity ? m->host_totals[0] : (unsigned)m->capacity;
     m->count_pending = false;
     return MMF_OK;
@@ -2046,6 +2069,7 @@ extern "C" int mmf_model_clean(mmf_model* m, int time, int time_delta, float dep
     // glGetQueryObjectuiv(countQuery) in the reference (Model.cpp:1166) stalls for the count; here it travels
     // to the host asynchronously and is picked up by the next call that needs it on the host
     MMF_HIP_TRY(hipMemcpyAsync(m->host_totals, m->totals, 16, hipMemcpyDeviceToHost, c->stream));
+    MMF_HIP_TRY(hipEventRecord(m->ev_count, c->stream));
     m->count_bound = n < (unsigned)m->capacity ? n : (unsigned)m->capacity;
     m->count_pending = true;
     m->cur = 1 - m->cur;

@@ -17,8 +17,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 W, H = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "640x480").split("x"))
 models = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 prefetch = (sys.argv[4] if len(sys.argv) > 4 else "1") != "0"
+headline = len(sys.argv) > 5 and sys.argv[5] == "headline"  # bench.py's N = 1 loop: 30 frames, reset when the sequence wraps
 K = synth.intrinsics(W, H)
-nf = 10
+nf = 30 if headline else 10
 poses = synth.trajectory(nf, seed=1)
 objs = synth.make_objects(7, seed=2) if models > 1 else None
 traj = synth.object_trajectories(objs, nf, seed=2) if objs else None
@@ -37,6 +38,14 @@ def frame_of(i):
 
 for i in range(n):
     k = frame_of(i)
+    if headline:
+        k = i % nf
+        if i and k == 0:
+            g.reset()
+        g.processFrame(rgb[k], depth[k], timestamp=i)
+        if (i + 1) % nf != 0:
+            g.prefetchFrame(rgb[(i + 1) % nf], depth[(i + 1) % nf])
+        continue
     if models > 1:
         g.processFrame(rgb[k], depth[k], timestamp=i, mask=mask[k], hasNewLabel=1 <= i < models)
     else:
