@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-frames", type=int, default=40)
+    ap.add_argument("--extras", action="store_true", help="also time the SURVEY 8(f) kernels beside the path: descriptor "
+                    "matcher and SuperPoint (MFMA), super-pixel resampling")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
@@ -443,6 +445,37 @@ def main():
         }
         if t_err is not None:
             result["last_frame_translation_error_m"] = t_err
+        if args.extras and not config5:
+            # the keypoint descriptor matcher: 1024 x 1024 descriptors of 256 floats on v_mfma_f32_32x32x2_f32
+            gen = torch.Generator(device="cpu").manual_seed(0)
+            dq = torch.nn.functional.normalize(torch.randn(1024, 256, generator=gen), dim=1).to(dev)
+            dt = torch.nn.functional.normalize(torch.randn(1024, 256, generator=gen), dim=1).to(dev)
+            from multimotionfusion_amd.matcher import matchDescriptors
+            matchDescriptors(ctx, dq, dt, 0.7)  # sizes the workspace
+            m_idx = torch.empty(1024, dtype=torch.int32, device=dev)
+            m_dist = torch.empty(1024, dtype=torch.float32, device=dev)
+            us_match = timed(lambda: ctx.lib.mmf_match_descriptors(ctx.handle, _p(dq), 1024, _p(dt), 1024, 256, 0.7, _p(m_idx), _p(m_dist)), reps=100)
+            flops = 2.0 * 1024 * 1024 * 256
+            result["matcher"] = {"us": us_match, "nq": 1024, "nt": 1024, "dim": 256, "TFLOPs": flops / us_match / 1e6,
+                                 "frac_f32_mfma_peak": flops / us_match / 1e6 / 157.3, "launches": 3}
+            # the SuperPoint network: one forward pass on an image of the bench size, random-init weights, f32 MFMA
+            from multimotionfusion_amd.superpoint import SuperPoint, forward_flops, random_weights
+            kp = SuperPoint(ctx, random_weights(0), max_width=W, max_height=H)
+            us_sp = timed(lambda: kp.enqueue(d_rgb[0]), reps=30)
+            fl_sp = float(forward_flops(W, H))
+            result["superpoint"] = {"us": us_sp, "GFLOP": fl_sp / 1e9, "TFLOPs": fl_sp / us_sp / 1e6,
+                                    "frac_f32_mfma_peak": fl_sp / us_sp / 1e6 / 157.3, "launches": 13, "dtype": "f32",
+                                    "weights": "random-init SuperPointNet architecture"}
+            kp.close()
+            # super-pixel resampling of a per-model map: a regular grid stands in for gSLICr's mask
+            S = 16
+            yy, xx = np.mgrid[0:H, 0:W]
+            labels = torch.from_numpy(((yy // S).clip(0, H // S - 1) * (W // S) + (xx // S).clip(0, W // S - 1)).astype(np.int32)).to(dev)
+            err_map = torch.rand((H, W), device=dev)
+            slic_out = torch.empty((H // S, W // S), dtype=torch.float32, device=dev)
+            slic_raw = lambda: ctx.lib.mmf_slic_downsample(ctx.handle, _p(labels), W, H, S, _p(err_map), 1, 0, 0, 0.0, _p(slic_out), None)  # noqa: E731
+            slic_raw()
+            result["slic_downsample"] = {"us": timed(slic_raw, reps=50), "superpixels": (H // S) * (W // S), "bytes_in": 8 * n0}
         if config5 and world > 1:
             result["config"]["scaling_note"] = ("weak scaling: the frame size is the N = 1 metric's (640x480) and every GPU runs one rigid-body "
                                                 "model; BASELINE.json configs[4] (1280x960) on the same ranks is the `config5` object of this "

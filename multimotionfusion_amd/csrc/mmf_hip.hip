@@ -767,6 +767,8 @@ struct mmf_odom {
     bool so3_prefetched = false;  // this frame's SO3 pre-alignment already ran (odom_prefetch_so3)
     bool pending_icp = false, pending_so3 = false;  // mode of the tracking call that is in flight (enqueue -> finish)
     hipStream_t track_stream = nullptr;             // the stream that call's chain runs on (the batch leader's)
+    hipEvent_t ev_result = nullptr;                 // recorded right behind the copy of the result towards the host
+    mmf_odom* result_of = nullptr;                  // the odometry (batch leader) whose ev_result covers this one's copy
     // measurement mode (mmf_odom_enable_timing): every producer / rgb_step launch of a tracking call carries its own
     // start / stop events (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps), the whole chain two more
     int timing = 0;  // 1: chain events only; 2: also every kernel of the chain
@@ -866,6 +868,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     o->gn_partials_res = (int2*)(base + o_pr), o->gn_ticket = (unsigned*)(base + o_tk);
     o->icp_err = (float*)(base + o_ei), o->rgb_err = (float*)(base + o_er);
     MMF_HIP_TRY(hipHostMalloc(&o->host_result, sizeof(OdomState), hipHostMallocDefault));
+    MMF_HIP_TRY(hipEventCreateWithFlags(&o->ev_result, hipEventDisableTiming));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
     *out = o;
     return MMF_OK;
@@ -881,6 +884,7 @@ extern "C" void mmf_odom_destroy(mmf_odom* o) {
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : o->ev_chain)
         if (e) (void)hipEventDestroy(e);
+    if (o->ev_result) (void)hipEventDestroy(o->ev_result);
     delete o;
 }
 
@@ -1461,8 +1465,11 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         MMF_HIP_TRY(hipMemcpyAsync(om->host_result, om->state, offsetof(OdomState, res_acc), hipMemcpyDeviceToHost, c->stream));
         om->pending_icp = icp, om->pending_so3 = so3 != 0;
         om->track_stream = c->stream;
+        om->result_of = o;
         if (om != o) om->so3_prefetched = false;
     }
+    // what finish waits for: the copies, not whatever the caller enqueues behind them on this stream
+    MMF_HIP_TRY(hipEventRecord(o->ev_result, c->stream));
     return MMF_OK;
 }
 
@@ -1487,8 +1494,8 @@ static bool odom_batchable(mmf_odom* o, int rgb_only, float icp_weight, int pyra
 static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
     mmf_ctx* c = o->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
-    MMF_HIP_TRY(wait_stream(o->track_stream ? o->track_stream : c->stream));  // the chain it rode on
-    o->track_stream = nullptr;
+    MMF_HIP_TRY(o->result_of ? wait_event(o->result_of->ev_result) : wait_stream(c->stream));  // the chain it rode on
+    o->track_stream = nullptr, o->result_of = nullptr;
     const bool icp = o->pending_icp, so3 = o->pending_so3;
     if (o->timing) {
         float ms = 0.f;
