@@ -17,6 +17,7 @@ ranks (weak scaling).  MMF_BENCH_WORKLOAD=config5 runs that workload at N = 1 to
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -220,10 +221,16 @@ def main():
             if state["frame"] and k == 0:  # sequence wrapped: start a fresh map (the trajectory jumps back)
                 mmf.reset()
             state["frame"] += 1
-            mmf.processFrame(d_rgb[k], d_depth[k], timestamp=i)
             kn = state["frame"] % len(frames)
-            if PREFETCH and kn != 0:  # the next frame's filter, pyramids and SO3 pre-alignment overlap this frame's fusion
-                mmf.prefetchFrame(d_rgb[kn], d_depth[kn])
+            # the next frame's buffers ride along (mmf_frame::next_*): its filter, pyramids and SO3 pre-alignment are
+            # enqueued while this call waits for its pose and overlap this frame's fusion on two side streams
+            nxt = (d_rgb[kn], d_depth[kn]) if PREFETCH and kn != 0 else None
+            if os.environ.get("MMF_BENCH_SEPARATE_PREFETCH"):
+                mmf.processFrame(d_rgb[k], d_depth[k], timestamp=i)
+                if nxt:
+                    mmf.prefetchFrame(*nxt)
+            else:
+                mmf.processFrame(d_rgb[k], d_depth[k], timestamp=i, next=nxt)
             return mmf.getCurrPose()
 
         def fence():
@@ -320,12 +327,30 @@ def main():
         for i in range(warmup):
             step(i)
         fence()
+        # the harness's own interpreter must not stall the frame loop: a generation-2 collection of CPython's cyclic GC
+        # (every object torch's import created: 35-41 ms, once, at an allocation count that falls inside the timed
+        # steps) showed up as one 41 ms step = 7 % of a 600-step run (MMF_BENCH_FRAME_TIMES=1 prints the per-step times)
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         pose = None
+        stamps = [] if os.environ.get("MMF_BENCH_FRAME_TIMES") else None  # diagnostic: per-step host times to stderr
+        lt = []
         for i in range(steps):
             pose = step(warmup + i)
+            if stamps is not None:
+                stamps.append(time.perf_counter())
+                lt.append(mmf.lastTimings())
         fence()
         dt = time.perf_counter() - t0
+        gc.enable()
+        if stamps:
+            d = np.diff(np.array([t0] + stamps)) * 1e6
+            print("[frame times us] min %.0f p10 %.0f median %.0f p90 %.0f max %.0f; thirds of the run: %s" % (
+                d.min(), np.percentile(d, 10), np.median(d), np.percentile(d, 90), d.max(),
+                [round(float(np.median(c))) for c in np.array_split(d, 3)]),
+                "; slowest steps (index, us, tracking phase us, processFrame us):",
+                [(int(j), round(float(d[j])), round(lt[j][0] * 1e6), round(lt[j][1] * 1e6)) for j in np.argsort(d)[-3:][::-1]], file=sys.stderr)
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 2
+#define MMF_ABI_VERSION 3
 
 typedef enum {
     MMF_OK = 0,
@@ -355,6 +355,11 @@ typedef struct {
     int icp_refine; /* odom_cfg.icp_refine */
     /* enable_multiple_models: the result of performSegmentation(frame) for THIS frame; NULL = ask the callback */
     const mmf_segmentation *segmentation;
+    /* optional hint (both or neither): the buffers the NEXT processFrame call will be given.  Their sensor-side
+     * preparation (mmf_fusion_prefetch_frame) is then enqueued inside this call, while the host waits for this frame's
+     * pose, instead of by a separate call afterwards.  Same contract: the next call gets these buffers, unchanged. */
+    const uint8_t *next_rgb;
+    const float *next_depth;
 } mmf_frame;
 
 /* called where the reference calls performSegmentation (:412): every model of this frame has been tracked

@@ -65,7 +65,7 @@ class mmf_frame(C.Structure):
     _fields_ = [("rgb", C.c_void_p), ("depth", C.c_void_p), ("timestamp", C.c_longlong),
                 ("in_pose", C.POINTER(C.c_float)), ("weight_multiplier", C.c_float), ("bootstrap", C.c_int),
                 ("init_transforms", C.POINTER(C.c_float)), ("n_init_transforms", C.c_int), ("icp_refine", C.c_int),
-                ("segmentation", C.POINTER(mmf_segmentation))]
+                ("segmentation", C.POINTER(mmf_segmentation)), ("next_rgb", C.c_void_p), ("next_depth", C.c_void_p)]
 
 
 SEGMENTATION_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(mmf_frame), C.POINTER(mmf_segmentation))

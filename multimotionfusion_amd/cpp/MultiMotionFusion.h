@@ -34,6 +34,10 @@ struct FrameDataDevice {
     const float* depth = nullptr;  // float32 metres, 0 = invalid
     const uint8_t* mask = nullptr;
     bool hasNewLabel = false;
+    // not in the reference (a LogReader knows its next frame): the buffers the NEXT call will be given; their
+    // sensor-side preparation is then enqueued while this call waits for its pose (mmf_frame::next_rgb / next_depth)
+    const uint8_t* nextRgb = nullptr;
+    const float* nextDepth = nullptr;
 };
 
 class ModelProjection;
@@ -275,9 +279,6 @@ class MultiMotionFusion {
     }
     bool processFrame(const FrameDataDevice& frame, const float* inPose = nullptr, const float weightMultiplier = 1.f,
                       const bool bootstrap = false) {
-        if (!frame.mask)
-            return finish(mmf_fusion_process_frame(f_, frame.rgb, frame.depth, frame.timestamp, inPose, weightMultiplier, bootstrap),
-                          "mmf_fusion_process_frame");
         mmf_segmentation seg;
         std::memset(&seg, 0, sizeof(seg));
         seg.mask = frame.mask, seg.has_new_label = frame.hasNewLabel;
@@ -285,7 +286,8 @@ class MultiMotionFusion {
         std::memset(&fr, 0, sizeof(fr));
         fr.rgb = frame.rgb, fr.depth = frame.depth, fr.timestamp = frame.timestamp;
         fr.in_pose = inPose, fr.weight_multiplier = weightMultiplier, fr.bootstrap = bootstrap, fr.icp_refine = 1;
-        fr.segmentation = &seg;
+        fr.segmentation = frame.mask ? &seg : nullptr;
+        fr.next_rgb = frame.nextRgb, fr.next_depth = frame.nextDepth;
         return finish(mmf_fusion_process_frame_ex(f_, &fr), "mmf_fusion_process_frame_ex");
     }
     // the same frame step with odom_cfg.init == "kp" (MultiMotionFusion.cpp:312-384): trackTransform is

@@ -67,6 +67,7 @@ struct mmf_fusion {
     // clean / fill-in read one while frame t+1's filter writes the other.
     float* filtered[2] = {nullptr, nullptr};
     int cur = 0;
+    GraphCache depth_chain_graphs, image_chain_graphs;  // the two launch chains of a prefetch (launch_graph.hpp)
     hipStream_t side = nullptr;   // depth chain: filter, depth pyramid, vertex / normal maps
     hipStream_t side2 = nullptr;  // image chain: intensity pyramid, gradients, SO3 pre-alignment
     float* side_partials = nullptr;   // reduction scratch of the SO3 launches on side2 (never the context's: the
@@ -486,6 +487,8 @@ static int fusion_spawn(mmf_fusion* f, FusionModel** out) {
     return MMF_OK;
 }
 
+static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* depth, int tick_at_use);
+
 static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     MMF_REQUIRE(f != nullptr && fr != nullptr, "mmf_fusion_process_frame: null argument");
     const uint8_t* rgb = fr->rgb;
@@ -502,6 +505,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     FusionModel* global = f->models[0];
     int rc = MMF_OK;
     bool prefetched = false;
+    bool next_prefetched = false;  // mmf_frame::next_* has been enqueued
     if (f->pre_valid) {  // whatever was prefetched has to be complete before this frame touches the same buffers
         MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch_done, 0));
         MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch2_done, 0));
@@ -627,7 +631,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 PrepStages stages;
                 for (size_t k = 0; k < tracked.size(); ++k)
                     collect_prep(stages, tracked[k], (k == 0 && tracked[k] == global && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE);
-                rc = stages.launch(st);
+                rc = stages.launch(st, graphs_enabled() ? &lead->odom->prep_graphs : nullptr);
                 if (rc) return rc;
                 batch_ok = odom_batchable(lead->odom, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom);
                 if (batch_ok) {
@@ -658,7 +662,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 if (!batched) {  // (a failed batch has prepared every model already)
                     PrepStages stages;
                     collect_prep(stages, fm, (fm == global && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE);
-                    rc = stages.launch(fm->lane->stream);
+                    rc = stages.launch(fm->lane->stream, graphs_enabled() ? &fm->odom->prep_graphs : nullptr);
                     if (rc) return rc;
                 } else if (k > 0) {  // prepared on the leader's stream
                     MMF_HIP_TRY(hipEventRecord(fm->ev_done, tracked[0]->lane->stream));
@@ -672,11 +676,30 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                                            fm->icp_error, fm->rgb_error);
                 if (rc) return rc;
             }
-            bool any_tracked = false;
+            // the sensor-side image ring (this frame's / last frame's intensity pyramid, RGBDOdometry.cpp:469-473) lives in
+            // the global odometry and advances when its chain is enqueued: when its owner is another rank, the swap
+            // happens here, whether or not this rank tracked anything (every rank's ring must advance with the global model's)
             const bool global_tracked = global->tracking;
+            const bool global_tracks_somewhere = !(have_init && !fr->icp_refine);
+            if (g.so3 && global_tracks_somewhere && !global_tracked)
+                for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(global->odom->last_next_image[i], global->odom->next_image[i]);
+            // mmf_frame::next_*: the next frame's sensor-side preparation is enqueued NOW, while the chains run and the host
+            // would only wait -- possible when every chain is on the context's stream (one model, or one batched chain led
+            // by the global model): an event behind the chain is then "nothing enqueued so far reads the odometries'
+            // sensor-side buffers or the other filtered-depth buffer" in stream order.  Otherwise: after the results.
+            bool inputs_free_early = false;
+            static const bool early = std::getenv("MMF_PREFETCH_EARLY") != nullptr;
+            if (early && fr->next_rgb && fr->next_depth && !tracked.empty() && tracked[0]->lane->stream == c->stream &&
+                (tracked.size() == 1 || batch_ok)) {
+                MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
+                f->inputs_free_recorded = true;
+                inputs_free_early = true;
+                rc = fusion_prefetch_impl(f, fr->next_rgb, fr->next_depth, f->tick + 1);
+                if (rc) return rc;
+                next_prefetched = true;
+            }
             for (size_t k = 0; k < n_models; ++k) {  // the results, model by model
                 FusionModel* fm = f->models[k];
-                any_tracked = any_tracked || fm->tracking;
                 float pose[16];
                 mmf_model_get_pose(fm->model, pose);
                 if (fm->tracking) {
@@ -691,13 +714,6 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     fm->tracking = false;
                 }
             }
-            // the sensor-side image ring (this frame's / last frame's intensity pyramid, RGBDOdometry.cpp:469-473) lives in
-            // the global odometry: when its owner is another rank, the swap its tracking does there happens here, whether
-            // or not this rank tracked anything (every rank's ring must advance with the global model's)
-            (void)any_tracked;
-            const bool global_tracks_somewhere = !(have_init && !fr->icp_refine);
-            if (g.so3 && global_tracks_somewhere && !global_tracked)
-                for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(global->odom->last_next_image[i], global->odom->next_image[i]);
             f->t_tracking_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_track).count();
             if (fr->bootstrap) {  // :397-400
                 MMF_REQUIRE(fr->in_pose != nullptr, "mmf_fusion_process_frame: bootstrap needs in_pose");
@@ -709,8 +725,10 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             }
             // from here on nothing enqueued reads the odometries' sensor-side buffers or the other filtered-depth
             // buffer (every lane's tracking has been awaited): the next frame's prefetch may start
-            MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
-            f->inputs_free_recorded = true;
+            if (!inputs_free_early) {
+                MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
+                f->inputs_free_recorded = true;
+            }
             if (one_pass) MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
 
             if (g.enable_multiple_models) {  // :407-622
@@ -836,6 +854,10 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
         MMF_HIP_TRY(hipEventRecord(fm->ev_done, fm->lane->stream));
         MMF_HIP_TRY(hipStreamWaitEvent(c->stream, fm->ev_done, 0));
     }
+    if (fr->next_rgb && fr->next_depth && !next_prefetched) {  // (first frame, dictated pose, several lanes)
+        rc = fusion_prefetch_impl(f, fr->next_rgb, fr->next_depth, f->tick);
+        if (rc) return rc;
+    }
     f->t_frame_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return MMF_OK;
 }
@@ -925,8 +947,8 @@ extern "C" int mmf_fusion_predict(mmf_fusion* f) {
 // The filter and the input-side preparation (vertex / normal maps, depth and intensity pyramids, gradients) of the
 // NEXT frame, enqueued on a second stream so that they run while the current frame is still being fused.
 // rgb / depth must stay unchanged until the mmf_fusion_process_frame call that consumes them (same pointers).
-extern "C" int mmf_fusion_prefetch_frame(mmf_fusion* f, const uint8_t* rgb, const float* depth) {
-    MMF_REQUIRE(f && rgb && depth, "mmf_fusion_prefetch_frame: null argument");
+// `tick_at_use`: the tick of the processFrame call these buffers are for
+static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* depth, int tick_at_use) {
     mmf_ctx* c = f->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     mmf_odom* odom = f->models[0]->odom;
@@ -947,28 +969,39 @@ extern "C" int mmf_fusion_prefetch_frame(mmf_fusion* f, const uint8_t* rgb, cons
     const mmf_fusion_config& g = f->cfg;
     float identity[16];
     identity16(identity);
-    hipStream_t img_stream = f->side2;
-    // image chain (second side stream): intensity pyramid + gradients, then the SO3 pre-alignment, which needs
-    // nothing but this frame's and the last frame's level-2 images
-    int rc = odom_prepare_batched(odom, nullptr, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity,
-                                  nullptr, nullptr, nullptr, nullptr, PREP_INPUT_IMAGE, img_stream);
-    if (rc) return rc;
-    odom->so3_prefetched = false;
-    if (g.so3 && f->tick > 1) {  // a model exists: the frame will be tracked, SO3 first
-        rc = odom_prefetch_so3(odom, img_stream, f->side_partials, f->side_ticket);
-        if (rc) return rc;
-    }
-    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch2_done, img_stream));
-    // depth chain (first side stream): filter, depth pyramid, vertex and normal maps
+    // depth chain (first side stream): filter, depth pyramid, vertex and normal maps.  Enqueued FIRST: it is five
+    // launches that start with the 40 us filter, while the image chain below is fifteen short ones -- behind those the
+    // filter started ~100 us later (one host enqueue per launch) and the next frame waited for it.
     float* target = f->filtered[1 - f->cur];
-    rc = filter_depth_on(c, f->side, depth, f->width, f->height, g.depth_cutoff, target);
+    Enqueuer qd(f->side, graphs_enabled() ? &f->depth_chain_graphs : nullptr);
+    int rc = filter_depth_on(c, qd, depth, f->width, f->height, g.depth_cutoff, target);
     if (rc) return rc;
     rc = odom_prepare_batched(odom, target, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity, nullptr,
-                              nullptr, nullptr, nullptr, PREP_INPUT_DEPTH, f->side);
+                              nullptr, nullptr, nullptr, PREP_INPUT_DEPTH, f->side, &qd);
     if (rc) return rc;
+    MMF_HIP_TRY(qd.flush());
     MMF_HIP_TRY(hipEventRecord(f->ev_prefetch_done, f->side));
+    hipStream_t img_stream = f->side2;
+    Enqueuer qi(img_stream, graphs_enabled() ? &f->image_chain_graphs : nullptr);
+    // image chain (second side stream): intensity pyramid + gradients, then the SO3 pre-alignment, which needs
+    // nothing but this frame's and the last frame's level-2 images
+    rc = odom_prepare_batched(odom, nullptr, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity, nullptr,
+                              nullptr, nullptr, nullptr, PREP_INPUT_IMAGE, img_stream, &qi);
+    if (rc) return rc;
+    odom->so3_prefetched = false;
+    if (g.so3 && tick_at_use > 1) {  // a model exists: the frame will be tracked, SO3 first
+        rc = odom_prefetch_so3(odom, qi, f->side_partials, f->side_ticket);
+        if (rc) return rc;
+    }
+    MMF_HIP_TRY(qi.flush());
+    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch2_done, img_stream));
     f->pre_valid = true, f->pre_rgb = rgb, f->pre_depth = depth;
     return MMF_OK;
+}
+
+extern "C" int mmf_fusion_prefetch_frame(mmf_fusion* f, const uint8_t* rgb, const float* depth) {
+    MMF_REQUIRE(f && rgb && depth, "mmf_fusion_prefetch_frame: null argument");
+    return fusion_prefetch_impl(f, rgb, depth, f->tick);
 }
 
 extern "C" int mmf_fusion_get_pose(mmf_fusion* f, float pose[16]) {

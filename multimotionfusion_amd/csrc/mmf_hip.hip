@@ -17,6 +17,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "launch_graph.hpp"
 #include "map_kernels.hpp"
 #include "prep_batch.hpp"
 #include "pose_algebra.hpp"
@@ -722,8 +723,22 @@ extern "C" int mmf_compute_derivative_images(mmf_ctx* c, const uint8_t* src, siz
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxTimedLaunches = 48;  // 19 iterations x (producer + step)
 
+// MMF_GRAPHS=1 sends the launch chains (preparation, Gauss-Newton chain, the two prefetch chains) as hipGraph replays
+// (launch_graph.hpp).  Off by default: measured on MI355X the host enqueues a chain in 44-127 us instead of 135-177 us,
+// but the GPU is what a frame waits for, and each graph launch starts ~10 us later than the first kernel of a
+// launch-by-launch chain does: first kernel .. chain end 362-366 us vs 341-343 us, frame 0.550-0.575 vs 0.517-0.525 ms.
+static bool graphs_enabled() {
+    static const bool on = []() {
+        const char* v = std::getenv("MMF_GRAPHS");
+        return v && v[0] && v[0] != '0';
+    }();
+    return on;
+}
+
 struct mmf_odom {
     mmf_ctx* ctx = nullptr;
+    GraphCache gn_graphs;    // the Gauss-Newton chain of odom_enqueue_tracking (launch_graph.hpp)
+    GraphCache prep_graphs;  // the model-side preparation launches in front of it (fusion_orchestrator.hpp)
     int width = 0, height = 0;
     float cx = 0, cy = 0, fx = 0, fy = 0;
     float dist_thres = 0, angle_thres = 0;
@@ -1051,7 +1066,7 @@ struct PrepBuilder {  // the jobs of one stage (possibly of several models); lau
         j.gx = (cols + kTileX - 1) / kTileX;
         return j;
     }
-    int launch(hipStream_t stream) {
+    int launch(Enqueuer& q) {
         for (size_t first = 0; first < jobs.size(); first += kMaxPrepJobs) {
             PrepBatch b;
             b.njobs = 0;
@@ -1062,8 +1077,7 @@ struct PrepBuilder {  // the jobs of one stage (possibly of several models); lau
                 j.first_block = blocks;
                 blocks += j.gx * ((j.rows + kTileY - 1) / kTileY);
             }
-            hipLaunchKernelGGL(prep_batch_kernel, dim3(blocks), tile_block(), 0, stream, b);
-            MMF_HIP_TRY(hipGetLastError());
+            q.launch(prep_batch_kernel, dim3(blocks), tile_block(), b);
         }
         jobs.clear();
         return MMF_OK;
@@ -1071,9 +1085,15 @@ struct PrepBuilder {  // the jobs of one stage (possibly of several models); lau
 };
 struct PrepStages {  // the four dependent launches of a frame's preparation
     PrepBuilder stage[4];
-    int launch(hipStream_t stream) {
+    int launch(Enqueuer& q) {  // recorded; the caller flushes
         for (PrepBuilder& pb : stage)
-            if (int rc = pb.launch(stream)) return rc;
+            if (int rc = pb.launch(q)) return rc;
+        return MMF_OK;
+    }
+    int launch(hipStream_t stream, GraphCache* cache = nullptr) {
+        Enqueuer q(stream, cache);
+        if (int rc = launch(q)) return rc;
+        MMF_HIP_TRY(q.flush());
         return MMF_OK;
     }
 };
@@ -1205,10 +1225,11 @@ static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float 
                                 const uint8_t* pred_image, int pred_channels, const float pose[16],
                                 const int* sel = nullptr, const float* alt_vertex = nullptr,
                                 const float* alt_normal = nullptr, const uint8_t* alt_image = nullptr,
-                                int side = PREP_ALL, hipStream_t stream = nullptr) {
+                                int side = PREP_ALL, hipStream_t stream = nullptr, Enqueuer* q = nullptr) {
     PrepStages stages;
     odom_prepare_collect(stages, o, depth_filtered, depth_cutoff, rgb, rgb_channels, pred_vertex, pred_normal, pred_image,
                          pred_channels, pose, sel, alt_vertex, alt_normal, alt_image, side);
+    if (q) return stages.launch(*q);
     return stages.launch(stream ? stream : o->ctx->stream);
 }
 
@@ -1233,9 +1254,7 @@ static IcpArgs odom_icp_args(mmf_odom* o, int level, float* err_map) {
 
 // the ten launches of the SO3 pre-alignment (RGBDOdometry.cpp:239-310): last frame's image against this frame's
 // at level 2 -- no model, no pose
-static int odom_enqueue_so3(mmf_odom* o, hipStream_t stream, float* partials = nullptr, unsigned* ticket = nullptr) {
-    mmf_ctx* c = o->ctx;
-    (void)c;
+static int odom_enqueue_so3(mmf_odom* o, Enqueuer& q, float* partials = nullptr, unsigned* ticket = nullptr) {
     if (!partials) partials = o->gn_partials_f, ticket = o->gn_ticket;
     const int lvl = 2, cols = o->width >> lvl, rows = o->height >> lvl;
     So3Args a;
@@ -1247,19 +1266,15 @@ static int odom_enqueue_so3(mmf_odom* o, hipStream_t stream, float* partials = n
     a.intr = level_intr(o->fx, o->fy, o->cx, o->cy, 2);
     a.cols_magic = (unsigned)((1ull << 32) / (unsigned)cols) + 1u;
     const int grid = reduce_grid(cols * rows, kBlock);
-    for (int i = 0; i < 10; ++i) {
-        hipLaunchKernelGGL((so3_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), 0, stream, o->state, a, partials, ticket);
-        MMF_HIP_TRY(hipGetLastError());
-    }
+    for (int i = 0; i < 10; ++i) q.launch((so3_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), o->state, a, partials, ticket);
     return MMF_OK;
 }
 
 // the SO3 pre-alignment of the NEXT frame ahead of its tracking, on `stream` (after that frame's intensity
 // pyramid): its begin part, then the ten launches; getIncrementalTransformation then skips both
-static int odom_prefetch_so3(mmf_odom* o, hipStream_t stream, float* partials, unsigned* ticket) {
-    hipLaunchKernelGGL(so3_begin_kernel, dim3(1), dim3(64), 0, stream, o->state, level_intr(o->fx, o->fy, o->cx, o->cy, 2));
-    MMF_HIP_TRY(hipGetLastError());
-    int rc = odom_enqueue_so3(o, stream, partials, ticket);
+static int odom_prefetch_so3(mmf_odom* o, Enqueuer& q, float* partials, unsigned* ticket) {
+    q.launch(so3_begin_kernel, dim3(1), dim3(64), o->state, level_intr(o->fx, o->fy, o->cx, o->cy, 2));
+    int rc = odom_enqueue_so3(o, q, partials, ticket);
     if (rc) return rc;
     o->so3_prefetched = true;
     return MMF_OK;
@@ -1321,12 +1336,14 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     b.first_intr = level_intr(o->fx, o->fy, o->cx, o->cy, MMF_NUM_PYRS - 1);
     o->n_timed = 0;
     if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[0], c->stream));
-    hipLaunchKernelGGL(odom_begin_kernel, dim3(ny), dim3(64), 0, c->stream, o->state, b, bd, poses);
-    MMF_HIP_TRY(hipGetLastError());
+    // from here to the last step: kernels only, all on the fused-producer path when `odom_batchable` -- recorded and
+    // sent as one graph launch (launch_graph.hpp).  The measurement modes and the other paths launch one by one.
+    Enqueuer q(c->stream, (graphs_enabled() && !o->timing && odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom)) ? &o->gn_graphs : nullptr);
+    q.launch(odom_begin_kernel, dim3(ny), dim3(64), o->state, b, bd, poses);
 
     const bool so3_ran_here = so3 && !o->so3_prefetched;  // in the leader's state: shared with the others at the first level begin
     if (so3 && !o->so3_prefetched) {  // :239-310
-        int rc = odom_enqueue_so3(o, c->stream);
+        int rc = odom_enqueue_so3(o, q);
         if (rc) return rc;
     }
     o->so3_prefetched = false;
@@ -1340,14 +1357,13 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         const int cols = o->width >> i, rows = o->height >> i;
         const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, i);
         if (rgb && !o->prep_batched) {  // :332-334
+            MMF_HIP_TRY(q.flush());
             int rc = launch_project(c, o->last_depth[i], cols, cols, rows, in, o->cloud[i]);
             if (rc) return rc;
         }
-        if (!begin_folded) {
-            hipLaunchKernelGGL(gn_level_begin_kernel, dim3(ny), dim3(64), 0, c->stream, o->state, first_level ? 1 : 0, in, bd,
-                               (first_level && so3_ran_here) ? 1 : 0);
-            MMF_HIP_TRY(hipGetLastError());
-        }
+        if (!begin_folded)
+            q.launch(gn_level_begin_kernel, dim3(ny), dim3(64), o->state, first_level ? 1 : 0, in, bd,
+                     (first_level && so3_ran_here) ? 1 : 0);
         first_level = false;
         begin_folded = false;
 
@@ -1381,7 +1397,13 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                     e0 = o->ev_kernel[2 * o->n_timed], e1 = o->ev_kernel[2 * o->n_timed + 1];
                     o->timed_kind[o->n_timed++] = i * 2;
                 }
-                if (ipx == 2)
+                if (!e0 && ipx == 2)
+                    q.launch((track_producer_kernel<2, true>), dim3(icp_records + res_records, ny), dim3(kBlock), o->state, ia,
+                             (unsigned)icp_records, ra, o->gn_partials_icp, o->gn_partials_res, bd);
+                else if (!e0)
+                    q.launch((track_producer_kernel<1, true>), dim3(icp_records + res_records, ny), dim3(kBlock), o->state, ia,
+                             (unsigned)icp_records, ra, o->gn_partials_icp, o->gn_partials_res, bd);
+                else if (ipx == 2)
                     hipExtLaunchKernelGGL((track_producer_kernel<2, true>), dim3(icp_records + res_records, ny), dim3(kBlock), 0,
                                           c->stream, e0, e1, 0, o->state, ia, (unsigned)icp_records, ra, o->gn_partials_icp,
                                           o->gn_partials_res, bd);
@@ -1392,6 +1414,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 MMF_HIP_TRY(hipGetLastError());
             } else {
                 MMF_REQUIRE(ny == 1, "odom_enqueue_tracking: this level cannot be batched");
+                MMF_HIP_TRY(q.flush());
                 if (rgb) {
                     if (res_vec4)
                         hipLaunchKernelGGL((rgb_residual_kernel<FINISH_GN, 4>), dim3(res_records), dim3(kBlock), 0,
@@ -1444,7 +1467,13 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                     e0 = o->ev_kernel[2 * o->n_timed], e1 = o->ev_kernel[2 * o->n_timed + 1];
                     o->timed_kind[o->n_timed++] = i * 2 + 1;
                 }
-                if (res_vec4)  // the 4-pixel correspondence pass wrote compact records
+                if (!e0 && res_vec4)  // the 4-pixel correspondence pass wrote compact records
+                    q.launch((rgb_step_kernel<FINISH_GN, 4, true>), dim3(grid, ny), dim3(kBlock), o->state, a, o->gn_partials_f,
+                             o->gn_ticket, bd);
+                else if (!e0)
+                    q.launch((rgb_step_kernel<FINISH_GN, 4, false>), dim3(grid, ny), dim3(kBlock), o->state, a, o->gn_partials_f,
+                             o->gn_ticket, bd);
+                else if (res_vec4)
                     hipExtLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, true>), dim3(grid, ny), dim3(kBlock), 0, c->stream, e0, e1,
                                           0, o->state, a, o->gn_partials_f, o->gn_ticket, bd);
                 else
@@ -1455,10 +1484,8 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         }
     }
 
-    if (!end_folded) {
-        hipLaunchKernelGGL(odom_end_kernel, dim3(ny), dim3(64), 0, c->stream, o->state, bd);
-        MMF_HIP_TRY(hipGetLastError());
-    }
+    if (!end_folded) q.launch(odom_end_kernel, dim3(ny), dim3(64), o->state, bd);
+    MMF_HIP_TRY(q.flush());
     if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[1], c->stream));
     for (unsigned m = 0; m < ny; ++m) {  // every model's result towards the host, on the chain's stream
         mmf_odom* om = batch ? batch->o[m] : o;
@@ -1467,6 +1494,11 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         om->track_stream = c->stream;
         om->result_of = o;
         if (om != o) om->so3_prefetched = false;
+        // the image ring (:469-473).  Host bookkeeping only -- the launches above hold their pointers by value -- and
+        // done here rather than when the result is picked up, so that the next frame's sensor-side preparation can be
+        // enqueued while this chain runs
+        if (so3)
+            for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(om->last_next_image[i], om->next_image[i]);
     }
     // what finish waits for: the copies, not whatever the caller enqueues behind them on this stream
     MMF_HIP_TRY(hipEventRecord(o->ev_result, c->stream));
@@ -1515,9 +1547,6 @@ static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
             }
         o->n_timed = 0;
     }
-
-    if (so3)  // :469-473
-        for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(o->last_next_image[i], o->next_image[i]);
 
     const OdomState* r = o->host_result;
     std::memcpy(trans, r->trans_out, sizeof(float) * 3);
@@ -1882,17 +1911,20 @@ extern "C" int mmf_model_count(mmf_model* m, unsigned* count) {
 }
 
 // MultiMotionFusion::filterDepth (MultiMotionFusion.cpp:897-904)
-static int filter_depth_on(mmf_ctx* c, hipStream_t stream, const float* depth, int cols, int rows, float max_depth,
-                           float* out) {
+static int filter_depth_on(mmf_ctx* c, Enqueuer& q, const float* depth, int cols, int rows, float max_depth, float* out) {
     MMF_REQUIRE(c && depth && out && cols > 0 && rows > 0, "mmf_filter_depth: bad argument");
     MMF_HIP_TRY(hipSetDevice(c->device));
     if (cols % 2 == 0 && ((uintptr_t)depth & 7u) == 0 && ((uintptr_t)out & 7u) == 0)  // two pixels per lane
-        hipLaunchKernelGGL(bilateral_filter2_kernel, tile_grid(cols / 2, rows), tile_block(), 0, stream, depth, cols, rows,
-                           max_depth, out);
+        q.launch(bilateral_filter2_kernel, tile_grid(cols / 2, rows), tile_block(), depth, cols, rows, max_depth, out);
     else
-        hipLaunchKernelGGL(bilateral_filter_kernel, tile_grid(cols, rows), tile_block(), 0, stream, depth, cols, rows,
-                           max_depth, out);
-    MMF_HIP_TRY(hipGetLastError());
+        q.launch(bilateral_filter_kernel, tile_grid(cols, rows), tile_block(), depth, cols, rows, max_depth, out);
+    return MMF_OK;
+}
+static int filter_depth_on(mmf_ctx* c, hipStream_t stream, const float* depth, int cols, int rows, float max_depth,
+                           float* out) {
+    Enqueuer q(stream, nullptr);
+    if (int rc = filter_depth_on(c, q, depth, cols, rows, max_depth, out)) return rc;
+    MMF_HIP_TRY(q.flush());
     return MMF_OK;
 }
 

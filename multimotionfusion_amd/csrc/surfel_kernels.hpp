@@ -1033,23 +1033,23 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
     // one memory round trip: the keep flag, this thread's share of the block sums (ten loads in flight; a loop
     // with a wait per iteration cost the late workgroups ~5 us) and, for the old surfels -- nearly all of which
     // survive -- the surfel itself, all issued before anything is consumed
+    // (every address is clamped and every load unconditional: behind `if (old)` / `if (live)` the compiler waited for
+    // the keep flag before it issued the rest and staged the surfel through LDS -- three dependent round trips, 17 us)
     const bool live = e < count + npix, old = e < count;
-    const unsigned kp = live ? keep[e] : 0u;
+    const int ec = min(e, count + npix - 1), eo = min(e, max(count - 1, 0));
+    const unsigned kp_raw = keep[ec];
     constexpr int kSumsPerThread = 10;  // 2560 workgroups = 655 k elements without the tail loop
     unsigned bs[kSumsPerThread];
+    const unsigned last_block = gridDim.x - 1;
 #pragma unroll
-    for (int u = 0; u < kSumsPerThread; ++u) {
-        const unsigned j = threadIdx.x + 256u * u;
-        bs[u] = j < blockIdx.x ? block_sums[j] : 0u;
-    }
-    float4 p, c, n;
-    float2 ct;
-    if (old) p = s.pos[e], c = s.col[e], n = s.nrm[e];
-    if (live) ct = conf_time[e];
+    for (int u = 0; u < kSumsPerThread; ++u) bs[u] = block_sums[min(threadIdx.x + 256u * u, last_block)];
+    const float4 p = s.pos[eo], c = s.col[eo], n = s.nrm[eo];
+    const float2 ct = conf_time[ec];
     __builtin_amdgcn_sched_barrier(0);
+    const unsigned kp = live ? kp_raw : 0u;
     unsigned part = 0;
 #pragma unroll
-    for (int u = 0; u < kSumsPerThread; ++u) part += bs[u];
+    for (int u = 0; u < kSumsPerThread; ++u) part += threadIdx.x + 256u * u < blockIdx.x ? bs[u] : 0u;
     for (unsigned j = threadIdx.x + 256u * kSumsPerThread; j < blockIdx.x; j += 256) part += block_sums[j];
     part = wave_sum_to_lane63(part);
     const unsigned long long ballot = __ballot(kp != 0u);
@@ -1064,15 +1064,17 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
     if (!kp) return;
     const unsigned k = base + (unsigned)__popcll(ballot & ((1ull << lane) - 1ull));
     if (k >= (unsigned)capacity) return;  // the reference's VBO is full: further primitives are dropped
-    if (!old) {  // a new measurement that survives (few): fetched now
+    if (old) {
+        dst.pos[k] = make_float4(p.x, p.y, p.z, ct.x);
+        dst.col[k] = make_float4(c.x, c.y, c.z, ct.y);
+        dst.nrm[k] = n;
+    } else {  // a new measurement that survives (few): fetched now
         const int d = e - count;
-        p = meas.pos[d], c = meas.col[d], n = meas.nrm[d];
+        const float4 mp = meas.pos[d], mc = meas.col[d], mn = meas.nrm[d];
+        dst.pos[k] = make_float4(mp.x, mp.y, mp.z, ct.x);
+        dst.col[k] = make_float4(mc.x, mc.y, mc.z, ct.y);
+        dst.nrm[k] = mn;
     }
-    p.w = ct.x;
-    c.w = ct.y;
-    dst.pos[k] = p;
-    dst.col[k] = c;
-    dst.nrm[k] = n;
 }
 
 // ---- fill-in (fill_vertex.frag, fill_normal.frag, fill_rgb.frag) + thumbnail count ------------------

@@ -46,16 +46,23 @@ class MultiMotionFusion:
         return o
 
     def processFrame(self, rgb, depth, timestamp=0, inPose=None, weightMultiplier=1.0, bootstrap=False, initTransform=None,
-                     icpRefine=True, mask=None, hasNewLabel=False, modelData=None, initTransforms=None):
+                     icpRefine=True, mask=None, hasNewLabel=False, modelData=None, initTransforms=None, next=None):
         """MultiMotionFusion::processFrame: rgb [H,W,3] uint8, depth [H,W] float32 (CUDA tensors).
         initTransform: `-init kp` (MultiMotionFusion.cpp:312-384) -- the 4x4 of Model::getLastTrackTransform, applied
         to the pose before the dense tracker (which then refines it when icpRefine, `-icp_refine`).
         mask / hasNewLabel / modelData: the SegmentationResult of this frame when enable_multiple_models is set
         (fullSegmentation as a CUDA uint8 [H,W] tensor of model ids; modelData: dicts with id, super_pixel_count,
-        avg_confidence, depth_mean, depth_std in list order).  initTransforms: one 4x4 per active model."""
-        if mask is not None or initTransforms is not None:
+        avg_confidence, depth_mean, depth_std in list order).  initTransforms: one 4x4 per active model.
+        next: (rgb, depth) the NEXT call will be given -- prefetchFrame folded into this call: the next frame's
+        sensor-side preparation is enqueued while this one waits for its pose (mmf_frame::next_rgb / next_depth)."""
+        if mask is not None or initTransforms is not None or next is not None:
             fr = mmf_frame()
             fr.rgb, fr.depth, fr.timestamp = _p(rgb), _p(depth), int(timestamp)
+            if next is not None:
+                fr.next_rgb, fr.next_depth = _p(next[0]), _p(next[1])
+            if initTransform is not None:
+                assert initTransforms is None
+                initTransforms = [initTransform]
             fr.weight_multiplier, fr.bootstrap, fr.icp_refine = float(weightMultiplier), int(bool(bootstrap)), int(bool(icpRefine))
             keep = []
             if inPose is not None:

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in syms:
         assert hasattr(lib, name), f"{name} declared in mmf_hip.h but not exported by libmmf_hip.so"
     assert sorted(_capi.SIGNATURES) == syms, set(_capi.SIGNATURES) ^ set(syms)
-    assert lib.mmf_abi_version() == 2
+    assert lib.mmf_abi_version() == 3
 
 
 def test_no_device_is_reported_not_emulated():
@@ -68,7 +68,7 @@ def test_cpp_shims_compile_and_link(tmp_path):
            "-D__HIP_PLATFORM_AMD__", "-isystem", "/opt/rocm/include", "-o", str(exe), f"-L{pkg}", "-lmmf_hip", "-lamdhip64", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
     subprocess.run(cmd, check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
-    assert out.strip() == "abi 2"
+    assert out.strip() == "abi 3"
 
 
 def test_compute_fusion_weight_matches_the_oracle_bit_for_bit():

@@ -299,6 +299,16 @@ def test_prefetched_frames_give_the_same_bits(gpu_ctx, w, h):
         assert np.array_equal(b.getCurrPose(), ref_poses[i]), i
     assert np.array_equal(b.getBackgroundModel().downloadMap().view(np.uint32), ref_map.view(np.uint32))
     b.close()
+    # the same through mmf_frame::next_*: the prefetch is enqueued inside processFrame while it waits for its pose
+    c = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    for i in range(n):
+        nxt = (rgb[i + 1], depth[i + 1]) if i + 1 < n else None
+        if i == 3:
+            nxt = (rgb[0], depth[0])  # a hint that turns out wrong: discarded by the next call
+        c.processFrame(rgb[i], depth[i], timestamp=i, next=nxt)
+        assert np.array_equal(c.getCurrPose(), ref_poses[i]), i
+    assert np.array_equal(c.getBackgroundModel().downloadMap().view(np.uint32), ref_map.view(np.uint32))
+    c.close()
 
 
 def test_prefetch_with_frames_that_are_not_tracked(gpu_ctx):
@@ -317,14 +327,15 @@ def test_prefetch_with_frames_that_are_not_tracked(gpu_ctx):
         g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
         out = []
         for i in range(n):
+            nxt = (rgb[i + 1], depth[i + 1]) if prefetch == "next" and i + 1 < n else None  # mmf_frame::next_*
             if i == 2:    # the caller dictates the pose: no tracking
-                g.processFrame(rgb[i], depth[i], timestamp=i, inPose=rel[i].astype(np.float32))
+                g.processFrame(rgb[i], depth[i], timestamp=i, inPose=rel[i].astype(np.float32), next=nxt)
             elif i == 4:  # keypoint transformation taken as it is: no tracking either
                 T = (np.linalg.inv(poses[i - 1]) @ poses[i]).astype(np.float32)
-                g.processFrame(rgb[i], depth[i], timestamp=i, initTransform=T, icpRefine=False)
+                g.processFrame(rgb[i], depth[i], timestamp=i, initTransform=T, icpRefine=False, next=nxt)
             else:
-                g.processFrame(rgb[i], depth[i], timestamp=i)
-            if prefetch and i + 1 < n:
+                g.processFrame(rgb[i], depth[i], timestamp=i, next=nxt)
+            if prefetch is True and i + 1 < n:
                 g.prefetchFrame(rgb[i + 1], depth[i + 1])
             out.append(g.getCurrPose().copy())
         surfels = g.getBackgroundModel().downloadMap()
@@ -332,10 +343,11 @@ def test_prefetch_with_frames_that_are_not_tracked(gpu_ctx):
         return out, surfels
 
     ref, ref_map = run(False)
-    got, got_map = run(True)
-    for i in range(n):
-        assert np.array_equal(ref[i], got[i]), i
-    assert np.array_equal(ref_map.view(np.uint32), got_map.view(np.uint32))
+    for mode in (True, "next"):
+        got, got_map = run(mode)
+        for i in range(n):
+            assert np.array_equal(ref[i], got[i]), (mode, i)
+        assert np.array_equal(ref_map.view(np.uint32), got_map.view(np.uint32)), mode
 
 
 def test_cpp_function_level_shim_on_the_device(tmp_path):
@@ -352,3 +364,42 @@ def test_cpp_function_level_shim_on_the_device(tmp_path):
                     "-lamdhip64", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "cudafuncs shim: ok" in r.stdout, (r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_graph_replay_gives_the_same_bits():
+    """MMF_GRAPHS=1 (csrc/launch_graph.hpp): the preparation, Gauss-Newton and prefetch launch chains go out as hipGraph
+    replays with per-frame argument updates -- same kernels, same arguments, so poses and surfels must not change.
+    (The switch is read once per process: two child processes.)"""
+    import hashlib  # noqa: F401
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, hashlib, numpy as np, torch\n"
+        f"sys.path.insert(0, {repo!r})\n"
+        "from multimotionfusion_amd import synth\n"
+        "from multimotionfusion_amd.cudafuncs import Context\n"
+        "from multimotionfusion_amd.fusion import MultiMotionFusion\n"
+        "w, h, n = 320, 240, 8\n"
+        "K = synth.intrinsics(w, h)\n"
+        "poses = synth.trajectory(n, seed=21)\n"
+        "fr = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]\n"
+        "up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
+        "rgb, depth = [up(f['rgb']) for f in fr], [up(f['depth']) for f in fr]\n"
+        "ctx = Context(0)\n"
+        "g = MultiMotionFusion(ctx, w, h, K['cx'], K['cy'], K['fx'], K['fy'])\n"
+        "hh = hashlib.sha256()\n"
+        "for i in range(n):\n"
+        "    g.processFrame(rgb[i], depth[i], timestamp=i, next=(rgb[i + 1], depth[i + 1]) if i + 1 < n else None)\n"
+        "    hh.update(np.ascontiguousarray(g.getCurrPose()).tobytes())\n"
+        "hh.update(np.ascontiguousarray(g.getBackgroundModel().downloadMap()).tobytes())\n"
+        "print('digest', hh.hexdigest())\n")
+    out = []
+    for graphs in ("0", "1"):
+        env = dict(os.environ, MMF_GRAPHS=graphs)
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0])
+    assert out[0] == out[1]

@@ -36,15 +36,18 @@ def frame_of(i):
     return p if p < nf else 2 * nf - 2 - p
 
 
+import time  # noqa: E402
+t_loop = time.perf_counter()
 for i in range(n):
+    if i == 40:
+        torch.cuda.synchronize()
+        t_loop = time.perf_counter()
     k = frame_of(i)
     if headline:
         k = i % nf
         if i and k == 0:
             g.reset()
-        g.processFrame(rgb[k], depth[k], timestamp=i)
-        if (i + 1) % nf != 0:
-            g.prefetchFrame(rgb[(i + 1) % nf], depth[(i + 1) % nf])
+        g.processFrame(rgb[k], depth[k], timestamp=i, next=(rgb[(i + 1) % nf], depth[(i + 1) % nf]) if (i + 1) % nf != 0 else None)
         continue
     if models > 1:
         g.processFrame(rgb[k], depth[k], timestamp=i, mask=mask[k], hasNewLabel=1 <= i < models)
@@ -54,6 +57,8 @@ for i in range(n):
             kn = frame_of(i + 1)
             g.prefetchFrame(rgb[kn], depth[kn])
 torch.cuda.synchronize()
+if n > 40:
+    print("ms per frame (after 40): %.4f" % ((time.perf_counter() - t_loop) / (n - 40) * 1e3))
 print("frames", n, "models", len(g.getModels()), "surfels", [m.lastCount() for m in g.getModels()])
 g.close()
 ctx.close()
