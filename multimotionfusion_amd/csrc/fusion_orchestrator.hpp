@@ -445,9 +445,9 @@ static int fusion_predict_model(mmf_fusion* f, FusionModel* fm) {
 // predictIndices -> fuse -> predictIndices -> clean of one model (:791-816 per model; models never read each
 // other's surfels, so running the four passes model by model on the model's own stream gives the same maps as
 // the reference's pass-by-pass loops over the list)
-static int fusion_fuse_clean_model(mmf_fusion* f, FusionModel* fm, float weighting) {
+static int fusion_fuse_clean_model(mmf_fusion* f, FusionModel* fm, float weighting, bool indices_done = false) {
     const mmf_fusion_config& g = f->cfg;
-    int rc = mmf_model_predict_indices(fm->model, f->tick, g.max_depth_processed, g.time_delta);
+    int rc = indices_done ? MMF_OK : mmf_model_predict_indices(fm->model, f->tick, g.max_depth_processed, g.time_delta);
     if (rc) return rc;
     rc = mmf_model_fuse(fm->model, f->tick, f->frame_rgb, f->mask, f->frame_depth, f->depth_filtered, g.max_depth_processed,
                         weighting);
@@ -506,6 +506,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     int rc = MMF_OK;
     bool prefetched = false;
     bool next_prefetched = false;  // mmf_frame::next_* has been enqueued
+    bool early_projections = false;  // the global model's predict + predictIndices went out before its pose reached the host
     if (f->pre_valid) {  // whatever was prefetched has to be complete before this frame touches the same buffers
         MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch_done, 0));
         MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch2_done, 0));
@@ -676,6 +677,20 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                                            fm->icp_error, fm->rgb_error);
                 if (rc) return rc;
             }
+            // One model on the context's stream, nothing between its tracking and its fusion that the host decides: the
+            // frame's first projections -- predict() (:675) and the first predictIndices (:792) -- are enqueued right here,
+            // behind the chain and the copy of its result, with the inverse pose read from the odometry's device state.
+            // They run while the host picks the pose up and prepares the fusion passes (that turnaround used to be ~25 us
+            // of idle GPU per frame).
+            if (tracked.size() == 1 && tracked[0] == global && global->lane->stream == c->stream && !fr->bootstrap &&
+                !have_init && !g.enable_multiple_models && !g.rgb_only && f->tracking_ok) {
+                global->model->t_inv_dev = global->odom->state->pose_inv;
+                rc = fusion_predict_model(f, global);
+                if (rc == MMF_OK) rc = mmf_model_predict_indices(global->model, f->tick, g.max_depth_processed, g.time_delta);
+                global->model->t_inv_dev = nullptr;
+                if (rc) return rc;
+                early_projections = true;
+            }
             // the sensor-side image ring (this frame's / last frame's intensity pyramid, RGBDOdometry.cpp:469-473) lives in
             // the global odometry and advances when its chain is enqueued: when its owner is another rank, the swap
             // happens here, whether or not this rank tracked anything (every rank's ring must advance with the global model's)
@@ -808,12 +823,15 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 rc = lane_wait(fm, f->ev_frame_ready);
                 if (rc) return rc;
             }
-            rc = fusion_predict_model(f, fm);
-            if (rc) return rc;
+            const bool early = early_projections && fm == global;  // its predict + predictIndices are already enqueued
+            if (!early) {
+                rc = fusion_predict_model(f, fm);
+                if (rc) return rc;
+            }
             if (!g.rgb_only && f->tracking_ok) {
                 float pose[16];
                 mmf_model_get_pose(fm->model, pose);
-                rc = fusion_fuse_clean_model(f, fm, fusion_weight(pose, fm->last_pose, weight_multiplier));
+                rc = fusion_fuse_clean_model(f, fm, fusion_weight(pose, fm->last_pose, weight_multiplier), early);
                 if (rc) return rc;
             }
         }
@@ -953,8 +971,15 @@ static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* 
     MMF_HIP_TRY(hipSetDevice(c->device));
     mmf_odom* odom = f->models[0]->odom;
     if (f->side == nullptr) {  // first use
+        if (std::getenv("MMF_SIDE_LOW_PRIORITY")) {
+            int lo = 0, hi = 0;
+            MMF_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            MMF_HIP_TRY(hipStreamCreateWithPriority(&f->side, hipStreamNonBlocking, lo));
+            MMF_HIP_TRY(hipStreamCreateWithPriority(&f->side2, hipStreamNonBlocking, lo));
+        } else {
         MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
         MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking));
+        }
         MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch_done, hipEventDisableTiming));
         MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch2_done, hipEventDisableTiming));
         MMF_HIP_TRY(hipMalloc(&f->side_partials, sizeof(float) * kMaxGrid * kPartialStride));

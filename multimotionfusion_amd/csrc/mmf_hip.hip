@@ -6,7 +6,9 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -58,14 +60,6 @@ static hipError_t wait_stream(hipStream_t s) {
     }
     return hipStreamSynchronize(s);
 }
-static hipError_t wait_event(hipEvent_t ev) {
-    for (int i = 0; i < 200000; ++i) {
-        const hipError_t e = hipEventQuery(ev);
-        if (e != hipErrorNotReady) return e;
-    }
-    return hipEventSynchronize(ev);
-}
-
 extern "C" int mmf_abi_version(void) { return MMF_ABI_VERSION; }
 extern "C" const char* mmf_last_error(void) { return g_last_error.c_str(); }
 
@@ -112,6 +106,11 @@ extern "C" int mmf_ctx_create(int device, void* stream, int private_stream, mmf_
         return fail(MMF_ERR_NO_DEVICE, m);
     }
     if (private_stream) {
+        if (std::getenv("MMF_MAIN_HIGH_PRIORITY")) {
+            int lo = 0, hi = 0;
+            MMF_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            MMF_HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+        } else
         MMF_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     } else {
@@ -767,7 +766,9 @@ struct mmf_odom {
     unsigned* gn_ticket = nullptr;
     float *icp_err = nullptr, *rgb_err = nullptr;  // Model::icpError / rgbError (R32F), written on the last level-0 iteration
     OdomState* state = nullptr;  // device
-    OdomState* host_result = nullptr;  // pinned
+    OdomState* host_result = nullptr;  // pinned, device visible: odom_publish_kernel writes it, the host polls publish_seq
+    OdomState* host_result_dev = nullptr;
+    unsigned publish_seq = 0;          // sequence number of the last chain enqueued
     bool have_tmp = false;  // vmaps_tmp filled by an initICP* call (ordering contract)
     // The reference COPIES its inputs at each init* call (RGBDOdometry.cpp:125,130; Model.cpp:359-388).
     // An owner that guarantees the images stay untouched until getIncrementalTransformation returns
@@ -782,8 +783,7 @@ struct mmf_odom {
     bool so3_prefetched = false;  // this frame's SO3 pre-alignment already ran (odom_prefetch_so3)
     bool pending_icp = false, pending_so3 = false;  // mode of the tracking call that is in flight (enqueue -> finish)
     hipStream_t track_stream = nullptr;             // the stream that call's chain runs on (the batch leader's)
-    hipEvent_t ev_result = nullptr;                 // recorded right behind the copy of the result towards the host
-    mmf_odom* result_of = nullptr;                  // the odometry (batch leader) whose ev_result covers this one's copy
+    mmf_odom* result_of = nullptr;                  // the odometry (batch leader) whose chain publishes this one's result
     // measurement mode (mmf_odom_enable_timing): every producer / rgb_step launch of a tracking call carries its own
     // start / stop events (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps), the whole chain two more
     int timing = 0;  // 1: chain events only; 2: also every kernel of the chain
@@ -882,8 +882,9 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     o->gn_partials_f = (float*)(base + o_pf), o->gn_partials_icp = (float*)(base + o_pi);
     o->gn_partials_res = (int2*)(base + o_pr), o->gn_ticket = (unsigned*)(base + o_tk);
     o->icp_err = (float*)(base + o_ei), o->rgb_err = (float*)(base + o_er);
-    MMF_HIP_TRY(hipHostMalloc(&o->host_result, sizeof(OdomState), hipHostMallocDefault));
-    MMF_HIP_TRY(hipEventCreateWithFlags(&o->ev_result, hipEventDisableTiming));
+    MMF_HIP_TRY(hipHostMalloc(&o->host_result, sizeof(OdomState), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(o->host_result, 0, sizeof(OdomState));
+    MMF_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&o->host_result_dev), o->host_result, 0));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
     *out = o;
     return MMF_OK;
@@ -899,7 +900,6 @@ extern "C" void mmf_odom_destroy(mmf_odom* o) {
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : o->ev_chain)
         if (e) (void)hipEventDestroy(e);
-    if (o->ev_result) (void)hipEventDestroy(o->ev_result);
     delete o;
 }
 
@@ -1487,9 +1487,13 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     if (!end_folded) q.launch(odom_end_kernel, dim3(ny), dim3(64), o->state, bd);
     MMF_HIP_TRY(q.flush());
     if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[1], c->stream));
+    PublishTargets to;
+    std::memset(&to, 0, sizeof(to));
+    const unsigned seq = ++o->publish_seq;
     for (unsigned m = 0; m < ny; ++m) {  // every model's result towards the host, on the chain's stream
         mmf_odom* om = batch ? batch->o[m] : o;
-        MMF_HIP_TRY(hipMemcpyAsync(om->host_result, om->state, offsetof(OdomState, res_acc), hipMemcpyDeviceToHost, c->stream));
+        to.host[m] = om->host_result_dev;
+        om->publish_seq = seq;
         om->pending_icp = icp, om->pending_so3 = so3 != 0;
         om->track_stream = c->stream;
         om->result_of = o;
@@ -1500,8 +1504,8 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         if (so3)
             for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(om->last_next_image[i], om->next_image[i]);
     }
-    // what finish waits for: the copies, not whatever the caller enqueues behind them on this stream
-    MMF_HIP_TRY(hipEventRecord(o->ev_result, c->stream));
+    hipLaunchKernelGGL(odom_publish_kernel, dim3(ny), dim3(64), 0, c->stream, o->state, to, seq, bd);
+    MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }
 
@@ -1526,7 +1530,23 @@ static bool odom_batchable(mmf_odom* o, int rgb_only, float icp_weight, int pyra
 static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
     mmf_ctx* c = o->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
-    MMF_HIP_TRY(o->result_of ? wait_event(o->result_of->ev_result) : wait_stream(c->stream));  // the chain it rode on
+    // the chain it rode on publishes into this odometry's pinned state and then stores the sequence number
+    if (o->result_of) {
+        const volatile unsigned* flag = &o->host_result->publish_seq;
+        bool seen = false;
+        const auto t_poll = std::chrono::steady_clock::now();
+        while (!seen) {  // a few seconds of polling at most, then the stream says why
+            for (int i = 0; i < 4096 && !seen; ++i) seen = *flag == o->publish_seq;
+            if (seen || std::chrono::steady_clock::now() - t_poll > std::chrono::seconds(5)) break;
+        }
+        if (!seen) {
+            MMF_HIP_TRY(hipStreamSynchronize(o->track_stream));
+            MMF_REQUIRE(*flag == o->publish_seq, "odometry: the tracking result did not reach the host");
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        MMF_HIP_TRY(wait_stream(c->stream));
+    }
     o->track_stream = nullptr, o->result_of = nullptr;
     const bool icp = o->pending_icp, so3 = o->pending_so3;
     if (o->timing) {
@@ -1694,6 +1714,8 @@ extern "C" int mmf_odom_time_icp_kernel(mmf_odom* o, int level, int reps, int va
 // =============================================================================================
 #include "surfel_kernels.hpp"
 
+constexpr int kCountWord = 8, kCountSeqWord = 9;  // in mmf_model::host_totals
+
 struct mmf_model {
     mmf_ctx* ctx = nullptr;
     int width = 0, height = 0;
@@ -1702,6 +1724,8 @@ struct mmf_model {
     float conf_threshold = 10.f;
     float max_depth = FLT_MAX;  // Model::maxDepth (Model.h:129, set per object from the segmentation: MultiMotionFusion.cpp:486,586)
     int capacity = 0;
+    const float* t_inv_dev = nullptr;  // set by the orchestrator around projections it enqueues before the tracked pose has
+                                       // reached the host: the device copy of inverse(pose) (OdomState::pose_inv)
     float pose[16];
     unsigned count = 0;  // host copy of the number of surfels in set[cur]
     // After clean() the new count is on its way to host_totals (asynchronous copy on the stream); until a host
@@ -1736,8 +1760,9 @@ struct mmf_model {
     // fill-in (Shaders/FillIn.cpp)
     float4 *fill_vertex = nullptr, *fill_normal = nullptr;
     uchar4* fill_image = nullptr;
-    unsigned* host_totals = nullptr;  // pinned
-    hipEvent_t ev_count = nullptr;    // the copy of the count towards host_totals has landed
+    unsigned* host_totals = nullptr;      // pinned, device visible: words 0..3 = copies of totals[], kCountWord / kCountSeqWord =
+    unsigned* host_totals_dev = nullptr;  // the count the last clean pass published and its sequence number
+    unsigned count_seq = 0;
 };
 
 static Cam make_cam(const mmf_model* m, bool double_reciprocal) {
@@ -1751,32 +1776,7 @@ static Cam make_cam(const mmf_model* m, bool double_reciprocal) {
     return c;
 }
 
-static void inverse4f_host(const float* m, float* inv) {  // Eigen `pose.inverse()` (ModelProjection.cpp:108)
-    const float s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2];
-    const float s2 = m[0] * m[7] - m[4] * m[3], s3 = m[1] * m[6] - m[5] * m[2];
-    const float s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
-    const float c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11];
-    const float c3 = m[9] * m[14] - m[13] * m[10], c2 = m[8] * m[15] - m[12] * m[11];
-    const float c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
-    const float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
-    const float id = 1.0f / det;
-    inv[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
-    inv[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
-    inv[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
-    inv[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
-    inv[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
-    inv[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
-    inv[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
-    inv[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
-    inv[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
-    inv[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
-    inv[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
-    inv[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
-    inv[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
-    inv[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
-    inv[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
-    inv[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
-}
+static void inverse4f_host(const float* m, float* inv) { inverse4f(m, inv); }  // Eigen `pose.inverse()` (ModelProjection.cpp:108)
 
 static inline dim3 grid1d(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
@@ -1851,8 +1851,9 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     // the key image starts empty and every resolve kernel hands it back empty
     hipLaunchKernelGGL(fill_u64_kernel, grid1d(npix), dim3(256), 0, c->stream, m->keys, npix, kEmptyKey);
     MMF_HIP_TRY(hipGetLastError());
-    MMF_HIP_TRY(hipHostMalloc(&m->host_totals, 64, hipHostMallocDefault));
-    MMF_HIP_TRY(hipEventCreateWithFlags(&m->ev_count, hipEventDisableTiming));
+    MMF_HIP_TRY(hipHostMalloc(&m->host_totals, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(m->host_totals, 0, 64);
+    MMF_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->host_totals_dev), m->host_totals, 0));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
     *out = m;
     return MMF_OK;
@@ -1864,7 +1865,6 @@ extern "C" void mmf_model_destroy(mmf_model* m) {
     (void)hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(m->slab);
     (void)hipHostFree(m->host_totals);
-    if (m->ev_count) (void)hipEventDestroy(m->ev_count);
     delete m;
 }
 
@@ -1896,8 +1896,21 @@ static int model_resolve_count(mmf_model* m) {
     if (!m->count_pending) return MMF_OK;
     // only the copy that follows the clean pass is awaited, not whatever has been enqueued since (a stream
     // synchronisation here idled the GPU for ~45 us per frame: the splat of the frame was already in the queue)
-    MMF_HIP_TRY(wait_event(m->ev_count));
-    m->count = m->host_totals[0] < (unsigned)m->capacity ? m->host_totals[0] : (unsigned)m->capacity;
+    // (it arrives without a runtime copy: the clean pass stores it into pinned memory, then the sequence number)
+    const volatile unsigned* flag = &m->host_totals[kCountSeqWord];
+    bool seen = false;
+    const auto t_poll = std::chrono::steady_clock::now();
+    while (!seen) {
+        for (int i = 0; i < 4096 && !seen; ++i) seen = *flag == m->count_seq;
+        if (seen || std::chrono::steady_clock::now() - t_poll > std::chrono::seconds(5)) break;
+    }
+    if (!seen) {
+        MMF_HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+        MMF_REQUIRE(*flag == m->count_seq, "model: the surfel count did not reach the host");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const unsigned total = m->host_totals[kCountWord];
+    m->count = total < (unsigned)m->capacity ? total : (unsigned)m->capacity;
     m->count_pending = false;
     return MMF_OK;
 }
@@ -1971,6 +1984,7 @@ extern "C" int mmf_model_initialise(mmf_model* m, const uint8_t* rgb, const floa
 static IndexArgs model_index_args(mmf_model* m, int time, float depth_cutoff, int time_delta) {
     IndexArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
+    a.t_inv_dev = m->t_inv_dev;
     a.c = make_cam(m, false);
     a.cols = m->width, a.rows = m->height;
     a.maxDepth = depth_cutoff;
@@ -2004,6 +2018,7 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     MMF_HIP_TRY(hipSetDevice(c->device));
     SplatArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
+    a.t_inv_dev = m->t_inv_dev;
     a.c = make_cam(m, false);
     a.cols = m->width, a.rows = m->height;
     a.maxDepth = depth_cutoff;
@@ -2039,6 +2054,7 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
     MMF_HIP_TRY(hipSetDevice(c->device));
     SplatArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
+    a.t_inv_dev = m->t_inv_dev;
     a.c = make_cam(m, false);
     a.cols = m->width, a.rows = m->height;
     a.maxDepth = depth_cutoff;
@@ -2103,12 +2119,11 @@ extern "C" int mmf_model_clean(mmf_model* m, int time, int time_delta, float dep
     hipLaunchKernelGGL(clean_flag_kernel, grid1d(n), dim3(256), 0, c->stream, m->set[m->cur], m->meas, m->flags_b, a,
                        m->index, m->vertConf, m->colorTime, depth_filtered, mask, m->flags_a, m->conf_time, m->block_sums);
     hipLaunchKernelGGL(clean_scatter_kernel, grid1d(n), dim3(256), 0, c->stream, m->set[m->cur], m->meas, (int)m->count,
-                       npix, m->flags_a, m->block_sums, m->conf_time, m->set[1 - m->cur], m->capacity, &m->totals[0]);
+                       npix, m->flags_a, m->block_sums, m->conf_time, m->set[1 - m->cur], m->capacity, &m->totals[0],
+                       m->host_totals_dev + kCountWord, ++m->count_seq);
     MMF_HIP_TRY(hipGetLastError());
-    // glGetQueryObjectuiv(countQuery) in the reference (Model.cpp:1166) stalls for the count; here it travels
-    // to the host asynchronously and is picked up by the next call that needs it on the host
-    MMF_HIP_TRY(hipMemcpyAsync(m->host_totals, m->totals, 16, hipMemcpyDeviceToHost, c->stream));
-    MMF_HIP_TRY(hipEventRecord(m->ev_count, c->stream));
+    // glGetQueryObjectuiv(countQuery) in the reference (Model.cpp:1166) stalls for the count; here the scatter's last
+    // workgroup stores it into the host's pinned words, where the next call that needs it on the host picks it up
     m->count_bound = n < (unsigned)m->capacity ? n : (unsigned)m->capacity;
     m->count_pending = true;
     m->cur = 1 - m->cur;

@@ -53,7 +53,11 @@ struct OdomState {
     int out_i[2];
     // outputs
     float trans_out[3], rot_out[9];
+    float pose_inv[16];  // inverse of [rot_out | trans_out; 0 0 0 1], as the host computes it for the projection passes
     OdomStats st;
+    // everything above travels to the host's (pinned, device-visible) copy of this struct at the end of a chain
+    // (odom_publish_kernel); this word follows it there, after a system-scope fence: the host polls it
+    unsigned publish_seq;
     // {count, sum diff^2} of the photometric correspondence pass of the current Gauss-Newton step,
     // accumulated with integer atomics (exact, order independent) over kResShards address pairs;
     // zeroed by gn_level_begin_kernel and by the finishing lane of every step
@@ -84,6 +88,34 @@ __device__ inline void inverse3f(const float* m, float* inv) {  // RGBDOdometry.
     inv[6] = c02 * id;
     inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
     inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+// Eigen `pose.inverse()` of the projection passes (ModelProjection.cpp:108): the host's inverse4f_host, term by term
+__host__ __device__ inline void inverse4f(const float* m, float* inv) {
+    const float s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2];
+    const float s2 = m[0] * m[7] - m[4] * m[3], s3 = m[1] * m[6] - m[5] * m[2];
+    const float s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+    const float c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11];
+    const float c3 = m[9] * m[14] - m[13] * m[10], c2 = m[8] * m[15] - m[12] * m[11];
+    const float c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    const float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    const float id = 1.0f / det;
+    inv[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
+    inv[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
+    inv[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
+    inv[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
+    inv[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
+    inv[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
+    inv[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
+    inv[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
+    inv[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
+    inv[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
+    inv[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
+    inv[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
+    inv[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
+    inv[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
+    inv[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
+    inv[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
 }
 
 __device__ inline void inverse3d(const double* m, double* inv) {

@@ -396,16 +396,32 @@ __global__ __launch_bounds__(256) void init_scatter_kernel(int n, SurfelSoA raw,
 }
 
 // ---- index map --------------------------------------------------------------------------------
+// The projection passes normally get the inverse model pose as a launch argument, computed on the host from the pose
+// the tracker returned.  The orchestrator enqueues the first projections of a frame BEFORE that pose has reached the
+// host (they then run while the host wakes up and prepares the fusion passes): the tracker's last step leaves the same
+// 16 floats -- same expression, same rounding -- in the odometry state, and the kernels read them from there.
+template <typename Args>
+__device__ __forceinline__ Args with_device_pose(const Args& in) {
+    Args a = in;
+    if (in.t_inv_dev) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a.t_inv.m[k] = in.t_inv_dev[k];
+    }
+    return a;
+}
+
 struct IndexArgs {
     Mat4 t_inv;
+    const float* t_inv_dev;  // non-null: the 16 floats to use instead of t_inv (see with_device_pose)
     Cam c;
     int cols, rows;
     float maxDepth;
     int time, timeDelta;
 };
 
-__global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, IndexArgs a,
+__global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, IndexArgs a_in,
                                                         unsigned long long* __restrict__ keys) {
+    const IndexArgs a = with_device_pose(a_in);
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= count) return;
     const float4 p = s.pos[id];
@@ -431,10 +447,11 @@ __global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, 
 // linear over the transposed images (it never needs a pixel's coordinates)
 // Every resolve kernel hands the key image back EMPTY (it is the only reader of a texel's key), so the
 // rasterising passes need no clearing launch in front of them.
-__global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexArgs a,
+__global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexArgs a_in,
                                                             unsigned long long* __restrict__ keys,
                                                             unsigned* __restrict__ index, float4* __restrict__ vertConf,
                                                             float4* __restrict__ colorTime, float4* __restrict__ normRad) {
+    const IndexArgs a = with_device_pose(a_in);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.cols * a.rows) return;
     const unsigned long long k = keys[i];
@@ -466,6 +483,7 @@ __global__ __launch_bounds__(256) void untranspose_kernel(const T* __restrict__ 
 // ---- splat prediction ----------------------------------------------------------------------------
 struct SplatArgs {
     Mat4 t_inv;
+    const float* t_inv_dev;  // non-null: the 16 floats to use instead of t_inv (see with_device_pose)
     Cam c;
     int cols, rows;
     float maxDepth, confThreshold;
@@ -537,9 +555,10 @@ __device__ __forceinline__ bool splat_fragment(const SplatFrag& f, const SplatAr
 // changed nothing).  Here the wave's sprite ROWS are laid end to end (inclusive scan of the sprite heights), lane l takes
 // rows l, l + 64, ..., finds the row's surfel by a binary search in the wave's scan and reads that surfel's set-up from
 // LDS.  The per-fragment arithmetic is the same function as before, and atomicMin does not care about the order.
-__global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, SplatArgs a,
+__global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, SplatArgs a_in,
                                                     unsigned long long* __restrict__ keys,
                                                     const unsigned* __restrict__ count_dev) {
+    const SplatArgs a = with_device_pose(a_in);
     __shared__ SplatFrag frag_lds[256];
     __shared__ int row_end[256];  // inclusive scan of the sprite heights inside each wave
     const int id = blockIdx.x * 256 + threadIdx.x;
@@ -648,11 +667,12 @@ __device__ __forceinline__ SplatTexel splat_resolve_px(int i, unsigned long long
     return t;
 }
 
-__global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatArgs a,
+__global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatArgs a_in,
                                                             unsigned long long* __restrict__ keys,
                                                             uchar4* __restrict__ image, float4* __restrict__ vertexConf,
                                                             float4* __restrict__ normalRadius,
                                                             unsigned short* __restrict__ time_out) {
+    const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
     if (!splat_tile_key(keys, a.cols, a.rows, px, py, k)) return;
@@ -664,9 +684,10 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatAr
 }
 
 // depth_splat.frag (ModelProjection::synthesizeDepth): the winner's corrected_pos.z, 0 where cleared
-__global__ __launch_bounds__(256) void splat_depth_resolve_kernel(SurfelSoA s, SplatArgs a,
+__global__ __launch_bounds__(256) void splat_depth_resolve_kernel(SurfelSoA s, SplatArgs a_in,
                                                                   unsigned long long* __restrict__ keys,
                                                                   float* __restrict__ depth) {
+    const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
     if (!splat_tile_key(keys, a.cols, a.rows, px, py, k)) return;
@@ -1026,7 +1047,8 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
                                                             const unsigned* __restrict__ keep,
                                                             const unsigned* __restrict__ block_sums,
                                                             const float2* __restrict__ conf_time, SurfelSoA dst,
-                                                            int capacity, unsigned* __restrict__ total_out) {
+                                                            int capacity, unsigned* __restrict__ total_out,
+                                                            unsigned* __restrict__ total_host, unsigned seq) {
     __shared__ unsigned wave_part[4], wave_kept[4];
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1058,9 +1080,16 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
     __syncthreads();
     unsigned base = wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3];
     for (int w = 0; w < wave; ++w) base += wave_kept[w];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-        *total_out = wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3] + wave_kept[0] + wave_kept[1] + wave_kept[2] +
-                     wave_kept[3];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const unsigned total = wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3] + wave_kept[0] + wave_kept[1] +
+                               wave_kept[2] + wave_kept[3];
+        *total_out = total;
+        if (total_host) {  // the host's pinned, device-visible copy: value, system-scope fence, then the sequence number it polls
+            total_host[0] = total;
+            __threadfence_system();
+            __hip_atomic_store(&total_host[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     if (!kp) return;
     const unsigned k = base + (unsigned)__popcll(ballot & ((1ull << lane) - 1ull));
     if (k >= (unsigned)capacity) return;  // the reference's VBO is full: further primitives are dropped
@@ -1122,7 +1151,7 @@ __global__ __launch_bounds__(256) void fill_in_kernel(const float4* __restrict__
 // combinedPredict's resolve and performFillIn in one pass over the image (MultiMotionFusion::predict runs them
 // back to back, MultiMotionFusion.cpp:863-875): the fill-in takes the prediction's texel from registers instead of
 // reading the three images back
-__global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, SplatArgs a, unsigned long long* __restrict__ keys,
+__global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, SplatArgs a_in, unsigned long long* __restrict__ keys,
                                                                  uchar4* __restrict__ image, float4* __restrict__ vertexConf,
                                                                  float4* __restrict__ normalRadius,
                                                                  unsigned short* __restrict__ time_out,
@@ -1130,6 +1159,7 @@ __global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, Sp
                                                                  const uint8_t* __restrict__ rgb, int passthrough_geom,
                                                                  int passthrough_rgb, float4* __restrict__ vertex_out,
                                                                  float4* __restrict__ normal_out, uchar4* __restrict__ image_out) {
+    const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
     if (!splat_tile_key(keys, a.cols, a.rows, px, py, k)) return;

@@ -570,6 +570,15 @@ __device__ __forceinline__ void odom_end(OdomState* st) {
     }
     for (int k = 0; k < 3; ++k) st->trans_out[k] = st->tcurr[k];
     for (int k = 0; k < 9; ++k) st->rot_out[k] = st->Rcurr[k];
+    // what the projection passes of this frame need, for the ones enqueued before the host has the pose
+    float m[16], inv[16];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) m[r * 4 + c] = st->Rcurr[r * 3 + c];
+        m[r * 4 + 3] = st->tcurr[r];
+    }
+    m[12] = m[13] = m[14] = 0.f, m[15] = 1.f;
+    inverse4f(m, inv);
+    for (int k = 0; k < 16; ++k) st->pose_inv[k] = inv[k];
 }
 
 // The two halves of one pass of rgbKernel (reduce.cu:504-535) over the PX records of a lane.
@@ -967,6 +976,26 @@ __global__ void gn_level_begin_kernel(OdomState* st, int first_level, LevelIntr 
     if (gridDim.x > 1) st = batch_shift(st, bd.d[blockIdx.x]);
     if (share_so3 && blockIdx.x > 0) so3_share(st, leader);
     gn_level_begin(st, first_level, intr);
+}
+
+// The result of a chain goes to the host WITHOUT a runtime copy.  hipMemcpyAsync(D2H) + hipEventRecord cost a blit
+// kernel and a marker on the stream, and -- what matters -- the next launches the host makes on that stream stall inside
+// hipLaunchKernel until the copy has run (60 us each in an API trace), so nothing could be enqueued behind the copy
+// while the chain was still running.  One wave per model copies the state words into the host's pinned, device-visible
+// OdomState, fences at system scope and then stores the sequence number the host is polling for.
+struct PublishTargets {
+    OdomState* host[kMaxBatch];
+};
+__global__ __launch_bounds__(64) void odom_publish_kernel(const OdomState* st, PublishTargets to, unsigned seq, BatchDelta bd) {
+    if (gridDim.x > 1) st = batch_shift(st, bd.d[blockIdx.x]);
+    OdomState* host = to.host[blockIdx.x];
+    const unsigned* src = reinterpret_cast<const unsigned*>(st);
+    unsigned* dst = reinterpret_cast<unsigned*>(host);
+    constexpr unsigned kWords = offsetof(OdomState, publish_seq) / 4;
+    for (unsigned i = threadIdx.x; i < kWords; i += 64) dst[i] = src[i];
+    __threadfence_system();
+    __builtin_amdgcn_s_barrier();  // one wave: every lane's stores are fenced before lane 0 publishes
+    if (threadIdx.x == 0) __hip_atomic_store(&host->publish_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void odom_end_kernel(OdomState* st, BatchDelta bd) {
