@@ -67,6 +67,15 @@ struct mmf_fusion {
     // clean / fill-in read one while frame t+1's filter writes the other.
     float* filtered[2] = {nullptr, nullptr};
     int cur = 0;
+    // The model side of the tracker's preparation (prediction -> model pyramids in the global frame, point clouds,
+    // intensity pyramid: Model::initICP's initICPModel / initRGBModel, Model.cpp:396-401) needs nothing of the next
+    // sensor frame.  With one model it is enqueued at the END of a frame, behind the final predict(), where the
+    // fusion stream would otherwise idle until the side streams have finished the next frame's sensor side; the next
+    // processFrame uses it if nothing it was computed from has changed since (pose, images, mode), else redoes it.
+    bool spec_valid = false;
+    float spec_pose[16];
+    unsigned long long spec_tex_gen = 0;
+    int spec_f2f = 0;
     GraphCache depth_chain_graphs, image_chain_graphs;  // the two launch chains of a prefetch (launch_graph.hpp)
     hipStream_t side = nullptr;   // depth chain: filter, depth pyramid, vertex / normal maps
     hipStream_t side2 = nullptr;  // image chain: intensity pyramid, gradients, SO3 pre-alignment
@@ -551,7 +560,14 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // generateCUDATextures (:302) + the sensor side of Model::initICP (Model.cpp:402-403: initICP, initRGB), once
             // for all models.  One model without pose initialisation: sensor side and model side share four launches.
             const auto t_track = std::chrono::steady_clock::now();
-            const bool one_pass = n_models == 1 && !have_init && fusion_owns(f, 0);
+            float pose_now[16];
+            mmf_model_get_pose(global->model, pose_now);
+            const bool spec_hit = f->spec_valid && n_models == 1 && !have_init && fusion_owns(f, 0) &&
+                                  std::memcmp(pose_now, f->spec_pose, sizeof(pose_now)) == 0 &&
+                                  global->model->tex_gen == f->spec_tex_gen && f->spec_f2f == g.frame_to_frame_rgb &&
+                                  global->odom->prep_batched;
+            f->spec_valid = false;
+            const bool one_pass = n_models == 1 && !have_init && fusion_owns(f, 0) && !spec_hit;
             if (!prefetched && !one_pass) {
                 float identity[16];
                 identity16(identity);
@@ -596,7 +612,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 // Model::performTracking (Model.cpp:409-433) with Model::initICP (:390-407).  requiresFillIn (:380,
                 // :877-895) is decided on the device: the preparation jobs pick their sources from the flag
                 const mmf_model* m = fm->model;
-                if (fm->fill_in) {
+                if (fm->fill_in && !spec_hit) {
                     hipLaunchKernelGGL(thumbnail_flag_kernel, dim3(1), dim3(256), 0, fm->lane->stream, m->image, m->width,
                                        m->height, 0.75f, reinterpret_cast<int*>(&m->totals[3]));
                     MMF_HIP_TRY(hipGetLastError());
@@ -660,7 +676,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             }
             for (size_t k = 0; k < tracked.size() && !batch_ok; ++k) {
                 FusionModel* fm = tracked[k];
-                if (!batched) {  // (a failed batch has prepared every model already)
+                if (spec_hit) {  // the model side was prepared at the end of the last frame; the sensor side by the prefetch
+                    fm->odom->depth_l0 = f->depth_filtered;  // (or just above)
+                } else if (!batched) {  // (a failed batch has prepared every model already)
                     PrepStages stages;
                     collect_prep(stages, fm, (fm == global && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE);
                     rc = stages.launch(fm->lane->stream, graphs_enabled() ? &fm->odom->prep_graphs : nullptr);
@@ -876,6 +894,28 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
         rc = fusion_prefetch_impl(f, fr->next_rgb, fr->next_depth, f->tick);
         if (rc) return rc;
     }
+    // next frame's model-side preparation, now (see mmf_fusion::spec_valid); behind the prefetch's enqueue: the side
+    // streams have the longer way to go
+    if (!g.enable_multiple_models && f->models.size() == 1 && fusion_owns(f, 0) && global->lane->stream == c->stream) {
+        const mmf_model* m = global->model;
+        if (global->fill_in) {  // requiresFillIn (:380, :877-895) of the next frame: decided on the device from this prediction
+            hipLaunchKernelGGL(thumbnail_flag_kernel, dim3(1), dim3(256), 0, c->stream, m->image, m->width, m->height, 0.75f,
+                               reinterpret_cast<int*>(&m->totals[3]));
+            MMF_HIP_TRY(hipGetLastError());
+        }
+        PrepStages stages;
+        const uint8_t* pi = (const uint8_t*)((g.frame_to_frame_rgb && global->fill_in) ? m->fill_image : m->image);
+        mmf_model_get_pose(global->model, f->spec_pose);
+        odom_prepare_collect(stages, global->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
+                             (const float*)m->normalRadius, pi, 4, f->spec_pose,
+                             global->fill_in ? reinterpret_cast<const int*>(&m->totals[3]) : nullptr, (const float*)m->fill_vertex,
+                             (const float*)m->fill_normal, (const uint8_t*)m->fill_image, PREP_MODEL_SIDE);
+        rc = stages.launch(c->stream, graphs_enabled() ? &global->odom->prep_graphs : nullptr);
+        if (rc) return rc;
+        f->spec_tex_gen = m->tex_gen;
+        f->spec_f2f = g.frame_to_frame_rgb;
+        f->spec_valid = true;
+    }
     f->t_frame_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return MMF_OK;
 }
@@ -1071,6 +1111,7 @@ extern "C" int mmf_fusion_reset(mmf_fusion* f) {
         fm->unseen = 0;
         fm->pose_log.clear();
     }
+    f->spec_valid = false;
     f->tick = 1;
     return MMF_OK;
 }

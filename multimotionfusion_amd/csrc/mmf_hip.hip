@@ -1724,6 +1724,7 @@ struct mmf_model {
     float conf_threshold = 10.f;
     float max_depth = FLT_MAX;  // Model::maxDepth (Model.h:129, set per object from the segmentation: MultiMotionFusion.cpp:486,586)
     int capacity = 0;
+    unsigned long long tex_gen = 0;    // bumped by every pass that rewrites the prediction / fill-in images
     const float* t_inv_dev = nullptr;  // set by the orchestrator around projections it enqueues before the tracked pose has
                                        // reached the host: the device copy of inverse(pose) (OdomState::pose_inv)
     float pose[16];
@@ -2016,6 +2017,7 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     MMF_REQUIRE(m != nullptr, "mmf_model_combined_predict: null model");
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
+    ++m->tex_gen;
     SplatArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
     a.t_inv_dev = m->t_inv_dev;
@@ -2134,6 +2136,7 @@ extern "C" int mmf_model_clean(mmf_model* m, int time, int time_delta, float dep
 extern "C" int mmf_model_perform_fill_in(mmf_model* m, const uint8_t* rgb, const float* depth_filtered,
                                          int frame_to_frame_rgb, int lost) {
     MMF_REQUIRE(m && rgb && depth_filtered, "mmf_model_perform_fill_in: null argument");
+    ++m->tex_gen;
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     const int npix = m->width * m->height;

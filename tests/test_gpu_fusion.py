@@ -105,14 +105,16 @@ def test_batched_preparation_matches_the_separate_kernels(gpu_ctx):
     g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
     g.processFrame(dev(f0["rgb"]), dev(f0["depth"]), timestamp=0)
     m = g.getBackgroundModel()
-    # what the tracker of frame 1 will be prepared from: after one frame the surfels are still unstable,
-    # the splat shows nothing and the fill-in images are used (Model.cpp:380-407)
-    names = ("fillVertex", "fillNormal", "fillImage") if m.requiresFillIn(0.75) else ("vertexConf", "normalRadius", "image")
-    vc, nr, img = (m.texture(n).clone() for n in names)
-    pose0 = g.getCurrPose().astype(np.float32)
     d_rgb1, d_depth1 = dev(f1["rgb"]), dev(f1["depth"])
     g.processFrame(d_rgb1, d_depth1, timestamp=1)
     batched = g.getFrameOdometry()
+    # After a frame the odometry holds frame 1's sensor side (prepared for its own tracking) and, already, the model side
+    # of the NEXT frame's tracking: prepared at the end of processFrame from the final prediction and the tracked pose.
+    # After two frames the surfels are still unstable, the splat shows nothing and the fill-in images are used
+    # (Model.cpp:380-407)
+    names = ("fillVertex", "fillNormal", "fillImage") if m.requiresFillIn(0.75) else ("vertexConf", "normalRadius", "image")
+    vc, nr, img = (m.texture(n).clone() for n in names)
+    pose0 = g.getCurrPose().astype(np.float32)
 
     ref = RGBDOdometry(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
     ref.initFirstRGB(dev(f0["rgb"]))
@@ -403,3 +405,54 @@ def test_graph_replay_gives_the_same_bits():
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0])
     assert out[0] == out[1]
+
+
+@pytest.mark.gpu
+def test_end_of_frame_model_preparation_is_dropped_when_its_inputs_change(gpu_ctx, orc):
+    """processFrame prepares the model side of the next frame's tracking at its end (from the final prediction and the
+    tracked pose).  That work must only be used if nothing changed in between: a pose set by the caller (checked against
+    the oracle orchestration with the same override), a predict() call, a pose dictated through inPose."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h, n = 160, 120, 6
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=29)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+    nudge = np.eye(4, dtype=np.float32)
+    nudge[0, 3], nudge[2, 3] = 0.004, -0.003
+
+    def run(mode):
+        g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+        out = []
+        for i in range(n):
+            if i == 3 and mode == "set_pose":  # overridePose between two frames
+                g.setModelPose(0, (g.getCurrPose() @ nudge).astype(np.float32))
+            if i == 3 and mode == "predict":   # rewrites the images the preparation read (same values: same result)
+                g.predict()
+            if i == 4 and mode == "in_pose":
+                g.processFrame(rgb[i], depth[i], timestamp=i, inPose=(np.linalg.inv(poses[0]) @ poses[i]).astype(np.float32))
+            else:
+                g.processFrame(rgb[i], depth[i], timestamp=i)
+            out.append(g.getCurrPose().copy())
+        surfels = g.getBackgroundModel().downloadMap()
+        g.close()
+        return out, surfels
+
+    ref, ref_map = run("plain")
+    got, got_map = run("predict")
+    for i in range(n):
+        assert np.array_equal(ref[i], got[i]), i
+    assert np.array_equal(ref_map.view(np.uint32), got_map.view(np.uint32))
+
+    for mode in ("set_pose", "in_pose"):
+        got, got_map = run(mode)
+        o = OracleFusion(orc, w, h, K)
+        for i, f in enumerate(frames):
+            if i == 3 and mode == "set_pose":
+                o.models[0].override_pose((o.pose @ nudge).astype(np.float32))
+            if i == 4 and mode == "in_pose":
+                o.process_frame(f["rgb"], f["depth"], in_pose=(np.linalg.inv(poses[0]) @ poses[i]).astype(np.float32))
+            else:
+                o.process_frame(f["rgb"], f["depth"])
+            assert np.abs(got[i] - o.pose).max() < 2e-5, (mode, i, np.abs(got[i] - o.pose).max())
+        assert abs(got_map.shape[0] - o.surfels.shape[0]) <= max(8, int(0.002 * o.surfels.shape[0])), mode
