@@ -254,7 +254,7 @@ def main():
             d_rgb = [up(f["rgb"]) for f in frames]
             d_depth = [up(f["depth"]) for f in frames]
             d_mask = [up(f["mask"]) for f in frames]
-        NB = 3  # frame k is processed, k + 1 already received, k + 2 being broadcast (RCCL's own stream)
+        NB = 4  # frame k is processed, k + 1 received and being prepared (mmf_frame::next_*), k + 2 being broadcast (RCCL's own stream)
         rgb_in = [torch.empty((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(NB)]
         depth_in = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(NB)]
         mask_in = [torch.zeros((H, W), dtype=torch.uint8, device=dev) for _ in range(NB)]
@@ -263,6 +263,9 @@ def main():
         mmf.setShard(rank, world)
         pending, posted = {}, set()
         state = {"frame": 0, "poses": None}
+        # (the gloo rehearsal puts several ranks on ONE GPU: with the side streams of the prefetch every cross-queue wait
+        # then costs a process time slice -- 44 ms instead of 1.7 ms per step at two ranks -- so it is off there by default)
+        PREFETCH_SHARD = os.environ.get("MMF_BENCH_PREFETCH", "1" if backend == "nccl" or world == 1 else "0") != "0"
 
         def step(i):
             n = state["frame"]
@@ -283,8 +286,9 @@ def main():
 
             post(n)
             post(n + 1)
-            for w_ in pending.pop(n, []):  # the compute stream waits for the collective; the host does not
-                w_.wait()
+            for m in (n, n + 1):  # the compute stream waits for the collectives of this frame and of the one it prefetches;
+                for w_ in pending.pop(m, []):  # the host does not
+                    w_.wait()
             post(n + 2)
             posted.discard(n - 1)
             if state["poses"] is not None:  # last step's all-gather: the poses of the models other ranks own
@@ -297,11 +301,13 @@ def main():
                 state["poses"] = None
             spawn = 1 <= n < world  # object id n appears in the mask of step n: a new label (one per frame)
             if world == 1:
-                kk = pingpong(n, N_FRAMES_OBJECTS)
-                mmf.processFrame(d_rgb[kk], d_depth[kk], timestamp=i, mask=d_mask[kk], hasNewLabel=False)
+                kk, kn = pingpong(n, N_FRAMES_OBJECTS), pingpong(n + 1, N_FRAMES_OBJECTS)
+                mmf.processFrame(d_rgb[kk], d_depth[kk], timestamp=i, mask=d_mask[kk], hasNewLabel=False,
+                                 next=(d_rgb[kn], d_depth[kn]) if PREFETCH_SHARD else None)
             else:
-                b = n % NB
-                mmf.processFrame(rgb_in[b], depth_in[b], timestamp=i, mask=mask_in[b], hasNewLabel=spawn)
+                b, bn = n % NB, (n + 1) % NB
+                mmf.processFrame(rgb_in[b], depth_in[b], timestamp=i, mask=mask_in[b], hasNewLabel=spawn,
+                                 next=(rgb_in[bn], depth_in[bn]) if PREFETCH_SHARD else None)
             if state.get("own") is None and ctx.lib.mmf_fusion_num_models(mmf.handle) > rank:
                 state["own"] = mmf.getModels()[rank]  # this rank's model has joined the list
             pose = state["own"].getPose() if state.get("own") is not None else np.eye(4, dtype=np.float32)
@@ -319,8 +325,9 @@ def main():
 
         text = (f"{W}x{H} synthetic RGB-D, moving rigid objects, mask = ground-truth ids: {world} rigid-body models (the static scene + "
                 f"{world - 1} objects), ONE PER GPU (mmf_fusion_set_shard): rank 0 broadcasts the frame (8 B/px, RCCL), every rank runs the "
-                "sensor-side preparation and processFrame for the model it owns (bilateral filter, dense ICP+RGB odometry, splat, index "
-                "map, fuse, clean), poses are all-gathered (72 B per rank); the sequence is played forwards and backwards (no reset)")
+                "sensor-side preparation (for the next frame on side streams, during the current frame's fusion) and processFrame for "
+                "the model it owns (bilateral filter, dense ICP+RGB odometry, splat, index map, fuse, clean), poses are all-gathered "
+                "(72 B per rank); the sequence is played forwards and backwards (no reset)")
         return mmf, step, fence, text
 
     def timed_run(step, fence, warmup, steps):

@@ -34,6 +34,17 @@ struct FusionModel {  // one ModelPointer of the reference's `models` list
     float* rgb_error = nullptr;
     hipEvent_t ev_done = nullptr;
     bool tracking = false;  // a tracking call is in flight on the lane
+    bool early_done = false;  // this frame's predict() + first predictIndices went out before the pose reached the host
+    // The model side of the tracker's preparation (prediction -> model pyramids in the global frame, point clouds,
+    // intensity pyramid: Model::initICP's initICPModel / initRGBModel, Model.cpp:396-401) needs nothing of the next
+    // sensor frame.  When this process runs ONE model it is enqueued at the END of a frame, behind the final predict(),
+    // where the model's stream would otherwise idle until the side streams have finished the next frame's sensor side;
+    // the next processFrame uses it if nothing it was computed from has changed since (pose, images, mode), else
+    // prepares as before.
+    bool spec_valid = false, spec_hit = false;
+    float spec_pose[16];
+    unsigned long long spec_tex_gen = 0;
+    int spec_f2f = 0;
     std::vector<PoseLogItem> pose_log;
 };
 
@@ -67,15 +78,6 @@ struct mmf_fusion {
     // clean / fill-in read one while frame t+1's filter writes the other.
     float* filtered[2] = {nullptr, nullptr};
     int cur = 0;
-    // The model side of the tracker's preparation (prediction -> model pyramids in the global frame, point clouds,
-    // intensity pyramid: Model::initICP's initICPModel / initRGBModel, Model.cpp:396-401) needs nothing of the next
-    // sensor frame.  With one model it is enqueued at the END of a frame, behind the final predict(), where the
-    // fusion stream would otherwise idle until the side streams have finished the next frame's sensor side; the next
-    // processFrame uses it if nothing it was computed from has changed since (pose, images, mode), else redoes it.
-    bool spec_valid = false;
-    float spec_pose[16];
-    unsigned long long spec_tex_gen = 0;
-    int spec_f2f = 0;
     GraphCache depth_chain_graphs, image_chain_graphs;  // the two launch chains of a prefetch (launch_graph.hpp)
     hipStream_t side = nullptr;   // depth chain: filter, depth pyramid, vertex / normal maps
     hipStream_t side2 = nullptr;  // image chain: intensity pyramid, gradients, SO3 pre-alignment
@@ -515,7 +517,6 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     int rc = MMF_OK;
     bool prefetched = false;
     bool next_prefetched = false;  // mmf_frame::next_* has been enqueued
-    bool early_projections = false;  // the global model's predict + predictIndices went out before its pose reached the host
     if (f->pre_valid) {  // whatever was prefetched has to be complete before this frame touches the same buffers
         MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch_done, 0));
         MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch2_done, 0));
@@ -560,14 +561,18 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // generateCUDATextures (:302) + the sensor side of Model::initICP (Model.cpp:402-403: initICP, initRGB), once
             // for all models.  One model without pose initialisation: sensor side and model side share four launches.
             const auto t_track = std::chrono::steady_clock::now();
-            float pose_now[16];
-            mmf_model_get_pose(global->model, pose_now);
-            const bool spec_hit = f->spec_valid && n_models == 1 && !have_init && fusion_owns(f, 0) &&
-                                  std::memcmp(pose_now, f->spec_pose, sizeof(pose_now)) == 0 &&
-                                  global->model->tex_gen == f->spec_tex_gen && f->spec_f2f == g.frame_to_frame_rgb &&
-                                  global->odom->prep_batched;
-            f->spec_valid = false;
-            const bool one_pass = n_models == 1 && !have_init && fusion_owns(f, 0) && !spec_hit;
+            for (size_t k = 0; k < n_models; ++k) {  // is last frame's end-of-frame preparation of a model still good?
+                FusionModel* fm = f->models[k];
+                float pose_now[16];
+                mmf_model_get_pose(fm->model, pose_now);
+                fm->spec_hit = fm->spec_valid && fusion_owns(f, k) && !have_init &&
+                               std::memcmp(pose_now, fm->spec_pose, sizeof(pose_now)) == 0 &&
+                               fm->model->tex_gen == fm->spec_tex_gen && fm->spec_f2f == g.frame_to_frame_rgb &&
+                               fm->odom->prep_batched;
+                fm->spec_valid = false;
+                fm->early_done = false;
+            }
+            const bool one_pass = n_models == 1 && !have_init && fusion_owns(f, 0) && !global->spec_hit;
             if (!prefetched && !one_pass) {
                 float identity[16];
                 identity16(identity);
@@ -612,7 +617,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 // Model::performTracking (Model.cpp:409-433) with Model::initICP (:390-407).  requiresFillIn (:380,
                 // :877-895) is decided on the device: the preparation jobs pick their sources from the flag
                 const mmf_model* m = fm->model;
-                if (fm->fill_in && !spec_hit) {
+                if (fm->fill_in && !fm->spec_hit) {
                     hipLaunchKernelGGL(thumbnail_flag_kernel, dim3(1), dim3(256), 0, fm->lane->stream, m->image, m->width,
                                        m->height, 0.75f, reinterpret_cast<int*>(&m->totals[3]));
                     MMF_HIP_TRY(hipGetLastError());
@@ -646,8 +651,13 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     MMF_HIP_TRY(hipStreamWaitEvent(st, tracked[k]->ev_done, 0));
                 }
                 PrepStages stages;
-                for (size_t k = 0; k < tracked.size(); ++k)
+                for (size_t k = 0; k < tracked.size(); ++k) {
+                    if (tracked[k]->spec_hit) {
+                        tracked[k]->odom->depth_l0 = f->depth_filtered;
+                        continue;
+                    }
                     collect_prep(stages, tracked[k], (k == 0 && tracked[k] == global && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE);
+                }
                 rc = stages.launch(st, graphs_enabled() ? &lead->odom->prep_graphs : nullptr);
                 if (rc) return rc;
                 batch_ok = odom_batchable(lead->odom, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom);
@@ -676,7 +686,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             }
             for (size_t k = 0; k < tracked.size() && !batch_ok; ++k) {
                 FusionModel* fm = tracked[k];
-                if (spec_hit) {  // the model side was prepared at the end of the last frame; the sensor side by the prefetch
+                if (fm->spec_hit) {  // the model side was prepared at the end of the last frame; the sensor side by the prefetch
                     fm->odom->depth_l0 = f->depth_filtered;  // (or just above)
                 } else if (!batched) {  // (a failed batch has prepared every model already)
                     PrepStages stages;
@@ -700,14 +710,16 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // behind the chain and the copy of its result, with the inverse pose read from the odometry's device state.
             // They run while the host picks the pose up and prepares the fusion passes (that turnaround used to be ~25 us
             // of idle GPU per frame).
-            if (tracked.size() == 1 && tracked[0] == global && global->lane->stream == c->stream && !fr->bootstrap &&
-                !have_init && !g.enable_multiple_models && !g.rgb_only && f->tracking_ok) {
-                global->model->t_inv_dev = global->odom->state->pose_inv;
-                rc = fusion_predict_model(f, global);
-                if (rc == MMF_OK) rc = mmf_model_predict_indices(global->model, f->tick, g.max_depth_processed, g.time_delta);
-                global->model->t_inv_dev = nullptr;
+            // (With several models it is one model per process in the sharded configuration: the segmentation between
+            // tracking and fusion touches masks, thresholds and the list, none of which a projection reads.)
+            if (tracked.size() == 1 && !fr->bootstrap && !have_init && !g.rgb_only && f->tracking_ok) {
+                FusionModel* fm = tracked[0];
+                fm->model->t_inv_dev = fm->odom->state->pose_inv;
+                rc = fusion_predict_model(f, fm);
+                if (rc == MMF_OK) rc = mmf_model_predict_indices(fm->model, f->tick, g.max_depth_processed, g.time_delta);
+                fm->model->t_inv_dev = nullptr;
                 if (rc) return rc;
-                early_projections = true;
+                fm->early_done = true;
             }
             // the sensor-side image ring (this frame's / last frame's intensity pyramid, RGBDOdometry.cpp:469-473) lives in
             // the global odometry and advances when its chain is enqueued: when its owner is another rank, the swap
@@ -841,7 +853,8 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 rc = lane_wait(fm, f->ev_frame_ready);
                 if (rc) return rc;
             }
-            const bool early = early_projections && fm == global;  // its predict + predictIndices are already enqueued
+            const bool early = fm->early_done;  // its predict + predictIndices are already enqueued
+            fm->early_done = false;
             if (!early) {
                 rc = fusion_predict_model(f, fm);
                 if (rc) return rc;
@@ -894,27 +907,34 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
         rc = fusion_prefetch_impl(f, fr->next_rgb, fr->next_depth, f->tick);
         if (rc) return rc;
     }
-    // next frame's model-side preparation, now (see mmf_fusion::spec_valid); behind the prefetch's enqueue: the side
+    // next frame's model-side preparation, now (see FusionModel::spec_valid); behind the prefetch's enqueue: the side
     // streams have the longer way to go
-    if (!g.enable_multiple_models && f->models.size() == 1 && fusion_owns(f, 0) && global->lane->stream == c->stream) {
-        const mmf_model* m = global->model;
-        if (global->fill_in) {  // requiresFillIn (:380, :877-895) of the next frame: decided on the device from this prediction
-            hipLaunchKernelGGL(thumbnail_flag_kernel, dim3(1), dim3(256), 0, c->stream, m->image, m->width, m->height, 0.75f,
-                               reinterpret_cast<int*>(&m->totals[3]));
-            MMF_HIP_TRY(hipGetLastError());
+    {
+        FusionModel* only = nullptr;
+        int owned = 0;
+        for (size_t k = 0; k < f->models.size(); ++k)
+            if (fusion_owns(f, k)) only = f->models[k], ++owned;
+        if (owned == 1) {
+            const mmf_model* m = only->model;
+            hipStream_t st = only->lane->stream;
+            if (only->fill_in) {  // requiresFillIn (:380, :877-895) of the next frame: decided on the device from this prediction
+                hipLaunchKernelGGL(thumbnail_flag_kernel, dim3(1), dim3(256), 0, st, m->image, m->width, m->height, 0.75f,
+                                   reinterpret_cast<int*>(&m->totals[3]));
+                MMF_HIP_TRY(hipGetLastError());
+            }
+            PrepStages stages;
+            const uint8_t* pi = (const uint8_t*)((g.frame_to_frame_rgb && only->fill_in) ? m->fill_image : m->image);
+            mmf_model_get_pose(only->model, only->spec_pose);
+            odom_prepare_collect(stages, only->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
+                                 (const float*)m->normalRadius, pi, 4, only->spec_pose,
+                                 only->fill_in ? reinterpret_cast<const int*>(&m->totals[3]) : nullptr, (const float*)m->fill_vertex,
+                                 (const float*)m->fill_normal, (const uint8_t*)m->fill_image, PREP_MODEL_SIDE);
+            rc = stages.launch(st, graphs_enabled() ? &only->odom->prep_graphs : nullptr);
+            if (rc) return rc;
+            only->spec_tex_gen = m->tex_gen;
+            only->spec_f2f = g.frame_to_frame_rgb;
+            only->spec_valid = true;
         }
-        PrepStages stages;
-        const uint8_t* pi = (const uint8_t*)((g.frame_to_frame_rgb && global->fill_in) ? m->fill_image : m->image);
-        mmf_model_get_pose(global->model, f->spec_pose);
-        odom_prepare_collect(stages, global->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
-                             (const float*)m->normalRadius, pi, 4, f->spec_pose,
-                             global->fill_in ? reinterpret_cast<const int*>(&m->totals[3]) : nullptr, (const float*)m->fill_vertex,
-                             (const float*)m->fill_normal, (const uint8_t*)m->fill_image, PREP_MODEL_SIDE);
-        rc = stages.launch(c->stream, graphs_enabled() ? &global->odom->prep_graphs : nullptr);
-        if (rc) return rc;
-        f->spec_tex_gen = m->tex_gen;
-        f->spec_f2f = g.frame_to_frame_rgb;
-        f->spec_valid = true;
     }
     f->t_frame_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return MMF_OK;
@@ -1111,7 +1131,7 @@ extern "C" int mmf_fusion_reset(mmf_fusion* f) {
         fm->unseen = 0;
         fm->pose_log.clear();
     }
-    f->spec_valid = false;
+    for (FusionModel* fm : all) fm->spec_valid = false;
     f->tick = 1;
     return MMF_OK;
 }
