@@ -113,13 +113,14 @@ def test_process_frame_objects_1280x960(gpu_ctx):
     rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
     mask = [dev(np.where(f["ids"] < 3, f["ids"], 0).astype(np.uint8)) for f in frames]
 
-    def run(shard=None):
+    def run(shard=None, hint=False):
         g = MultiMotionFusion(gpu_ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1, preallocated_models=2)
         if shard is not None:
             g.setShard(*shard)
         out = []
         for i in range(n):
-            g.processFrame(rgb[i], depth[i], timestamp=i, mask=mask[i], hasNewLabel=1 <= i <= 2)
+            nxt = (rgb[i + 1], depth[i + 1]) if hint and i + 1 < n else None  # mmf_frame::next_*: the bench's sharded step
+            g.processFrame(rgb[i], depth[i], timestamp=i, mask=mask[i], hasNewLabel=1 <= i <= 2, next=nxt)
             out.append([m.getPose() for m in g.getModels()])
         models = g.getModels()
         res = dict(poses=out, ids=[m.id for m in models], conf=[m.confidenceThreshold() for m in models],
@@ -150,3 +151,13 @@ def test_process_frame_objects_1280x960(gpu_ctx):
         assert np.array_equal(a["poses"][i][1], c["poses"][i][1]), i
     assert np.array_equal(a["maps"][1].view(np.uint32), c["maps"][1].view(np.uint32))
     assert c["counts"][0] == 0 and c["counts"][2] == 0  # the other models are bookkeeping only here
+    # the same shard with the next frame's buffers handed in (sensor-side preparation on the side streams; this rank's one
+    # model also gets its projections before the pose wait and its model-side preparation at the end of the frame)
+    d = run(shard=(1, 3), hint=True)
+    for i in range(1, n):
+        assert np.array_equal(a["poses"][i][1], d["poses"][i][1]), i
+    assert np.array_equal(a["maps"][1].view(np.uint32), d["maps"][1].view(np.uint32))
+    e = run(shard=(0, 3), hint=True)  # and the rank that owns the static scene
+    for i in range(n):
+        assert np.array_equal(a["poses"][i][0], e["poses"][i][0]), i
+    assert np.array_equal(a["maps"][0].view(np.uint32), e["maps"][0].view(np.uint32))
