@@ -78,6 +78,7 @@ struct mmf_fusion {
     // clean / fill-in read one while frame t+1's filter writes the other.
     float* filtered[2] = {nullptr, nullptr};
     int cur = 0;
+    mmf_odom* so3_odom = nullptr;  // whose state holds the prefetched SO3 pre-alignment of the next frame
     GraphCache depth_chain_graphs, image_chain_graphs;  // the two launch chains of a prefetch (launch_graph.hpp)
     hipStream_t side = nullptr;   // depth chain: filter, depth pyramid, vertex / normal maps
     hipStream_t side2 = nullptr;  // image chain: intensity pyramid, gradients, SO3 pre-alignment
@@ -525,7 +526,10 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     }
     const bool track = f->tick > 1 && (fr->bootstrap || !fr->in_pose);  // :299 "regular execution"
     // a prefetched SO3 pre-alignment only counts for the frame it was computed for, and only when that frame is tracked
-    if (!prefetched || !track || (have_init && !fr->icp_refine)) global->odom->so3_prefetched = false;
+    mmf_odom* const so3_pre = f->so3_odom;  // the odometry the prefetch ran the SO3 loop in (the one model this process runs)
+    f->so3_odom = nullptr;
+    if (so3_pre && (!prefetched || !track || (have_init && !fr->icp_refine))) so3_pre->so3_prefetched = false;
+    if (so3_pre != global->odom) global->odom->so3_prefetched = false;
     if (prefetched) {  // the filter (:262) and the input-side preparation already ran on the side stream
         f->cur ^= 1;
         f->depth_filtered = f->filtered[f->cur];
@@ -627,6 +631,11 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 std::memcpy(fm->last_pose, pose, sizeof(pose));  // lastPose = pose (Model.cpp:412)
                 fm->tracking = true;
                 tracked.push_back(fm);
+            }
+            if (so3_pre && so3_pre->so3_prefetched) {  // ... in a model that is not tracked here on its own after all
+                bool used = tracked.size() == 1 && tracked[0]->odom == so3_pre;
+                used = used || (!tracked.empty() && tracked[0]->odom == so3_pre);  // the leader of a batch
+                if (!used) so3_pre->so3_prefetched = false;
             }
             // ONE chain of launches for all tracked models (gridDim.y = model) when every level runs on the fused
             // producer path and no model went through a pose-initialisation round on its own stream; else one chain
@@ -1075,8 +1084,25 @@ static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* 
     if (rc) return rc;
     odom->so3_prefetched = false;
     if (g.so3 && tick_at_use > 1) {  // a model exists: the frame will be tracked, SO3 first
-        rc = odom_prefetch_so3(odom, qi, f->side_partials, f->side_ticket);
+        // Every model's odometry runs the same pre-alignment on the same two images (RGBDOdometry.cpp:239-310 has no model
+        // input).  It is computed in the state of the model that will consume it: the global model's, or -- when this
+        // process runs exactly one other model (a rank of the shard) -- that model's, whose sensor-side pointers alias
+        // the global odometry's.
+        mmf_odom* target = odom;
+        int owned = 0;
+        for (size_t k = 0; k < f->models.size(); ++k)
+            if (fusion_owns(f, k)) {
+                ++owned;
+                target = f->models[k]->odom;
+            }
+        if (owned != 1) target = odom;
+        if (target != odom) {
+            odom_alias_sensor_side(target, odom);
+            target->so3_prefetched = false;
+        }
+        rc = odom_prefetch_so3(target, qi, f->side_partials, f->side_ticket);
         if (rc) return rc;
+        f->so3_odom = target;
     }
     MMF_HIP_TRY(qi.flush());
     MMF_HIP_TRY(hipEventRecord(f->ev_prefetch2_done, img_stream));
@@ -1132,6 +1158,7 @@ extern "C" int mmf_fusion_reset(mmf_fusion* f) {
         fm->pose_log.clear();
     }
     for (FusionModel* fm : all) fm->spec_valid = false;
+    f->so3_odom = nullptr;
     f->tick = 1;
     return MMF_OK;
 }

@@ -29,6 +29,8 @@ rgb, depth = [up(f["rgb"]) for f in frames], [up(f["depth"]) for f in frames]
 mask = [up(np.where(f["ids"] < models, f["ids"], 0).astype(np.uint8)) for f in frames]
 ctx = Context(0)
 g = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=int(models > 1), preallocated_models=models - 1)
+if os.environ.get("MMF_PROFILE_SHARD"):  # "rank/world": this process runs only the models with index % world == rank (no collectives here)
+    g.setShard(*(int(v) for v in os.environ["MMF_PROFILE_SHARD"].split("/")))
 
 
 def frame_of(i):
@@ -50,7 +52,9 @@ for i in range(n):
         g.processFrame(rgb[k], depth[k], timestamp=i, next=(rgb[(i + 1) % nf], depth[(i + 1) % nf]) if (i + 1) % nf != 0 else None)
         continue
     if models > 1:
-        g.processFrame(rgb[k], depth[k], timestamp=i, mask=mask[k], hasNewLabel=1 <= i < models)
+        kn = frame_of(i + 1)
+        g.processFrame(rgb[k], depth[k], timestamp=i, mask=mask[k], hasNewLabel=1 <= i < models,
+                       next=(rgb[kn], depth[kn]) if prefetch else None)
     else:
         g.processFrame(rgb[k], depth[k], timestamp=i)
         if prefetch:
