@@ -456,3 +456,32 @@ def test_end_of_frame_model_preparation_is_dropped_when_its_inputs_change(gpu_ct
                 o.process_frame(f["rgb"], f["depth"])
             assert np.abs(got[i] - o.pose).max() < 2e-5, (mode, i, np.abs(got[i] - o.pose).max())
         assert abs(got_map.shape[0] - o.surfels.shape[0]) <= max(8, int(0.002 * o.surfels.shape[0])), mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,nframes", [(160, 120, 6), (320, 240, 5)])
+def test_process_frame_with_dictated_poses_is_bit_exact(gpu_ctx, orc, w, h, nframes):
+    """processFrame with the pose handed in (inPose, MultiMotionFusion.cpp:299, 668-671) runs everything but the tracker:
+    filter, predict, index map, fuse (computeFusionWeight of an unmoved pose), index map, clean, predict + fill-in.
+    Without the tracker's float32 sums in the loop the whole sequence is integer / per-pixel arithmetic: the map must equal
+    the oracle orchestration's bit for bit after EVERY frame (the free-running sequence test can only bound the drift)."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(nframes, seed=23)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    o = OracleFusion(orc, w, h, K)
+    for i, f in enumerate(frames):
+        P = (np.linalg.inv(poses[0]) @ poses[i]).astype(np.float32)
+        nxt = (dev(frames[i + 1]["rgb"]), dev(frames[i + 1]["depth"])) if i + 1 < nframes else None
+        if i == 0:
+            g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=i)
+            o.process_frame(f["rgb"], f["depth"])
+        else:
+            g.processFrame(dev(f["rgb"]), dev(f["depth"]), timestamp=i, inPose=P, next=nxt if i % 2 else None)
+            o.process_frame(f["rgb"], f["depth"], in_pose=P)
+        assert np.array_equal(g.getCurrPose(), o.pose), i
+        sg, so = g.getBackgroundModel().downloadMap(), o.surfels
+        assert sg.shape == so.shape, (i, sg.shape, so.shape)
+        assert np.array_equal(sg.view(np.uint32), so.view(np.uint32)), (i, int((sg.view(np.uint32) != so.view(np.uint32)).sum()))
+    g.close()
