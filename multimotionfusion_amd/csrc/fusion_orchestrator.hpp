@@ -737,10 +737,10 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             const bool global_tracks_somewhere = !(have_init && !fr->icp_refine);
             if (g.so3 && global_tracks_somewhere && !global_tracked)
                 for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(global->odom->last_next_image[i], global->odom->next_image[i]);
-            // mmf_frame::next_*: the next frame's sensor-side preparation is enqueued NOW, while the chains run and the host
-            // would only wait -- possible when every chain is on the context's stream (one model, or one batched chain led
-            // by the global model): an event behind the chain is then "nothing enqueued so far reads the odometries'
-            // sensor-side buffers or the other filtered-depth buffer" in stream order.  Otherwise: after the results.
+            // EXPERIMENT (MMF_PREFETCH_EARLY=1, off; profiles/r02_ab_graphs_prefetch.txt): mmf_frame::next_* enqueued
+            // here, while the chains run and the host would only wait, instead of at the end of the call.  Correct (an
+            // event behind the chain orders it) but 20 % SLOWER: the side streams then sit on a barrier packet for the
+            // whole chain, and a dependent chain on another queue runs slower next to parked queues (308 -> 370-450 us).
             bool inputs_free_early = false;
             static const bool early = std::getenv("MMF_PREFETCH_EARLY") != nullptr;
             if (early && fr->next_rgb && fr->next_depth && !tracked.empty() && tracked[0]->lane->stream == c->stream &&
@@ -1040,15 +1040,8 @@ static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* 
     MMF_HIP_TRY(hipSetDevice(c->device));
     mmf_odom* odom = f->models[0]->odom;
     if (f->side == nullptr) {  // first use
-        if (std::getenv("MMF_SIDE_LOW_PRIORITY")) {
-            int lo = 0, hi = 0;
-            MMF_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            MMF_HIP_TRY(hipStreamCreateWithPriority(&f->side, hipStreamNonBlocking, lo));
-            MMF_HIP_TRY(hipStreamCreateWithPriority(&f->side2, hipStreamNonBlocking, lo));
-        } else {
         MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
         MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking));
-        }
         MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch_done, hipEventDisableTiming));
         MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch2_done, hipEventDisableTiming));
         MMF_HIP_TRY(hipMalloc(&f->side_partials, sizeof(float) * kMaxGrid * kPartialStride));

@@ -106,11 +106,6 @@ extern "C" int mmf_ctx_create(int device, void* stream, int private_stream, mmf_
         return fail(MMF_ERR_NO_DEVICE, m);
     }
     if (private_stream) {
-        if (std::getenv("MMF_MAIN_HIGH_PRIORITY")) {
-            int lo = 0, hi = 0;
-            MMF_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            MMF_HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
-        } else
         MMF_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     } else {
