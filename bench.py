@@ -262,7 +262,7 @@ def main():
                                 preallocated_models=0)
         mmf.setShard(rank, world)
         pending, posted = {}, set()
-        state = {"frame": 0, "poses": None}
+        state = {"frame": 0}
         # (the gloo rehearsal puts several ranks on ONE GPU: with the side streams of the prefetch every cross-queue wait
         # then costs a process time slice -- 44 ms instead of 1.7 ms per step at two ranks -- so it is off there by default)
         PREFETCH_SHARD = os.environ.get("MMF_BENCH_PREFETCH", "1" if backend == "nccl" or world == 1 else "0") != "0"
@@ -291,14 +291,7 @@ def main():
                     w_.wait()
             post(n + 2)
             posted.discard(n - 1)
-            if state["poses"] is not None:  # last step's all-gather: the poses of the models other ranks own
-                work, recs = state["poses"]
-                work.wait()
-                got = torch.stack(recs).cpu().numpy()
-                for r in range(min(world, ctx.lib.mmf_fusion_num_models(mmf.handle))):
-                    if r != rank:
-                        mmf.setModelPose(r, got[r, :16].reshape(4, 4))
-                state["poses"] = None
+            take_poses(n - 2)  # the all-gather of two steps ago: long complete, the host does not wait for the GPU here
             spawn = 1 <= n < world  # object id n appears in the mask of step n: a new label (one per frame)
             if world == 1:
                 kk, kn = pingpong(n, N_FRAMES_OBJECTS), pingpong(n + 1, N_FRAMES_OBJECTS)
@@ -311,13 +304,72 @@ def main():
             if state.get("own") is None and ctx.lib.mmf_fusion_num_models(mmf.handle) > rank:
                 state["own"] = mmf.getModels()[rank]  # this rank's model has joined the list
             pose = state["own"].getPose() if state.get("own") is not None else np.eye(4, dtype=np.float32)
-            if world > 1:  # every rank learns every model's pose (18 floats per rank), without a host round trip
-                state["poses"] = shard.gather_poses_async(pose, 0.0, 0.0, dev)
+            give_pose(n, pose)
             return pose
+
+        # Every rank learns every model's pose (18 floats per rank) without a host round trip in the step: the record goes
+        # up from pinned memory behind the frame's work, the all-gather follows it on RCCL's stream, a side stream brings
+        # the result down into pinned memory and records an event; the step that starts two frames later reads it.
+        # (Reading last step's result with .cpu() made the host wait for the GPU to drain the frame every step.)
+        n_slots = 3
+        slots = []
+        copy_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+        for _ in range(n_slots if world > 1 else 0):
+            slots.append({"rec_pin": torch.zeros(18, dtype=torch.float32).pin_memory(), "rec_dev": torch.zeros(18, dtype=torch.float32, device=dev),
+                          "out": [torch.empty(18, dtype=torch.float32, device=dev) for _ in range(world)],
+                          "got_pin": torch.zeros((world, 18), dtype=torch.float32).pin_memory(), "ev": torch.cuda.Event(), "step": -1})
+
+        # (as with the prefetch: ranks that SHARE a GPU pay a process time slice per cross-queue wait -- 9-50 ms per step in
+        # the two-rank gloo rehearsal -- so there the record is read back directly; MMF_BENCH_POSE_EXCHANGE overrides)
+        ASYNC_POSES = os.environ.get("MMF_BENCH_POSE_EXCHANGE", "async" if backend == "nccl" else "simple") == "async"
+
+        def give_pose(n, pose):
+            if world == 1:
+                return
+            if not ASYNC_POSES:
+                state["poses"] = shard.gather_poses_async(pose, 0.0, 0.0, dev)
+                return
+            sl = slots[n % n_slots]
+            sl["rec_pin"][:16] = torch.from_numpy(np.ascontiguousarray(pose, dtype=np.float32).reshape(16))
+            sl["rec_dev"].copy_(sl["rec_pin"], non_blocking=True)
+            work = dist.all_gather(sl["out"], sl["rec_dev"], async_op=True)
+            with torch.cuda.stream(copy_stream):
+                work.wait()  # the side stream waits for the collective
+                sl["got_pin"].copy_(torch.stack(sl["out"]), non_blocking=True)
+                sl["ev"].record(copy_stream)
+            sl["step"] = n
+
+        def take_poses(n):
+            if world == 1:
+                return
+            if not ASYNC_POSES:
+                if state.get("poses") is not None:  # last step's all-gather
+                    work, recs = state["poses"]
+                    work.wait()
+                    got = torch.stack(recs).cpu().numpy()
+                    for r in range(min(world, ctx.lib.mmf_fusion_num_models(mmf.handle))):
+                        if r != rank:
+                            mmf.setModelPose(r, got[r, :16].reshape(4, 4))
+                    state["poses"] = None
+                return
+            if n < 0:
+                return
+            sl = slots[n % n_slots]
+            if sl["step"] != n:
+                return
+            sl["ev"].synchronize()
+            got = sl["got_pin"].numpy()
+            for r in range(min(world, ctx.lib.mmf_fusion_num_models(mmf.handle))):
+                if r != rank:
+                    mmf.setModelPose(r, got[r, :16].reshape(4, 4).copy())
+            sl["step"] = -1
 
         def fence():
             if world > 1:
-                if state["poses"] is not None:
+                for sl in slots:
+                    if sl["step"] >= 0:
+                        sl["ev"].synchronize()
+                if state.get("poses") is not None:
                     state["poses"][0].wait()
                     state["poses"] = None
                 dist.barrier()
