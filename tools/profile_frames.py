@@ -28,7 +28,9 @@ up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
 rgb, depth = [up(f["rgb"]) for f in frames], [up(f["depth"]) for f in frames]
 mask = [up(np.where(f["ids"] < models, f["ids"], 0).astype(np.uint8)) for f in frames]
 ctx = Context(0)
-g = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=int(models > 1), preallocated_models=models - 1)
+sharded = bool(os.environ.get("MMF_PROFILE_SHARD"))  # like bench.py's sharded step: models are created when they are spawned
+g = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=int(models > 1),
+                      preallocated_models=0 if sharded else models - 1)
 if os.environ.get("MMF_PROFILE_SHARD"):  # "rank/world": this process runs only the models with index % world == rank (no collectives here)
     g.setShard(*(int(v) for v in os.environ["MMF_PROFILE_SHARD"].split("/")))
 
