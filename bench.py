@@ -565,7 +565,9 @@ def main():
                                                 "model; BASELINE.json configs[4] (1280x960) on the same ranks is the `config5` object of this "
                                                 "line, its N = 1 counterpart `MMF_BENCH_WORKLOAD=config5 python bench.py` (profiles/)")
 
-    if rank == 0 and world == 1 and not config5:
+    # MMF_BENCH_HEADLINE_ONLY=1: only the frames of the N = 1 metric (for profiler runs whose per-kernel statistics must
+    # not mix in the 1 .. 8-model sweep and the host-upload variant below)
+    if rank == 0 and world == 1 and not config5 and os.environ.get("MMF_BENCH_HEADLINE_ONLY", "") != "1":
         # ---- several rigid-body models on ONE GPU, each on its own stream (configs[3]): 640x480, moving objects, mask = GT ids
         mmf.close()
         Ko, _, oframes = object_sequence(synth, W, H, 7)
