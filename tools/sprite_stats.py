@@ -66,3 +66,17 @@ for grp, name in ((64, "wave"), (256, "workgroup")):
     print("%s: fragments mean %.0f p99 %.0f max %.0f (max / mean = %.1f); rows-balanced cost = sum over lanes' rows x widest row: mean %.0f max %.0f" % (
         name, tot.mean(), np.percentile(tot, 99), tot.max(), tot.max() / max(tot.mean(), 1), (rows.sum(1) / 64 * rows.max(1)).mean() if grp == 64 else 0,
         (rows.sum(1) / 64 * rows.max(1)).max() if grp == 64 else 0))
+# bounding boxes of the sprites of 256 consecutive surfels (would an LDS tile hold a workgroup's depth test?)
+m = len(area) // 256 * 256
+cxp = (K["fx"] * P[:m, 0] / np.maximum(P[:m, 2], 1e-6) + K["cx"]).reshape(-1, 256)
+cyp = (K["fy"] * P[:m, 1] / np.maximum(P[:m, 2], 1e-6) + K["cy"]).reshape(-1, 256)
+okm = ok[:m].reshape(-1, 256)
+bw, bh = [], []
+for r in range(cxp.shape[0]):
+    if okm[r].sum() == 0:
+        continue
+    bw.append(cxp[r][okm[r]].max() - cxp[r][okm[r]].min() + 8)
+    bh.append(cyp[r][okm[r]].max() - cyp[r][okm[r]].min() + 8)
+ba = np.array(bw) * np.array(bh)
+print("workgroup bounding boxes (px^2): median %.0f p75 %.0f p90 %.0f; <= 2048: %.0f %%, <= 4096: %.0f %%, <= 8192: %.0f %%" % (
+    np.median(ba), np.percentile(ba, 75), np.percentile(ba, 90), 100 * (ba <= 2048).mean(), 100 * (ba <= 4096).mean(), 100 * (ba <= 8192).mean()))
