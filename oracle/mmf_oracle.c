@@ -10,6 +10,7 @@
 #include <float.h>
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1081,6 +1082,10 @@ void orc_odom_get_incremental_transformation(orc_odometry *o, float trans[3], fl
         for (int x = 0; x < 3; ++x)
             for (int y = 0; y < 3; ++y) resultRt[x * 4 + y] = resultR[x * 3 + y];
 
+    /* diagnostics (tests / tools only): ORC_TRACE_GN=1 prints every iteration's residual statistics,
+     * ORC_MAX_GN_ITERS=n stops after n solved iterations */
+    const int trace_gn = getenv("ORC_TRACE_GN") != NULL;
+    const int max_gn_iters = getenv("ORC_MAX_GN_ITERS") ? atoi(getenv("ORC_MAX_GN_ITERS")) : -1;
     for (int i = NUM_PYRS - 1; i >= 0; --i) {
         const int cols = o->width >> i, rows = o->height >> i;
         float fx, fy, cx, cy;
@@ -1116,6 +1121,10 @@ void orc_odom_get_incremental_transformation(orc_odometry *o, float trans[3], fl
             }
             const float tmpError = (float)(sqrt((double)sigma) / rgbSize); /* :373 */
             float sigmaVal = (tmpError == 0) ? 1 : (float)rgbSize;
+            if (trace_gn)
+                fprintf(stderr, "[orc gn] level %d iteration %d: count %d sigma %d error %.9g last %.9g%s\n", i, j, rgbSize, sigma,
+                        (double)tmpError, (double)o->st.lastRGBError, (rgb_only && tmpError > o->st.lastRGBError) ? " -> break" : "");
+            if (max_gn_iters >= 0 && o->st.iterations_run >= max_gn_iters) goto done_levels;
             if (rgb_only && tmpError > o->st.lastRGBError) break;
             o->st.lastRGBError = tmpError;
             o->st.lastRGBCount = (float)rgbSize;
@@ -1192,6 +1201,7 @@ void orc_odom_get_incremental_transformation(orc_odometry *o, float trans[3], fl
         }
     }
 
+done_levels:
     if (rgb) { /* :464-467 */
         const float dx = tcurr[0] - tprev[0], dy = tcurr[1] - tprev[1], dz = tcurr[2] - tprev[2];
         if (sqrtf(dx * dx + dy * dy + dz * dz) > 0.3) {

@@ -485,3 +485,36 @@ def test_process_frame_with_dictated_poses_is_bit_exact(gpu_ctx, orc, w, h, nfra
         assert sg.shape == so.shape, (i, sg.shape, so.shape)
         assert np.array_equal(sg.view(np.uint32), so.view(np.uint32)), (i, int((sg.view(np.uint32) != so.view(np.uint32)).sum()))
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [dict(icp_weight=100.0), dict(rgb_only=1), dict(so3=0, pyramid=0, fast_odom=1), dict(so3=0)])
+def test_process_frame_sequence_in_other_tracking_modes(gpu_ctx, orc, mode):
+    """The frame step in the tracker's other modes (RGBDOdometry.cpp:221-222, 312-314; MultiMotionFusion.cpp:791: no
+    fusion with rgbOnly) against the oracle orchestration in the same mode -- with the next-frame hint, so that the
+    side-stream preparation, the projections enqueued before the pose wait (off with rgbOnly) and the end-of-frame
+    preparation all run in each mode.
+    rgbOnly is the photometric term alone, six degrees of freedom from ~10^4 gradient pixels with a `break` as soon as
+    the error rises (RGBDOdometry.cpp:376-378): the float32 summation order moves its poses by 3e-7 .. 6e-5 (twelve
+    scenes, tools/dbg_rgbonly3.py), and in one of thirteen it flipped one of those breaks (seven iterations instead of
+    six, 2.5 cm).  The test therefore also compares the iteration counts, and bounds the pose at 2e-4 in that mode."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h, n = 320, 240, 5
+    K = synth.intrinsics(w, h)
+    seed = 41 if mode.get("rgb_only") else 37
+    tol = 2e-4 if mode.get("rgb_only") else 2e-5
+    poses = synth.trajectory(n, seed=seed)
+    frames = [synth.render(p, w, h, seed=i + (seed if mode.get("rgb_only") else 0)) for i, p in enumerate(poses)]
+    rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+    g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], **mode)
+    omode = {k: (bool(v) if k != "icp_weight" else v) for k, v in mode.items()}
+    o = OracleFusion(orc, w, h, K, **omode)
+    for i, f in enumerate(frames):
+        g.processFrame(rgb[i], depth[i], timestamp=i, next=(rgb[i + 1], depth[i + 1]) if i + 1 < n else None)
+        o.process_frame(f["rgb"], f["depth"])
+        pg = g.getCurrPose()
+        assert np.abs(pg - o.pose).max() <= tol, (mode, i, np.abs(pg - o.pose).max())
+        assert g.getFrameOdometry().iterations_run == o.models[0].odom.stats().iterations_run, (mode, i)
+        ng, no = g.getBackgroundModel().lastCount(), o.surfels.shape[0]
+        assert abs(ng - no) <= max(8, 0.002 * no), (mode, i, ng, no)
+    g.close()
