@@ -35,6 +35,7 @@ struct FusionModel {  // one ModelPointer of the reference's `models` list
     hipEvent_t ev_done = nullptr;
     bool tracking = false;  // a tracking call is in flight on the lane
     bool early_done = false;  // this frame's predict() + first predictIndices went out before the pose reached the host
+    bool early_fused = false;  // ... and so did its fuse / predictIndices / clean
     // The model side of the tracker's preparation (prediction -> model pyramids in the global frame, point clouds,
     // intensity pyramid: Model::initICP's initICPModel / initRGBModel, Model.cpp:396-401) needs nothing of the next
     // sensor frame.  When this process runs ONE model it is enqueued at the END of a frame, behind the final predict(),
@@ -574,7 +575,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                                fm->model->tex_gen == fm->spec_tex_gen && fm->spec_f2f == g.frame_to_frame_rgb &&
                                fm->odom->prep_batched;
                 fm->spec_valid = false;
-                fm->early_done = false;
+                fm->early_done = fm->early_fused = false;
             }
             const bool one_pass = n_models == 1 && !have_init && fusion_owns(f, 0) && !global->spec_hit;
             if (!prefetched && !one_pass) {
@@ -714,6 +715,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                                            fm->icp_error, fm->rgb_error);
                 if (rc) return rc;
             }
+            bool inputs_free_early = false;
             // One model on the context's stream, nothing between its tracking and its fusion that the host decides: the
             // frame's first projections -- predict() (:675) and the first predictIndices (:792) -- are enqueued right here,
             // behind the chain and the copy of its result, with the inverse pose read from the odometry's device state.
@@ -723,12 +725,27 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // tracking and fusion touches masks, thresholds and the list, none of which a projection reads.)
             if (tracked.size() == 1 && !fr->bootstrap && !have_init && !g.rgb_only && f->tracking_ok) {
                 FusionModel* fm = tracked[0];
-                fm->model->t_inv_dev = fm->odom->state->pose_inv;
+                mmf_model* m = fm->model;
+                // "nothing enqueued so far reads the odometries' sensor-side buffers or the other filtered-depth buffer" holds
+                // HERE, behind the one chain of this process; the passes enqueued next do not read them either.  (Recorded
+                // behind them, the event kept the next frame's side-stream work waiting until the clean pass had run.)
+                MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, fm->lane->stream));
+                f->inputs_free_recorded = true;
+                inputs_free_early = true;
+                m->t_inv_dev = fm->odom->state->pose_inv;
                 rc = fusion_predict_model(f, fm);
-                if (rc == MMF_OK) rc = mmf_model_predict_indices(fm->model, f->tick, g.max_depth_processed, g.time_delta);
-                fm->model->t_inv_dev = nullptr;
+                if (rc == MMF_OK) rc = mmf_model_predict_indices(m, f->tick, g.max_depth_processed, g.time_delta);
+                fm->early_done = rc == MMF_OK;
+                // Without a segmentation the mask of the frame is known (all zeros) and nothing the host decides lies
+                // between tracking and fusion: fuse -> predictIndices -> clean (:791-816) follow at once, with the pose and
+                // Model::computeFusionWeight taken from the device state (odom_end, odom_fusion_weight_kernel).
+                if (rc == MMF_OK && !g.enable_multiple_models) {
+                    m->pose_dev = fm->odom->state->pose_out, m->weight_dev = &fm->odom->state->fusion_weight;
+                    rc = fusion_fuse_clean_model(f, fm, weight_multiplier, true);
+                    fm->early_fused = rc == MMF_OK;
+                }
+                m->t_inv_dev = m->pose_dev = m->weight_dev = nullptr;
                 if (rc) return rc;
-                fm->early_done = true;
             }
             // the sensor-side image ring (this frame's / last frame's intensity pyramid, RGBDOdometry.cpp:469-473) lives in
             // the global odometry and advances when its chain is enqueued: when its owner is another rank, the swap
@@ -741,7 +758,6 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // here, while the chains run and the host would only wait, instead of at the end of the call.  Correct (an
             // event behind the chain orders it) but 20 % SLOWER: the side streams then sit on a barrier packet for the
             // whole chain, and a dependent chain on another queue runs slower next to parked queues (308 -> 370-450 us).
-            bool inputs_free_early = false;
             static const bool early = std::getenv("MMF_PREFETCH_EARLY") != nullptr;
             if (early && fr->next_rgb && fr->next_depth && !tracked.empty() && tracked[0]->lane->stream == c->stream &&
                 (tracked.size() == 1 || batch_ok)) {
@@ -868,12 +884,13 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 rc = fusion_predict_model(f, fm);
                 if (rc) return rc;
             }
-            if (!g.rgb_only && f->tracking_ok) {
+            if (!g.rgb_only && f->tracking_ok && !fm->early_fused) {
                 float pose[16];
                 mmf_model_get_pose(fm->model, pose);
                 rc = fusion_fuse_clean_model(f, fm, fusion_weight(pose, fm->last_pose, weight_multiplier), early);
                 if (rc) return rc;
             }
+            fm->early_fused = false;
         }
     }
     for (size_t k = 0; k < f->models.size(); ++k) {  // predict() (:821)

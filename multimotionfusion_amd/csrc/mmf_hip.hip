@@ -1499,7 +1499,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         if (so3)
             for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(om->last_next_image[i], om->next_image[i]);
     }
-    hipLaunchKernelGGL(odom_publish_kernel, dim3(ny), dim3(64), 0, c->stream, o->state, to, seq, bd);
+    hipLaunchKernelGGL(odom_publish_kernel, dim3(ny), dim3(128), 0, c->stream, o->state, to, seq, bd);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }
@@ -1720,6 +1720,8 @@ struct mmf_model {
     float max_depth = FLT_MAX;  // Model::maxDepth (Model.h:129, set per object from the segmentation: MultiMotionFusion.cpp:486,586)
     int capacity = 0;
     unsigned long long tex_gen = 0;    // bumped by every pass that rewrites the prediction / fill-in images
+    const float* pose_dev = nullptr;    // likewise the pose itself and computeFusionWeight(1) (OdomState::pose_out,
+    const float* weight_dev = nullptr;  // fusion_weight) for a fuse pass; `weighting` is then the multiplier
     const float* t_inv_dev = nullptr;  // set by the orchestrator around projections it enqueues before the tracked pose has
                                        // reached the host: the device copy of inverse(pose) (OdomState::pose_inv)
     float pose[16];
@@ -2081,6 +2083,7 @@ extern "C" int mmf_model_fuse(mmf_model* m, int time, const uint8_t* rgb, const 
     a.cols = m->width, a.rows = m->height;
     a.time = time;
     a.weighting = weighting;
+    a.pose_dev = m->pose_dev, a.weight_dev = m->weight_dev, a.weight_mult = weighting;
     a.maskID = m->id;
     a.maxDepth = depth_cutoff < m->max_depth ? depth_cutoff : m->max_depth;  // std::min(depthCutoff, maxDepth) (Model.cpp:928)
     a.count = (int)m->count;
@@ -2104,6 +2107,7 @@ extern "C" int mmf_model_clean(mmf_model* m, int time, int time_delta, float dep
     const int npix = m->width * m->height;
     CleanArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
+    a.t_inv_dev = m->t_inv_dev;
     a.c = make_cam(m, false);
     a.cols = m->width, a.rows = m->height;
     a.time = time, a.timeDelta = time_delta;

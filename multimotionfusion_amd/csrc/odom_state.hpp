@@ -54,6 +54,8 @@ struct OdomState {
     // outputs
     float trans_out[3], rot_out[9];
     float pose_inv[16];  // inverse of [rot_out | trans_out; 0 0 0 1], as the host computes it for the projection passes
+    float pose_out[16];  // [rot_out | trans_out; 0 0 0 1]
+    float fusion_weight; // Model::computeFusionWeight(1) of this pose against the pose the chain started from (odom_fusion_weight_kernel)
     OdomStats st;
     // everything above travels to the host's (pinned, device-visible) copy of this struct at the end of a chain
     // (odom_publish_kernel); this word follows it there, after a system-scope fence: the host polls it

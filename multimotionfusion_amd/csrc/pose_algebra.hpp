@@ -1,5 +1,10 @@
-// pose_algebra.hpp -- host-side pose algebra of the orchestrator: Model::computeFusionWeight and
+// pose_algebra.hpp -- pose algebra of the orchestrator: Model::computeFusionWeight and
 // Model::rodrigues2 (Core/Model/Model.cpp:876-891, 1301-1342) with the Eigen operations they call.
+// Host code in the reference; here callable on both sides (MMF_HD): the host uses it wherever it has the pose, and the
+// last step of a tracking chain evaluates the fusion weight on the device so that the fusion passes of the frame can be
+// enqueued before the pose has reached the host (same float operations in the same order; the one double-precision
+// library call, acos, differs between the two C libraries by at most an ulp of a double, far below the float the
+// result is rounded to).
 //
 // Eigen (an unpinned system package of the reference, absent here) is restated from its published
 // algorithm: JacobiSVD of a real square matrix = two-sided Jacobi sweeps over the pairs (1,0), (2,0),
@@ -11,29 +16,33 @@
 #pragma once
 #include <cfloat>
 #include <cmath>
-#include <cstring>
-#include <utility>
+
+#if defined(__HIPCC__)
+#define MMF_HD __host__ __device__
+#else
+#define MMF_HD
+#endif
 
 namespace mmf {
 namespace host {
 
 struct Givens {  // Eigen::JacobiRotation<float>
     float c = 1.f, s = 0.f;
-    Givens transpose() const { return Givens{c, -s}; }
-    Givens operator*(const Givens& o) const { return Givens{c * o.c - s * o.s, c * o.s + s * o.c}; }
-    bool identity() const { return c == 1.f && s == 0.f; }
+    MMF_HD Givens transpose() const { return Givens{c, -s}; }
+    MMF_HD Givens operator*(const Givens& o) const { return Givens{c * o.c - s * o.s, c * o.s + s * o.c}; }
+    MMF_HD bool identity() const { return c == 1.f && s == 0.f; }
 };
 
 struct Mat3 {
     float m[3][3];
-    static Mat3 eye() {
+    MMF_HD static Mat3 eye() {
         Mat3 r;
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) r.m[i][j] = i == j ? 1.f : 0.f;
         return r;
     }
     // rows p, q <- j applied on the left
-    void rotate_rows(int p, int q, const Givens& j) {
+    MMF_HD void rotate_rows(int p, int q, const Givens& j) {
         if (j.identity()) return;
         for (int k = 0; k < 3; ++k) {
             const float x = m[p][k], y = m[q][k];
@@ -42,7 +51,7 @@ struct Mat3 {
         }
     }
     // columns p, q <- j applied on the right (Eigen rotates them by j.transpose())
-    void rotate_cols(int p, int q, const Givens& j) {
+    MMF_HD void rotate_cols(int p, int q, const Givens& j) {
         const Givens t = j.transpose();
         if (t.identity()) return;
         for (int k = 0; k < 3; ++k) {
@@ -54,7 +63,7 @@ struct Mat3 {
 };
 
 // JacobiRotation::makeJacobi for the symmetric 2x2 block [x y; y z]
-inline Givens jacobi_of_symmetric(float x, float y, float z) {
+MMF_HD inline Givens jacobi_of_symmetric(float x, float y, float z) {
     const float deno = 2.f * std::fabs(y);
     if (deno < FLT_MIN) return Givens{};
     const float tau = (x - z) / deno;
@@ -66,7 +75,7 @@ inline Givens jacobi_of_symmetric(float x, float y, float z) {
 }
 
 // internal::real_2x2_jacobi_svd on the (p, q) block of w
-inline void svd_2x2(const Mat3& w, int p, int q, Givens& left, Givens& right) {
+MMF_HD inline void svd_2x2(const Mat3& w, int p, int q, Givens& left, Givens& right) {
     float a = w.m[p][p], b = w.m[p][q], c = w.m[q][p], d = w.m[q][q];
     Givens rot1;
     const float t = a + d, diff = c - b;
@@ -87,7 +96,7 @@ inline void svd_2x2(const Mat3& w, int p, int q, Givens& left, Givens& right) {
 }
 
 // Eigen::JacobiSVD<Matrix3f>(a, ComputeFullU | ComputeFullV)
-inline void jacobi_svd3(const Mat3& a, Mat3& U, float sv[3], Mat3& V) {
+MMF_HD inline void jacobi_svd3(const Mat3& a, Mat3& U, float sv[3], Mat3& V) {
     float scale = 0.f;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) scale = std::fabs(a.m[i][j]) > scale ? std::fabs(a.m[i][j]) : scale;
@@ -129,16 +138,18 @@ inline void jacobi_svd3(const Mat3& a, Mat3& U, float sv[3], Mat3& V) {
             if (sv[k] > sv[pos]) pos = k;
         if (sv[pos] == 0.f) break;
         if (pos == i) continue;
-        std::swap(sv[i], sv[pos]);
+        const float tsv = sv[i];
+        sv[i] = sv[pos], sv[pos] = tsv;
         for (int r = 0; r < 3; ++r) {
-            std::swap(U.m[r][i], U.m[r][pos]);
-            std::swap(V.m[r][i], V.m[r][pos]);
+            const float tu = U.m[r][i], tv = V.m[r][i];
+            U.m[r][i] = U.m[r][pos], U.m[r][pos] = tu;
+            V.m[r][i] = V.m[r][pos], V.m[r][pos] = tv;
         }
     }
 }
 
 // Model::rodrigues2 (Model.cpp:1301-1342)
-inline void rodrigues2(const Mat3& matrix, float out[3]) {
+MMF_HD inline void rodrigues2(const Mat3& matrix, float out[3]) {
     Mat3 U, V, R;
     float sv[3];
     jacobi_svd3(matrix, U, sv, V);
@@ -179,7 +190,7 @@ inline void rodrigues2(const Mat3& matrix, float out[3]) {
 }
 
 // row-major 4x4 float product, terms summed in k order
-inline void matmul4(const float* a, const float* b, float* out) {
+MMF_HD inline void matmul4(const float* a, const float* b, float* out) {
     float r[16];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
@@ -187,13 +198,13 @@ inline void matmul4(const float* a, const float* b, float* out) {
             for (int k = 1; k < 4; ++k) acc = acc + a[4 * i + k] * b[4 * k + j];
             r[4 * i + j] = acc;
         }
-    std::memcpy(out, r, sizeof(r));
+    for (int k = 0; k < 16; ++k) out[k] = r[k];
 }
 
-inline float norm3(float x, float y, float z) { return std::sqrt((x * x + y * y) + z * z); }
+MMF_HD inline float norm3(float x, float y, float z) { return std::sqrt((x * x + y * y) + z * z); }
 
 // Model::computeFusionWeight (Model.cpp:876-891); pose_inv = getPose().inverse()
-inline float compute_fusion_weight(const float* pose_inv, const float* last_pose, float weight_multiplier) {
+MMF_HD inline float compute_fusion_weight(const float* pose_inv, const float* last_pose, float weight_multiplier) {
     float diff[16], rv[3];
     matmul4(pose_inv, last_pose, diff);  // getLastTransform() (Model.h:305)
     Mat3 rot;

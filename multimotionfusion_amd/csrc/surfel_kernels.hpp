@@ -705,6 +705,9 @@ __global__ __launch_bounds__(256) void splat_depth_resolve_kernel(SurfelSoA s, S
 // ---- fusion: data association (data.vert) ----------------------------------------------------------
 struct FuseArgs {
     Mat4 pose;
+    const float* pose_dev;    // non-null: the model pose (16 floats) to use instead of `pose`, and
+    const float* weight_dev;  // computeFusionWeight(1) to use instead of `weighting` / weight_mult -- for a fuse pass that
+    float weight_mult;        // is enqueued before the tracked pose has reached the host (with_device_pose)
     Cam c;  // ifx, ify = (float)(1.0 / fx) computed in double on the host (Model.cpp:920-921)
     int cols, rows;
     int time;
@@ -722,8 +725,14 @@ constexpr unsigned kNoWinner = 0xFFFFFFFFu;
 __global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restrict__ rgb, const float* __restrict__ depth_raw,
                                                         const float* __restrict__ depth_fil, const uint8_t* __restrict__ mask,
                                                         const unsigned* __restrict__ index, const float4* __restrict__ vertConf,
-                                                        const float4* __restrict__ normRad, FuseArgs a, SurfelSoA meas,
+                                                        const float4* __restrict__ normRad, FuseArgs a_in, SurfelSoA meas,
                                                         unsigned* __restrict__ new_flags, unsigned* __restrict__ winner) {
+    FuseArgs a = a_in;
+    if (a_in.pose_dev) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a.pose.m[k] = a_in.pose_dev[k];
+        a.weighting = *a_in.weight_dev * a_in.weight_mult;  // (computeFusionWeight's last operation)
+    }
     const int d = blockIdx.x * 256 + threadIdx.x;
     const int cols = a.cols, rows = a.rows;
     if (d >= cols * rows) return;
@@ -876,6 +885,7 @@ __global__ __launch_bounds__(256) void fuse_update_kernel(SurfelSoA s, int count
 // ---- clean: copy_unstable.vert:53-150 ---------------------------------------------------------------
 struct CleanArgs {
     Mat4 t_inv;
+    const float* t_inv_dev;  // non-null: the 16 floats to use instead of t_inv (with_device_pose)
     Cam c;
     int cols, rows;
     int time, timeDelta;
@@ -1023,12 +1033,13 @@ __device__ __forceinline__ unsigned clean_flag_one(int e, SurfelSoA s, SurfelSoA
 // keep[e] for every candidate, and -- so that the compaction needs no separate scan launches -- the
 // number of kept candidates of each 256-candidate workgroup in block_sums[blockIdx.x]
 __global__ __launch_bounds__(256) void clean_flag_kernel(SurfelSoA s, SurfelSoA meas, const unsigned* __restrict__ new_flags,
-                                                         CleanArgs a, const unsigned* __restrict__ index,
+                                                         CleanArgs a_in, const unsigned* __restrict__ index,
                                                          const float4* __restrict__ vertConf,
                                                          const float4* __restrict__ colorTime,
                                                          const float* __restrict__ depth_in, const uint8_t* __restrict__ mask,
                                                          unsigned* __restrict__ keep, float2* __restrict__ conf_time,
                                                          unsigned* __restrict__ block_sums) {
+    const CleanArgs a = with_device_pose(a_in);
     const int e = blockIdx.x * 256 + threadIdx.x;
     unsigned k = 0u;
     if (e < a.count + a.npix) {

@@ -578,7 +578,7 @@ __device__ __forceinline__ void odom_end(OdomState* st) {
     }
     m[12] = m[13] = m[14] = 0.f, m[15] = 1.f;
     inverse4f(m, inv);
-    for (int k = 0; k < 16; ++k) st->pose_inv[k] = inv[k];
+    for (int k = 0; k < 16; ++k) st->pose_inv[k] = inv[k], st->pose_out[k] = m[k];
 }
 
 // The two halves of one pass of rgbKernel (reduce.cu:504-535) over the PX records of a lane.
@@ -986,15 +986,33 @@ __global__ void gn_level_begin_kernel(OdomState* st, int first_level, LevelIntr 
 struct PublishTargets {
     OdomState* host[kMaxBatch];
 };
-__global__ __launch_bounds__(64) void odom_publish_kernel(const OdomState* st, PublishTargets to, unsigned seq, BatchDelta bd) {
+// A second wave evaluates Model::computeFusionWeight (Model.cpp:876-891) of the tracked pose against lastPose = the pose the
+// chain started from (Model.cpp:412) with weightMultiplier 1 (the multiplier is the last factor: the fuse pass applies
+// it) for a fuse pass enqueued before the host has the pose: the JacobiSVD is a few microseconds on one lane, beside the
+// copy instead of in front of the frame's next kernel, and nothing the host waits for.
+__device__ __forceinline__ void odom_fusion_weight(OdomState* st) {
+    float last[16];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) last[r * 4 + c] = st->Rprev[r * 3 + c];
+        last[r * 4 + 3] = st->tprev[r];
+    }
+    last[12] = last[13] = last[14] = 0.f, last[15] = 1.f;
+    float inv[16];
+    for (int k = 0; k < 16; ++k) inv[k] = st->pose_inv[k];
+    st->fusion_weight = mmf::host::compute_fusion_weight(inv, last, 1.0f);
+}
+__global__ __launch_bounds__(128) void odom_publish_kernel(OdomState* st, PublishTargets to, unsigned seq, BatchDelta bd) {
     if (gridDim.x > 1) st = batch_shift(st, bd.d[blockIdx.x]);
+    if (threadIdx.x >= 64) {
+        if (threadIdx.x == 64) odom_fusion_weight(st);
+        return;
+    }
     OdomState* host = to.host[blockIdx.x];
     const unsigned* src = reinterpret_cast<const unsigned*>(st);
     unsigned* dst = reinterpret_cast<unsigned*>(host);
     constexpr unsigned kWords = offsetof(OdomState, publish_seq) / 4;
     for (unsigned i = threadIdx.x; i < kWords; i += 64) dst[i] = src[i];
-    __threadfence_system();
-    __builtin_amdgcn_s_barrier();  // one wave: every lane's stores are fenced before lane 0 publishes
+    __threadfence_system();  // executed by the one copying wave as a whole: every lane's stores are out before lane 0 publishes
     if (threadIdx.x == 0) __hip_atomic_store(&host->publish_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
