@@ -583,8 +583,9 @@ def main():
                 if i == m + 10:
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                kk = pingpong(i, N_FRAMES_OBJECTS)
-                g.processFrame(o_rgb[kk], o_depth[kk], timestamp=i, mask=o_mask[kk], hasNewLabel=1 <= i < m)
+                kk, kn = pingpong(i, N_FRAMES_OBJECTS), pingpong(i + 1, N_FRAMES_OBJECTS)
+                g.processFrame(o_rgb[kk], o_depth[kk], timestamp=i, mask=o_mask[kk], hasNewLabel=1 <= i < m,
+                               next=(o_rgb[kn], o_depth[kn]))  # the next frame's sensor side on the side streams, as in the headline loop
                 if i >= m + 10:
                     track_s += g.lastTimings()[0]
             torch.cuda.synchronize()
@@ -597,7 +598,8 @@ def main():
                           "surfels": [mm.lastCount() for mm in g.getModels()]})
             g.close()
         result["multi_model"] = {"what": f"{W}x{H}, static scene + (m - 1) moving objects, mask = ground-truth ids, every model on its own "
-                                         "stream with its own reduction scratch, sensor-side preparation shared; tracking_phase = host wall "
+                                         "stream with its own reduction scratch, sensor-side preparation shared (the next frame's on side "
+                                         "streams during the current frame's fusion); tracking_phase = host wall "
                                          "clock from the first enqueue to the last pose; aggregate = m x 388.6 MB / tracking_phase",
                                  "sweep": sweep}
         # ---- host FrameData hand-over: the same static sequence with the upload inside processFrame (pinned double buffers)

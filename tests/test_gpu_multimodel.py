@@ -135,7 +135,7 @@ def test_batched_chain_equals_one_chain_per_model(gpu_ctx):
     K, poses, traj, frames, objs = scene(w, h, n_frames, n_obj, seed=31)
     rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
 
-    def run(batch):
+    def run(batch, hint=False):
         g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1, preallocated_models=n_obj,
                               batch_tracking=batch)
         known, out, keep = [0], [], []
@@ -144,7 +144,8 @@ def test_batched_chain_equals_one_chain_per_model(gpu_ctx):
             if spawn:
                 known.append(i)
             keep.append(dev(gt_mask(f["ids"], known)))
-            g.processFrame(rgb[i], depth[i], timestamp=i, mask=keep[-1], hasNewLabel=spawn)
+            nxt = (rgb[i + 1], depth[i + 1]) if hint and i + 1 < n_frames else None  # mmf_frame::next_*
+            g.processFrame(rgb[i], depth[i], timestamp=i, mask=keep[-1], hasNewLabel=spawn, next=nxt)
             out.append([m.getPose() for m in g.getModels()])
         maps = [m.downloadMap() for m in g.getModels()]
         stats = [(g.getModelOdometry(k).lastICPCount, g.getModelOdometry(k).lastRGBCount, g.getModelOdometry(k).iterations_run) for k in range(len(maps))]
@@ -153,6 +154,12 @@ def test_batched_chain_equals_one_chain_per_model(gpu_ctx):
         return out, maps, stats, err
 
     a, b = run(1), run(0)
+    c = run(1, hint=True)  # and with the next frame's sensor side (and SO3 pre-alignment) prepared on the side streams
+    for i in range(n_frames):
+        for pa, pc in zip(a[0][i], c[0][i]):
+            assert np.array_equal(pa, pc), i
+    for sa, sc in zip(a[1], c[1]):
+        assert np.array_equal(sa.view(np.uint32), sc.view(np.uint32))
     for i in range(n_frames):
         assert len(a[0][i]) == len(b[0][i]) == min(i, n_obj) + 1
         for k, (pa, pb) in enumerate(zip(a[0][i], b[0][i])):
