@@ -472,6 +472,9 @@ int mmf_fusion_pose_log(mmf_fusion *f, int index, long long *ts, float *p7, int 
 /* test hook: the device build's mmf_expf and the packed exponential of the two-pixel bilateral filter on n arguments
  * (the packed one is defined for x <= 0 or NaN only) */
 int mmf_debug_expf(mmf_ctx *ctx, const float *x_dev, int n, float *out_mmf_dev, float *out_packed_dev);
+/* test / A-B hook: 1 = run the Gauss-Newton chain as one launch per iteration where it applies (the default), 0 = always as
+ * producer + step launches, -1 = what the environment says (MMF_GN_FUSED=0 turns it off).  Process wide. */
+int mmf_debug_set_gn_fused(int on);
 /* Model::computeFusionWeight (Model.cpp:876-891) for pose / lastPose (host 4x4), exported for tests */
 int mmf_compute_fusion_weight(const float pose[16], const float last_pose[16], float multiplier, float *out);
 

@@ -198,6 +198,7 @@ SIGNATURES = {
     "mmf_shard_broadcast_frame": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
     "mmf_shard_gather_poses": (_i, [_vp, _vp]),
     "mmf_debug_expf": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "mmf_debug_set_gn_fused": (_i, [_i]),
     "mmf_fusion_set_shard": (_i, [_vp, _i, _i]),
     "mmf_fusion_owns_model": (_i, [_vp, _i]),
     "mmf_fusion_set_model_pose": (_i, [_vp, _i, _fp]),

@@ -24,6 +24,7 @@
 #include "prep_batch.hpp"
 #include "pose_algebra.hpp"
 #include "track_kernels.hpp"
+#include "gn_fused.hpp"
 
 using namespace mmf;
 
@@ -759,6 +760,7 @@ struct mmf_odom {
     float* gn_partials_icp = nullptr;
     int2* gn_partials_res = nullptr;
     unsigned* gn_ticket = nullptr;
+    float* gn_rec[2] = {nullptr, nullptr};  // ping-pong partial records of the one-launch-per-iteration chain (gn_fused.hpp)
     float *icp_err = nullptr, *rgb_err = nullptr;  // Model::icpError / rgbError (R32F), written on the last level-0 iteration
     OdomState* state = nullptr;  // device
     OdomState* host_result = nullptr;  // pinned, device visible: odom_publish_kernel writes it, the host polls publish_seq
@@ -846,6 +848,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     const size_t o_pf = carve(sizeof(float) * kMaxGrid * kPartialStride), o_pi = carve(sizeof(float) * kMaxIcpGrid * kPartialStride),
                  o_pr = carve(sizeof(int2) * kMaxGrid), o_tk = carve(sizeof(unsigned) * kTicketWords), o_ei = carve(n0 * 4),
                  o_er = carve(n0 * 4);
+    const size_t o_rec0 = carve(sizeof(float) * kGnMaxGroups * kGnRec), o_rec1 = carve(sizeof(float) * kGnMaxGroups * kGnRec);
     o->slab_bytes = off;
     hipError_t e = hipMalloc(&o->slab, o->slab_bytes);
     if (e != hipSuccess) {
@@ -877,6 +880,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     o->gn_partials_f = (float*)(base + o_pf), o->gn_partials_icp = (float*)(base + o_pi);
     o->gn_partials_res = (int2*)(base + o_pr), o->gn_ticket = (unsigned*)(base + o_tk);
     o->icp_err = (float*)(base + o_ei), o->rgb_err = (float*)(base + o_er);
+    o->gn_rec[0] = (float*)(base + o_rec0), o->gn_rec[1] = (float*)(base + o_rec1);
     MMF_HIP_TRY(hipHostMalloc(&o->host_result, sizeof(OdomState), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(o->host_result, 0, sizeof(OdomState));
     MMF_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&o->host_result_dev), o->host_result, 0));
@@ -1292,6 +1296,7 @@ struct TrackBatch {
 };
 
 static bool odom_batchable(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom);
+static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom);
 
 static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float rot[9], int rgb_only, float icp_weight,
                                  int pyramid, int fast_odom, int so3, float* icp_err_dev, float* rgb_err_dev,
@@ -1315,6 +1320,13 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
             if (rc) return rc;
         }
 
+    const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};  // :312-314
+    // both terms on and every level fits: ONE launch per iteration (gn_fused.hpp) instead of producer + step
+    const bool fused_chain = odom_fused_chain_ok(o, rgb_only, icp_weight, pyramid, fast_odom) &&
+                             (ny == 1 || odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom));
+    int first_iter_level = MMF_NUM_PYRS - 1;  // the coarsest level that runs iterations
+    while (first_iter_level > 0 && !iterations[first_iter_level]) --first_iter_level;
+
     BeginArgs b;
     std::memcpy(b.trans, trans, sizeof(b.trans));
     std::memcpy(b.rot, rot, sizeof(b.rot));
@@ -1328,7 +1340,8 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     // nothing runs between the beginning and the first level's begin unless the SO3 loop does: one launch
     const bool fold_first_level = !so3 || o->so3_prefetched;
     b.fold_level_begin = fold_first_level ? 1 : 0;
-    b.first_intr = level_intr(o->fx, o->fy, o->cx, o->cy, MMF_NUM_PYRS - 1);
+    // the one-launch chain has no per-level begin: its first launch reads what this one prepares
+    b.first_intr = level_intr(o->fx, o->fy, o->cx, o->cy, fused_chain ? first_iter_level : MMF_NUM_PYRS - 1);
     o->n_timed = 0;
     if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[0], c->stream));
     // from here to the last step: kernels only, all on the fused-producer path when `odom_batchable` -- recorded and
@@ -1343,12 +1356,71 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     }
     o->so3_prefetched = false;
 
-    const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};  // :312-314
+    if (fused_chain) {
+        int it = 0;
+        unsigned prev_groups = 0;
+        bool first = true;
+        GnIterArgs a;
+        std::memset(&a, 0, sizeof(a));
+        for (int i = MMF_NUM_PYRS - 1; i >= 0; --i) {
+            if (!iterations[i]) continue;
+            const int cols = o->width >> i, rows = o->height >> i;
+            const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, i);
+            if (!o->prep_batched) {  // :332-334
+                MMF_HIP_TRY(q.flush());
+                int rc = launch_project(c, o->last_depth[i], cols, cols, rows, in, o->cloud[i]);
+                if (rc) return rc;
+            }
+            if (first && !fold_first_level)  // the SO3 loop ran in between: seed resultRt from its result now
+                q.launch(gn_level_begin_kernel, dim3(ny), dim3(64), o->state, 1, in, bd, so3_ran_here ? 1 : 0);
+            first = false;
+            const float min_scale = (float)(std::pow((double)o->min_grad[i], 2.0) / std::pow((double)o->sobel_scale, 2.0));
+            const int groups = (cols * rows / 4 + kBlock - 1) / kBlock;
+            for (int j = 0; j < iterations[i]; ++j) {
+                const bool last_l0 = (i == 0 && j == iterations[i] - 1);
+                a.ra = make_residual_args(min_scale, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0,
+                                          o->prep_batched ? o->last_depth[i] : o->next_depth[i], 0, o->last_image[i], 0,
+                                          o->next_image[i], 0, o->corres[i], o->max_depth_delta_rgb, cols, rows,
+                                          last_l0 ? rgb_err_dev : nullptr, 0);
+                a.ra.intr = in;
+                a.ia = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
+                a.cloud = o->cloud[i];
+                a.fx = in.fx, a.fy = in.fy, a.sobel_scale = o->sobel_scale;
+                a.intr = in;
+                a.it = it;
+                a.prev_groups = prev_groups;
+                a.rec_in = o->gn_rec[(it + 1) & 1], a.rec_out = o->gn_rec[it & 1];
+                const bool err = last_l0 && (icp_err_dev || rgb_err_dev);
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (o->timing >= 2 && o->n_timed < kMaxTimedLaunches) {
+                    e0 = o->ev_kernel[2 * o->n_timed], e1 = o->ev_kernel[2 * o->n_timed + 1];
+                    o->timed_kind[o->n_timed++] = i * 2;
+                }
+                if (e0 && err)
+                    hipExtLaunchKernelGGL((gn_iter_kernel<true>), dim3(groups, ny), dim3(kBlock), 0, c->stream, e0, e1, 0, o->state, a, bd);
+                else if (e0)
+                    hipExtLaunchKernelGGL((gn_iter_kernel<false>), dim3(groups, ny), dim3(kBlock), 0, c->stream, e0, e1, 0, o->state, a, bd);
+                else if (err)
+                    q.launch((gn_iter_kernel<true>), dim3(groups, ny), dim3(kBlock), o->state, a, bd);
+                else
+                    q.launch((gn_iter_kernel<false>), dim3(groups, ny), dim3(kBlock), o->state, a, bd);
+                MMF_HIP_TRY(hipGetLastError());
+                ++it;
+                prev_groups = (unsigned)groups;
+            }
+        }
+        // the last solve + RGBDOdometry.cpp:464-467: one workgroup per model
+        a.it = it;
+        a.prev_groups = prev_groups;
+        a.rec_in = o->gn_rec[(it + 1) & 1], a.rec_out = nullptr;
+        a.intr = level_intr(o->fx, o->fy, o->cx, o->cy, 0);
+        q.launch(gn_final_kernel, dim3(ny), dim3(kBlock), o->state, a, bd);
+    }
     bool first_level = true;
-    bool end_folded = false;  // odom_end ran in the finishing lane of the frame's last rgb_step
+    bool end_folded = fused_chain;  // odom_end ran in the finishing lane of the frame's last rgb_step (or in gn_final_kernel)
     bool begin_folded = fold_first_level;  // this level's gn_level_begin already ran (in odom_begin_kernel, or in the
                                            // last rgb_step of the level before)
-    for (int i = MMF_NUM_PYRS - 1; i >= 0; --i) {
+    for (int i = MMF_NUM_PYRS - 1; i >= 0 && !fused_chain; --i) {
         const int cols = o->width >> i, rows = o->height >> i;
         const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, i);
         if (rgb && !o->prep_batched) {  // :332-334
@@ -1521,6 +1593,37 @@ static bool odom_batchable(mmf_odom* o, int rgb_only, float icp_weight, int pyra
     return true;
 }
 
+// can the chain run as one launch per iteration (gn_iter_kernel)?  Both terms on, four pixels per lane at every level,
+// every level's grid small enough to be resident at once (the count barrier inside the launch).  MMF_GN_FUSED=0 keeps the
+// two-launch chain (A/B runs, and the test that compares the two).
+static std::atomic<int> g_gn_fused{-1};  // -1: MMF_GN_FUSED decides (default on); 0 / 1: mmf_debug_set_gn_fused
+extern "C" int mmf_debug_set_gn_fused(int on) {
+    g_gn_fused.store(on < 0 ? -1 : (on ? 1 : 0));
+    return MMF_OK;
+}
+static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom) {
+    static const bool env_enabled = []() {
+        const char* v = std::getenv("MMF_GN_FUSED");
+        return !(v && v[0] == '0');
+    }();
+    const int forced = g_gn_fused.load();
+    const bool enabled = forced < 0 ? env_enabled : forced != 0;
+    const bool icp = !rgb_only && icp_weight > 0, rgb = rgb_only || icp_weight < 100;
+    if (!enabled || !icp || !rgb || rgb_only) return false;
+    const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};
+    for (int i = 0; i < MMF_NUM_PYRS; ++i) {
+        if (!iterations[i]) continue;
+        const int cols = o->width >> i, rows = o->height >> i;
+        RgbResidualArgs ra = make_residual_args(1.f, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0,
+                                                o->prep_batched ? o->last_depth[i] : o->next_depth[i], 0, o->last_image[i], 0,
+                                                o->next_image[i], 0, o->corres[i], o->max_depth_delta_rgb, cols, rows, o->rgb_err, 0);
+        IcpArgs ia = odom_icp_args(o, i, o->icp_err);
+        if (!residual_vec4_ok(ra) || icp_max_px(ia, 4) != 4 || !ia.prev_packed) return false;
+        if ((cols * rows / 4 + kBlock - 1) / kBlock > kGnMaxGroups) return false;
+    }
+    return true;
+}
+
 // second half: wait for the stream, hand the result out
 static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
     mmf_ctx* c = o->ctx;
@@ -1564,6 +1667,7 @@ static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
     }
 
     const OdomState* r = o->host_result;
+    MMF_REQUIRE(!r->gn_fault, "odometry: a Gauss-Newton launch gave up waiting for its own workgroups (count barrier)");
     std::memcpy(trans, r->trans_out, sizeof(float) * 3);
     std::memcpy(rot, r->rot_out, sizeof(float) * 9);
     // members the reference leaves untouched in a given mode keep their previous values

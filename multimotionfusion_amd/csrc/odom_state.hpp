@@ -56,6 +56,7 @@ struct OdomState {
     float pose_inv[16];  // inverse of [rot_out | trans_out; 0 0 0 1], as the host computes it for the projection passes
     float pose_out[16];  // [rot_out | trans_out; 0 0 0 1]
     float fusion_weight; // Model::computeFusionWeight(1) of this pose against the pose the chain started from (odom_fusion_weight_kernel)
+    int gn_fault;  // the count barrier of a gn_iter_kernel launch timed out (a workgroup of the launch never arrived)
     OdomStats st;
     // everything above travels to the host's (pinned, device-visible) copy of this struct at the end of a chain
     // (odom_publish_kernel); this word follows it there, after a system-scope fence: the host polls it
@@ -68,6 +69,14 @@ struct OdomState {
     // cost ~7 us -- more than the pass itself (and 4x that at 1280x960)
     // Count and sum travel in ONE 64-bit atomic: count << 40 | sum (sum < 2^40 per shard: 255^2 x 16 M pixels).
     alignas(128) unsigned long long res_acc[16 * 16];
+    // ---- one-launch-per-iteration chain (gn_fused.hpp) ----
+    // Launch `it` accumulates {arrivals, count, sum diff^2} into gn_acc[it % 3] (the same sharding as res_acc), the
+    // prologue of launch it + 1 reads it for the statistics, and launch it + 1 zeroes gn_acc[(it + 2) % 3]: a
+    // buffer is never read, added to and zeroed by workgroups of the same launch.
+    alignas(128) unsigned long long gn_acc[3][16 * 16];
+    // the running transform: launch `it` reads gn_rt[it & 1] (it = 0: resultRt) and its workgroup 0 stores the updated
+    // one to gn_rt[(it + 1) & 1], so no workgroup reads what another workgroup of the same launch writes
+    double gn_rt[2][16];
 };
 constexpr int kResShards = 16;
 constexpr int kResStride = 16;  // 64-bit words between two shards (128 B)
@@ -485,11 +494,67 @@ __device__ __forceinline__ double combine_element(OdomState* st, int l, double w
         v = l < 36 ? (double)tot_rgb[idx] + w * w * (double)tot_icp[idx] : (double)tot_rgb[idx] + w * (double)tot_icp[idx];
     else
         v = tot_icp ? (double)tot_icp[idx] : (double)tot_rgb[idx];
-    if (l < 36)
-        st->st.lastA[l] = v;
-    else
-        st->st.lastb[l - 36] = v;
+    if (st) {  // nullptr: no store (gn_iter_kernel: only the chain's last solve is visible to the host)
+        if (l < 36)
+            st->st.lastA[l] = v;
+        else
+            st->st.lastb[l - 36] = v;
+    }
     return v;
+}
+
+// What one Gauss-Newton step leaves for the next pass: the pose for the ICP reduction and K R K^-1, K t for the
+// photometric correspondence pass (RGBDOdometry.cpp:348-358, 450-460).
+struct GnPose {
+    float Rcurr[9], tcurr[3], krkinv[9], kt[3];
+};
+
+// solve the combined system and update the running transform (RGBDOdometry.cpp:435-460 + OdometryProvider.h:69-89):
+// pure function of its arguments, resultRt in / out.  Shared by the finishing lane of rgb_step_kernel / icp_finish_kernel
+// and by the prologue of gn_iter_kernel (every workgroup runs it there, on identical inputs).
+__device__ inline void gn_solve_core(const double* A, const double* b, double* resultRt, const float* Rprev, const float* tprev,
+                                     const LevelIntr& in, GnPose& out) {
+    MMF_SOLVE_STAMP(1);
+    double result[6];
+    ldlt_solve_recip<6>(A, b, result);
+    MMF_SOLVE_STAMP(2);
+
+    double Rup[9];
+    const double rvec[3] = {result[3], result[4], result[5]};
+    rodrigues(rvec, Rup);
+    // resultRt <- [Rup | result(0..2); 0 0 0 1] * resultRt, both with a (0 0 0 1) last row.  The
+    // translation column multiplies that last row as in the reference's full 4x4 product
+    // (OdometryProvider.h:81-88): for finite numbers it adds an exact 0 or result[r], but a non-finite
+    // solution (singular system, e.g. a frame without any correspondence) must poison the whole
+    // matrix the way it does there, not only its translation.
+    {
+        double nr[12];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c)
+                nr[r * 4 + c] = Rup[r * 3 + 0] * resultRt[c] + Rup[r * 3 + 1] * resultRt[4 + c] +
+                                Rup[r * 3 + 2] * resultRt[8 + c] + result[r] * resultRt[12 + c];
+        for (int k = 0; k < 12; ++k) resultRt[k] = nr[k];
+    }
+
+    MMF_SOLVE_STAMP(14);
+    float Ro[9], to[3], RoT[9], ti[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) Ro[r * 3 + c] = (float)resultRt[r * 4 + c];
+        to[r] = (float)resultRt[r * 4 + 3];
+    }
+    // currentT = [Rprev|tprev] * rgbOdom.inverse(); isometry inverse = (R^T, -R^T t)
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) RoT[r * 3 + c] = Ro[c * 3 + r];
+    for (int r = 0; r < 3; ++r)
+        ti[r] = -RoT[r * 3 + 0] * to[0] + -RoT[r * 3 + 1] * to[1] + -RoT[r * 3 + 2] * to[2];
+    matmul<3, float>(Rprev, RoT, out.Rcurr);
+    for (int r = 0; r < 3; ++r) {
+        float s = 0;
+        for (int k = 0; k < 3; ++k) s += Rprev[r * 3 + k] * ti[k];
+        out.tcurr[r] = s + tprev[r];
+    }
+    rgb_prepare(resultRt, in, out.krkinv, out.kt);  // parameters of the next iteration's correspondence pass
+    MMF_SOLVE_STAMP(15);
 }
 
 // preA / preb (optional): the combined system, already stored to lastA / lastb (combine_element)
@@ -521,49 +586,9 @@ __device__ inline void solve_and_update(OdomState* st, const SolveIn& si, const 
         for (int k = 0; k < 36; ++k) A[k] = A_rgb[k];
         for (int k = 0; k < 6; ++k) b[k] = b_rgb[k];
     }
-    MMF_SOLVE_STAMP(1);
-    double result[6];
-    ldlt_solve_recip<6>(A, b, result);
-    MMF_SOLVE_STAMP(2);
+    GnPose np;
+    gn_solve_core(A, b, resultRt, Rprev, tprev, in, np);
 
-    double Rup[9];
-    const double rvec[3] = {result[3], result[4], result[5]};
-    rodrigues(rvec, Rup);
-    // resultRt <- [Rup | result(0..2); 0 0 0 1] * resultRt, both with a (0 0 0 1) last row.  The
-    // translation column multiplies that last row as in the reference's full 4x4 product
-    // (OdometryProvider.h:81-88): for finite numbers it adds an exact 0 or result[r], but a non-finite
-    // solution (singular system, e.g. a frame without any correspondence) must poison the whole
-    // matrix the way it does there, not only its translation.
-    {
-        double nr[12];
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 4; ++c)
-                nr[r * 4 + c] = Rup[r * 3 + 0] * resultRt[c] + Rup[r * 3 + 1] * resultRt[4 + c] +
-                                Rup[r * 3 + 2] * resultRt[8 + c] + result[r] * resultRt[12 + c];
-        for (int k = 0; k < 12; ++k) resultRt[k] = nr[k];
-    }
-
-    MMF_SOLVE_STAMP(14);
-    float Ro[9], to[3], RoT[9], ti[3], Rcurr[9], tcurr[3];
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) Ro[r * 3 + c] = (float)resultRt[r * 4 + c];
-        to[r] = (float)resultRt[r * 4 + 3];
-    }
-    // currentT = [Rprev|tprev] * rgbOdom.inverse(); isometry inverse = (R^T, -R^T t)
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) RoT[r * 3 + c] = Ro[c * 3 + r];
-    for (int r = 0; r < 3; ++r)
-        ti[r] = -RoT[r * 3 + 0] * to[0] + -RoT[r * 3 + 1] * to[1] + -RoT[r * 3 + 2] * to[2];
-    matmul<3, float>(Rprev, RoT, Rcurr);
-    for (int r = 0; r < 3; ++r) {
-        float s = 0;
-        for (int k = 0; k < 3; ++k) s += Rprev[r * 3 + k] * ti[k];
-        tcurr[r] = s + tprev[r];
-    }
-    float krkinv[9], kt[3];
-    rgb_prepare(resultRt, in, krkinv, kt);  // parameters of the next iteration's correspondence pass
-
-    MMF_SOLVE_STAMP(15);
     // exit stores
     st->st.iterations_run = iters + 1;
     if (!preA) {
@@ -572,12 +597,12 @@ __device__ inline void solve_and_update(OdomState* st, const SolveIn& si, const 
     }
     for (int k = 0; k < 16; ++k) st->resultRt[k] = resultRt[k];
     for (int k = 0; k < 9; ++k) {
-        st->Rcurr[k] = Rcurr[k];
-        st->krkinv[k] = krkinv[k];
+        st->Rcurr[k] = np.Rcurr[k];
+        st->krkinv[k] = np.krkinv[k];
     }
     for (int k = 0; k < 3; ++k) {
-        st->tcurr[k] = tcurr[k];
-        st->kt[k] = kt[k];
+        st->tcurr[k] = np.tcurr[k];
+        st->kt[k] = np.kt[k];
     }
     if (tot_icp) {  // RGBDOdometry.cpp:412-413
         st->st.lastICPError = sqrtf(tot_icp[27]) / tot_icp[28];

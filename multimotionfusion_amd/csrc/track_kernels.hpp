@@ -618,7 +618,7 @@ __device__ __forceinline__ void rgb_gather(const RgbStepArgs& a, const int4 (&ra
     }
 }
 template <int PX>
-__device__ __forceinline__ void rgb_rows(const RgbStepArgs& a, float sigma, bool live, const RgbLane<PX>& l,
+__device__ __forceinline__ void rgb_rows(float sobel_scale, float fx, float fy, float sigma, bool live, const RgbLane<PX>& l,
                                          float (&sum)[29]) {
 #pragma unroll
     for (int p = 0; p < PX; ++p) {  // branch free
@@ -628,10 +628,10 @@ __device__ __forceinline__ void rgb_rows(const RgbStepArgs& a, float sigma, bool
         if (sigma == -1) w = 1;
         const float X = l.X[p], Y = l.Y[p], Z = l.Z[p];
         const float invz = 1.0f / Z;  // (float)(1.0 / Z): double rounding is innocuous for division
-        const float dI_dx = w * a.sobel_scale * l.gx[p];
-        const float dI_dy = w * a.sobel_scale * l.gy[p];
-        const float v0 = dI_dx * a.fx * invz;
-        const float v1 = dI_dy * a.fy * invz;
+        const float dI_dx = w * sobel_scale * l.gx[p];
+        const float dI_dy = w * sobel_scale * l.gy[p];
+        const float v0 = dI_dx * fx * invz;
+        const float v1 = dI_dy * fy * invz;
         const float v2 = -(v0 * X + v1 * Y) * invz;
         float row[7] = {v0, v1, v2, -Z * v1 + Y * v2, Z * v0 - X * v2, -Y * v0 + X * v1, -w * l.c[p].diff};
 #pragma unroll
@@ -712,13 +712,13 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     if (sigma == 1234.5f && lane.X[0] == 1234.5f && lane.gx[0] == 77 && lane.gy[PX - 1] == 78) sum[0] = lane.Z[PX - 1];
     MMF_STAMP(3);
 #endif
-    rgb_rows<PX>(a, sigma, live, lane, sum);
+    rgb_rows<PX>(a.sobel_scale, a.fx, a.fy, sigma, live, lane, sum);
     // images beyond the grid's single pass
     for (i0 += gridDim.x * kBlock * PX; i0 < N; i0 += gridDim.x * kBlock * PX) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) raws[q] = reinterpret_cast<const int4*>(recs + (size_t)i0 * REC)[q];
         rgb_gather<PX, COMPACT>(a, raws, i0, lane);
-        rgb_rows<PX>(a, sigma, true, lane, sum);
+        rgb_rows<PX>(a.sobel_scale, a.fx, a.fy, sigma, true, lane, sum);
     }
 
 #ifdef MMF_STAMPS
@@ -962,6 +962,8 @@ __global__ void odom_begin_kernel(OdomState* st, BeginArgs a, BatchDelta bd, Beg
     st->icp_weight = a.icp_weight;
     st->level_break = 0;
     st->st.iterations_run = 0;
+    st->gn_fault = 0;
+    for (int k = 0; k < kResShards; ++k) st->gn_acc[0][kResStride * k] = 0ull;  // the first gn_iter_kernel launch adds here
     if (!a.so3_prefetched)
         so3_begin(st, a.so3_intr, a.so3);
     else if (blockIdx.x > 0)

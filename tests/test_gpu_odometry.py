@@ -105,6 +105,51 @@ def test_incremental_transformation_matches_oracle(gpu_ctx, orc, w, h, mode):
     g.close()
 
 
+@pytest.mark.parametrize("mode", [MODES[0], MODES[3]], ids=["icp+rgb+so3", "fast"])
+@pytest.mark.parametrize("w,h", [(640, 480), (320, 240), (64, 48)])
+def test_one_launch_chain_equals_two_launch_chain(gpu_ctx, w, h, mode):
+    """gn_iter_kernel (one launch per Gauss-Newton iteration, csrc/gn_fused.hpp) against the producer + step chain it
+    replaces: same per-pixel arithmetic, so the correspondence counts, the inlier counts and both error images are
+    bit-identical; the float sums differ in summation order only."""
+    lib = gpu_ctx.lib
+    out = []
+    for fused in (1, 0):
+        assert lib.mmf_debug_set_gn_fused(fused) == 0
+        try:
+            from multimotionfusion_amd.odometry import RGBDOdometry
+            K, prev, cur, fp, fc = frame_pair(w, h, seed=3)
+            g = RGBDOdometry(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+            pose = prev.astype(np.float32)
+            g.initFirstRGB(dev(fp["rgb"]))
+            g.initICPModel(dev(fp["vertex"]), dev(fp["normal"]), 15.0, pose)
+            g.initRGBModel(dev(fp["rgb"]))
+            g.buildDepthPyramid(dev(fc["depth"]))
+            g.initICP(depthCutoff=15.0)
+            g.initRGB(dev(fc["rgb"]))
+            icp_err = torch.zeros(h, w, device="cuda")
+            rgb_err = torch.zeros(h, w, device="cuda")
+            t, R = g.getIncrementalTransformation(prev[:3, 3], prev[:3, :3], icpErrorSurface=icp_err, rgbErrorSurface=rgb_err,
+                                                  **mode)
+            out.append(dict(t=t, R=R, iters=g.iterations_run, icp_count=g.lastICPCount, rgb_count=g.lastRGBCount,
+                            icp_error=g.lastICPError, rgb_error=g.lastRGBError, A=g.lastA.copy(),
+                            icp_err=icp_err.cpu().numpy(), rgb_err=rgb_err.cpu().numpy()))
+            g.close()
+        finally:
+            lib.mmf_debug_set_gn_fused(-1)
+    a, b = out
+    assert a["iters"] == b["iters"] == (3 if mode["fastOdom"] else 19)
+    if np.isnan(b["t"]).any():
+        assert np.isnan(a["t"]).any()
+        return
+    assert np.linalg.norm(a["t"] - b["t"]) <= 1e-6 and np.abs(a["R"] - b["R"]).max() <= 1e-6
+    assert abs(a["icp_count"] - b["icp_count"]) <= 2 and abs(a["rgb_count"] - b["rgb_count"]) <= 2  # ties after 18 float steps
+    assert np.abs(a["A"] - b["A"]).max() <= 1e-4 * np.abs(b["A"]).max()
+    if a["icp_count"] == b["icp_count"] and a["rgb_count"] == b["rgb_count"]:
+        # the 19th iteration starts from poses that differ in their last bits: distances move by ulps, a few pixels flip
+        assert np.mean(np.abs(a["icp_err"] - b["icp_err"]) > 1e-5) < 1e-3
+        assert np.mean(a["rgb_err"] != b["rgb_err"]) < 1e-3
+
+
 def test_call_order_contract(gpu_ctx):
     """initRGB* before initICPModel must fail loudly (RGBDOdometry.cpp:197,202 NOTE)."""
     from multimotionfusion_amd import MmfError
