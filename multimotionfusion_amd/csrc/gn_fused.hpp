@@ -34,6 +34,7 @@ constexpr int kGnRec = 64;          // floats per workgroup record: [0, 32) ICP 
 constexpr int kGnMaxGroups = 512;   // workgroups per model per launch: all resident at once, <= 32 arrivals per shard
 constexpr int kGnArriveShift = 58;  // counter word: arrivals << 58 | count << 40 | sum diff^2 (per shard: < 2^6, 2^18, 2^40)
 constexpr int kGnMaxPolls = 1 << 17;
+constexpr int kGnMaxWaves = 8;      // a workgroup is 256 .. 512 threads: the host sizes it so that a launch has <= one workgroup per CU
 
 struct GnIterArgs {
     IcpArgs ia;
@@ -45,15 +46,20 @@ struct GnIterArgs {
     unsigned prev_groups;  // partial records the previous launch wrote
     const float* rec_in;
     float* rec_out;
+    double ifx, ify;  // 1.0 / (double)intr.fx, 1.0 / (double)intr.fy
+    int poll_sleep;  // s_sleep(1) repetitions between two polls of the count barrier
+    int lanes;       // lanes of a workgroup that take pixels (<= blockDim.x, the rest only help with the reductions)
 };
 
 struct GnLds {
     float group[16][kGnRec + 4];
     float total[kGnRec];
-    float wave[4][kGnRec];
+    float wave[kGnMaxWaves][kGnRec];
     double sol[42];
     float pose[24];  // Rcurr[9], tcurr[3], krkinv[9], kt[3]
-    int wsum[4][2];
+    double sd[16];   // the running transform the solve starts from
+    float sf[13];    // Rprev[9], tprev[3], icp_weight
+    int wsum[kGnMaxWaves][2];
     unsigned bar[4];
 };
 
@@ -72,13 +78,38 @@ __device__ __forceinline__ void gn_read_counts(const OdomState* st, int it, int&
     count = (int)c, sigma = (int)s;
 }
 
-// Sums the previous launch's records, solves, leaves the new pose in lds.pose (all threads must call; ends with a
-// barrier).  lead: this workgroup also stores the running transform for the next launch.  FINAL: the chain's last solve
+// Sums the previous launch's records, solves, leaves the new pose in lds.pose.  Two halves so that the caller can place
+// pose-independent work between the issue of the loads and their first use.  All threads call both; the second ends with a
+// barrier.
+struct GnRecLoads {
+    static constexpr int U = 20;  // 16 x 20 = 320 records per pass: the 300 of a 640x480 launch in one round trip
+    v4u r[U];
+    double sd;  // lane t < 16 of the first wave: element t of the running transform
+    float sf;   // lane 16 + k: Rprev[k], tprev[k - 9], icp_weight (k = 12)
+};
+// The loads the critical path of the launch starts with: issued before anything else.  The solve's state is fetched by
+// 29 lanes, one word each (lane-dependent addresses: a uniform load hipcc sinks into the one lane's branch that uses it,
+// where it is a cold ~1 us round trip in the middle of the solve).
+__device__ __forceinline__ void gn_records_issue(const OdomState* st, const GnIterArgs& a, GnRecLoads& rl) {
+    if (a.it == 0 || threadIdx.x >= 256) return;  // uniform per wave; the first four waves fetch the records
+    const auto rsrc = partials_rsrc(a.rec_in, a.prev_groups * (kGnRec / kPartialStride));
+    const int q = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int u = 0; u < GnRecLoads::U; ++u)  // reads past the last record return zero
+        rl.r[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((u * 16 + r0) * kGnRec + q * 4) * sizeof(float)), 0, 0);
+    const int t = threadIdx.x;
+    rl.sd = st->gn_rt[a.it & 1][t & 15];
+    const int k = t < 16 ? 0 : (t > 28 ? 12 : t - 16);
+    const float* fsrc = k < 9 ? &st->Rprev[k] : (k < 12 ? &st->tprev[k - 9] : &st->icp_weight);
+    rl.sf = *fsrc;
+}
+
+// lead: this workgroup also stores the running transform for the next launch.  FINAL: the chain's last solve
 // (gn_final_kernel): everything the host reads goes to the state, then odom_end.
 template <bool FINAL>
-__device__ __forceinline__ void gn_prologue(OdomState* st, const GnIterArgs& a, GnLds& lds, bool lead) {
+__device__ __forceinline__ void gn_prologue(OdomState* st, const GnIterArgs& a, GnRecLoads& rl, GnLds& lds, bool lead) {
     const int tid = threadIdx.x;
-    if (a.it == 0) {  // kernel argument: uniform
+    if (a.it == 0) {  // nothing to solve yet: the pose the beginning left in the state
         if (tid < 9)
             lds.pose[tid] = st->Rcurr[tid];
         else if (tid < 12)
@@ -91,68 +122,73 @@ __device__ __forceinline__ void gn_prologue(OdomState* st, const GnIterArgs& a, 
         __syncthreads();
         return;
     }
-    {   // every record load of the workgroup in flight before the first use; reads past the last record return zero
+    if (tid < 256) {
         const auto rsrc = partials_rsrc(a.rec_in, a.prev_groups * (kGnRec / kPartialStride));
         const int q = tid & 15, r0 = tid >> 4;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        constexpr int U = 20;  // 16 x 20 = 320 records per pass: the 300 of a 640x480 launch in one round trip
-        for (unsigned base = 0; base < a.prev_groups; base += 16 * U) {
-            v4u r[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                r[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((base + u * 16 + r0) * kGnRec + q * 4) * sizeof(float)), 0, 0);
+        for (int u = 0; u < GnRecLoads::U; ++u)
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + __builtin_bit_cast(float, (unsigned)rl.r[u][j]);
+        for (unsigned base = 16 * GnRecLoads::U; base < a.prev_groups; base += 16 * GnRecLoads::U) {  // more than 320 records
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = acc[j] + __builtin_bit_cast(float, (unsigned)r[u][j]);
+            for (int u = 0; u < GnRecLoads::U; ++u)
+                rl.r[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((base + u * 16 + r0) * kGnRec + q * 4) * sizeof(float)), 0, 0);
+#pragma unroll
+            for (int u = 0; u < GnRecLoads::U; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = acc[j] + __builtin_bit_cast(float, (unsigned)rl.r[u][j]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) lds.group[r0][q * 4 + j] = acc[j];
+        if (tid < 16) lds.sd[tid] = rl.sd;
+        else if (tid < 29) lds.sf[tid - 16] = rl.sf;
     }
-    // the state the solve reads (wave-uniform scalar loads; written by the previous launch or the beginning)
-    const double w = st->icp_weight;
-    double rt[16];
-    float Rprev[9], tprev[3];
-    for (int k = 0; k < 16; ++k) rt[k] = st->gn_rt[a.it & 1][k];
-    for (int k = 0; k < 9; ++k) Rprev[k] = st->Rprev[k];
-    for (int k = 0; k < 3; ++k) tprev[k] = st->tprev[k];
     __syncthreads();
-    if (tid < kGnRec) {
+    if (!FINAL) MMF_STAMP(3);
+    // From here to the pose one wave works alone (its LDS accesses execute in program order: no workgroup barriers):
+    // the 64 totals, RGBDOdometry.cpp:431-435 with one element of the combined system per lane, the solve on lane 0.
+    if (tid < 64) {
         float s = lds.group[0][tid];
 #pragma unroll
         for (int g = 1; g < 16; ++g) s = s + lds.group[g][tid];
         lds.total[tid] = s;
-    }
-    __syncthreads();
-    // RGBDOdometry.cpp:431-435, one element per lane
-    if (tid < 42) lds.sol[tid] = combine_element(FINAL ? st : nullptr, tid, w, lds.total + 32, lds.total);
-    __syncthreads();
-    if (tid == 0) {
-        double A[36], b[6];
-        for (int k = 0; k < 36; ++k) A[k] = lds.sol[k];
-        for (int k = 0; k < 6; ++k) b[k] = lds.sol[36 + k];
-        GnPose np;
-        gn_solve_core(A, b, rt, Rprev, tprev, a.intr, np);
-        for (int k = 0; k < 9; ++k) lds.pose[k] = np.Rcurr[k], lds.pose[12 + k] = np.krkinv[k];
-        for (int k = 0; k < 3; ++k) lds.pose[9 + k] = np.tcurr[k], lds.pose[21 + k] = np.kt[k];
-        if (FINAL) {
-            int count, sigma;
-            gn_read_counts(st, a.it - 1, count, sigma);
-            const ResidualDecision dec = residual_decide(count, sigma, 0, 0.f);
-            st->sigma = sigma;
-            st->rgbCount = count;
-            st->sigmaVal = dec.sigmaVal;
-            st->st.lastRGBError = dec.tmpError;
-            st->st.lastRGBCount = (float)count;
-            st->st.lastICPError = sqrtf(lds.total[27]) / lds.total[28];  // RGBDOdometry.cpp:412-413
-            st->st.lastICPCount = lds.total[28];
-            st->st.iterations_run = a.it;
-            for (int k = 0; k < 16; ++k) st->resultRt[k] = rt[k];
-            for (int k = 0; k < 9; ++k) st->Rcurr[k] = np.Rcurr[k], st->krkinv[k] = np.krkinv[k];
-            for (int k = 0; k < 3; ++k) st->tcurr[k] = np.tcurr[k], st->kt[k] = np.kt[k];
-            odom_end(st);
-        } else if (lead) {
-            for (int k = 0; k < 16; ++k) st->gn_rt[(a.it + 1) & 1][k] = rt[k];
+        __builtin_amdgcn_wave_barrier();
+        const double w = (double)lds.sf[12];
+        if (tid < 42) lds.sol[tid] = combine_element(FINAL ? st : nullptr, tid, w, lds.total + 32, lds.total);
+        __builtin_amdgcn_wave_barrier();
+        if (!FINAL) MMF_STAMP(4);
+        if (tid == 0) {
+            double A[36], b[6], rt[16];
+            float Rprev[9], tprev[3];
+            for (int k = 0; k < 36; ++k) A[k] = lds.sol[k];
+            for (int k = 0; k < 6; ++k) b[k] = lds.sol[36 + k];
+            for (int k = 0; k < 16; ++k) rt[k] = lds.sd[k];
+            for (int k = 0; k < 9; ++k) Rprev[k] = lds.sf[k];
+            for (int k = 0; k < 3; ++k) tprev[k] = lds.sf[9 + k];
+            GnPose np;
+            gn_solve_core(A, b, rt, Rprev, tprev, a.intr, np, a.ifx, a.ify);
+            for (int k = 0; k < 9; ++k) lds.pose[k] = np.Rcurr[k], lds.pose[12 + k] = np.krkinv[k];
+            for (int k = 0; k < 3; ++k) lds.pose[9 + k] = np.tcurr[k], lds.pose[21 + k] = np.kt[k];
+            if (FINAL) {
+                int count, sigma;
+                gn_read_counts(st, a.it - 1, count, sigma);
+                const ResidualDecision dec = residual_decide(count, sigma, 0, 0.f);
+                st->sigma = sigma;
+                st->rgbCount = count;
+                st->sigmaVal = dec.sigmaVal;
+                st->st.lastRGBError = dec.tmpError;
+                st->st.lastRGBCount = (float)count;
+                st->st.lastICPError = sqrtf(lds.total[27]) / lds.total[28];  // RGBDOdometry.cpp:412-413
+                st->st.lastICPCount = lds.total[28];
+                st->st.iterations_run = a.it;
+                for (int k = 0; k < 16; ++k) st->resultRt[k] = rt[k];
+                for (int k = 0; k < 9; ++k) st->Rcurr[k] = np.Rcurr[k], st->krkinv[k] = np.krkinv[k];
+                for (int k = 0; k < 3; ++k) st->tcurr[k] = np.tcurr[k], st->kt[k] = np.kt[k];
+                odom_end(st);
+            } else if (lead) {
+                for (int k = 0; k < 16; ++k) st->gn_rt[(a.it + 1) & 1][k] = rt[k];
+            }
         }
     }
     __syncthreads();
@@ -170,63 +206,89 @@ __device__ __forceinline__ void gn_batch_shift(OdomState*& st, GnIterArgs& a, co
     a.rec_in = batch_shift(a.rec_in, d), a.rec_out = batch_shift(a.rec_out, d);
 }
 
-// ERR: the launch also writes the two error images (the last level-0 iteration, RGBDOdometry.cpp:367,408).
-// Needs cols % 4 == 0, 16-byte aligned rows, the packed model maps, (cols * rows / 4) <= 256 * kGnMaxGroups.
-template <bool ERR>
-__global__ __launch_bounds__(kBlock, 2) void gn_iter_kernel(OdomState* st, GnIterArgs a, BatchDelta bd) {
+// PX consecutive int16 of one row as one load
+template <int PX>
+__device__ __forceinline__ void load_i16(const int16_t* __restrict__ p, int (&out)[PX]) {
+    if constexpr (PX == 4) {
+        const short4 t = *reinterpret_cast<const short4*>(p);
+        out[0] = t.x, out[1] = t.y, out[2] = t.z, out[3] = t.w;
+    } else if constexpr (PX == 2) {
+        const short2 t = *reinterpret_cast<const short2*>(p);
+        out[0] = t.x, out[1] = t.y;
+    } else {
+        out[0] = *p;
+    }
+}
+
+// PX pixels per lane (4, 2 or 1: the host picks it per level so that a launch has a few hundred workgroups whatever the
+// level's size).  ERR: the launch also writes the two error images (the last level-0 iteration, RGBDOdometry.cpp:367,408).
+// Needs cols % 4 == 0, 16-byte aligned rows, the packed model maps; blockDim.x = 256 .. 512 (a multiple of 64) >= a.lanes.
+template <int PX, bool ERR>
+__global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st, GnIterArgs a, BatchDelta bd) {
     __shared__ GnLds lds;
     if (gridDim.y > 1) gn_batch_shift(st, a, bd);
+    const OdomState* __restrict__ stc = st;  // what this launch only reads: scalar loads
+    MMF_STAMP(5);
+    using T = typename std::conditional<PX == 1, float, v2f>::type;
+    using L = lanevec<T>;
+    constexpr int W = L::W, NV = PX / W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cols = a.ra.cols, rows = a.ra.rows, N4 = (cols * rows) / 4;
-    int g = blockIdx.x * kBlock + tid;
-    const bool live = g < N4;  // lanes past the end stay active for the reductions: pixel group 0, masked
-    g = live ? g : 0;
-    const int k0 = g * 4;
+    const int cols = a.ra.cols, rows = a.ra.rows, N = cols * rows;
+    const int nwaves = blockDim.x >> 6;
+    int k0 = (blockIdx.x * a.lanes + tid) * PX;
+    const bool live = tid < a.lanes && k0 < N;  // the other lanes stay active for the reductions: pixel 0, masked
+    k0 = live ? k0 : 0;
     const int i = (int)__umulhi((unsigned)k0, a.ra.cols_magic), j0 = k0 - i * cols;
+    const int jq = j0 & ~3, p0 = j0 & 3;  // the lane's pixels are [p0, p0 + PX) of the 4-pixel group at column jq
+
+    // ---- the launch's critical path starts with the previous launch's records and the solve's state ----
+    GnRecLoads rl;
+    gn_records_issue(st, a, rl);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- loads that do not depend on the pose: the photometric pass's images, the current vertex / normal maps ----
     unsigned ww[4][3];
-    const bool has_l = j0 >= 4, has_r = j0 + 4 < cols;
+    const bool has_l = jq >= 4, has_r = jq + 4 < cols;
 #pragma unroll
     for (int dr = -2; dr <= 1; ++dr) {
         const int u = min(max(i + dr, 0), rows - 1);
-        const uint8_t* rowp = a.ra.next_image + (size_t)u * a.ra.ni_stride + j0;
+        const uint8_t* rowp = a.ra.next_image + (size_t)u * a.ra.ni_stride + jq;
         ww[dr + 2][1] = *reinterpret_cast<const unsigned*>(rowp);
         ww[dr + 2][0] = *reinterpret_cast<const unsigned*>(rowp - (has_l ? 4 : 0));
         ww[dr + 2][2] = *reinterpret_cast<const unsigned*>(rowp + (has_r ? 4 : 0));
     }
-    const unsigned own = *reinterpret_cast<const unsigned*>(a.ra.next_image + (size_t)i * a.ra.ni_stride + j0);
-    const short4 gx = *reinterpret_cast<const short4*>(a.ra.dIdx + (size_t)i * a.ra.d_stride + j0);
-    const short4 gy = *reinterpret_cast<const short4*>(a.ra.dIdy + (size_t)i * a.ra.d_stride + j0);
-    const float4 dv = *reinterpret_cast<const float4*>(a.ra.next_depth + (size_t)i * a.ra.nd_stride + j0);
-    float cur[6][4];
+    const unsigned own = *reinterpret_cast<const unsigned*>(a.ra.next_image + (size_t)i * a.ra.ni_stride + jq);
+    int valxs[PX], valys[PX];
+    float d1s[PX];
+    load_i16<PX>(a.ra.dIdx + (size_t)i * a.ra.d_stride + j0, valxs);
+    load_i16<PX>(a.ra.dIdy + (size_t)i * a.ra.d_stride + j0, valys);
+    load_px<PX>(a.ra.next_depth + (size_t)i * a.ra.nd_stride + j0, d1s);
+    float cur[6][PX];
     {
         const float* pv = a.ia.vmap_curr.base + (size_t)i * a.ia.vmap_curr.stride + j0;
         const float* pn = a.ia.nmap_curr.base + (size_t)i * a.ia.nmap_curr.stride + j0;
         const size_t sv = (size_t)rows * a.ia.vmap_curr.stride, sn = (size_t)rows * a.ia.nmap_curr.stride;
-        load_px<4>(pv, cur[0]);
-        load_px<4>(pv + sv, cur[1]);
-        load_px<4>(pv + 2 * sv, cur[2]);
-        load_px<4>(pn, cur[3]);
-        load_px<4>(pn + sn, cur[4]);
-        load_px<4>(pn + 2 * sn, cur[5]);
+        load_px<PX>(pv, cur[0]);
+        load_px<PX>(pv + sv, cur[1]);
+        load_px<PX>(pv + 2 * sv, cur[2]);
+        load_px<PX>(pn, cur[3]);
+        load_px<PX>(pn + sn, cur[4]);
+        load_px<PX>(pn + 2 * sn, cur[5]);
     }
+    // the model pose of the frame (constant over the chain)
+    IcpPose P;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P.Rprev_inv[k] = stc->Rprev_inv[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P.tprev[k] = stc->tprev[k];
     __builtin_amdgcn_sched_barrier(0);
     MMF_STAMP(0);
 
     // the counters of the launch after this one start from zero (nobody else touches that buffer during this launch)
     if (blockIdx.x == 0 && tid >= 64 && tid < 64 + kResShards) st->gn_acc[(a.it + 1) % 3][kResStride * (tid - 64)] = 0ull;
 
-    gn_prologue<false>(st, a, lds, blockIdx.x == 0);
-    MMF_STAMP(1);
-    IcpPose P;
-    float K[9], kt[3];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) P.Rcurr[k] = uniform_f(lds.pose[k]), K[k] = uniform_f(lds.pose[12 + k]), P.Rprev_inv[k] = st->Rprev_inv[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) P.tcurr[k] = uniform_f(lds.pose[9 + k]), kt[k] = uniform_f(lds.pose[21 + k]), P.tprev[k] = st->tprev[k];
-
-    // ---- photometric correspondence search, part 1: validity windows, gradient test, warp (reduce.cu:773-812) ----
+    // what the correspondence search can decide without the pose (reduce.cu:773-797): the 4x4 "all neighbours > 0"
+    // windows from the twelve words, the gradient test -- while the record loads are in flight
     unsigned nz[3] = {0x80808080u, 0x80808080u, 0x80808080u};
 #pragma unroll
     for (int dr = -2; dr <= 1; ++dr) {
@@ -236,72 +298,90 @@ __global__ __launch_bounds__(kBlock, 2) void gn_iter_kernel(OdomState* st, GnIte
     }
     const unsigned okw = (has_l ? byte_flags_to_bits(nz[0]) : 0xFu) | (byte_flags_to_bits(nz[1]) << 4) |
                          ((has_r ? byte_flags_to_bits(nz[2]) : 0xFu) << 8);
-    const int valxs[4] = {gx.x, gx.y, gx.z, gx.w}, valys[4] = {gy.x, gy.y, gy.z, gy.w};
-    const float d1s[4] = {dv.x, dv.y, dv.z, dv.w};
-    bool inb[4];
-    int u0s[4], v0s[4];
-    float td1s[4];
+    bool cand[PX];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int x = j0 + p, y = i;
-        const bool valid = live && x < cols - 5 && y < rows - 1 && ((okw >> (p + 2)) & 0xFu) == 0xFu;
+    for (int p = 0; p < PX; ++p) {
+        const int x = j0 + p;
+        const bool valid = live && x < cols - 5 && i < rows - 1 && ((okw >> (p0 + p + 2)) & 0xFu) == 0xFu;
         const float mTwo = (float)((valxs[p] * valxs[p]) + (valys[p] * valys[p]));
+        cand[p] = valid && mTwo >= a.ra.min_scale && !(d1s[p] != d1s[p]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    gn_prologue<false>(st, a, rl, lds, blockIdx.x == 0);
+    MMF_STAMP(8);
+    float K[9], kt[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P.Rcurr[k] = uniform_f(lds.pose[k]), K[k] = uniform_f(lds.pose[12 + k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P.tcurr[k] = uniform_f(lds.pose[9 + k]), kt[k] = uniform_f(lds.pose[21 + k]);
+
+    // ---- photometric correspondence search: warp (reduce.cu:799-812), then its gathers at once ----
+    bool inb[PX];
+    int u0s[PX], v0s[PX];
+    float td1s[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        const int x = j0 + p, y = i;
         const float d1 = d1s[p];
         inb[p] = false;
         u0s[p] = v0s[p] = 0;
         td1s[p] = 0.f;
-        if (valid && mTwo >= a.ra.min_scale && !(d1 != d1)) {  // kept under its `if`: whole waves skip the divisions
+        if (cand[p]) {  // kept under its `if`: whole waves skip the divisions
             td1s[p] = (float)(d1 * (K[6] * x + K[7] * y + K[8]) + kt[2]);
             u0s[p] = float2int_rn((d1 * (K[0] * x + K[1] * y + K[2]) + kt[0]) / td1s[p]);
             v0s[p] = float2int_rn((d1 * (K[3] * x + K[4] * y + K[5]) + kt[1]) / td1s[p]);
             inb[p] = u0s[p] >= 0 && v0s[p] >= 0 && u0s[p] < cols && v0s[p] < rows;
         }
     }
-    // ---- ICP, part 1: projection into the model's camera (reduce.cu:257-273) ----
-    IcpProj<v2f> pr[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        f3t<v2f> v;
-        v.x = v2f{cur[0][2 * h], cur[0][2 * h + 1]};
-        v.y = v2f{cur[1][2 * h], cur[1][2 * h + 1]};
-        v.z = v2f{cur[2][2 * h], cur[2][2 * h + 1]};
-        pr[h] = icp_project_v<v2f>(P, a.ia, v);
-    }
-    MMF_STAMP(2);
-
-    // ---- every gather of the lane in one round trip: last-frame depth + intensity + point cloud at the warped pixel,
-    //      model vertex + normal at the projected pixel; addresses clamped, masks applied afterwards ----
     struct f3pk {
         float x, y, z;
     };
-    float d0s[4];
-    uint8_t lis[4];
-    f3pk cl[4], gv[4], gn[4];
+    float d0s[PX];
+    uint8_t lis[PX];
+    f3pk cl[PX], gv[PX], gn[PX];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < PX; ++p) {  // addresses clamped, masks applied afterwards
         const int gu = inb[p] ? u0s[p] : 0, gvv = inb[p] ? v0s[p] : 0;
         d0s[p] = a.ra.last_depth[(size_t)gvv * a.ra.ld_stride + gu];
         lis[p] = a.ra.last_image[(size_t)gvv * a.ra.li_stride + gu];
-        cl[p] = *reinterpret_cast<const f3pk*>(a.cloud + (size_t)(gvv * cols + gu) * 3);
+        cl[p] = *reinterpret_cast<const f3pk*>(a.cloud + (size_t)(gvv * cols + gu) * 3);  // rgbStep's point (reduce.cu:522)
     }
+    __builtin_amdgcn_sched_barrier(0);
+    MMF_STAMP(9);
+
+    // ---- ICP: projection into the model's camera (reduce.cu:257-273) while those are in flight, then its gathers ----
+    IcpProj<T> pr[NV];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f3pk* src = reinterpret_cast<const f3pk*>(a.ia.prev_packed) + 2 * ((size_t)pr[q / 2].uy[q % 2] * cols + pr[q / 2].ux[q % 2]);
+    for (int h = 0; h < NV; ++h) {
+        f3t<T> v;
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            L::set(v.x, e, cur[0][h * W + e]);
+            L::set(v.y, e, cur[1][h * W + e]);
+            L::set(v.z, e, cur[2][h * W + e]);
+        }
+        pr[h] = icp_project_v<T>(P, a.ia, v);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+        const f3pk* src = reinterpret_cast<const f3pk*>(a.ia.prev_packed) + 2 * ((size_t)pr[q / W].uy[q % W] * cols + pr[q / W].ux[q % W]);
         gv[q] = src[0];
         gn[q] = src[1];
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- photometric, part 2: accept / reject (reduce.cu:813-836), the workgroup's {count, sum diff^2} ----
-    RgbLane<4> ph;
+    // ---- photometric: accept / reject (reduce.cu:813-836), the workgroup's {count, sum diff^2}, arrival ----
+    RgbLane<PX> ph;
     int cnt = 0, sq = 0;
-    float perr[4];
+    float perr[PX];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < PX; ++p) {
         const bool hit = inb[p] && d0s[p] > 0 && fabsf(td1s[p] - d0s[p]) <= a.ra.max_depth_delta && lis[p] != 0;
-        const int idiff = (int)((own >> (8 * p)) & 0xFFu) - (int)lis[p];  // == (float)next - (float)last, exactly
-        const int vy = hit ? idiff * idiff : 0;                             // == (int)(diff * diff)
+        const int idiff = (int)((own >> (8 * (p0 + p))) & 0xFFu) - (int)lis[p];  // == (float)next - (float)last, exactly
+        const int vy = hit ? idiff * idiff : 0;                                   // == (int)(diff * diff)
         perr[p] = hit ? 0.001f * vy : 0.0f;
         cnt += hit ? 1 : 0;
         sq += vy;
@@ -310,76 +390,84 @@ __global__ __launch_bounds__(kBlock, 2) void gn_iter_kernel(OdomState* st, GnIte
         ph.X[p] = cl[p].x, ph.Y[p] = cl[p].y, ph.Z[p] = cl[p].z;
         ph.gx[p] = valxs[p], ph.gy[p] = valys[p];
     }
-    if (ERR && a.ra.err_map && live)
-        *reinterpret_cast<float4*>(a.ra.err_map + (size_t)i * a.ra.err_stride + j0) = make_float4(perr[0], perr[1], perr[2], perr[3]);
+    if (ERR && a.ra.err_map && live) store_px<PX>(a.ra.err_map + (size_t)i * a.ra.err_stride + j0, perr);
+#ifdef MMF_STAMPS
+    MMF_STAMP(6);
+#endif
     cnt = wave_sum_to_lane63(cnt);
     sq = wave_sum_to_lane63(sq);
     if (lane == 63) lds.wsum[wave][0] = cnt, lds.wsum[wave][1] = sq;
     __syncthreads();
     if (tid == 0) {  // one arrival per workgroup
-        const unsigned c = (unsigned)(lds.wsum[0][0] + lds.wsum[1][0] + lds.wsum[2][0] + lds.wsum[3][0]);
-        const unsigned s = (unsigned)(lds.wsum[0][1] + lds.wsum[1][1] + lds.wsum[2][1] + lds.wsum[3][1]);
-        const unsigned long long word = (1ull << kGnArriveShift) | ((unsigned long long)c << kResCountShift) | (unsigned long long)s;
+        unsigned c = 0, s2 = 0;
+        for (int wv = 0; wv < nwaves; ++wv) c += (unsigned)lds.wsum[wv][0], s2 += (unsigned)lds.wsum[wv][1];
+        const unsigned long long word = (1ull << kGnArriveShift) | ((unsigned long long)c << kResCountShift) | (unsigned long long)s2;
         (void)__hip_atomic_fetch_add(&st->gn_acc[a.it % 3][kResStride * (blockIdx.x % kResShards)], word, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
     }
-    MMF_STAMP(3);
+    __builtin_amdgcn_sched_barrier(0);
+    MMF_STAMP(10);
 
-    // ---- ICP, part 2: Jacobian rows of the four pixels (reduce.cu:275-368) while the other workgroups arrive ----
-    v2f isum[29];
-    float ierr[4];
+    // ---- ICP: Jacobian rows (reduce.cu:275-368) while the other workgroups arrive ----
+    T isum[29];
+    float ierr[PX];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        f3t<v2f> n, vp, np;
-        n.x = v2f{cur[3][2 * h], cur[3][2 * h + 1]};
-        n.y = v2f{cur[4][2 * h], cur[4][2 * h + 1]};
-        n.z = v2f{cur[5][2 * h], cur[5][2 * h + 1]};
-        vp.x = v2f{gv[2 * h].x, gv[2 * h + 1].x}, vp.y = v2f{gv[2 * h].y, gv[2 * h + 1].y}, vp.z = v2f{gv[2 * h].z, gv[2 * h + 1].z};
-        np.x = v2f{gn[2 * h].x, gn[2 * h + 1].x}, np.y = v2f{gn[2 * h].y, gn[2 * h + 1].y}, np.z = v2f{gn[2 * h].z, gn[2 * h + 1].z};
-        float er[2];
+    for (int h = 0; h < NV; ++h) {
+        f3t<T> n, vp, np;
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            L::set(n.x, e, cur[3][h * W + e]), L::set(n.y, e, cur[4][h * W + e]), L::set(n.z, e, cur[5][h * W + e]);
+            L::set(vp.x, e, gv[h * W + e].x), L::set(vp.y, e, gv[h * W + e].y), L::set(vp.z, e, gv[h * W + e].z);
+            L::set(np.x, e, gn[h * W + e].x), L::set(np.y, e, gn[h * W + e].y), L::set(np.z, e, gn[h * W + e].z);
+        }
+        float er[W];
         if (h == 0)
-            icp_rows_v<ERR, true, v2f>(P, a.ia, pr[h], live, n, vp, np, isum, er);
+            icp_rows_v<ERR, true, T>(P, a.ia, pr[h], live, n, vp, np, isum, er);
         else
-            icp_rows_v<ERR, false, v2f>(P, a.ia, pr[h], live, n, vp, np, isum, er);
-        if (ERR) ierr[2 * h] = er[0], ierr[2 * h + 1] = er[1];
+            icp_rows_v<ERR, false, T>(P, a.ia, pr[h], live, n, vp, np, isum, er);
+        if (ERR) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) ierr[h * W + e] = er[e];
+        }
     }
-    if (ERR && a.ia.err_map && live) store_px<4>(a.ia.err_map + (size_t)i * a.ia.err_stride + j0, ierr);
-    MMF_STAMP(4);
+    if (ERR && a.ia.err_map && live) store_px<PX>(a.ia.err_map + (size_t)i * a.ia.err_stride + j0, ierr);
+    __builtin_amdgcn_sched_barrier(0);
+    MMF_STAMP(11);
 
     // ---- the count barrier: wave 0 polls the 16 shards until every workgroup of this model has arrived ----
     if (wave == 0) {
         const unsigned long long* acc = st->gn_acc[a.it % 3];
-        unsigned c = 0, s = 0, ok = 0;
+        unsigned c = 0, s2 = 0, ok = 0;
         for (int poll = 0; poll < kGnMaxPolls; ++poll) {
             const unsigned long long v = lane < kResShards ? __hip_atomic_load(acc + kResStride * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             unsigned arr = wave_sum_to_lane63((unsigned)(v >> kGnArriveShift));
             c = wave_sum_to_lane63((unsigned)(v >> kResCountShift) & 0x3FFFFu);
-            s = wave_sum_to_lane63((unsigned)v);  // wraps at 2^32 like the reference's int
+            s2 = wave_sum_to_lane63((unsigned)v);  // wraps at 2^32 like the reference's int
             arr = (unsigned)__builtin_amdgcn_readlane((int)arr, 63);
             if (arr == gridDim.x) {
                 ok = 1;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
         }
-        if (lane == 63) lds.bar[0] = c, lds.bar[1] = s, lds.bar[2] = ok;
+        if (lane == 63) lds.bar[0] = c, lds.bar[1] = s2, lds.bar[2] = ok;
     }
     __syncthreads();
-    MMF_STAMP(5);
+    MMF_STAMP(12);
     if (!lds.bar[2] && blockIdx.x == 0 && tid == 0) st->gn_fault = 1;  // a workgroup of this launch never arrived
     const ResidualDecision dec = residual_decide((int)lds.bar[0], (int)lds.bar[1], 0, 0.f);  // RGBDOdometry.cpp:373-385
 
-    // ---- photometric, part 3: rgbStep's rows (reduce.cu:504-535) ----
+    // ---- photometric: rgbStep's rows (reduce.cu:504-535) ----
     float psum[29];
 #pragma unroll
     for (int k = 0; k < 29; ++k) psum[k] = 0.f;
-    rgb_rows<4>(a.sobel_scale, a.fx, a.fy, dec.sigmaVal, live, ph, psum);
+    rgb_rows<PX>(a.sobel_scale, a.fx, a.fy, dec.sigmaVal, live, ph, psum);
 
     // ---- both sum sets over the workgroup -> one 256-byte record ----
     {
         float s32[32];
 #pragma unroll
-        for (int k = 0; k < 29; ++k) s32[k] = isum[k].x + isum[k].y;
+        for (int k = 0; k < 29; ++k) s32[k] = L::hsum(isum[k]);
         s32[29] = s32[30] = s32[31] = 0.f;
         const float t = wave_sum_transposed(s32);
         if ((lane & 1) == 0) lds.wave[wave][lane >> 1] = t;
@@ -391,14 +479,14 @@ __global__ __launch_bounds__(kBlock, 2) void gn_iter_kernel(OdomState* st, GnIte
     }
     __syncthreads();
     if (tid < 16) {
-        float4 s;
-        s.x = lds.wave[0][tid * 4 + 0] + lds.wave[1][tid * 4 + 0] + lds.wave[2][tid * 4 + 0] + lds.wave[3][tid * 4 + 0];
-        s.y = lds.wave[0][tid * 4 + 1] + lds.wave[1][tid * 4 + 1] + lds.wave[2][tid * 4 + 1] + lds.wave[3][tid * 4 + 1];
-        s.z = lds.wave[0][tid * 4 + 2] + lds.wave[1][tid * 4 + 2] + lds.wave[2][tid * 4 + 2] + lds.wave[3][tid * 4 + 2];
-        s.w = lds.wave[0][tid * 4 + 3] + lds.wave[1][tid * 4 + 3] + lds.wave[2][tid * 4 + 3] + lds.wave[3][tid * 4 + 3];
+        float4 s = *reinterpret_cast<const float4*>(&lds.wave[0][tid * 4]);
+        for (int wv = 1; wv < nwaves; ++wv) {  // fixed order: the launch geometry decides the sum, not the timing
+            const float4 t = *reinterpret_cast<const float4*>(&lds.wave[wv][tid * 4]);
+            s.x = s.x + t.x, s.y = s.y + t.y, s.z = s.z + t.z, s.w = s.w + t.w;
+        }
         *reinterpret_cast<float4*>(a.rec_out + (size_t)blockIdx.x * kGnRec + tid * 4) = s;
     }
-    MMF_STAMP(6);
+    MMF_STAMP(13);
 }
 
 // the chain's last solve + RGBDOdometry.cpp:464-467, 475-476: one workgroup per model
@@ -409,7 +497,9 @@ __global__ __launch_bounds__(kBlock) void gn_final_kernel(OdomState* st, GnIterA
         st = batch_shift(st, d);
         a.rec_in = batch_shift(a.rec_in, d);
     }
-    gn_prologue<true>(st, a, lds, true);
+    GnRecLoads rl;
+    gn_records_issue(st, a, rl);
+    gn_prologue<true>(st, a, rl, lds, true);
 }
 
 }  // namespace mmf

@@ -6,6 +6,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cfloat>
 #include <chrono>
@@ -1296,6 +1297,42 @@ struct TrackBatch {
 };
 
 static bool odom_batchable(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom);
+// Launch geometry of gn_iter_kernel at a level of n pixels.  The launch is a chain of latencies -- prologue, two memory
+// round trips, the count barrier -- and every workgroup waits at that barrier for the slowest one, so (measured on MI355X,
+// tools/gn_ab.sh): at most one workgroup per CU (two on a CU reach the barrier 1.6 us after the others); four waves per
+// workgroup where that fits (a fifth wave doubles up on one SIMD and is the long pole of every arithmetic phase); as few
+// pixels per lane as those two allow (a lane's serial arithmetic is on the critical path: 320x240 takes 9.0 us with 2
+// pixels per lane in 150 workgroups, 10.6 with 4 in 75, 11.1 with 1 in 256 workgroups of five waves).
+// MMF_GN_PX="p0,p1,p2" forces the pixels per lane of a level, MMF_GN_GROUPS the workgroup limit (tuning aids).
+struct GnGeometry {
+    int px, lanes, threads, groups;
+};
+static bool gn_geometry(int level, int n, GnGeometry* out) {
+    static const std::array<int, 3> forced = []() {
+        std::array<int, 3> f{{0, 0, 0}};
+        if (const char* e = std::getenv("MMF_GN_PX")) std::sscanf(e, "%d,%d,%d", &f[0], &f[1], &f[2]);
+        return f;
+    }();
+    static const int max_groups = []() { const char* e = std::getenv("MMF_GN_GROUPS"); return e ? std::atoi(e) : 256; }();
+    const int want = (level >= 0 && level < 3) ? forced[level] : 0;
+    auto allowed = [&](int px) { return !(want == 1 || want == 2 || want == 4) || px == want; };
+    for (int px = 1; px <= 4; px *= 2) {  // four waves per workgroup
+        const int groups = (n / px + kBlock - 1) / kBlock;
+        if (!allowed(px) || groups > max_groups || groups > kGnMaxGroups) continue;
+        *out = GnGeometry{px, kBlock, kBlock, groups};
+        return true;
+    }
+    for (int px = 4; px >= 1; px /= 2) {  // larger workgroups, as few of them as the limit asks for
+        if (!allowed(px)) continue;
+        const int total = n / px;
+        const int lanes = std::max(kBlock, (total + max_groups - 1) / max_groups);
+        const int groups = (total + lanes - 1) / lanes;
+        if (lanes > 64 * kGnMaxWaves || groups > kGnMaxGroups) continue;
+        *out = GnGeometry{px, lanes, (lanes + 63) / 64 * 64, groups};
+        return true;
+    }
+    return false;
+}
 static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom);
 
 static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float rot[9], int rgb_only, float icp_weight,
@@ -1362,6 +1399,8 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         bool first = true;
         GnIterArgs a;
         std::memset(&a, 0, sizeof(a));
+        static const int poll_sleep = []() { const char* e = std::getenv("MMF_GN_SLEEP"); return e ? std::atoi(e) : 1; }();
+        a.poll_sleep = poll_sleep;
         for (int i = MMF_NUM_PYRS - 1; i >= 0; --i) {
             if (!iterations[i]) continue;
             const int cols = o->width >> i, rows = o->height >> i;
@@ -1375,7 +1414,10 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 q.launch(gn_level_begin_kernel, dim3(ny), dim3(64), o->state, 1, in, bd, so3_ran_here ? 1 : 0);
             first = false;
             const float min_scale = (float)(std::pow((double)o->min_grad[i], 2.0) / std::pow((double)o->sobel_scale, 2.0));
-            const int groups = (cols * rows / 4 + kBlock - 1) / kBlock;
+            GnGeometry geo;
+            MMF_REQUIRE(gn_geometry(i, cols * rows, &geo), "odom_enqueue_tracking: no launch geometry for this level");
+            const int px = geo.px, groups = geo.groups;
+            a.lanes = geo.lanes;
             for (int j = 0; j < iterations[i]; ++j) {
                 const bool last_l0 = (i == 0 && j == iterations[i] - 1);
                 a.ra = make_residual_args(min_scale, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0,
@@ -1387,6 +1429,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 a.cloud = o->cloud[i];
                 a.fx = in.fx, a.fy = in.fy, a.sobel_scale = o->sobel_scale;
                 a.intr = in;
+                a.ifx = 1.0 / (double)in.fx, a.ify = 1.0 / (double)in.fy;
                 a.it = it;
                 a.prev_groups = prev_groups;
                 a.rec_in = o->gn_rec[(it + 1) & 1], a.rec_out = o->gn_rec[it & 1];
@@ -1396,14 +1439,23 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                     e0 = o->ev_kernel[2 * o->n_timed], e1 = o->ev_kernel[2 * o->n_timed + 1];
                     o->timed_kind[o->n_timed++] = i * 2;
                 }
-                if (e0 && err)
-                    hipExtLaunchKernelGGL((gn_iter_kernel<true>), dim3(groups, ny), dim3(kBlock), 0, c->stream, e0, e1, 0, o->state, a, bd);
-                else if (e0)
-                    hipExtLaunchKernelGGL((gn_iter_kernel<false>), dim3(groups, ny), dim3(kBlock), 0, c->stream, e0, e1, 0, o->state, a, bd);
-                else if (err)
-                    q.launch((gn_iter_kernel<true>), dim3(groups, ny), dim3(kBlock), o->state, a, bd);
-                else
-                    q.launch((gn_iter_kernel<false>), dim3(groups, ny), dim3(kBlock), o->state, a, bd);
+#define MMF_GN_LAUNCH(PXV, ERRV)                                                                                              \
+    do {                                                                                                                      \
+        if (e0)                                                                                                               \
+            hipExtLaunchKernelGGL((gn_iter_kernel<PXV, ERRV>), dim3(groups, ny), dim3(geo.threads), 0, c->stream, e0, e1, 0,      \
+                                  o->state, a, bd);                                                                           \
+        else                                                                                                                  \
+            q.launch((gn_iter_kernel<PXV, ERRV>), dim3(groups, ny), dim3(geo.threads), o->state, a, bd);                       \
+    } while (0)
+                switch (px * 2 + (err ? 1 : 0)) {
+                    case 9: MMF_GN_LAUNCH(4, true); break;
+                    case 8: MMF_GN_LAUNCH(4, false); break;
+                    case 5: MMF_GN_LAUNCH(2, true); break;
+                    case 4: MMF_GN_LAUNCH(2, false); break;
+                    case 3: MMF_GN_LAUNCH(1, true); break;
+                    default: MMF_GN_LAUNCH(1, false); break;
+                }
+#undef MMF_GN_LAUNCH
                 MMF_HIP_TRY(hipGetLastError());
                 ++it;
                 prev_groups = (unsigned)groups;
@@ -1414,6 +1466,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         a.prev_groups = prev_groups;
         a.rec_in = o->gn_rec[(it + 1) & 1], a.rec_out = nullptr;
         a.intr = level_intr(o->fx, o->fy, o->cx, o->cy, 0);
+        a.ifx = 1.0 / (double)a.intr.fx, a.ify = 1.0 / (double)a.intr.fy;
         q.launch(gn_final_kernel, dim3(ny), dim3(kBlock), o->state, a, bd);
     }
     bool first_level = true;
@@ -1619,7 +1672,8 @@ static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int
                                                 o->next_image[i], 0, o->corres[i], o->max_depth_delta_rgb, cols, rows, o->rgb_err, 0);
         IcpArgs ia = odom_icp_args(o, i, o->icp_err);
         if (!residual_vec4_ok(ra) || icp_max_px(ia, 4) != 4 || !ia.prev_packed) return false;
-        if ((cols * rows / 4 + kBlock - 1) / kBlock > kGnMaxGroups) return false;
+        GnGeometry geo;
+        if (!gn_geometry(i, cols * rows, &geo)) return false;
     }
     return true;
 }

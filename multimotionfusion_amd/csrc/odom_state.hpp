@@ -130,6 +130,7 @@ __host__ __device__ inline void inverse4f(const float* m, float* inv) {
 }
 
 __device__ inline void inverse3d(const double* m, double* inv) {
+#pragma clang fp contract(fast)
     const double c00 = m[4] * m[8] - m[5] * m[7];
     const double c01 = m[5] * m[6] - m[3] * m[8];
     const double c02 = m[3] * m[7] - m[4] * m[6];
@@ -186,6 +187,7 @@ __device__ inline void matmul(const T* a, const T* b, T* c) {  // c may alias a 
 }
 
 __device__ inline void rodrigues(const double* src, double* R) {  // OdometryProvider.h:32-67
+#pragma clang fp contract(fast)
     double rx = src[0], ry = src[1], rz = src[2];
     const double theta = sqrt(rx * rx + ry * ry + rz * rz);
     for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
@@ -199,6 +201,32 @@ __device__ inline void rodrigues(const double* src, double* R) {  // OdometryPro
         const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
         const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
         for (int k = 0; k < 9; ++k) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+    }
+}
+
+// The same rotation for the small increments of a Gauss-Newton step, without square root, division, sine or cosine:
+// with y = |r|^2, R = cos(t) I + ((1 - cos t) / t^2) r r^T + (sin(t) / t) [r]x, and both quotients are short series in y
+// (|r| < 1/8: the first omitted terms are < 2e-25).  Mathematically the reference's formula (OdometryProvider.h:32-67
+// normalises r first); the results differ by rounding (~1e-16), the chain of dependent double-precision instructions on
+// the one lane that runs it is a quarter as long.  Larger angles take the literal form.
+__device__ inline void rodrigues_increment(const double* src, double* R) {
+#pragma clang fp contract(fast)
+    const double rx = src[0], ry = src[1], rz = src[2];
+    const double y = rx * rx + ry * ry + rz * rz;
+    if (!(y < 0.015625)) {  // |r| >= 1/8 (or not a number)
+        rodrigues(src, R);
+        return;
+    }
+    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    if (y >= DBL_EPSILON * DBL_EPSILON) {  // theta >= DBL_EPSILON (:38)
+        // sin(t) / t and (1 - cos t) / t^2
+        const double a = 1.0 + y * (-1.0 / 6 + y * (1.0 / 120 + y * (-1.0 / 5040 + y * (1.0 / 362880 + y * (-1.0 / 39916800 + y * (1.0 / 6227020800.0))))));
+        const double b = 0.5 + y * (-1.0 / 24 + y * (1.0 / 720 + y * (-1.0 / 40320 + y * (1.0 / 3628800 + y * (-1.0 / 479001600 + y * (1.0 / 87178291200.0))))));
+        const double c = 1.0 - b * y;
+        const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+        const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int k = 0; k < 9; ++k) R[k] = c * I[k] + b * rrt[k] + a * r_x[k];
     }
 }
 
@@ -234,6 +262,9 @@ __device__ inline void ldlt_solve(const T* A, const T* b, T* x) {
 // double divisions on the critical path; each result changes by at most an ulp or two).
 template <int N>
 __device__ inline void ldlt_solve_recip(const double* A, const double* b, double* x) {
+    // double-precision host algebra of the reference: contraction moves a result by ~1e-16 relative and halves the
+    // instruction count of the one lane that runs it (the translation unit is built with -ffp-contract=off)
+#pragma clang fp contract(fast)
     double L[N * N], D[N], iD[N], y[N];
     for (int j = 0; j < N; ++j) {
         double d = A[j * N + j];
@@ -399,7 +430,11 @@ __device__ inline void so3_finish(OdomState* st, const float* tot, const LevelIn
 // float-cast rotations and orthogonal only to ~1e-7, which the reference's general inverse does
 // not assume either), and K = [fx 0 cx; 0 fy cy; 0 0 1].  The results differ from the literal
 // 4x4 formulas by O(1e-16) relative before the cast to float, with ~5x fewer double operations.
-__device__ inline void rgb_prepare(const double* resultRt, const LevelIntr& in, float* krkinv, float* kt) {
+// ifx, ify: 1.0 / (double)in.fx and 1.0 / (double)in.fy when the caller has them (the host computes the same IEEE quotient
+// once per launch instead of one lane per workgroup per iteration); 0 = divide here
+__device__ inline void rgb_prepare(const double* resultRt, const LevelIntr& in, float* krkinv, float* kt, double ifx_in = 0.0,
+                                   double ify_in = 0.0) {
+#pragma clang fp contract(fast)
     const double fx = in.fx, fy = in.fy, cx = in.cx, cy = in.cy;
     // Rt = resultRt^-1
     const double A3[9] = {resultRt[0], resultRt[1], resultRt[2], resultRt[4], resultRt[5],
@@ -417,7 +452,7 @@ __device__ inline void rgb_prepare(const double* resultRt, const LevelIntr& in, 
         KR[6 + c] = R[6 + c];
     }
     // (K R) K^-1 with K^-1 = [1/fx 0 -cx/fx; 0 1/fy -cy/fy; 0 0 1]
-    const double ifx = 1.0 / fx, ify = 1.0 / fy;
+    const double ifx = ifx_in != 0.0 ? ifx_in : 1.0 / fx, ify = ify_in != 0.0 ? ify_in : 1.0 / fy;
     for (int r = 0; r < 3; ++r) {
         const double a = KR[r * 3 + 0] * ifx, b = KR[r * 3 + 1] * ify;
         krkinv[r * 3 + 0] = (float)a;
@@ -513,7 +548,7 @@ struct GnPose {
 // pure function of its arguments, resultRt in / out.  Shared by the finishing lane of rgb_step_kernel / icp_finish_kernel
 // and by the prologue of gn_iter_kernel (every workgroup runs it there, on identical inputs).
 __device__ inline void gn_solve_core(const double* A, const double* b, double* resultRt, const float* Rprev, const float* tprev,
-                                     const LevelIntr& in, GnPose& out) {
+                                     const LevelIntr& in, GnPose& out, double ifx = 0.0, double ify = 0.0) {
     MMF_SOLVE_STAMP(1);
     double result[6];
     ldlt_solve_recip<6>(A, b, result);
@@ -521,13 +556,14 @@ __device__ inline void gn_solve_core(const double* A, const double* b, double* r
 
     double Rup[9];
     const double rvec[3] = {result[3], result[4], result[5]};
-    rodrigues(rvec, Rup);
+    rodrigues_increment(rvec, Rup);
     // resultRt <- [Rup | result(0..2); 0 0 0 1] * resultRt, both with a (0 0 0 1) last row.  The
     // translation column multiplies that last row as in the reference's full 4x4 product
     // (OdometryProvider.h:81-88): for finite numbers it adds an exact 0 or result[r], but a non-finite
     // solution (singular system, e.g. a frame without any correspondence) must poison the whole
     // matrix the way it does there, not only its translation.
     {
+#pragma clang fp contract(fast)
         double nr[12];
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 4; ++c)
@@ -553,7 +589,7 @@ __device__ inline void gn_solve_core(const double* A, const double* b, double* r
         for (int k = 0; k < 3; ++k) s += Rprev[r * 3 + k] * ti[k];
         out.tcurr[r] = s + tprev[r];
     }
-    rgb_prepare(resultRt, in, out.krkinv, out.kt);  // parameters of the next iteration's correspondence pass
+    rgb_prepare(resultRt, in, out.krkinv, out.kt, ifx, ify);  // parameters of the next iteration's correspondence pass
     MMF_SOLVE_STAMP(15);
 }
 

@@ -106,7 +106,9 @@ def test_incremental_transformation_matches_oracle(gpu_ctx, orc, w, h, mode):
 
 
 @pytest.mark.parametrize("mode", [MODES[0], MODES[3]], ids=["icp+rgb+so3", "fast"])
-@pytest.mark.parametrize("w,h", [(640, 480), (320, 240), (64, 48)])
+# (sizes whose coarsest level is a few hundred pixels are left out: the Gauss-Newton iterations there are chaotic -- 11 ICP
+# inliers at 16x12 -- and any two summation orders part ways)
+@pytest.mark.parametrize("w,h", [(640, 480), (320, 240), (160, 120)])
 def test_one_launch_chain_equals_two_launch_chain(gpu_ctx, w, h, mode):
     """gn_iter_kernel (one launch per Gauss-Newton iteration, csrc/gn_fused.hpp) against the producer + step chain it
     replaces: same per-pixel arithmetic, so the correspondence counts, the inlier counts and both error images are
