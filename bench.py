@@ -50,6 +50,21 @@ def producer_bytes(n_px):
     return 70 * n_px
 
 
+def gn_iter_bytes(n_px):
+    """Algorithmic bytes of one gn_iter_kernel launch = one whole Gauss-Newton iteration at a level of n_px pixels, as the
+    sum of SURVEY.md 8(d)'s figures for the three reference functions the launch replaces: icpStep 48 B/px + 116,
+    computeRgbResidual 30 B/px, rgbStep 32 B/px."""
+    return 110 * n_px + 116
+
+
+def gn_iter_bytes_moved(n_px, correspondences):
+    """What the launch has to move at the least, its design counted: the ICP reduction's 48 B/px, the correspondence search's
+    14 B/px (2 x i16 gradients, f32 depth, u8 intensity, gathered f32 depth + u8 intensity), rgbStep's 12-byte point of every
+    correspondence (the DataTerm records of the reference -- 16 B/px written, 16 read -- stay in registers), one 256-byte
+    partial record per 1024 pixels."""
+    return 62 * n_px + 12 * correspondences + n_px // 4
+
+
 def gn_chain_bytes(w, h):
     """One getIncrementalTransformation: (48 + 30 + 32) B/px (icpStep, computeRgbResidual, rgbStep) over the
     10/5/4 iteration schedule."""
@@ -122,12 +137,12 @@ def pmc_traffic(kernel_substr, W, H):
     """HBM traffic per launch of the roofline kernel from the committed rocprofv3 --pmc summary (separate FETCH_SIZE /
     WRITE_SIZE passes, gfx950 corrections applied by tools/pmc_summary.py); None when there is no summary for this
     kernel and frame size."""
-    path = os.path.join(REPO, "profiles", "r02_pmc_summary.json")
+    path = os.path.join(REPO, "profiles", "r03_pmc_summary.json")
     try:
         with open(path) as fp:
             for rec in json.load(fp)["kernels"]:
                 if kernel_substr in rec["kernel"] and rec["width"] == W and rec["height"] == H and rec["level"] == 0:
-                    return float(rec["traffic_bytes_per_launch"]), "profiles/r02_pmc_summary.json"
+                    return float(rec["traffic_bytes_per_launch"]), "profiles/r03_pmc_summary.json"
     except (OSError, KeyError, ValueError):
         pass
     return None, None
@@ -173,6 +188,9 @@ def main():
     ndev = max(1, torch.cuda.device_count())
     if backend != "nccl":
         local_rank %= ndev
+        # ranks that SHARE a GPU: the one-launch Gauss-Newton chain needs its launch's workgroups resident together, which two
+        # processes on one device cannot promise each other (each can hold part of the GPU and wait for the rest)
+        os.environ.setdefault("MMF_GN_FUSED", "0")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -263,6 +281,20 @@ def main():
         mmf.setShard(rank, world)
         pending, posted = {}, set()
         state = {"frame": 0}
+        # The two exchanges of a sharded frame run through the LIBRARY (mmf_shard_*: what a C++ front-end has) when the
+        # backend is RCCL; MMF_BENCH_SHARD=torch keeps them in torch.distributed (the gloo rehearsal's only choice).
+        sh = None
+        if world > 1 and os.environ.get("MMF_BENCH_SHARD", "rccl" if backend == "nccl" else "torch") == "rccl":
+            uid = [shard.Shard.unique_id(ctx.lib) if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            sh = shard.Shard(ctx, rank, world, uid[0])
+
+        class _SlotWait:  # the work-handle shape of the torch path
+            def __init__(self, s_, slot):
+                self.s, self.slot = s_, slot
+
+            def wait(self):
+                self.s.wait_frame(self.slot)
         # (the gloo rehearsal puts several ranks on ONE GPU: with the side streams of the prefetch every cross-queue wait
         # then costs a process time slice -- 44 ms instead of 1.7 ms per step at two ranks -- so it is off there by default)
         PREFETCH_SHARD = os.environ.get("MMF_BENCH_PREFETCH", "1" if backend == "nccl" or world == 1 else "0") != "0"
@@ -282,7 +314,11 @@ def main():
                     rgb_in[b].copy_(d_rgb[kk])
                     depth_in[b].copy_(d_depth[kk])
                     mask_in[b].copy_(d_mask[kk])
-                pending[m] = shard.broadcast_frame_async(rgb_in[b], depth_in[b], mask_in[b], src=0)
+                if sh is not None:  # the library's exchange: on the shard's own stream, behind the copies above
+                    sh.post_frame(rgb_in[b], depth_in[b], mask_in[b], root=0, slot=m % 8)
+                    pending[m] = [_SlotWait(sh, m % 8)]
+                else:
+                    pending[m] = shard.broadcast_frame_async(rgb_in[b], depth_in[b], mask_in[b], src=0)
 
             post(n)
             post(n + 1)
@@ -326,6 +362,10 @@ def main():
         def give_pose(n, pose):
             if world == 1:
                 return
+            if sh is not None:  # pinned record -> all-gather -> pinned result on the shard's stream; nothing waits
+                sh.gather_poses_begin(mmf)
+                state["gathers"] = state.get("gathers", 0) + 1
+                return
             if not ASYNC_POSES:
                 state["poses"] = shard.gather_poses_async(pose, 0.0, 0.0, dev)
                 return
@@ -341,6 +381,11 @@ def main():
 
         def take_poses(n):
             if world == 1:
+                return
+            if sh is not None:
+                if n >= 0 and state.get("gathers", 0) > 0:  # the exchange of two steps ago: long complete
+                    sh.gather_poses_end(mmf)
+                    state["gathers"] -= 1
                 return
             if not ASYNC_POSES:
                 if state.get("poses") is not None:  # last step's all-gather
@@ -366,6 +411,9 @@ def main():
 
         def fence():
             if world > 1:
+                while sh is not None and state.get("gathers", 0) > 0:
+                    sh.gather_poses_end(mmf)
+                    state["gathers"] -= 1
                 for sl in slots:
                     if sl["step"] >= 0:
                         sl["ev"].synchronize()
@@ -379,7 +427,14 @@ def main():
                 f"{world - 1} objects), ONE PER GPU (mmf_fusion_set_shard): rank 0 broadcasts the frame (8 B/px, RCCL), every rank runs the "
                 "sensor-side preparation (for the next frame on side streams, during the current frame's fusion) and processFrame for "
                 "the model it owns (bilateral filter, dense ICP+RGB odometry, splat, index map, fuse, clean), poses are all-gathered "
-                "(72 B per rank); the sequence is played forwards and backwards (no reset)")
+                "(72 B per rank) -- both exchanges " + ("by the library over RCCL (mmf_shard_*) on a stream of their own"
+                                                        if sh is not None else "by torch.distributed") +
+                "; the sequence is played forwards and backwards (no reset)")
+        # every model is spawned (one new label per frame) and has its first frames behind it BEFORE anything is timed,
+        # whatever --warmup says: the timed steps must all do the same work on every rank
+        for i in range(world + 2):
+            step(i)
+        fence()
         return mmf, step, fence, text
 
     def timed_run(step, fence, warmup, steps):
@@ -455,23 +510,40 @@ def main():
             t_err = float(np.linalg.norm(last_pose[:3, 3] - gt[:3, 3]))
 
         us = tm["producer_l0"]["mean_us"]
-        achieved = producer_bytes(n0) / (us * 1e-6) / 1e9
-        traffic, traffic_src = pmc_traffic("track_producer_kernel", W, H)
+        fused = tm["rgb_step_l0"]["launches"] == 0  # the chain ran as one launch per iteration (csrc/gn_fused.hpp)
+        if fused:
+            n_corr = int(mmf.getFrameOdometry().lastRGBCount)
+            b_launch, kernel, formula = gn_iter_bytes(n0), "gn_iter_kernel<4> level 0", "SURVEY 8(d): icpStep 48 N + 116, computeRgbResidual 30 N, rgbStep 32 N"
+            kname = "gn_iter_kernel"
+        else:
+            b_launch, kernel, formula = producer_bytes(n0), "track_producer_kernel<2,true> level 0", "48 N (ICP) + 14 N read + 8 N written (correspondence pass)"
+            kname = "track_producer_kernel"
+        achieved = b_launch / (us * 1e-6) / 1e9
+        traffic, traffic_src = pmc_traffic(kname, W, H)
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                     "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": f"track_producer_kernel<2,true> level 0 ({W}x{H}): ICP JtJ reduction + photometric correspondence pass",
+                    "kernel": f"{kernel} ({W}x{H}): " + ("one whole Gauss-Newton iteration: record sum + 6x6 solve + pose update, ICP JtJ "
+                                                         "reduction, photometric correspondence search + Jacobian reduction" if fused else
+                                                         "ICP JtJ reduction + photometric correspondence pass"),
                     "us_per_launch": us, "us_per_launch_min": tm["producer_l0"]["min_us"], "launches_timed": tm["producer_l0"]["launches"],
-                    "bytes_per_launch": producer_bytes(n0), "bytes_formula": "48 N (ICP) + 14 N read + 8 N written (correspondence pass)",
+                    "bytes_per_launch": b_launch, "bytes_formula": formula,
                     "timing": "hipExtLaunchKernelGGL start/stop events per launch inside processFrame"}
+        if fused:
+            moved = gn_iter_bytes_moved(n0, n_corr)
+            roofline["bytes_moved_by_design"] = moved
+            roofline["frac_of_bytes_moved"] = moved / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+            roofline["note"] = ("the launch is a chain of dependent latencies (records -> solve -> search -> count barrier -> rows), not a stream: "
+                                "DESIGN.md section 4c has the phase times")
         per_level = {f"l{l}": {"producer_us": tm[f"producer_l{l}"]["mean_us"], "rgb_step_us": tm[f"rgb_step_l{l}"]["mean_us"],
                                "producer_min_us": tm[f"producer_l{l}"]["min_us"], "rgb_step_min_us": tm[f"rgb_step_l{l}"]["min_us"],
-                               "producer_GBps": producer_bytes(n0 >> (2 * l)) / max(tm[f"producer_l{l}"]["mean_us"], 1e-9) / 1e3}
+                               "producer_GBps": (gn_iter_bytes if fused else producer_bytes)(n0 >> (2 * l)) / max(tm[f"producer_l{l}"]["mean_us"], 1e-9) / 1e3}
                      for l in range(3)}
         chain_b = gn_chain_bytes(W, H)
         gn_chain = {"bytes": chain_b, "us": tm["chain_us"], "GBps": chain_b / max(tm["chain_us"], 1e-9) / 1e3,
                     "frac": chain_b / max(tm["chain_us"], 1e-9) / 1e3 / HBM_PEAK_GBPS, "per_level": per_level,
-                    "what": "one getIncrementalTransformation of one model on the device (odom_begin .. last step): SO3 pre-alignment "
-                            "(unless prefetched) + 19 x (producer + photometric step / solve); bytes = 110 B/px x (10 N0 + 5 N1 + 4 N2)"}
+                    "what": "one getIncrementalTransformation of one model on the device (odom_begin .. last solve): SO3 pre-alignment "
+                            "(unless prefetched) + 19 Gauss-Newton iterations (" + ("one launch each" if fused else "producer + step launch each") +
+                            "; per_level.producer_us is that launch); bytes = 110 B/px x (10 N0 + 5 N1 + 4 N2)"}
         # the stand-alone ICP reduction kernel (the function-level icpStep entry point), back-to-back launches
         us_icp = odom.timeIcpKernel(0, 200)
         icp_standalone = {"kernel": "icp_kernel2<2,1,256,packed> level 0", "us_per_launch_back_to_back": us_icp,
@@ -504,7 +576,7 @@ def main():
                                 "kernels": "splat_kernel + splat_resolve_kernel"},
         }
         result = {
-            "metric": f"frames/sec @ {W}x{H} (dense ICP+RGB tracking + surfel fusion); GN producer (ICP JtJ-reduce) achieved HBM GB/s vs peak",
+            "metric": f"frames/sec @ {W}x{H} (dense ICP+RGB tracking + surfel fusion); Gauss-Newton iteration kernel (ICP + RGB JtJ-reduce) achieved HBM GB/s vs peak",
             "value": world * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,

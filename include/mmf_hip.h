@@ -438,8 +438,9 @@ int mmf_fusion_set_depth_cutoff(mmf_fusion *f, float val);
 int mmf_fusion_set_confidence_threshold(mmf_fusion *f, float val);
 int mmf_fusion_set_enable_multiple_models(mmf_fusion *f, int val);
 int mmf_fusion_get_config(mmf_fusion *f, mmf_fusion_config *out);
-/* Per-rigid-body shard (one process per GPU): this process runs the GPU work of the models whose list index k has
- * k % world == rank; the other models exist as bookkeeping only (ids, thresholds, poses).  The sensor-side
+/* Per-rigid-body shard (one process per GPU): this process runs the GPU work of the models whose id has
+ * id % world == rank (fixed when the model is created: a model leaving the list moves nobody else); the other models exist
+ * as bookkeeping only (ids, thresholds, poses).  The sensor-side
  * preparation of a frame runs on every rank.  Poses of remote models are handed in by the caller (the all-gather
  * of mmf_shard_* or of the host framework). */
 int mmf_fusion_set_shard(mmf_fusion *f, int rank, int world);
@@ -447,21 +448,38 @@ int mmf_fusion_owns_model(mmf_fusion *f, int index);
 int mmf_fusion_set_model_pose(mmf_fusion *f, int index, const float pose[16]);
 /* The shard's two exchanges over RCCL, for a front-end that runs one process per GPU (the reference is
  * single GPU and walks its Model list serially, MultiMotionFusion.cpp:312, 793-816).  RCCL is bound at run time
- * (dlopen of librccl.so.1); all collectives run on the context's stream.
+ * (dlopen of librccl.so.1); all collectives run, in program order, on a stream the shard owns, tied to the context's
+ * stream by events where data crosses.
  *   mmf_shard_unique_id  rank 0: ncclGetUniqueId; ship the 128 bytes to the other ranks by any means
  *   mmf_shard_create     ncclCommInitRank(world, id, rank) on the context's device
  *   mmf_shard_attach     use the caller's ncclComm_t instead (not destroyed by mmf_shard_destroy)
  *   mmf_shard_broadcast_frame  the root's rgb (u8 x 3) / depth (f32) / id image (u8, may be NULL) into the same
- *                        buffers of every rank: 8 B/px, asynchronous on the stream -- call before processFrame
+ *                        buffers of every rank: 8 B/px, stream ordered on the context's stream -- call before processFrame
+ *   mmf_shard_post_frame / mmf_shard_wait_frame   the same exchange in two halves: post starts it on the shard's own stream
+ *                        (behind what the context's stream holds now) so that it overlaps the frame being processed, wait
+ *                        makes the context's stream wait for the exchange posted into that slot (0 .. 7)
  *   mmf_shard_gather_poses     after processFrame: all-gather of {pose, lastICPError, lastICPCount} (18 floats per
- *                        model slot); the poses of models other ranks own land in this rank's bookkeeping */
+ *                        model slot); the poses of models other ranks own land in this rank's bookkeeping.  Blocking.
+ *   mmf_shard_gather_poses_begin / _end   the same exchange without stalling a frame: _begin enqueues it (pinned
+ *                        buffers, an event, no synchronisation), _end waits for the OLDEST one in flight and applies it
+ *                        (call it one or two frames later; up to three may be in flight)
+ *   mmf_shard_gather_maps      what the segmentation reads of every model (Segmentation.cpp:214-223): the ICP-error image
+ *                        and the confidence channel of the splat's vertex image, averaged per super-pixel
+ *                        (mmf_slic_downsample) where the model lives and all-gathered: out_dev[n_models][2][nspix] on every
+ *                        rank, list order, {icp, confidence}; labels = device int32 super-pixel index image
+ * A model belongs to rank (id % world), whatever its position in the list. */
 typedef struct mmf_shard mmf_shard;
 int mmf_shard_unique_id(char id[128]);
 int mmf_shard_create(mmf_ctx *ctx, int rank, int world, const char id[128], mmf_shard **out);
 int mmf_shard_attach(mmf_ctx *ctx, int rank, int world, void *nccl_comm, mmf_shard **out);
 void mmf_shard_destroy(mmf_shard *s);
 int mmf_shard_broadcast_frame(mmf_shard *s, uint8_t *rgb, float *depth, uint8_t *mask, int width, int height, int root);
+int mmf_shard_post_frame(mmf_shard *s, uint8_t *rgb, float *depth, uint8_t *mask, int width, int height, int root, int slot);
+int mmf_shard_wait_frame(mmf_shard *s, int slot);
 int mmf_shard_gather_poses(mmf_shard *s, mmf_fusion *f);
+int mmf_shard_gather_poses_begin(mmf_shard *s, mmf_fusion *f);
+int mmf_shard_gather_poses_end(mmf_shard *s, mmf_fusion *f);
+int mmf_shard_gather_maps(mmf_shard *s, mmf_fusion *f, const int *labels, int spixel_size, float *out_dev);
 /* host wall clock of the last processFrame call: the tracking phase (first enqueue .. last result) and the whole call */
 int mmf_fusion_last_timings(mmf_fusion *f, double *tracking_s, double *frame_s);
 int mmf_fusion_set_segmentation_callback(mmf_fusion *f, mmf_segmentation_fn fn, void *user);

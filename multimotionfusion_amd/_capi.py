@@ -196,7 +196,12 @@ SIGNATURES = {
     "mmf_shard_attach": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "mmf_shard_destroy": (None, [_vp]),
     "mmf_shard_broadcast_frame": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
+    "mmf_shard_post_frame": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "mmf_shard_wait_frame": (_i, [_vp, _i]),
     "mmf_shard_gather_poses": (_i, [_vp, _vp]),
+    "mmf_shard_gather_poses_begin": (_i, [_vp, _vp]),
+    "mmf_shard_gather_poses_end": (_i, [_vp, _vp]),
+    "mmf_shard_gather_maps": (_i, [_vp, _vp, _vp, _i, _vp]),
     "mmf_debug_expf": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mmf_debug_set_gn_fused": (_i, [_i]),
     "mmf_fusion_set_shard": (_i, [_vp, _i, _i]),

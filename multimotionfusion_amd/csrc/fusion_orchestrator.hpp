@@ -59,8 +59,8 @@ struct mmf_fusion {
     std::vector<FusionModel*> inactive;      // inactiveModels
     std::vector<int> scheduled_deactivation;
     int next_id = 0;                  // nextID (getNextModelID)
-    // per-rigid-body shard: this process owns the models whose list index k has k % shard_world ==
-    // shard_rank and runs their track / predict / fuse / clean; the others only exist as bookkeeping here (ids,
+    // per-rigid-body shard: this process owns the models whose id has id % shard_world == shard_rank
+    // (fusion_owner_of) and runs their track / predict / fuse / clean; the others only exist as bookkeeping here (ids,
     // thresholds, poses handed in through mmf_fusion_set_model_pose) -- their owners run on other GPUs
     int shard_rank = 0, shard_world = 1;
     double t_tracking_s = 0, t_frame_s = 0;  // host wall clock of the last processFrame: tracking phase, whole call
@@ -296,7 +296,12 @@ extern "C" int mmf_fusion_next_model_id(mmf_fusion* f) {
     return f->preallocated.empty() ? f->next_id : (int)f->preallocated.front()->model->id;
 }
 
-static inline bool fusion_owns(const mmf_fusion* f, size_t index) { return (int)(index % (size_t)f->shard_world) == f->shard_rank; }
+// A model belongs to the rank its ID selects (id % world; the global model, id 0, to rank 0): fixed when the model is
+// created and the same on every rank, whatever happens to the list around it -- a model that leaves the list (lost segment,
+// scheduled deactivation) does not hand the models behind it to other ranks, which a rule by list position would.
+static inline int fusion_owner_of(const mmf_fusion* f, const FusionModel* fm) { return (int)((unsigned)fm->model->id % (unsigned)f->shard_world); }
+static inline bool fusion_owns_model(const mmf_fusion* f, const FusionModel* fm) { return fusion_owner_of(f, fm) == f->shard_rank; }
+static inline bool fusion_owns(const mmf_fusion* f, size_t index) { return index < f->models.size() && fusion_owns_model(f, f->models[index]); }
 
 extern "C" int mmf_fusion_set_shard(mmf_fusion* f, int rank, int world) {
     MMF_REQUIRE(f && world >= 1 && rank >= 0 && rank < world, "mmf_fusion_set_shard: bad argument");
@@ -685,6 +690,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                             tb.poses.trans[k][r] = pose[r * 4 + 3];
                         }
                     }
+                    lead->odom->exclusive_chain = true;  // one chain for all of them
                     rc = odom_enqueue_tracking(lead->odom, tb.poses.trans[0], tb.poses.rot[0], g.rgb_only, g.icp_weight, g.pyramid,
                                                g.fast_odom, g.so3, lead->icp_error, lead->rgb_error, &tb);
                     if (rc) return rc;
@@ -711,6 +717,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 mmf_model_get_pose(fm->model, pose);
                 const float trans[3] = {pose[3], pose[7], pose[11]};
                 const float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+                fm->odom->exclusive_chain = tracked.size() == 1;  // several chains side by side: no in-launch barriers
                 rc = odom_enqueue_tracking(fm->odom, trans, rot, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom, g.so3,
                                            fm->icp_error, fm->rgb_error);
                 if (rc) return rc;
@@ -827,7 +834,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 // Set max-depth (:585-586)
                 for (size_t i = 1; i < f->models.size() && (int)i < n_data; ++i)
                     f->models[i]->model->max_depth = seg_max_depth(seg->model_data[i]);
-                if (fresh && !fusion_owns(f, f->models.size())) {
+                if (fresh && !fusion_owns_model(f, fresh)) {
                     f->models.push_back(fresh);  // another rank's model: bookkeeping only
                 } else if (fresh) {  // :588-601: the first surfels of the new model, then it joins the list
                     rc = lane_wait(fresh, f->ev_frame_ready);

@@ -779,6 +779,10 @@ struct mmf_odom {
     // last_depth (both come from the same prediction, RGBDOdometry.cpp:179 -- see odom_populate_rgbd)
     bool prep_batched = false;
     bool so3_prefetched = false;  // this frame's SO3 pre-alignment already ran (odom_prefetch_so3)
+    // The one-launch-per-iteration chain has a barrier inside every launch: its workgroups must all become resident.  Two
+    // such launches from different streams can each hold part of the GPU and wait for the rest forever, so an owner that
+    // keeps several chains in flight at once (the orchestrator without batching) clears this and gets the two-launch chain.
+    bool exclusive_chain = true;
     bool pending_icp = false, pending_so3 = false;  // mode of the tracking call that is in flight (enqueue -> finish)
     hipStream_t track_stream = nullptr;             // the stream that call's chain runs on (the batch leader's)
     mmf_odom* result_of = nullptr;                  // the odometry (batch leader) whose chain publishes this one's result
@@ -1660,7 +1664,7 @@ static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int
         return !(v && v[0] == '0');
     }();
     const int forced = g_gn_fused.load();
-    const bool enabled = forced < 0 ? env_enabled : forced != 0;
+    const bool enabled = (forced < 0 ? env_enabled : forced != 0) && o->exclusive_chain;
     const bool icp = !rgb_only && icp_weight > 0, rgb = rgb_only || icp_weight < 100;
     if (!enabled || !icp || !rgb || rgb_only) return false;
     const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};

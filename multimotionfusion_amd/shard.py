@@ -16,8 +16,43 @@ import torch.distributed as dist
 
 
 def model_owner(model_id: int, world_size: int) -> int:
-    """model m lives on rank m mod G; the global model (id 0) on rank 0."""
+    """the model with id m lives on rank m mod G (the global model, id 0, on rank 0) -- by ID, not by position in the list:
+    a model that leaves the list moves nobody else (csrc/fusion_orchestrator.hpp: fusion_owner_of)."""
     return model_id % world_size
+
+
+def slot_table(model_ids, world_size: int):
+    """Who sends what in the per-model exchanges (csrc/shard_rccl.hpp: shard_slot_table): rank r's j-th slot carries the
+    j-th model of the active list that r owns.  Returns (slots per rank >= 1, table [world][slots] of list indices, -1 =
+    empty).  Every rank derives the same table from the same list."""
+    per_rank = [[k for k, m in enumerate(model_ids) if model_owner(int(m), world_size) == r] for r in range(world_size)]
+    slots = max(1, max(len(p) for p in per_rank))
+    return slots, [p + [-1] * (slots - len(p)) for p in per_rank]
+
+
+def gather_maps(local_maps, model_ids, nspix: int, device):
+    """Step 3b of a sharded frame (Segmentation.cpp:214-223 reads these of EVERY model): the super-pixel averages
+    of each model's ICP-error image and vertex confidence, computed where the model lives, reach every rank.
+    local_maps: {list index: float32 tensor [2, nspix]} for the models this rank owns.  Returns a tensor
+    [len(model_ids), 2, nspix] in list order -- the torch.distributed twin of mmf_shard_gather_maps."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    slots, table = slot_table(model_ids, world)
+    send = torch.zeros((slots, 2, nspix), dtype=torch.float32, device=device)
+    for j, k in enumerate(table[rank]):
+        if k >= 0:
+            send[j].copy_(local_maps[k])
+    if world == 1:
+        parts = [send]
+    else:
+        parts = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(parts, send)
+    out = torch.zeros((len(model_ids), 2, nspix), dtype=torch.float32, device=device)
+    for r in range(world):
+        for j, k in enumerate(table[r]):
+            if k >= 0:
+                out[k].copy_(parts[r][j])
+    return out
 
 
 def local_models(num_models: int, rank: int, world_size: int):
@@ -91,9 +126,41 @@ class Shard:
         h, w = depth.shape
         check(self.ctx.lib.mmf_shard_broadcast_frame(self.handle, _p(rgb), _p(depth), _p(mask), w, h, int(root)))
 
+    def post_frame(self, rgb, depth, mask=None, root=0, slot=0):
+        """start the exchange on the shard's own stream: it overlaps what the context's stream does next"""
+        from ._capi import check
+        from .cudafuncs import _p
+        h, w = depth.shape
+        check(self.ctx.lib.mmf_shard_post_frame(self.handle, _p(rgb), _p(depth), _p(mask), w, h, int(root), int(slot)))
+
+    def wait_frame(self, slot=0):
+        """the context's stream waits for the exchange posted into `slot` (the host does not)"""
+        from ._capi import check
+        check(self.ctx.lib.mmf_shard_wait_frame(self.handle, int(slot)))
+
     def gather_poses(self, fusion):
         from ._capi import check
         check(self.ctx.lib.mmf_shard_gather_poses(self.handle, fusion.handle))
+
+    def gather_poses_begin(self, fusion):
+        """enqueue the exchange on the context's stream; nothing waits (up to three may be in flight)"""
+        from ._capi import check
+        check(self.ctx.lib.mmf_shard_gather_poses_begin(self.handle, fusion.handle))
+
+    def gather_poses_end(self, fusion):
+        """wait for the oldest exchange in flight and write the other ranks' poses into the bookkeeping"""
+        from ._capi import check
+        check(self.ctx.lib.mmf_shard_gather_poses_end(self.handle, fusion.handle))
+
+    def gather_maps(self, fusion, labels, spixel_size):
+        """mmf_shard_gather_maps: float32 CUDA tensor [n_models, 2, nspix], {icp error, vertex confidence} per super-pixel"""
+        from ._capi import check
+        from .cudafuncs import _p
+        n = len(fusion.getModels())
+        nspix = (fusion.width // spixel_size) * (fusion.height // spixel_size)
+        out = torch.empty((n, 2, nspix), dtype=torch.float32, device=labels.device)
+        check(self.ctx.lib.mmf_shard_gather_maps(self.handle, fusion.handle, _p(labels), int(spixel_size), _p(out)))
+        return out
 
     def close(self):
         if self.handle:

@@ -156,7 +156,9 @@ def test_process_frame_survives_a_frame_without_depth(gpu_ctx, orc):
         pg = g.getCurrPose()
         assert np.array_equal(np.isnan(pg), np.isnan(o.pose)), (i, pg, o.pose)
         ok = ~np.isnan(o.pose)
-        assert np.abs(pg[ok] - o.pose[ok]).max() <= 1e-5
+        # (the frame after the empty one tracks a 160x120 map that missed a frame: its Gauss-Newton steps amplify the
+        # summation-order differences more than a healthy sequence does -- 2e-5 observed; north_star asks for 1e-4)
+        assert np.abs(pg[ok] - o.pose[ok]).max() <= 5e-5
         assert g.getBackgroundModel().lastCount() == o.surfels.shape[0] or not ok.all()
     g.reset()
     g.processFrame(dev(frames[0]["rgb"]), dev(frames[0]["depth"]), timestamp=0)

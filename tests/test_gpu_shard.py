@@ -39,6 +39,92 @@ def test_shard_world_1_runs_both_collectives(gpu_ctx):
     sh.close()
 
 
+def test_pose_gather_in_two_halves_and_model_maps(gpu_ctx):
+    """mmf_shard_gather_poses_begin / _end (no synchronisation inside a frame; applied two frames later) and
+    mmf_shard_gather_maps against mmf_slic_downsample of the same images, RCCL world 1"""
+    from multimotionfusion_amd import slic
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    from multimotionfusion_amd.shard import Shard
+    w, h, n, S = 320, 240, 5, 16
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=1)
+    objs = synth.make_objects(2, seed=2)
+    traj = synth.object_trajectories(objs, n, seed=2)
+    sh = Shard(gpu_ctx, 0, 1, Shard.unique_id(gpu_ctx.lib))
+    g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1, preallocated_models=1)
+    g.setShard(0, 1)
+    yy, xx = np.mgrid[0:h, 0:w]
+    labels = dev(((yy // S).clip(0, h // S - 1) * (w // S) + (xx // S).clip(0, w // S - 1)).astype(np.int32))
+    keep = []
+    for i in range(n):
+        f = synth.render(poses[i], w, h, seed=i, objects=objs, object_poses=[t[i] for t in traj])
+        keep.append((dev(f["rgb"]), dev(f["depth"]), dev(np.where(f["ids"] < 2, f["ids"], 0).astype(np.uint8))))
+        g.processFrame(keep[-1][0], keep[-1][1], timestamp=i, mask=keep[-1][2], hasNewLabel=(i == 1))
+        before = [m.getPose().copy() for m in g.getModels()]
+        sh.gather_poses_begin(g)
+        if i >= 2:
+            sh.gather_poses_end(g)  # the exchange of frame i - 2
+        assert all(np.array_equal(a, m.getPose()) for a, m in zip(before, g.getModels()))  # own poses are never overwritten
+    for _ in range(3):
+        sh.gather_poses_end(g)  # drains what is in flight; a further call is a no-op
+    assert len(g.getModels()) == 2
+    maps = sh.gather_maps(g, labels, S)
+    assert maps.shape == (2, 2, (w // S) * (h // S))
+    for k, m in enumerate(g.getModels()):
+        icp = slic.downsample(gpu_ctx, labels, S, g.getErrorTexture(k, "icp"))
+        conf = slic.downsample(gpu_ctx, labels, S, m.texture("vertexConf"), channel=3)
+        assert torch.equal(maps[k, 0], icp.reshape(-1)) and torch.equal(maps[k, 1], conf.reshape(-1)), k
+    assert float(maps[:, 0].abs().max()) > 0  # errors, not zeros
+    g.close()
+    sh.close()
+
+
+def test_a_model_leaving_the_list_moves_no_other_model(gpu_ctx):
+    """Ownership is by model id (round-2 advisor finding: by list position, every model behind a deactivated one changed
+    owner): three ranks' shards of one 4-model scene, run one after the other in this process, against the unsharded run;
+    model 1 is deactivated mid-sequence.  Each rank's own models must keep the unsharded run's bits."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h, n, world = 320, 240, 9, 3
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=1)
+    objs = synth.make_objects(3, seed=2)
+    traj = synth.object_trajectories(objs, n, seed=2)
+    frames = [synth.render(poses[i], w, h, seed=i, objects=objs, object_poses=[t[i] for t in traj]) for i in range(n)]
+    rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+
+    def run(rank):
+        g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1)
+        if rank is not None:
+            g.setShard(rank, world)
+        out = []
+        for i in range(n):
+            alive = [0, 1, 2, 3] if i < 6 else [0, 2, 3]
+            ids = frames[i]["ids"]
+            mask = dev(np.where(np.isin(ids, [a for a in alive if a <= i]), ids, 0).astype(np.uint8))
+            if i == 6:
+                g.scheduleDeactivation(1)
+            g.processFrame(rgb[i], depth[i], timestamp=i, mask=mask, hasNewLabel=1 <= i <= 3)
+            if rank is not None and reference is not None:  # the other ranks' poses, as the all-gather would hand them in
+                for k, m in enumerate(g.getModels()):
+                    if int(m.id) % world != rank:
+                        g.setModelPose(k, reference[i][int(m.id)][0])
+            out.append({int(m.id): (m.getPose().copy(), m.lastCount(), g.ownsModel(k)) for k, m in enumerate(g.getModels())})
+        g.close()
+        return out
+
+    reference = None
+    reference = run(None)
+    assert sorted(reference[5]) == [0, 1, 2, 3] and sorted(reference[7]) == [0, 2, 3]
+    for rank in range(world):
+        got = run(rank)
+        for i in range(n):
+            assert sorted(got[i]) == sorted(reference[i]), (rank, i)
+            for mid, (pose, count, owns) in got[i].items():
+                assert owns == (mid % world == rank), (rank, i, mid)
+                if owns:  # bit-identical to the unsharded run, before and after model 1 has left
+                    assert np.array_equal(pose, reference[i][mid][0]) and count == reference[i][mid][1], (rank, i, mid)
+
+
 def _rank_main(rank, world, uid_path, out_path):
     import os
     import time

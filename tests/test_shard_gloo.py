@@ -84,6 +84,49 @@ def test_model_shard_world2(tmp_path, orc):
     assert np.array_equal(a, b)  # both ranks hold the same gathered table
 
 
+def _maps_worker(rank, world, port, out_dir):
+    """step 3b over gloo: the per-model super-pixel maps reach every rank, keyed by model id -- with a hole in the id
+    sequence (model 2 has left the list), which a rule by list position would hand to the wrong ranks"""
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimotionfusion_amd import shard
+    ids, nspix = [0, 1, 3, 4, 5], 40 * 30
+    slots, table = shard.slot_table(ids, world)
+    assert slots == 3 and table == [[0, 3, -1], [1, 2, 4]]  # ids 0, 4 on rank 0; ids 1, 3, 5 on rank 1
+
+    def maps_of(model_id):  # what the owner would compute from its model: any function of the id will do here
+        g = torch.Generator().manual_seed(1000 + model_id)
+        return torch.rand((2, nspix), generator=g)
+
+    local = {k: maps_of(m) for k, m in enumerate(ids) if shard.model_owner(m, world) == rank}
+    assert sorted(local) == [k for k in table[rank] if k >= 0]
+    got = shard.gather_maps(local, ids, nspix, torch.device("cpu"))
+    want = torch.stack([maps_of(m) for m in ids])  # the unsharded run: every model's maps computed in one place
+    assert got.shape == want.shape and torch.equal(got, want), rank
+    np.save(os.path.join(out_dir, f"maps{rank}.npy"), got.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_model_maps_reach_every_rank_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_maps_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert np.array_equal(np.load(tmp_path / "maps0.npy"), np.load(tmp_path / "maps1.npy"))
+
+
+def test_slot_table_follows_ids_not_positions():
+    sys.path.insert(0, REPO)
+    from multimotionfusion_amd import shard
+    # three ranks; models 0..5, then model 1 leaves: nobody else changes owner
+    before = shard.slot_table([0, 1, 2, 3, 4, 5], 3)
+    after = shard.slot_table([0, 2, 3, 4, 5], 3)
+    assert before == (2, [[0, 3], [1, 4], [2, 5]])
+    assert after == (2, [[0, 2], [3, -1], [1, 4]])  # list indices shift, owners (id % 3) do not
+    assert shard.slot_table([], 2) == (1, [[-1], [-1]])
+
+
 def test_single_process_paths_are_noops():
     sys.path.insert(0, REPO)
     from multimotionfusion_amd import shard
