@@ -674,20 +674,33 @@ def main():
                                          "streams during the current frame's fusion); tracking_phase = host wall "
                                          "clock from the first enqueue to the last pose; aggregate = m x 388.6 MB / tracking_phase",
                                  "sweep": sweep}
-        # ---- host FrameData hand-over: the same static sequence with the upload inside processFrame (pinned double buffers)
-        g = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], icp_weight=ICP_WEIGHT)
-        n_steps = 60
-        for i in range(10 + n_steps):
-            if i == 10:
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-            k = i % (N_FRAMES - 1)
-            g.processFrameHost(frames[k]["rgb"], frames[k]["depth"], timestamp=i)
-        torch.cuda.synchronize()
-        result["with_host_upload"] = {"frames_per_s": n_steps / (time.perf_counter() - t1), "bytes_per_frame": 7 * n0,
-                                      "what": "mmf_fusion_process_frame_host: rgb + depth copied into pinned staging and uploaded on the "
-                                              "fusion's stream inside processFrame (no prefetch); never part of `value`"}
-        g.close()
+        # ---- host FrameData hand-over: the same static sequence with the upload inside processFrame, the way the reference's
+        # front-end hands frames over (FrameData in host memory, MultiMotionFusion.cpp:221, 261); the reader is one frame ahead
+        # (GUI/MainController.cpp:547-590), so the next frame is announced with each call (mmf_fusion_process_frame_host_next)
+        def host_loop(announce):
+            g = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], icp_weight=ICP_WEIGHT)
+            n_steps, t1 = 90, 0.0
+            for i in range(10 + n_steps):
+                if i == 10:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                k = i % len(frames)
+                if i and k == 0:
+                    g.reset()
+                kn = (i + 1) % len(frames)
+                nxt = (frames[kn]["rgb"], frames[kn]["depth"]) if announce and kn != 0 else None
+                g.processFrameHost(frames[k]["rgb"], frames[k]["depth"], timestamp=i, next=nxt)
+            torch.cuda.synchronize()
+            fps = n_steps / (time.perf_counter() - t1)
+            g.close()
+            return fps
+
+        result["with_host_upload"] = {"frames_per_s": host_loop(True), "frames_per_s_without_announcement": host_loop(False),
+                                      "bytes_per_frame": 7 * n0,
+                                      "what": "mmf_fusion_process_frame_host_next: rgb + depth in host memory; the frame announced for the next "
+                                              "call is copied into pinned staging and uploaded on a stream of its own while this frame is "
+                                              "tracked, its sensor-side preparation overlaps this frame's fusion (as in the headline loop); "
+                                              "without announcement: staged and uploaded at the start of its own call; never part of `value`"}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(frames, K, W, H)
     fence()

@@ -385,6 +385,14 @@ int mmf_fusion_process_frame_ex(mmf_fusion *f, const mmf_frame *frame);
 int mmf_fusion_process_frame_host(mmf_fusion *f, const uint8_t *rgb_host, const float *depth_host,
                                   const uint8_t *mask_host, int has_new_label, long long timestamp,
                                   const float *in_pose, float weight_multiplier, int bootstrap);
+/* The same with the NEXT call's host frame announced (both pointers or neither; the next call must be given exactly these
+ * pointers, contents unchanged): the host-memory form of mmf_frame::next_rgb / next_depth.  That frame is staged and
+ * uploaded on a stream of its own while this frame is tracked, and its sensor-side preparation overlaps this frame's
+ * fusion -- what a front-end that reads frames ahead (GUI/MainController.cpp:547-590: logReader->getNext()) gets for free. */
+int mmf_fusion_process_frame_host_next(mmf_fusion *f, const uint8_t *rgb_host, const float *depth_host,
+                                       const uint8_t *mask_host, int has_new_label, long long timestamp,
+                                       const float *in_pose, float weight_multiplier, int bootstrap,
+                                       const uint8_t *next_rgb_host, const float *next_depth_host);
 /* processFrame with the tracker initialised from keypoint tracks: odom_cfg.init == "kp"
  * (MultiMotionFusion.cpp:312-384).  init_transform = RigidRANSAC::Result::transformation of
  * Model::getLastTrackTransform (row-major 4x4, mmf_ransac_estimate): the camera model's pose becomes

@@ -164,6 +164,7 @@ SIGNATURES = {
     "mmf_fusion_depth_filtered": (_vp, [_vp]),
     "mmf_fusion_process_frame_ex": (_i, [_vp, C.POINTER(mmf_frame)]),
     "mmf_fusion_process_frame_host": (_i, [_vp, _vp, _vp, _vp, _i, C.c_longlong, _fp, _f, _i]),
+    "mmf_fusion_process_frame_host_next": (_i, [_vp, _vp, _vp, _vp, _i, C.c_longlong, _fp, _f, _i, _vp, _vp]),
     "mmf_fusion_predict": (_i, [_vp]),
     "mmf_fusion_set_tick": (_i, [_vp, _i]),
     "mmf_fusion_num_models": (_i, [_vp]),

@@ -93,10 +93,26 @@ struct mmf_fusion {
     bool pre_valid = false;
     const uint8_t* pre_rgb = nullptr;
     const float* pre_depth = nullptr;
-    // host FrameData hand-over (mmf_fusion_process_frame_host): pinned staging + device copies, double buffered
-    uint8_t* up_pin[2] = {nullptr, nullptr};
-    uint8_t* up_dev[2] = {nullptr, nullptr};
+    // host FrameData hand-over (mmf_fusion_process_frame_host[_next]): pinned staging + device copies in a ring of three
+    // (the frame being processed, the next one being uploaded, one whose readers may still be running), uploads on a
+    // stream of their own
+    static constexpr int kUp = 3;
+    uint8_t* up_pin[kUp] = {nullptr, nullptr, nullptr};
+    uint8_t* up_dev[kUp] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_up[kUp] = {nullptr, nullptr, nullptr};  // upload stream: slot k is on the device
+    bool up_recorded[kUp] = {false, false, false};
+    hipStream_t up_stream = nullptr;
+    hipEvent_t ev_up_begin = nullptr;  // fusion stream -> upload stream
     int up_cur = 0;
+    // the NEXT call's host frame, handed in as a hint: staged and uploaded while the host would only wait for this
+    // frame's pose (fusion_stage_host_next), its sensor-side preparation enqueued like a device-side hint's
+    struct HostNext {
+        const uint8_t* rgb = nullptr;
+        const float* depth = nullptr;
+        int slot = -1;
+        bool pending = false;  // still to be staged
+        bool staged = false;   // on its way to (or on) the device in `slot`
+    } host_next;
 };
 
 static void identity16(float* m) {
@@ -257,10 +273,14 @@ extern "C" void mmf_fusion_destroy(mmf_fusion* f) {
     (void)hipFree(f->mask);
     (void)hipFree(f->side_partials);
     (void)hipFree(f->side_ticket);
-    for (int i = 0; i < 2; ++i) {
+    if (f->up_stream) (void)hipStreamSynchronize(f->up_stream);
+    for (int i = 0; i < mmf_fusion::kUp; ++i) {
         if (f->up_pin[i]) (void)hipHostFree(f->up_pin[i]);
         (void)hipFree(f->up_dev[i]);
+        if (f->ev_up[i]) (void)hipEventDestroy(f->ev_up[i]);
     }
+    if (f->up_stream) (void)hipStreamDestroy(f->up_stream);
+    if (f->ev_up_begin) (void)hipEventDestroy(f->ev_up_begin);
     if (f->ev_inputs_free) (void)hipEventDestroy(f->ev_inputs_free);
     if (f->ev_frame_ready) (void)hipEventDestroy(f->ev_frame_ready);
     if (f->ev_prefetch_done) (void)hipEventDestroy(f->ev_prefetch_done);
@@ -506,6 +526,7 @@ static int fusion_spawn(mmf_fusion* f, FusionModel** out) {
 }
 
 static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* depth, int tick_at_use);
+static int fusion_stage_host_next(mmf_fusion* f);
 
 static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     MMF_REQUIRE(f != nullptr && fr != nullptr, "mmf_fusion_process_frame: null argument");
@@ -775,6 +796,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 if (rc) return rc;
                 next_prefetched = true;
             }
+            // a host frame announced for the next call: staged and sent up now, while the GPU tracks and the host would only wait
+            rc = fusion_stage_host_next(f);
+            if (rc) return rc;
             for (size_t k = 0; k < n_models; ++k) {  // the results, model by model
                 FusionModel* fm = f->models[k];
                 float pose[16];
@@ -996,45 +1020,102 @@ extern "C" int mmf_fusion_process_frame_init(mmf_fusion* f, const uint8_t* rgb, 
     return fusion_process_frame_impl(f, &fr);
 }
 
-// processFrame(const FrameData&) with the frame still in host memory (the reference uploads FrameData::rgb / depth
-// to GL textures at :221, :261): rgb, depth and the optional id image go through pinned staging buffers into
-// device copies, double buffered so that frame t+1 can be staged while frame t's last passes still read theirs.
-extern "C" int mmf_fusion_process_frame_host(mmf_fusion* f, const uint8_t* rgb_host, const float* depth_host,
-                                             const uint8_t* mask_host, int has_new_label, long long timestamp,
-                                             const float* in_pose, float weight_multiplier, int bootstrap) {
+// ---- processFrame(const FrameData&) with the frame still in host memory ------------------------------------------
+// The reference uploads FrameData::rgb / depth to GL textures at :221, :261.  Here rgb, depth (and the optional id image)
+// go through pinned staging buffers into device copies, three deep, on a stream of their own.
+static int fusion_up_init(mmf_fusion* f) {
+    if (f->up_pin[0]) return MMF_OK;
+    const size_t total = (size_t)f->width * f->height * 8;  // 8 B/px: depth f32, rgb u8 x 3, id u8
+    for (int i = 0; i < mmf_fusion::kUp; ++i) {
+        MMF_HIP_TRY(hipHostMalloc((void**)&f->up_pin[i], total, hipHostMallocDefault));
+        MMF_HIP_TRY(hipMalloc((void**)&f->up_dev[i], total));
+        MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_up[i], hipEventDisableTiming));
+    }
+    MMF_HIP_TRY(hipStreamCreateWithFlags(&f->up_stream, hipStreamNonBlocking));
+    MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_up_begin, hipEventDisableTiming));
+    return MMF_OK;
+}
+// host -> pinned -> device of rgb + depth into `slot`, on the upload stream; ev_up[slot] marks the arrival
+static int fusion_up_stage(mmf_fusion* f, int slot, const uint8_t* rgb_host, const float* depth_host) {
+    const size_t npix = (size_t)f->width * f->height;
+    // the staging buffer's previous upload must have left it (round-2 advisor finding: nothing made sure of that)
+    if (f->up_recorded[slot]) MMF_HIP_TRY(hipEventSynchronize(f->ev_up[slot]));
+    std::memcpy(f->up_pin[slot], depth_host, npix * 4);
+    std::memcpy(f->up_pin[slot] + npix * 4, rgb_host, npix * 3);
+    // the device copy's last readers are frames enqueued before this call (ev_up_begin: recorded when the call began --
+    // NOT now: by now this frame's whole tracking chain sits on the fusion's stream and the upload is meant to overlap it)
+    MMF_HIP_TRY(hipStreamWaitEvent(f->up_stream, f->ev_up_begin, 0));
+    MMF_HIP_TRY(hipMemcpyAsync(f->up_dev[slot], f->up_pin[slot], npix * 7, hipMemcpyHostToDevice, f->up_stream));
+    MMF_HIP_TRY(hipEventRecord(f->ev_up[slot], f->up_stream));
+    f->up_recorded[slot] = true;
+    return MMF_OK;
+}
+// the hinted next frame: called inside processFrame where the host would only wait for the pose (the GPU is busy with this
+// frame's tracking, the copy engine is idle), or at the latest when the call returns
+static int fusion_stage_host_next(mmf_fusion* f) {
+    mmf_fusion::HostNext& hn = f->host_next;
+    if (!hn.pending) return MMF_OK;
+    hn.pending = false;
+    int rc = fusion_up_stage(f, hn.slot, hn.rgb, hn.depth);
+    if (rc) return rc;
+    hn.staged = true;
+    return MMF_OK;
+}
+
+// next_rgb_host / next_depth_host (both or neither): the frame the NEXT call will be given (same pointers, contents
+// unchanged until then) -- the host-memory form of mmf_frame::next_*: it is staged and uploaded during this call and its
+// sensor-side preparation overlaps this frame's fusion, so the next call starts with its frame on the device.
+extern "C" int mmf_fusion_process_frame_host_next(mmf_fusion* f, const uint8_t* rgb_host, const float* depth_host,
+                                                  const uint8_t* mask_host, int has_new_label, long long timestamp,
+                                                  const float* in_pose, float weight_multiplier, int bootstrap,
+                                                  const uint8_t* next_rgb_host, const float* next_depth_host) {
     MMF_REQUIRE(f != nullptr, "mmf_fusion_process_frame_host: null fusion object");
     if (!rgb_host || !depth_host || timestamp < 0) return fail(MMF_ERR_INVALID, "invalid image data");  // :209-212
     mmf_ctx* c = f->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
+    if (int rc = fusion_up_init(f)) return rc;
     const size_t npix = (size_t)f->width * f->height;
-    const size_t o_depth = 0, o_rgb = npix * 4, o_mask = npix * 7, total = npix * 8;  // 8 B/px
-    if (!f->up_pin[0])
-        for (int i = 0; i < 2; ++i) {
-            MMF_HIP_TRY(hipHostMalloc((void**)&f->up_pin[i], total, hipHostMallocDefault));
-            MMF_HIP_TRY(hipMalloc((void**)&f->up_dev[i], total));
-        }
-    const int b = f->up_cur;
-    f->up_cur ^= 1;
-    std::memcpy(f->up_pin[b] + o_depth, depth_host, npix * 4);
-    std::memcpy(f->up_pin[b] + o_rgb, rgb_host, npix * 3);
-    size_t bytes = npix * 7;
-    if (mask_host) {
-        std::memcpy(f->up_pin[b] + o_mask, mask_host, npix);
-        bytes = total;
+    const size_t o_depth = 0, o_rgb = npix * 4, o_mask = npix * 7;
+    mmf_fusion::HostNext& hn = f->host_next;
+    MMF_HIP_TRY(hipEventRecord(f->ev_up_begin, c->stream));
+    int slot;
+    if (hn.staged && hn.rgb == rgb_host && hn.depth == depth_host) {  // announced by the previous call: already on its way
+        slot = hn.slot;
+    } else {
+        if (hn.staged || hn.pending) f->pre_rgb = nullptr, f->pre_depth = nullptr;  // what was prepared belongs to a frame that never came
+        slot = f->up_cur;                                                          // (its device buffer is about to be reused)
+        if (int rc = fusion_up_stage(f, slot, rgb_host, depth_host)) return rc;
     }
-    MMF_HIP_TRY(hipMemcpyAsync(f->up_dev[b], f->up_pin[b], bytes, hipMemcpyHostToDevice, c->stream));
+    hn = mmf_fusion::HostNext();
+    f->up_cur = (slot + 1) % mmf_fusion::kUp;
+    MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_up[slot], 0));
     mmf_frame fr;
     std::memset(&fr, 0, sizeof(fr));
-    fr.rgb = f->up_dev[b] + o_rgb, fr.depth = (const float*)(f->up_dev[b] + o_depth), fr.timestamp = timestamp;
+    fr.rgb = f->up_dev[slot] + o_rgb, fr.depth = (const float*)(f->up_dev[slot] + o_depth), fr.timestamp = timestamp;
     fr.in_pose = in_pose, fr.weight_multiplier = weight_multiplier, fr.bootstrap = bootstrap;
     fr.icp_refine = 1;
     mmf_segmentation seg;
     std::memset(&seg, 0, sizeof(seg));
-    if (mask_host) {
-        seg.mask = f->up_dev[b] + o_mask, seg.has_new_label = has_new_label;
+    if (mask_host) {  // the id image is this frame's segmentation result: it cannot be announced a frame ahead
+        std::memcpy(f->up_pin[slot] + o_mask, mask_host, npix);
+        MMF_HIP_TRY(hipMemcpyAsync(f->up_dev[slot] + o_mask, f->up_pin[slot] + o_mask, npix, hipMemcpyHostToDevice, c->stream));
+        seg.mask = f->up_dev[slot] + o_mask, seg.has_new_label = has_new_label;
         fr.segmentation = &seg;
     }
-    return fusion_process_frame_impl(f, &fr);
+    if (next_rgb_host && next_depth_host) {
+        hn.rgb = next_rgb_host, hn.depth = next_depth_host, hn.slot = f->up_cur, hn.pending = true;
+        fr.next_rgb = f->up_dev[hn.slot] + o_rgb, fr.next_depth = (const float*)(f->up_dev[hn.slot] + o_depth);
+    }
+    int rc = fusion_process_frame_impl(f, &fr);
+    if (rc) return rc;
+    return fusion_stage_host_next(f);  // (paths that enqueue no prefetch never reached the staging point)
+}
+
+extern "C" int mmf_fusion_process_frame_host(mmf_fusion* f, const uint8_t* rgb_host, const float* depth_host,
+                                             const uint8_t* mask_host, int has_new_label, long long timestamp,
+                                             const float* in_pose, float weight_multiplier, int bootstrap) {
+    return mmf_fusion_process_frame_host_next(f, rgb_host, depth_host, mask_host, has_new_label, timestamp, in_pose,
+                                              weight_multiplier, bootstrap, nullptr, nullptr);
 }
 
 // MultiMotionFusion::predict (:863-875) as a public call (the GUI re-predicts when a view changes)
@@ -1073,6 +1154,12 @@ static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* 
         MMF_HIP_TRY(hipMemsetAsync(f->side_ticket, 0, sizeof(unsigned) * kTicketWords, f->side2));
     }
     f->pre_valid = false;  // an earlier prefetch is simply overwritten: same streams, same order
+    if (f->host_next.slot >= 0 && f->up_dev[0] && rgb == f->up_dev[f->host_next.slot] + (size_t)f->width * f->height * 4) {
+        // the hinted frame comes from host memory (mmf_fusion_process_frame_host_next): behind its upload
+        if (int rc0 = fusion_stage_host_next(f)) return rc0;
+        MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_up[f->host_next.slot], 0));
+        MMF_HIP_TRY(hipStreamWaitEvent(f->side2, f->ev_up[f->host_next.slot], 0));
+    }
     if (f->inputs_free_recorded) {
         MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_inputs_free, 0));
         MMF_HIP_TRY(hipStreamWaitEvent(f->side2, f->ev_inputs_free, 0));

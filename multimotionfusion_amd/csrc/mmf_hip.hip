@@ -1363,8 +1363,10 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
 
     const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};  // :312-314
     // both terms on and every level fits: ONE launch per iteration (gn_fused.hpp) instead of producer + step
+    // (more than two models: the batched two-launch chain is faster -- 8 models 1.56 ms against 2.0 -- because a model's
+    // workgroups hold their CUs at the count barrier while the next models' wait for a place)
     const bool fused_chain = odom_fused_chain_ok(o, rgb_only, icp_weight, pyramid, fast_odom) &&
-                             (ny == 1 || odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom));
+                             (ny == 1 || (ny <= 2 && odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom)));
     int first_iter_level = MMF_NUM_PYRS - 1;  // the coarsest level that runs iterations
     while (first_iter_level > 0 && !iterations[first_iter_level]) --first_iter_level;
 

@@ -142,16 +142,21 @@ class MultiMotionFusion:
         check(self.ctx.lib.mmf_fusion_schedule_deactivation(self.handle, int(model_id)))
 
     def processFrameHost(self, rgb, depth, timestamp=0, mask=None, hasNewLabel=False, inPose=None, weightMultiplier=1.0,
-                         bootstrap=False):
-        """processFrame(const FrameData&) with HOST numpy arrays: staged through pinned buffers and uploaded inside."""
-        rgb = np.ascontiguousarray(rgb, np.uint8)
-        depth = np.ascontiguousarray(depth, np.float32)
+                         bootstrap=False, next=None):
+        """processFrame(const FrameData&) with HOST numpy arrays: staged through pinned buffers and uploaded inside.
+        next = (rgb, depth) of the NEXT call (C-contiguous uint8 / float32 arrays, the very objects that call will pass):
+        uploaded and prepared during this one (mmf_fusion_process_frame_host_next)."""
+        assert rgb.dtype == np.uint8 and depth.dtype == np.float32 and rgb.flags.c_contiguous and depth.flags.c_contiguous
         m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
         pose = np.ascontiguousarray(np.asarray(inPose, np.float32).reshape(16)) if inPose is not None else None
-        check(self.ctx.lib.mmf_fusion_process_frame_host(self.handle, rgb.ctypes.data, depth.ctypes.data,
-                                                         m.ctypes.data if m is not None else None, int(bool(hasNewLabel)),
-                                                         int(timestamp), fptr(pose) if pose is not None else None,
-                                                         float(weightMultiplier), int(bool(bootstrap))))
+        nr = nd = None
+        if next is not None:
+            nr, nd = next
+            assert nr.dtype == np.uint8 and nd.dtype == np.float32 and nr.flags.c_contiguous and nd.flags.c_contiguous
+        check(self.ctx.lib.mmf_fusion_process_frame_host_next(
+            self.handle, rgb.ctypes.data, depth.ctypes.data, m.ctypes.data if m is not None else None, int(bool(hasNewLabel)),
+            int(timestamp), fptr(pose) if pose is not None else None, float(weightMultiplier), int(bool(bootstrap)),
+            nr.ctypes.data if nr is not None else None, nd.ctypes.data if nd is not None else None))
 
     def predict(self):
         check(self.ctx.lib.mmf_fusion_predict(self.handle))

@@ -53,6 +53,51 @@ def test_host_frame_upload_gives_the_same_bits_as_device_frames(gpu_ctx):
     b.close()
 
 
+def test_host_frames_announced_one_call_ahead_give_the_same_bits(gpu_ctx):
+    """mmf_fusion_process_frame_host_next: the next call's host frame is staged, uploaded and prepared during this call.
+    Same poses and surfels as device-resident frames -- also when an announced frame never comes (another one is passed), when
+    nothing is announced for a frame, and when the same host arrays are refilled between calls (a reader's double buffer)."""
+    import numpy as np
+    import torch
+    from multimotionfusion_amd import synth
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h, n = 320, 240, 9
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=19)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    a = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    b = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    # the front-end's two frame buffers, refilled in turn
+    buf = [(np.empty_like(frames[0]["rgb"]), np.empty_like(frames[0]["depth"])) for _ in range(2)]
+    decoy = (frames[0]["rgb"].copy(), frames[0]["depth"].copy())
+
+    def fill(slot, i):
+        buf[slot][0][...] = frames[i]["rgb"]
+        buf[slot][1][...] = frames[i]["depth"]
+
+    keep = []
+    fill(0, 0)
+    for i in range(n):
+        keep.append((torch.from_numpy(frames[i]["rgb"]).cuda(), torch.from_numpy(frames[i]["depth"]).cuda()))
+        a.processFrame(*keep[-1], timestamp=i)
+        cur = buf[i % 2]
+        if i + 1 < n and i not in (3, 5):
+            fill((i + 1) % 2, i + 1)  # the reader has the next frame already
+            nxt = buf[(i + 1) % 2]
+        elif i == 3:
+            nxt = decoy  # announced, but the next call brings another frame
+        else:
+            nxt = None  # nothing announced
+        b.processFrameHost(cur[0], cur[1], timestamp=i, next=nxt)
+        if i + 1 < n and i in (3, 5):
+            fill((i + 1) % 2, i + 1)
+        assert np.array_equal(a.getCurrPose(), b.getCurrPose()), i
+    assert np.array_equal(a.getBackgroundModel().downloadMap().view(np.uint32), b.getBackgroundModel().downloadMap().view(np.uint32))
+    assert np.array_equal(b.getTexture("RGB").cpu().numpy(), frames[-1]["rgb"])
+    a.close()
+    b.close()
+
+
 def test_runtime_setters_take_effect_at_the_next_frame(gpu_ctx):
     """setFastOdom / setPyramid / setSo3 / setIcpWeight / setRgbOnly change the NEXT processFrame like a GUI checkbox
     (MultiMotionFusion.cpp:1064-1116): iteration counts and the tracker's mode follow them."""
