@@ -278,6 +278,11 @@ int mmf_model_requires_fill_in(mmf_model *m, float ratio, int *result);
 /* Model::downloadMap (Model.cpp:1353-1384): count_out surfels of 12 floats
  * {x y z conf | colour24 unused initTime timestamp | nx ny nz radius} (Vertex::SIZE = 48) */
 int mmf_model_download_map(mmf_model *m, float *host_aos, unsigned max_surfels, unsigned *count_out);
+/* Model::getModel() (Model.h:297; OutputBuffer of Core/Model/Buffers.h:3-6): the surfel store as it stands, in place --
+ * three device arrays of float4 {xyz, confidence}, {colour24, unused, initTime, timestamp}, {normal xyz, radius} and the
+ * number of surfels; valid until this model's next fuse / clean / initialise. */
+int mmf_model_surfel_arrays(mmf_model *m, const float **pos_conf, const float **colour_time, const float **normal_radius,
+                            unsigned *count);
 /* inverse of download (tests, -restore) */
 int mmf_model_upload_map(mmf_model *m, const float *host_aos, unsigned count);
 /* device image behind a GPUTexture getter (ModelProjection.h:52-77, Model.h:232-244).

@@ -204,6 +204,7 @@ SIGNATURES = {
     "mmf_shard_gather_poses_end": (_i, [_vp, _vp]),
     "mmf_shard_gather_maps": (_i, [_vp, _vp, _vp, _i, _vp]),
     "mmf_debug_expf": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "mmf_model_surfel_arrays": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint)]),
     "mmf_debug_set_gn_fused": (_i, [_i]),
     "mmf_fusion_set_shard": (_i, [_vp, _i, _i]),
     "mmf_fusion_owns_model": (_i, [_vp, _i]),

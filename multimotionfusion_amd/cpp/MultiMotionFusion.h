@@ -9,6 +9,8 @@
 // spawning policy, redetection) are kept as recorded no-ops so those call sites need no #ifdef.
 #pragma once
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <map>
@@ -40,11 +42,85 @@ struct FrameDataDevice {
     const float* nextDepth = nullptr;
 };
 
+// The frame geometry the reference keeps in two process-wide singletons (Core/Utils/Resolution.h:26-67,
+// Core/Utils/Intrinsics.h:24-66): set once by the front-end (GUI/MainController.cpp:147-148), read by the constructors.
+class Resolution {
+   public:
+    static const Resolution& getInstance() { return instance(); }
+    static void setResolution(int width, int height) { instance().w_ = width, instance().h_ = height; }
+    const int& width() const { return check(), w_; }
+    const int& height() const { return check(), h_; }
+    const int& cols() const { return check(), w_; }
+    const int& rows() const { return check(), h_; }
+    int numPixels() const { return check(), w_ * h_; }
+
+   private:
+    static Resolution& instance() {
+        static Resolution r;
+        return r;
+    }
+    void check() const {
+        if (w_ <= 0 || h_ <= 0) {
+            std::fprintf(stderr, "You haven't initialised the Resolution class!\n");
+            std::exit(-1);
+        }
+    }
+    int w_ = 0, h_ = 0;
+};
+class Intrinsics {
+   public:
+    static const Intrinsics& getInstance() { return instance(); }
+    static void setIntrinics(float fx = 0, float fy = 0, float cx = 0, float cy = 0) {  // (sic: the reference's spelling)
+        Intrinsics& i = instance();
+        i.fx_ = fx, i.fy_ = fy, i.cx_ = cx, i.cy_ = cy;
+        i.check();
+    }
+    const float& fx() const { return check(), fx_; }
+    const float& fy() const { return check(), fy_; }
+    const float& cx() const { return check(), cx_; }
+    const float& cy() const { return check(), cy_; }
+
+   private:
+    static Intrinsics& instance() {
+        static Intrinsics i;
+        return i;
+    }
+    void check() const {
+        if (fx_ == 0 || fy_ == 0) {
+            std::fprintf(stderr, "You haven't initialised the Intrinsics class!\n");
+            std::exit(-1);
+        }
+    }
+    float fx_ = 0, fy_ = 0, cx_ = 0, cy_ = 0;
+};
+
+struct OdometryConfig {  // Core/Model/Model.h:45-61
+    std::string init;
+    std::string init_frame;
+    int init_lvl = 0;
+    bool icp_refine = false;
+    int segm_lvl = 0;
+};
+struct SegmentationConfiguration {  // Core/Segmentation/Segmentation.h:72-80 (the segmentation itself stays in the reference)
+    std::string mode;
+    int sp_size = 16;
+};
+
+// Model::getModel()'s return type (Core/Model/Buffers.h:3-6).  The reference hands out the GL names of the vertex buffer that
+// holds the surfels (48-byte Vertex records); here the store is three float4 arrays in HBM, handed out in place.
+struct OutputBuffer {
+    const float* positionConfidence = nullptr;  // device, [count][4]: x y z confidence
+    const float* colourTime = nullptr;          // device, [count][4]: colour24-as-float, unused, initTime, timestamp
+    const float* normalRadius = nullptr;        // device, [count][4]: nx ny nz radius
+    unsigned count = 0;
+};
+
 class ModelProjection;
 
 class Model {
    public:
     static const int MAX_VERTICES = 1024 * 1024;  // Model.cpp:119-126
+    enum class MatchingType { Drost };            // Model.h:112 (model matching stays in the reference)
 
     struct surfel_t {  // Model.h:247-264, Vertex::SIZE = 48
         float position[3], confidence;
@@ -112,7 +188,10 @@ class Model {
         initICP(tryFillIn, frameToFrameRGB, maxDepthProcessed, rgb);
         float trans[3] = {pose[3], pose[7], pose[11]};
         float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
-        mmf::check(mmf_odom_get_incremental_transformation(o_, trans, rot, rgbOnly, icpWeight, pyramid, fastOdom, so3, nullptr, nullptr),
+        // enableErrorRecording (every Model of the reference is created with it): icpError / rgbError are written
+        mmf::check(mmf_odom_get_incremental_transformation(o_, trans, rot, rgbOnly, icpWeight, pyramid, fastOdom, so3,
+                                                           const_cast<float*>(getICPErrorTexture()->ptr<float>()),
+                                                           const_cast<float*>(getRGBErrorTexture()->ptr<float>())),
                    "mmf_odom_get_incremental_transformation");
         for (int r = 0; r < 3; ++r) {
             for (int c = 0; c < 3; ++c) pose[4 * r + c] = rot[3 * r + c];
@@ -185,6 +264,17 @@ class Model {
     }
     void getPose(float pose[16]) const { mmf::check(mmf_model_get_pose(m_, pose), "mmf_model_get_pose"); }
     const float* getLastPose() const { return lastPose_; }
+#ifdef MMF_HAVE_EIGEN
+    Eigen::Matrix4f getPose() const {  // Model.h:292
+        Eigen::Matrix<float, 4, 4, Eigen::RowMajor> p;
+        getPose(p.data());
+        return p;
+    }
+    void overridePose(const Eigen::Matrix4f& pose) {  // Model.h:301-304
+        const Eigen::Matrix<float, 4, 4, Eigen::RowMajor> p = pose;
+        overridePose(p.data());
+    }
+#endif
     std::vector<surfel_t> downloadMap() const {  // Model.cpp:1353-1384
         std::vector<surfel_t> out(lastCount());
         unsigned got = 0;
@@ -193,6 +283,21 @@ class Model {
                        "mmf_model_download_map");
         out.resize(got);
         return out;
+    }
+    // Model.h:297: the surfel store the last fuse / clean left, in place (valid until this model's next fuse / clean)
+    const OutputBuffer& getModel() {
+        mmf::check(mmf_model_surfel_arrays(m_, &vbo_.positionConfidence, &vbo_.colourTime, &vbo_.normalRadius, &vbo_.count),
+                   "mmf_model_surfel_arrays");
+        return vbo_;
+    }
+    // Model.h:278-284: the error images of the last tracking (R32F, written on the last level-0 iteration) and the
+    // confidence-carrying vertex image of the splat -- what Segmentation.cpp:218-219 reads of every model
+    GPUTexture* getICPErrorTexture() { return error_texture(icp_tex_, "icp_error"); }
+    GPUTexture* getRGBErrorTexture() { return error_texture(rgb_tex_, "rgb_error"); }
+    std::vector<float> downloadICPErrorTexture() { return download_f32(getICPErrorTexture()->ptr<float>(), (size_t)width_ * height_); }
+    std::vector<float> downloadRGBErrorTexture() { return download_f32(getRGBErrorTexture()->ptr<float>(), (size_t)width_ * height_); }
+    std::vector<float> downloadVertexConfTexture() {  // RGBA32F: x y z confidence
+        return download_f32(static_cast<const float*>(texture("vertexConf")), (size_t)width_ * height_ * 4);
     }
     RGBDOdometry::Stats getFrameOdometryStats() const {
         RGBDOdometry::Stats s;
@@ -235,6 +340,21 @@ class Model {
     static void identity(float* m) {
         for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? 1.f : 0.f;
     }
+    GPUTexture* error_texture(std::unique_ptr<GPUTexture>& t, const char* name) {
+        void* p = nullptr;
+        size_t b = 0;
+        mmf::check(mmf_odom_buffer(o_, name, 0, &p, &b), "mmf_odom_buffer");
+        if (!t)
+            t.reset(new GPUTexture(p, width_, height_, GPUTexture::R32F, name));
+        else
+            t->rebind(p);
+        return t.get();
+    }
+    static std::vector<float> download_f32(const float* dev, size_t n) {  // GPUTexture::downloadTexture (cv::Mat in the reference)
+        std::vector<float> host(n);
+        if (hipMemcpy(host.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) host.clear();
+        return host;
+    }
     mmf_model* m_ = nullptr;
     mmf_odom* o_ = nullptr;
     bool owned_ = false;
@@ -242,6 +362,8 @@ class Model {
     bool fill_in_ = false;
     float lastPose_[16];
     std::vector<int64_t> timestamp_ns_;
+    OutputBuffer vbo_;
+    std::unique_ptr<GPUTexture> icp_tex_, rgb_tex_;
 };
 
 typedef std::shared_ptr<Model> ModelPointer;
@@ -257,6 +379,45 @@ class MultiMotionFusion {
         mmf::check(mmf_fusion_create(ctx.get(), width, height, cx, cy, fx, fy, cfg, &f_), "mmf_fusion_create");
         mmf::check(mmf_fusion_get_config(f_, &cfg_), "mmf_fusion_get_config");
     }
+    // The reference's own argument list (Core/MultiMotionFusion.h:54-61, .cpp:21-97): the frame geometry comes from the
+    // Resolution / Intrinsics singletons, the device context is the process-wide default one (device 0, like the reference's
+    // cudaGetDeviceProperties(&prop, 0)).  Arguments of subsystems that stay in the reference (loop closure, relocalisation,
+    // ferns, model matching, keypoint predictor path, segmentation mode) are recorded; closeLoops must be false, as the
+    // front-end passes it (GUI/MainController.cpp:361, 514-515: openLoop is hard-wired).
+    MultiMotionFusion(const int timeDelta = 200, const int countThresh = 35000, const float errThresh = 5e-05f, const float covThresh = 1e-05f,
+                      const bool closeLoops = false, const bool iclnuim = false, const bool reloc = false, const float photoThresh = 115,
+                      const float initConfidenceGlobal = 4, const float initConfidenceObject = 2, const float depthCut = 3,
+                      const float icpThresh = 10, const bool fastOdom = false, const float fernThresh = 0.3095f, const bool so3 = true,
+                      const bool frameToFrameRGB = false, const unsigned modelSpawnOffset = 20,
+                      const Model::MatchingType /*matchingType*/ = Model::MatchingType::Drost, const std::string& exportDirectory = "",
+                      const bool exportSegmentationResults = false, const std::string keypoint_predictor_path = {},
+                      const OdometryConfig& odom_cfg = {}, const SegmentationConfiguration& segm_cfg = {})
+        : width_(Resolution::getInstance().width()), height_(Resolution::getInstance().height()), odom_cfg_(odom_cfg), segm_cfg_(segm_cfg),
+          exportDirectory_(exportDirectory) {
+        if (closeLoops) {
+            std::fprintf(stderr, "MultiMotionFusion: loop closure is not part of this path (the front-end runs with openLoop)\n");
+            std::exit(-1);
+        }
+        mmf_fusion_config cfg;
+        mmf::check(mmf_fusion_default_config(&cfg), "mmf_fusion_default_config");
+        cfg.time_delta = timeDelta, cfg.conf_global_init = initConfidenceGlobal, cfg.conf_object_init = initConfidenceObject;
+        cfg.depth_cutoff = depthCut, cfg.icp_weight = icpThresh, cfg.fast_odom = fastOdom, cfg.so3 = so3;
+        cfg.frame_to_frame_rgb = frameToFrameRGB;
+        other_["countThresh"] = (float)countThresh, other_["errThresh"] = errThresh, other_["covThresh"] = covThresh;
+        other_["iclnuim"] = iclnuim, other_["reloc"] = reloc, other_["photoThresh"] = photoThresh, other_["fernThresh"] = fernThresh;
+        other_["modelSpawnOffset"] = (float)modelSpawnOffset, other_["exportSegmentationResults"] = exportSegmentationResults;
+        other_["hasKeypointPredictor"] = !keypoint_predictor_path.empty();
+        const Intrinsics& K = Intrinsics::getInstance();
+        mmf::check(mmf_fusion_create(defaultContext().get(), width_, height_, K.cx(), K.cy(), K.fx(), K.fy(), &cfg, &f_), "mmf_fusion_create");
+        mmf::check(mmf_fusion_get_config(f_, &cfg_), "mmf_fusion_get_config");
+    }
+    static mmf::Context& defaultContext() {
+        static mmf::Context ctx(0);
+        return ctx;
+    }
+    const OdometryConfig& getOdometryConfig() const { return odom_cfg_; }
+    const SegmentationConfiguration& getSegmentationConfiguration() const { return segm_cfg_; }
+
     virtual ~MultiMotionFusion() {
         for (auto& kv : textures_) delete kv.second;
         models_.clear();
@@ -273,10 +434,30 @@ class MultiMotionFusion {
     // returns false after a regular frame (MultiMotionFusion.cpp:209-212, 853).  The frame is uploaded inside (:221, :261).
     bool processFrame(const FrameData& frame, const float* inPose = nullptr, const float weightMultiplier = 1.f,
                       void* /*GroundTruthOdometryInterface*/ = nullptr, const bool bootstrap = false) {
-        return finish(mmf_fusion_process_frame_host(f_, frame.rgb, frame.depth, frame.mask, frame.hasNewLabel, frame.timestamp, inPose,
-                                                    weightMultiplier, bootstrap),
+        const FrameData next = next_;  // announced by announceNextFrame (one call only)
+        next_ = FrameData();
+        return finish(mmf_fusion_process_frame_host_next(f_, frame.rgb, frame.depth, frame.mask, frame.hasNewLabel, frame.timestamp, inPose,
+                                                         weightMultiplier, bootstrap, next.rgb, next.depth),
                       "mmf_fusion_process_frame_host");
     }
+    // not in the reference: a front-end whose reader is one frame ahead (GUI/MainController.cpp:547-590) announces the frame
+    // the NEXT processFrame call will bring (same buffers, unchanged until then): it is uploaded while this one is tracked
+    // and prepared while this one is fused.  Optional; a frame that was announced and never comes costs nothing but the copy.
+    void announceNextFrame(const FrameData& next) { next_ = next; }
+#ifdef MMF_HAVE_EIGEN
+    // the reference's exact signature (MultiMotionFusion.h:78-80) and pose getter (:196)
+    bool processFrame(const FrameData& frame, const Eigen::Matrix4f* inPose, const float weightMultiplier = 1.f,
+                      void* gt_pose = nullptr, const bool bootstrap = false) {
+        if (!inPose) return processFrame(frame, static_cast<const float*>(nullptr), weightMultiplier, gt_pose, bootstrap);
+        const Eigen::Matrix<float, 4, 4, Eigen::RowMajor> p = *inPose;
+        return processFrame(frame, p.data(), weightMultiplier, gt_pose, bootstrap);
+    }
+    Eigen::Matrix4f getCurrPose() const {
+        Eigen::Matrix<float, 4, 4, Eigen::RowMajor> p;
+        mmf::check(mmf_fusion_get_pose(f_, p.data()), "mmf_fusion_get_pose");
+        return p;
+    }
+#endif
     bool processFrame(const FrameDataDevice& frame, const float* inPose = nullptr, const float weightMultiplier = 1.f,
                       const bool bootstrap = false) {
         mmf_segmentation seg;
@@ -388,7 +569,9 @@ class MultiMotionFusion {
     int getTimeDelta() { return refresh().time_delta; }
     float getMaxDepthProcessed() { return refresh().max_depth_processed; }
     void getCurrPose(float pose[16]) const { mmf::check(mmf_fusion_get_pose(f_, pose), "mmf_fusion_get_pose"); }
-    void exportPoses(const std::string& exportDir = "") { mmf::check(mmf_fusion_export_poses(f_, exportDir.c_str()), "mmf_fusion_export_poses"); }
+    void exportPoses(const std::string& exportDir = "") {  // (the reference writes into the constructor's exportDirectory)
+        mmf::check(mmf_fusion_export_poses(f_, (exportDir.empty() ? exportDirectory_ : exportDir).c_str()), "mmf_fusion_export_poses");
+    }
     mmf_odom* getFrameOdometryHandle() { return mmf_fusion_odometry(f_); }
     mmf_fusion* handle() const { return f_; }
 
@@ -408,8 +591,12 @@ class MultiMotionFusion {
     mmf_fusion* f_ = nullptr;
     mmf_fusion_config cfg_;
     int width_, height_;
+    OdometryConfig odom_cfg_;
+    SegmentationConfiguration segm_cfg_;
+    std::string exportDirectory_;
     ModelList models_;
     std::map<std::string, GPUTexture*> textures_;
     std::map<std::string, float> other_;
     bool lost_ = false;
+    FrameData next_;
 };

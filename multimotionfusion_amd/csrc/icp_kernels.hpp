@@ -218,7 +218,9 @@ __device__ __forceinline__ void icp_rows_v(const IcpPose& P, const IcpArgs& a, c
 // CHECK_BREAK: return when st->level_break is set -- tested only after the current-frame loads have been
 // issued: the state was written by the previous kernel's finishing lane and reading it is a cold
 // ~1 us round trip that should overlap those loads, not precede them.
-template <typename T, int NV, int BLOCK, bool PACKED, bool ERR, bool CHECK_BREAK = false>
+// MULTI: the grid is smaller than the image: every lane walks it with the grid's stride (sums start from zero and
+// every pass accumulates); else ONE pass and the first vector's products initialise the sums.
+template <typename T, int NV, int BLOCK, bool PACKED, bool ERR, bool CHECK_BREAK = false, bool MULTI = false>
 __device__ __forceinline__ void icp_block2(const OdomState* __restrict__ st, const IcpArgs& a,
                                            float* __restrict__ partials, GridReduceLds<float, BLOCK>& lds,
                                            unsigned bid, unsigned nblocks) {
@@ -228,14 +230,21 @@ __device__ __forceinline__ void icp_block2(const OdomState* __restrict__ st, con
     const int level_break = CHECK_BREAK ? st->level_break : 0;
 
     T sum[29];
+    if (MULTI) {
+#pragma unroll
+        for (int k = 0; k < 29; ++k) sum[k] = L::splat(0.f);
+    }
     const unsigned N = (unsigned)(a.cols * a.rows);
     const int rows = a.rows;
-    {   // ONE pass: the host sizes the grid to cover the image (N % PX == 0).  Lanes past the end
-        // stay active for the wave reduction: they recompute pixel 0 and contribute zeros.
-        unsigned i0 = (bid * BLOCK + threadIdx.x) * PX;
+    const unsigned stride = nblocks * BLOCK * PX;
+    // ONE pass unless MULTI: the host sizes the grid to cover the image (N % PX == 0).  Lanes past the end
+    // stay active for the wave reduction: they recompute pixel 0 and contribute zeros.
+    for (unsigned first = (bid * BLOCK + threadIdx.x) * PX;; first += stride) {
+        unsigned i0 = first;
         const bool live = i0 < N;
         i0 = live ? i0 : 0u;
-        const unsigned y = __umulhi(i0, a.cols_magic);
+        // cols_magic == 0: the image is too large for the multiply-high (i0 * cols >= 2^32)
+        const unsigned y = a.cols_magic ? __umulhi(i0, a.cols_magic) : i0 / (unsigned)a.cols;
         const unsigned x = i0 - y * (unsigned)a.cols;
 
         // ---- round trip 1: the lane's current vertices and normals, six loads in flight ----
@@ -329,7 +338,7 @@ __device__ __forceinline__ void icp_block2(const OdomState* __restrict__ st, con
                 L::set(n.z, e, cur[5][g * W + e]);
             }
             float er[W];
-            if (g == 0)
+            if (g == 0 && !MULTI)
                 icp_rows_v<ERR, true, T>(P, a, pr[g], live, n, vp[g], np[g], sum, er);
             else
                 icp_rows_v<ERR, false, T>(P, a, pr[g], live, n, vp[g], np[g], sum, er);
@@ -339,6 +348,7 @@ __device__ __forceinline__ void icp_block2(const OdomState* __restrict__ st, con
             }
         }
         if (ERR && live) store_px<PX>(a.err_map + (size_t)y * a.err_stride + x, errs);
+        if (!MULTI || first + stride >= N || first + stride < first) break;  // (the lanes of a wave leave together or at the tail)
     }
 
     float s32[32];

@@ -226,7 +226,8 @@ static float sq_min_ge(float t) {
 static void icp_args_derive(IcpArgs& a) {
     a.dist_sq_max = sq_max_le(a.dist_thres);
     a.sine_sq_min = sq_min_ge(a.angle_thres);
-    a.cols_magic = (unsigned)((1ull << 32) / (unsigned)a.cols) + 1u;
+    // i / cols == umulhi(i, magic) as long as i * cols < 2^32; larger images divide (0 selects that)
+    a.cols_magic = (long long)a.cols * a.rows * a.cols < (1ll << 32) ? (unsigned)((1ull << 32) / (unsigned)a.cols) + 1u : 0u;
 }
 
 // pixels per lane the vector loads allow for these maps (4, 2 or 1)
@@ -240,7 +241,7 @@ static int icp_max_px(const IcpArgs& a, int px) {
     while (px > 1 && !ok(px)) px /= 2;
     return px;
 }
-// icp_kernel2 is single pass (its grid must cover the image) and divides by multiply-high
+// can ONE pass of kMaxIcpGrid workgroups cover the image?  (larger ones: the multi-pass instantiation)
 static bool icp2_fits(const IcpArgs& a, int block, int px) {
     const long long n = (long long)a.cols * a.rows;
     return n * a.cols < (1ll << 32) && (long long)kMaxIcpGrid * block * px >= n;
@@ -273,9 +274,13 @@ static hipError_t launch_icp(mmf_ctx* c, OdomState* st, IcpArgs a, int variant =
             default: MMF_ICP2(2, 1, 256);
         }
 #undef MMF_ICP2
-    } else {  // very large images: the grid-stride first-generation kernel
-        grid = reduce_grid(a.cols * a.rows, 256);
-        hipLaunchKernelGGL((icp_kernel<1, 256, MODE>), dim3(grid), dim3(256), 0, c->stream, st, a, partials);
+    } else {  // very large images: kMaxIcpGrid workgroups walk the image, one pixel per lane and pass
+        grid = kMaxIcpGrid;
+        const bool packed = gen != 1 && a.prev_packed != nullptr;
+        if (packed)
+            hipLaunchKernelGGL((icp_kernel2<1, 1, 256, true, MODE, true>), dim3(grid), dim3(256), 0, c->stream, st, a, partials);
+        else
+            hipLaunchKernelGGL((icp_kernel2<1, 1, 256, false, MODE, true>), dim3(grid), dim3(256), 0, c->stream, st, a, partials);
     }
     if (records_out) *records_out = grid;
     return hipGetLastError();
@@ -1831,6 +1836,8 @@ extern "C" int mmf_odom_buffer(mmf_odom* o, const char* name, int level, void** 
     else if (s == "dIdx") p = o->dIdx[level], b = n * 2;
     else if (s == "dIdy") p = o->dIdy[level], b = n * 2;
     else if (s == "corres") p = o->corres[level], b = n * sizeof(mmf_dataterm);
+    else if (s == "icp_error") p = o->icp_err, b = (size_t)o->width * o->height * 4;  // Model::icpError / rgbError (R32F, full size;
+    else if (s == "rgb_error") p = o->rgb_err, b = (size_t)o->width * o->height * 4;  // `level` is ignored)
     else return fail(MMF_ERR_INVALID, "mmf_odom_buffer: unknown buffer name '" + s + "'");
     *dev_ptr = p;
     *bytes = b;
@@ -2323,6 +2330,20 @@ extern "C" int mmf_model_requires_fill_in(mmf_model* m, float ratio, int* result
     int rc = model_read_totals(m);
     if (rc) return rc;
     *result = ((float)m->host_totals[2] / (float)(dr * dc) < ratio) ? 1 : 0;
+    return MMF_OK;
+}
+
+// Model::getModel() (Model.h:297, Model.cpp:357: the vertex buffer the last fuse / clean left = vbos[target]) as a view of the
+// surfel store in HBM: three float4 arrays and the number of surfels in them.  The pointers stay valid until
+// the next fuse / clean / initialise of this model (the two stores ping-pong).
+extern "C" int mmf_model_surfel_arrays(mmf_model* m, const float** pos_conf, const float** colour_time, const float** normal_radius,
+                                       unsigned* count) {
+    MMF_REQUIRE(m && pos_conf && colour_time && normal_radius && count, "mmf_model_surfel_arrays: null argument");
+    if (int rc0 = model_resolve_count(m)) return rc0;
+    *pos_conf = reinterpret_cast<const float*>(m->set[m->cur].pos);
+    *colour_time = reinterpret_cast<const float*>(m->set[m->cur].col);
+    *normal_radius = reinterpret_cast<const float*>(m->set[m->cur].nrm);
+    *count = m->count;
     return MMF_OK;
 }
 

@@ -52,136 +52,17 @@ __device__ __forceinline__ void accumulate_se3(float (&sum)[29], const float (&r
     sum[28] = sum[28] + found;
 }
 
-// One pixel of ICPReduction::search + getProducts (reduce.cu:257-368), given its current
-// vertex / normal.  Branch-free up to the gather so a lane's four pixels issue their gathers
-// back to back.
-struct IcpPixel {
-    f3 vcurr_g, vcurr_cp;
-    int ux, uy;
-    bool inside;
-};
-
-__device__ __forceinline__ IcpPixel icp_project(const OdomState* st, const IcpArgs& a, f3 vcurr) {
-    const m33& Rcurr = *reinterpret_cast<const m33*>(st->Rcurr);
-    const m33& Rprev_inv = *reinterpret_cast<const m33*>(st->Rprev_inv);
-    const f3 tcurr = make_f3(st->tcurr[0], st->tcurr[1], st->tcurr[2]);
-    const f3 tprev = make_f3(st->tprev[0], st->tprev[1], st->tprev[2]);
-    IcpPixel p;
-    p.vcurr_g = Rcurr * vcurr + tcurr;
-    p.vcurr_cp = Rprev_inv * (p.vcurr_g - tprev);
-    p.ux = float2int_rn(p.vcurr_cp.x * a.intr.fx / p.vcurr_cp.z + a.intr.cx);
-    p.uy = float2int_rn(p.vcurr_cp.y * a.intr.fy / p.vcurr_cp.z + a.intr.cy);
-    p.inside = !(p.ux < 0 || p.uy < 0 || p.ux >= a.cols || p.uy >= a.rows || p.vcurr_cp.z < 0);
-    return p;
-}
-
-__device__ __forceinline__ void icp_row(const OdomState* st, const IcpArgs& a, const IcpPixel& p,
-                                        f3 ncurr, f3 vprev_g, f3 nprev_g, float (&row)[7],
-                                        float& found_f, float& err) {
-    const m33& Rcurr = *reinterpret_cast<const m33*>(st->Rcurr);
-    const m33& Rprev_inv = *reinterpret_cast<const m33*>(st->Rprev_inv);
-    const f3 tprev = make_f3(st->tprev[0], st->tprev[1], st->tprev[2]);
-    const f3 ncurr_g = Rcurr * ncurr;
-    const float dist = norm(vprev_g - p.vcurr_g);
-    const float sine = norm(cross(ncurr_g, nprev_g));
-    err = p.inside ? (isfinite(dist) ? dist : 0.0f) : 0.0f;  // reduce.cu:275,299
-    const bool found = p.inside && (sine < a.angle_thres && dist <= a.dist_thres &&
-                                    !(ncurr.x != ncurr.x) && !(nprev_g.x != nprev_g.x));
-#pragma unroll
-    for (int k = 0; k < 7; ++k) row[k] = 0.f;
-    if (found) {  // reduce.cu:320-329
-        const f3 s_cp = Rprev_inv * (p.vcurr_g - tprev);
-        const f3 d_cp = Rprev_inv * (vprev_g - tprev);
-        const f3 n_cp = Rprev_inv * nprev_g;
-        const f3 c = cross(s_cp, n_cp);
-        row[0] = n_cp.x;
-        row[1] = n_cp.y;
-        row[2] = n_cp.z;
-        row[3] = c.x;
-        row[4] = c.y;
-        row[5] = c.z;
-        row[6] = dot(n_cp, s_cp - d_cp);
-    }
-    found_f = found ? 1.0f : 0.0f;
-}
-
-// PX pixels per lane per pass (PX = 4 / 2: one 16 / 8-byte load per plane; needs cols % PX == 0
-// and PX*4-byte aligned rows, else PX = 1); BLOCK threads per workgroup.
-//
-// The kernel only PRODUCES one 128-byte partial record per workgroup (plain stores): the record
-// sum, the 6x6 solve and the pose update run in the consumer kernel that follows on the stream
-// (icp_finish_kernel, or the finishing workgroup of rgb_step_kernel).  A kernel boundary is
-// cheaper than an in-launch hand-off here: it needs no write-through drain, no ticket atomics
-// and no second round of loads inside this launch.
-template <int PX, int BLOCK>
-__device__ __forceinline__ void icp_block(const OdomState* __restrict__ st, const IcpArgs& a,
-                                          float* __restrict__ partials, GridReduceLds<float, BLOCK>& lds,
-                                          unsigned bid, unsigned nblocks) {
-    constexpr int kBlock = BLOCK;
-    float sum[29];
-#pragma unroll
-    for (int k = 0; k < 29; ++k) sum[k] = 0.f;
-
-    const int N = a.cols * a.rows;
-    const int rows = a.rows;
-    for (int i0 = (bid * kBlock + threadIdx.x) * PX; i0 < N; i0 += nblocks * kBlock * PX) {
-        const int y = i0 / a.cols;
-        const int x = i0 - y * a.cols;
-
-        float vx[PX], vy[PX], vz[PX], nx[PX], ny[PX], nz[PX];
-        load_px<PX>(a.vmap_curr.base + (size_t)y * a.vmap_curr.stride + x, vx);
-        load_px<PX>(a.vmap_curr.base + (size_t)(y + rows) * a.vmap_curr.stride + x, vy);
-        load_px<PX>(a.vmap_curr.base + (size_t)(y + 2 * rows) * a.vmap_curr.stride + x, vz);
-        load_px<PX>(a.nmap_curr.base + (size_t)y * a.nmap_curr.stride + x, nx);
-        load_px<PX>(a.nmap_curr.base + (size_t)(y + rows) * a.nmap_curr.stride + x, ny);
-        load_px<PX>(a.nmap_curr.base + (size_t)(y + 2 * rows) * a.nmap_curr.stride + x, nz);
-
-        IcpPixel px[PX];
-        f3 vp[PX], np[PX];
-#pragma unroll
-        for (int p = 0; p < PX; ++p) px[p] = icp_project(st, a, make_f3(vx[p], vy[p], vz[p]));
-        // all gathers of the group issued before any is consumed; pixels that project outside
-        // read element 0 (a valid address) and are masked afterwards
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            const int ux = px[p].inside ? px[p].ux : 0, uy = px[p].inside ? px[p].uy : 0;
-            const size_t ov = (size_t)uy * a.vmap_g_prev.stride + ux;
-            const size_t on = (size_t)uy * a.nmap_g_prev.stride + ux;
-            const size_t pv = (size_t)rows * a.vmap_g_prev.stride, pn = (size_t)rows * a.nmap_g_prev.stride;
-            vp[p] = make_f3(a.vmap_g_prev.base[ov], a.vmap_g_prev.base[ov + pv], a.vmap_g_prev.base[ov + 2 * pv]);
-            np[p] = make_f3(a.nmap_g_prev.base[on], a.nmap_g_prev.base[on + pn], a.nmap_g_prev.base[on + 2 * pn]);
-        }
-        float errs[PX];
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            float row[7], found;
-            icp_row(st, a, px[p], make_f3(nx[p], ny[p], nz[p]), vp[p], np[p], row, found, errs[p]);
-            accumulate_se3(sum, row, found);
-        }
-        if (a.err_map) store_px<PX>(a.err_map + (size_t)y * a.err_stride + x, errs);
-    }
-
-    block_reduce_store<29, BLOCK, false>(sum, partials, lds, bid, nblocks);
-}
-
-template <int PX, int BLOCK, int MODE>
-__global__ __launch_bounds__(BLOCK) void icp_kernel(const OdomState* __restrict__ st, IcpArgs a,
-                                                    float* __restrict__ partials) {
-    __shared__ GridReduceLds<float, BLOCK> lds;
-    if (MODE == FINISH_GN && st->level_break) return;
-    icp_block<PX, BLOCK>(st, a, partials, lds, blockIdx.x, gridDim.x);
-}
-
-// second-generation ICP producer (icp_kernels.hpp): W pixels per lane vector x NV vectors per lane
-template <int W, int NV, int BLOCK, bool PACKED, int MODE>
+// the ICP producer (icp_kernels.hpp): W pixels per lane vector x NV vectors per lane.  MULTI: the grid does not cover
+// the image (more pixels than kMaxIcpGrid workgroups take in one pass): every lane walks the image with the grid's stride.
+template <int W, int NV, int BLOCK, bool PACKED, int MODE, bool MULTI = false>
 __global__ __launch_bounds__(BLOCK) void icp_kernel2(const OdomState* __restrict__ st, IcpArgs a,
                                                      float* __restrict__ partials) {
     __shared__ GridReduceLds<float, BLOCK> lds;
     using T = typename std::conditional<W == 2, v2f, float>::type;
     if (a.err_map)
-        icp_block2<T, NV, BLOCK, PACKED, true, MODE == FINISH_GN>(st, a, partials, lds, blockIdx.x, gridDim.x);
+        icp_block2<T, NV, BLOCK, PACKED, true, MODE == FINISH_GN, MULTI>(st, a, partials, lds, blockIdx.x, gridDim.x);
     else
-        icp_block2<T, NV, BLOCK, PACKED, false, MODE == FINISH_GN>(st, a, partials, lds, blockIdx.x, gridDim.x);
+        icp_block2<T, NV, BLOCK, PACKED, false, MODE == FINISH_GN, MULTI>(st, a, partials, lds, blockIdx.x, gridDim.x);
 }
 
 // One workgroup: sums the ICP partial records of the preceding launch.  MODE RAW: totals ->
@@ -235,66 +116,6 @@ __device__ __forceinline__ void residual_publish(const OdomState* st, int2* __re
     }
 }
 
-template <bool ACC>
-__device__ __forceinline__ void residual_block(const OdomState* __restrict__ st, const RgbResidualArgs& a,
-                                               int2* __restrict__ partials, GridReduceLds<int, kBlock>& lds,
-                                               unsigned bid, unsigned nblocks) {
-    int sum[2] = {0, 0};
-    const int N = a.cols * a.rows, cols = a.cols, rows = a.rows;
-    const float* K = st->krkinv;
-    const float ktx = st->kt[0], kty = st->kt[1], ktz = st->kt[2];
-
-    for (int k = bid * kBlock + threadIdx.x; k < N; k += nblocks * kBlock) {
-        const int i = k / cols, j0 = k - i * cols;
-        mmf_dataterm c;
-        c.zero_x = c.zero_y = c.one_x = c.one_y = 0;
-        c.diff = 0.f;
-        c.valid = 0;
-        c.pad_[0] = c.pad_[1] = c.pad_[2] = 0;
-        int vx = 0, vy = 0;
-        if (j0 < cols - 5 && i < rows - 1) {  // reduce.cu:773
-            bool valid = true;
-            for (int u = max(i - 2, 0); u < min(i + 2, rows); u++)
-                for (int v = max(j0 - 2, 0); v < min(j0 + 2, cols); v++)
-                    valid = valid && (a.next_image[(size_t)u * a.ni_stride + v] > 0);
-            if (valid) {
-                const int valx = a.dIdx[(size_t)i * a.d_stride + j0], valy = a.dIdy[(size_t)i * a.d_stride + j0];
-                const float mTwo = (float)((valx * valx) + (valy * valy));
-                if (mTwo >= a.min_scale) {
-                    const int y = i, x = j0;
-                    const float d1 = a.next_depth[(size_t)y * a.nd_stride + x];
-                    if (!(d1 != d1)) {
-                        const float td1 = (float)(d1 * (K[6] * x + K[7] * y + K[8]) + ktz);
-                        const int u0 = float2int_rn((d1 * (K[0] * x + K[1] * y + K[2]) + ktx) / td1);
-                        const int v0 = float2int_rn((d1 * (K[3] * x + K[4] * y + K[5]) + kty) / td1);
-                        if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
-                            const float d0 = a.last_depth[(size_t)v0 * a.ld_stride + u0];
-                            const uint8_t li = a.last_image[(size_t)v0 * a.li_stride + u0];
-                            if (d0 > 0 && fabsf(td1 - d0) <= a.max_depth_delta && li != 0) {
-                                c.zero_x = (int16_t)u0;
-                                c.zero_y = (int16_t)v0;
-                                c.one_x = (int16_t)x;
-                                c.one_y = (int16_t)y;
-                                c.diff = (float)a.next_image[(size_t)y * a.ni_stride + x] - (float)li;
-                                c.valid = 1;
-                                vx = 1;
-                                vy = (int)(c.diff * c.diff);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (a.err_map) a.err_map[(size_t)i * a.err_stride + j0] = c.valid ? 0.001f * vy : 0.0f;
-        *reinterpret_cast<int4*>(&a.corres[k]) = *reinterpret_cast<const int4*>(&c);
-        sum[0] += vx;
-        sum[1] += vy;
-    }
-
-    block_sum2<kBlock>(sum[0], sum[1], lds);
-    residual_publish<ACC>(st, partials, bid, sum[0], sum[1]);
-}
-
 // Compact correspondence record of the Gauss-Newton loop (8 bytes instead of the 16-byte DataTerm of
 // the stand-alone computeRgbResidual): `one` is the pixel's own position (implicit in the record index)
 // and diff is an integer in [-255, 255].  Halves the write traffic of this pass and the read traffic of
@@ -313,38 +134,82 @@ __device__ __forceinline__ unsigned byte_flags_to_bits(unsigned m) { return (((m
 // Four consecutive pixels of a row per lane: one 4-byte load of the intensities, one 8-byte load of
 // each gradient image, one 16-byte load of the depth, 16-byte stores of the records; the 4x4 "all
 // neighbours > 0" windows of the four pixels are evaluated from three aligned 32-bit words per image
-// row (12 loads instead of 64) with byte-parallel bit arithmetic.  Needs cols % 4 == 0 and 16-byte
-// aligned rows.  GN: inside the Gauss-Newton loop (compact records, atomic totals, break flag).
-template <bool GN>
+// row (12 loads instead of 64) with byte-parallel bit arithmetic.  GN: inside the Gauss-Newton loop
+// (atomic totals, break flag).
+// ALIGNED: cols % 4 == 0 and 16-byte aligned rows; the records of the Gauss-Newton loop are then the compact ones.
+// !ALIGNED: any width and pitch: a row is cut into groups of four pixels with a ragged last group, the same words are
+// put together from single bytes (a byte outside the image counts as set: the reference's window loops skip it), the
+// other loads and all stores go pixel by pixel, records are full DataTerms.  Same evaluation, same bits.
+template <bool GN, bool ALIGNED = true>
 __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st, const RgbResidualArgs& a,
                                                 int2* __restrict__ partials, GridReduceLds<int, kBlock>& lds,
                                                 unsigned bid, unsigned nblocks) {
     int sum[2] = {0, 0};
     MMF_STAMP(8);
-    const int cols = a.cols, rows = a.rows, N4 = (cols * rows) / 4;
+    const int cols = a.cols, rows = a.rows;
+    const int gpr = ALIGNED ? cols / 4 : (cols + 3) / 4;  // groups per row
+    const int N4 = gpr * rows;
     const float* K = st->krkinv;
     const float ktx = st->kt[0], kty = st->kt[1], ktz = st->kt[2];
     const int level_break = GN ? st->level_break : 0;  // consumed after the image loads are in flight
 
     for (int g = bid * kBlock + threadIdx.x; g < N4; g += nblocks * kBlock) {
-        const int k0 = g * 4;
-        const int i = (int)__umulhi((unsigned)k0, a.cols_magic), j0 = k0 - i * cols;
+        int i, j0;
+        if (ALIGNED) {
+            i = (int)__umulhi((unsigned)(g * 4), a.cols_magic), j0 = g * 4 - i * cols;
+        } else {
+            i = g / gpr, j0 = (g - i * gpr) * 4;
+        }
+        const int k0 = i * cols + j0;  // index of the group's first record
         // twelve unconditional word loads from clamped addresses (conditions applied afterwards), so
         // they and the four loads below are one round trip
         unsigned ww[4][3];
-        const bool has_l = j0 >= 4, has_r = j0 + 4 < cols;
+        bool has_l = j0 >= 4, has_r = j0 + 4 < cols;
+        unsigned own;
+        short4 gx, gy;
+        float4 dv;
+        if (ALIGNED) {
 #pragma unroll
-        for (int dr = -2; dr <= 1; ++dr) {
-            const int u = min(max(i + dr, 0), rows - 1);
-            const uint8_t* rowp = a.next_image + (size_t)u * a.ni_stride + j0;
-            ww[dr + 2][1] = *reinterpret_cast<const unsigned*>(rowp);
-            ww[dr + 2][0] = *reinterpret_cast<const unsigned*>(rowp - (has_l ? 4 : 0));
-            ww[dr + 2][2] = *reinterpret_cast<const unsigned*>(rowp + (has_r ? 4 : 0));
+            for (int dr = -2; dr <= 1; ++dr) {
+                const int u = min(max(i + dr, 0), rows - 1);
+                const uint8_t* rowp = a.next_image + (size_t)u * a.ni_stride + j0;
+                ww[dr + 2][1] = *reinterpret_cast<const unsigned*>(rowp);
+                ww[dr + 2][0] = *reinterpret_cast<const unsigned*>(rowp - (has_l ? 4 : 0));
+                ww[dr + 2][2] = *reinterpret_cast<const unsigned*>(rowp + (has_r ? 4 : 0));
+            }
+            own = *reinterpret_cast<const unsigned*>(a.next_image + (size_t)i * a.ni_stride + j0);
+            gx = *reinterpret_cast<const short4*>(a.dIdx + (size_t)i * a.d_stride + j0);
+            gy = *reinterpret_cast<const short4*>(a.dIdy + (size_t)i * a.d_stride + j0);
+            dv = *reinterpret_cast<const float4*>(a.next_depth + (size_t)i * a.nd_stride + j0);
+        } else {
+            auto word = [&](const uint8_t* rowp, int c0) {  // columns c0 .. c0 + 3 of one image row
+                unsigned w = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int c = c0 + b;
+                    const unsigned v = (c >= 0 && c < cols) ? rowp[min(max(c, 0), cols - 1)] : 0xFFu;
+                    w |= v << (8 * b);
+                }
+                return w;
+            };
+#pragma unroll
+            for (int dr = -2; dr <= 1; ++dr) {
+                const uint8_t* rowp = a.next_image + (size_t)min(max(i + dr, 0), rows - 1) * a.ni_stride;
+                ww[dr + 2][0] = word(rowp, j0 - 4), ww[dr + 2][1] = word(rowp, j0), ww[dr + 2][2] = word(rowp, j0 + 4);
+            }
+            has_l = has_r = true;  // the outside columns are in the words, as set bytes
+            own = word(a.next_image + (size_t)i * a.ni_stride, j0);
+            int16_t gxs[4], gys[4];
+            float dvs[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int x = min(j0 + p, cols - 1);  // (pixels past the row's end fail `x < cols - 5` below)
+                gxs[p] = a.dIdx[(size_t)i * a.d_stride + x], gys[p] = a.dIdy[(size_t)i * a.d_stride + x];
+                dvs[p] = a.next_depth[(size_t)i * a.nd_stride + x];
+            }
+            gx = make_short4(gxs[0], gxs[1], gxs[2], gxs[3]), gy = make_short4(gys[0], gys[1], gys[2], gys[3]);
+            dv = make_float4(dvs[0], dvs[1], dvs[2], dvs[3]);
         }
-        const unsigned own = *reinterpret_cast<const unsigned*>(a.next_image + (size_t)i * a.ni_stride + j0);
-        const short4 gx = *reinterpret_cast<const short4*>(a.dIdx + (size_t)i * a.d_stride + j0);
-        const short4 gy = *reinterpret_cast<const short4*>(a.dIdy + (size_t)i * a.d_stride + j0);
-        const float4 dv = *reinterpret_cast<const float4*>(a.next_depth + (size_t)i * a.nd_stride + j0);
         __builtin_amdgcn_sched_barrier(0);
         if (level_break) return;  // wave-uniform; the state read overlapped the loads above
         // nonzero masks of columns j0-4 .. j0+7 (bit b <-> column j0-4+b) ANDed over rows i-2 .. i+1;
@@ -419,12 +284,12 @@ __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st
             errs[p] = hit ? 0.001f * vy : 0.0f;
             sum[0] += hit ? 1 : 0;
             sum[1] += vy;
-            if (GN) {
+            if (GN && ALIGNED) {
                 pk[p].zero_x = hit ? (int16_t)u0s[p] : (int16_t)0;
                 pk[p].zero_y = hit ? (int16_t)v0s[p] : (int16_t)0;
                 pk[p].diff = hit ? (int16_t)idiff : (int16_t)0;
                 pk[p].valid = hit ? (int16_t)1 : (int16_t)0;
-            } else {
+            } else if (ALIGNED || x < cols) {
                 mmf_dataterm c;
                 c.zero_x = hit ? (int16_t)u0s[p] : (int16_t)0;
                 c.zero_y = hit ? (int16_t)v0s[p] : (int16_t)0;
@@ -436,13 +301,20 @@ __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st
                 *reinterpret_cast<int4*>(&a.corres[k0 + p]) = *reinterpret_cast<const int4*>(&c);
             }
         }
-        if (GN) {  // 4 x 8 bytes = two 16-byte stores
+        if (GN && ALIGNED) {  // 4 x 8 bytes = two 16-byte stores
             int4* dst = reinterpret_cast<int4*>(reinterpret_cast<CorresPk*>(a.corres) + k0);
             dst[0] = *reinterpret_cast<const int4*>(&pk[0]);
             dst[1] = *reinterpret_cast<const int4*>(&pk[2]);
         }
-        if (a.err_map)
-            *reinterpret_cast<float4*>(a.err_map + (size_t)i * a.err_stride + j0) = make_float4(errs[0], errs[1], errs[2], errs[3]);
+        if (a.err_map) {
+            if (ALIGNED) {
+                *reinterpret_cast<float4*>(a.err_map + (size_t)i * a.err_stride + j0) = make_float4(errs[0], errs[1], errs[2], errs[3]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (j0 + p < cols) a.err_map[(size_t)i * a.err_stride + j0 + p] = errs[p];
+            }
+        }
     }
 
     MMF_STAMP(12);
@@ -457,9 +329,9 @@ __global__ __launch_bounds__(kBlock) void rgb_residual_kernel(const OdomState* _
     __shared__ GridReduceLds<int, kBlock> lds;
     if (MODE == FINISH_GN && PX != 4 && st->level_break) return;
     if (PX == 4)
-        residual_block4<MODE == FINISH_GN>(st, a, partials, lds, blockIdx.x, gridDim.x);
+        residual_block4<MODE == FINISH_GN, true>(st, a, partials, lds, blockIdx.x, gridDim.x);
     else
-        residual_block<MODE == FINISH_GN>(st, a, partials, lds, blockIdx.x, gridDim.x);
+        residual_block4<MODE == FINISH_GN, false>(st, a, partials, lds, blockIdx.x, gridDim.x);
 }
 
 // ---- several rigid-body models in ONE launch ----------------------------------------------------------------

@@ -189,9 +189,56 @@ int main(int argc, char** argv) {
                     model.computeFusionWeight(1.f));
         CHECK(std::fabs(p[3] - 0.005f) < 0.002f && st.iterations_run == 19 && model.lastCount() > 0.8 * W * H);
         CHECK(model.computeFusionWeight(1.f) >= 0.5f && model.computeFusionWeight(1.f) < 1.f);  // the camera moved 5 mm
+        // what Segmentation.cpp:218-219 reads of a model, and Model::getModel() (Model.h:278-297)
+        const std::vector<float> icpErr = model.downloadICPErrorTexture(), vertConf = model.downloadVertexConfTexture();
+        CHECK(icpErr.size() == (size_t)W * H && vertConf.size() == (size_t)W * H * 4 && model.getRGBErrorTexture()->width == W);
+        size_t withError = 0, badConf = 0;
+        for (float e : icpErr) withError += e > 0.f;
+        for (size_t i = 0; i < (size_t)W * H; ++i) badConf += !(vertConf[4 * i + 3] >= 0.f);
+        // (a two-frame map is all unstable surfels: the splat shows none of them yet, the tracker ran on the fill-in images)
+        CHECK(withError > 1000 && badConf == 0);
+        const OutputBuffer& vbo = model.getModel();
+        const std::vector<Model::surfel_t> host = model.downloadMap();
+        CHECK(vbo.count == model.lastCount() && vbo.count == host.size() && vbo.positionConfidence && vbo.colourTime && vbo.normalRadius);
+        float first[4], lastn[4];
+        CHECK(hipMemcpy(first, vbo.positionConfidence, sizeof(first), hipMemcpyDeviceToHost) == hipSuccess);
+        CHECK(hipMemcpy(lastn, vbo.normalRadius + 4 * (size_t)(vbo.count - 1), sizeof(lastn), hipMemcpyDeviceToHost) == hipSuccess);
+        CHECK(first[0] == host.front().position[0] && first[3] == host.front().confidence && lastn[3] == host.back().radius);
         ctx.synchronize();
         for (int k = 0; k < 2; ++k) (void)hipFree(d_rgb[k]), (void)hipFree(d_depth[k]);
         (void)hipFree(d_mask), (void)hipFree(d_filtered);
+    }
+    // ---- the reference's own constructor (Core/MultiMotionFusion.h:54-61) over the Resolution / Intrinsics singletons,
+    //      as GUI/MainController.cpp:147-148, 514-517 use them; the reader announces the next frame with each call
+    {
+        Resolution::setResolution(W, H);
+        Intrinsics::setIntrinics(FX, FY, CX, CY);
+        CHECK(Resolution::getInstance().numPixels() == W * H && Intrinsics::getInstance().cx() == CX);
+        OdometryConfig odom_cfg;
+        SegmentationConfiguration segm_cfg;
+        MultiMotionFusion ref(200, 35000, 5e-05f, 1e-05f, /*closeLoops*/ false, false, false, 115, /*confGlobal*/ 10.f, /*confObject*/ 0.01f,
+                              /*depthCut*/ 15.f, /*icpWeight*/ 10.f, false, 0.3095f, true, false, 20, Model::MatchingType::Drost, exportDir, false,
+                              std::string(), odom_cfg, segm_cfg);
+        std::vector<Frame> frames;
+        for (int i = 0; i < 4; ++i) frames.push_back(render(0.004f * i, 0.f));
+        for (int i = 0; i < 4; ++i) {
+            FrameData frame, next;
+            frame.timestamp = 33 * i, frame.rgb = frames[i].rgb.data(), frame.depth = frames[i].depth.data();
+            if (i + 1 < 4) {
+                next.timestamp = 33 * (i + 1), next.rgb = frames[i + 1].rgb.data(), next.depth = frames[i + 1].depth.data();
+                ref.announceNextFrame(next);
+            }
+            CHECK(ref.processFrame(frame) == false);
+        }
+        float p[16];
+        ref.getCurrPose(p);
+        CHECK(std::fabs(p[3] - 0.012f) < 0.004f && ref.getTick() == 5 && ref.getTimeDelta() == 200);
+        ModelPointer bg = ref.getBackgroundModel();
+        CHECK(bg->getModel().count == bg->lastCount() && bg->lastCount() > (unsigned)(0.8 * W * H));
+        CHECK(bg->getICPErrorTexture()->bytes() == (size_t)W * H * 4);
+        size_t withError = 0;
+        for (float e : bg->downloadICPErrorTexture()) withError += e > 0.f;
+        CHECK(withError > 1000);
     }
     std::printf("main controller sequence: ok\n");
     return 0;

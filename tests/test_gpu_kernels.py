@@ -12,7 +12,7 @@ from helpers import ANGLE_THRESH, DIST_THRESH, assert_bit_equal, frame_pair, se3
 
 pytestmark = pytest.mark.gpu
 
-SIZES = [(640, 480), (160, 120), (100, 52)]  # last: not a multiple of the 64x4 tile nor of 4
+SIZES = [(640, 480), (160, 120), (100, 52), (106, 50)]  # (100, 52): not a multiple of the 64x4 tile; 106: no multiple of four (ragged pixel groups, byte-wise loads)
 
 
 def dev(a):
@@ -150,6 +150,34 @@ def test_icp_step_parity(gpu_ctx, orc, w, h):
                               DIST_THRESH, ANGLE_THRESH)
     assert_bit_equal(A2, A, "icp A determinism")
     assert_bit_equal(b2, b, "icp b determinism")
+
+
+def test_icp_step_image_larger_than_one_pass(gpu_ctx, orc):
+    """More pixels than the ICP producer's largest grid takes in one pass (8192 workgroups x 256 lanes): the multi-pass
+    instantiation walks the image with the grid's stride."""
+    from multimotionfusion_amd import cudafuncs as cf
+    w, h = 2048, 1040
+    K, prev, cur, fp, fc = frame_pair(w, h)
+    vm, nm, vg, ng = maps_for(orc, K, fc, prev.astype(np.float32))
+    intr = cf.CameraModel(K["fx"], K["fy"], K["cx"], K["cy"])
+    Rprev = prev[:3, :3].astype(np.float32)
+    Rprev_inv = np.linalg.inv(Rprev).astype(np.float32)
+    tprev = prev[:3, 3].astype(np.float32)
+    err = torch.full((h, w), -1.0, device="cuda")
+    A, b, res = cf.icpStep(gpu_ctx, Rprev, tprev, dev(vm), dev(nm), Rprev_inv, tprev, intr, dev(vg), dev(ng), DIST_THRESH, ANGLE_THRESH, err)
+    out, ref_err = orc.icp_step(Rprev, tprev, vm, nm, Rprev_inv, tprev, K["fx"], K["fy"], K["cx"], K["cy"], vg, ng, DIST_THRESH,
+                                ANGLE_THRESH, want_err=True)
+    assert res[1] == out[28] and out[28] > 0.2 * w * h
+    assert_bit_equal(err.cpu().numpy(), ref_err, "icp error map")
+    got = np.zeros(29)
+    k = 0
+    for i in range(6):
+        for j in range(i, 7):
+            got[k] = b[i] if j == 6 else A[i, j]
+            k += 1
+    got[27], got[28] = res
+    tol = se3_sum_tolerance(out)
+    assert np.all(np.abs(got - out) <= tol), np.abs(got - out) / np.maximum(tol, 1e-30)
 
 
 def test_icp_step_edge_cases(gpu_ctx, orc):
