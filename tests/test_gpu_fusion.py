@@ -220,13 +220,13 @@ def test_klg_replay_equals_direct_processing(gpu_ctx, tmp_path):
     assert len(lines) == n and lines[0] == "1000 0 0 0 0 0 0 1" and all(len(l.split()) == 8 for l in lines)
 
 
-@pytest.mark.parametrize("icp_refine", [True, False])
-def test_process_frame_keypoint_initialisation(gpu_ctx, orc, icp_refine):
+@pytest.mark.parametrize("icp_refine,w,h,n", [(True, 320, 240, 4), (False, 320, 240, 4), (True, 640, 480, 3)],
+                         ids=["refine", "no-refine", "refine-640x480"])  # the last: the size BASELINE.json's configs[2] names
+def test_process_frame_keypoint_initialisation(gpu_ctx, orc, icp_refine, w, h, n):
     """`-init kp` (MultiMotionFusion.cpp:312-384): the pose is first moved by the keypoint-track transformation,
     the map fused once at that pose, then (with -icp_refine) the dense tracker refines it.  The transformation
     here is the true inter-frame motion, slightly perturbed -- what RigidRANSAC delivers on good tracks."""
     from multimotionfusion_amd.fusion import MultiMotionFusion
-    w, h, n = 320, 240, 4
     K = synth.intrinsics(w, h)
     poses = synth.trajectory(n, seed=11)
     frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]

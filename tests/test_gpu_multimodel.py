@@ -57,8 +57,17 @@ def model_data(mask, depth, ids):
 
 @pytest.mark.parametrize("w,h,with_data,sync", [(320, 240, False, False), (320, 240, True, True)])
 def test_three_objects_spawned_one_per_frame(gpu_ctx, orc, w, h, with_data, sync):
+    objects_against_the_oracle(gpu_ctx, orc, w, h, with_data, sync, 6, 3)
+
+
+def test_two_objects_at_640x480(gpu_ctx, orc):
+    """the multi-model frame step at the size BASELINE.json names (configs[3]): camera + two objects spawned one per frame,
+    every frame from the oracle orchestration's state (oracle/fusion.py)"""
+    objects_against_the_oracle(gpu_ctx, orc, 640, 480, True, True, 4, 2)
+
+
+def objects_against_the_oracle(gpu_ctx, orc, w, h, with_data, sync, n_frames, n_obj):
     from multimotionfusion_amd.fusion import MultiMotionFusion
-    n_frames, n_obj = 6, 3
     K, poses, traj, frames, objs = scene(w, h, n_frames, n_obj)
     g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1, preallocated_models=1,
                           pose_logging=1)
@@ -101,7 +110,7 @@ def test_three_objects_spawned_one_per_frame(gpu_ctx, orc, w, h, with_data, sync
                 a.overridePose(b.pose)
             g.predict()
     if sync:
-        assert len(object_diffs) >= 6 and np.median(object_diffs) <= 1e-5, object_diffs
+        assert len(object_diffs) >= min(6, n_obj) and np.median(object_diffs) <= 1e-5, object_diffs
     # pose log (MultiMotionFusion.cpp:829-846): one entry per frame the model was in the list, object->world
     from multimotionfusion_amd.klg import pose_7d
     gm = g.getModels()
