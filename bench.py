@@ -170,8 +170,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-frames", type=int, default=40)
-    ap.add_argument("--extras", action="store_true", help="also time the SURVEY 8(f) kernels beside the path: descriptor "
-                    "matcher and SuperPoint (MFMA), super-pixel resampling")
+    ap.add_argument("--extras", action="store_true", default=True, help="also time the SURVEY 8(f) kernels beside the path: descriptor "
+                    "matcher and SuperPoint (MFMA), super-pixel resampling (on by default: a few seconds)")
+    ap.add_argument("--no-extras", dest="extras", action="store_false")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
@@ -640,6 +641,71 @@ def main():
     # MMF_BENCH_HEADLINE_ONLY=1: only the frames of the N = 1 metric (for profiler runs whose per-kernel statistics must
     # not mix in the 1 .. 8-model sweep and the host-upload variant below)
     if rank == 0 and world == 1 and not config5 and os.environ.get("MMF_BENCH_HEADLINE_ONLY", "") != "1":
+        # ---- a MATURE map at the metric's frame size (SURVEY 8(d) states the surfel-pass bytes at ~1 M surfels; the headline
+        # loop resets its map every 30 frames).  The map of the sequence so far is replicated 1 + 3 times, the copies pushed
+        # 2, 4 and 6 cm along the viewing rays behind the surfaces (occluded: what a store that has seen a room from many sides is
+        # full of), uploaded, and the sequence continues on it: frames/s, then the five passes of a frame one by one between
+        # HIP events on the stream (predictIndices, fuse, predictIndices, clean, combinedPredict: Model::fuse / clean are the
+        # C ABI's own entry points).
+        try:
+            base = model.downloadMap()
+            reps = [base]
+            for step_m in (0.02, 0.04, 0.06):
+                cp = base.copy()
+                d = cp[:, :3] / np.maximum(np.linalg.norm(cp[:, :3], axis=1, keepdims=True), 1e-6)
+                cp[:, :3] += step_m * d  # the map lives in the first camera's frame: rays from the origin
+                reps.append(cp)
+            for cp in reps:  # stable surfels (confidence above the global threshold of 10), seen at this tick: the clean pass keeps
+                cp[:, 3] = np.maximum(cp[:, 3], 20.0)  # them; left unstable, the occluded copies die of old age within 20 frames
+                cp[:, 7] = float(mmf.getTick())
+            big = np.concatenate(reps)[: 1024 * 1024 - 310000]  # leave room for a frame's new surfels
+            model.uploadMap(big)
+            mmf.predict()
+            k0 = state["frame"] % len(frames)
+            seq = [(k0 + j) % len(frames) for j in range(1, 25) if (k0 + j) % len(frames) != 0]
+            n_in = model.lastCount()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for j, k in enumerate(seq):
+                mmf.processFrame(d_rgb[k], d_depth[k], timestamp=100000 + j)
+            torch.cuda.synchronize()
+            mature_fps = len(seq) / (time.perf_counter() - t1)
+            n_mid = model.lastCount()
+            tick = mmf.getTick()
+            zero_mask = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+            filt = mmf.getTexture("DEPTH_METRIC_FILTERED")
+            kk = seq[-1]
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+            passes = {"predictIndices": [], "fuse": [], "predictIndices_2": [], "clean": [], "combinedPredict": []}
+            for rep in range(5):
+                evs[0].record()
+                model.predictIndices(tick, 20.0, 200)
+                evs[1].record()
+                model.fuse(tick, d_rgb[kk], zero_mask, d_depth[kk], filt, 20.0, 1.0)
+                evs[2].record()
+                model.predictIndices(tick, 20.0, 200)
+                evs[3].record()
+                model.clean(tick, 200, 20.0, filt, zero_mask, 3.0)
+                evs[4].record()
+                model.combinedPredict(20.0, tick, tick, 200)
+                evs[5].record()
+                evs[5].synchronize()
+                for j, name in enumerate(passes):
+                    passes[name].append(evs[j].elapsed_time(evs[j + 1]) * 1e3)
+            n_out = model.lastCount()
+            b_idx_m, b_spl_m = 48 * n_out + 52 * n0, 48 * n_out + 38 * n0
+            result["mature_map"] = {
+                "surfels_uploaded": int(n_in), "surfels_after_%d_frames" % len(seq): int(n_mid), "surfels_at_pass_timing": int(n_out),
+                "frames_per_s": mature_fps, "ms_per_frame": 1e3 / mature_fps,
+                "passes_us": {k_: float(np.median(v)) for k_, v in passes.items()},
+                "predictIndices_frac": b_idx_m / np.median(passes["predictIndices"]) / 1e3 / HBM_PEAK_GBPS,
+                "combinedPredict_frac": b_spl_m / np.median(passes["combinedPredict"]) / 1e3 / HBM_PEAK_GBPS,
+                "fuse_clean_frac": 2 * 96 * n_out / (np.median(passes["fuse"]) + np.median(passes["clean"])) / 1e3 / HBM_PEAK_GBPS,
+                "what": "640x480, the sequence continued on a store of ~740 k STABLE surfels (the sequence's own map + three copies pushed "
+                        "2 / 4 / 6 cm behind the surfaces, confidence 20); passes timed one by one between HIP events, median of 5 rounds; fractions = "
+                        "SURVEY 8(d) bytes (48 count + 52 W H, 48 count + 38 W H, 2 x 96 count) over time over 8 TB/s"}
+        except Exception as exc:  # the leg must never cost the line
+            result["mature_map"] = {"error": repr(exc)}
         # ---- several rigid-body models on ONE GPU, each on its own stream (configs[3]): 640x480, moving objects, mask = GT ids
         mmf.close()
         Ko, _, oframes = object_sequence(synth, W, H, 7)
