@@ -106,8 +106,10 @@ __device__ __forceinline__ void gn_records_issue(const OdomState* st, const GnIt
 
 // lead: this workgroup also stores the running transform for the next launch.  FINAL: the chain's last solve
 // (gn_final_kernel): everything the host reads goes to the state, then odom_end.
+// Part 1 ends with the workgroup's first barrier (the record sums are in LDS); part 2 is the one wave's work up to the pose
+// and ends with the second.  Between the two the other waves are free: the caller gives them pose-independent work.
 template <bool FINAL>
-__device__ __forceinline__ void gn_prologue(OdomState* st, const GnIterArgs& a, GnRecLoads& rl, GnLds& lds, bool lead) {
+__device__ __forceinline__ void gn_prologue_sums(OdomState* st, const GnIterArgs& a, GnRecLoads& rl, GnLds& lds, bool lead) {
     const int tid = threadIdx.x;
     if (a.it == 0) {  // nothing to solve yet: the pose the beginning left in the state
         if (tid < 9)
@@ -119,7 +121,6 @@ __device__ __forceinline__ void gn_prologue(OdomState* st, const GnIterArgs& a, 
         else if (tid < 24)
             lds.pose[tid] = st->kt[tid - 21];
         if (lead && tid >= 64 && tid < 80) st->gn_rt[1][tid - 64] = st->resultRt[tid - 64];
-        __syncthreads();
         return;
     }
     if (tid < 256) {
@@ -146,6 +147,15 @@ __device__ __forceinline__ void gn_prologue(OdomState* st, const GnIterArgs& a, 
     }
     __syncthreads();
     if (!FINAL) MMF_STAMP(3);
+}
+
+template <bool FINAL>
+__device__ __forceinline__ void gn_prologue_solve(OdomState* st, const GnIterArgs& a, GnLds& lds, bool lead) {
+    const int tid = threadIdx.x;
+    if (a.it == 0) {
+        __syncthreads();
+        return;
+    }
     // From here to the pose one wave works alone (its LDS accesses execute in program order: no workgroup barriers):
     // the 64 totals, RGBDOdometry.cpp:431-435 with one element of the combined system per lane, the solve on lane 0.
     if (tid < 64) {
@@ -288,7 +298,9 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
     if (blockIdx.x == 0 && tid >= 64 && tid < 64 + kResShards) st->gn_acc[(a.it + 1) % 3][kResStride * (tid - 64)] = 0ull;
 
     // what the correspondence search can decide without the pose (reduce.cu:773-797): the 4x4 "all neighbours > 0"
-    // windows from the twelve words, the gradient test -- while the record loads are in flight
+    // windows from the twelve words, the gradient test -- done by the waves that wait for the solve, beside it
+    bool cand[PX];
+    auto pose_free_work = [&]() {
     unsigned nz[3] = {0x80808080u, 0x80808080u, 0x80808080u};
 #pragma unroll
     for (int dr = -2; dr <= 1; ++dr) {
@@ -298,7 +310,6 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
     }
     const unsigned okw = (has_l ? byte_flags_to_bits(nz[0]) : 0xFu) | (byte_flags_to_bits(nz[1]) << 4) |
                          ((has_r ? byte_flags_to_bits(nz[2]) : 0xFu) << 8);
-    bool cand[PX];
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
         const int x = j0 + p;
@@ -307,8 +318,14 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
         cand[p] = valid && mTwo >= a.ra.min_scale && !(d1s[p] != d1s[p]);
     }
     __builtin_amdgcn_sched_barrier(0);
-
-    gn_prologue<false>(st, a, rl, lds, blockIdx.x == 0);
+    };
+    gn_prologue_sums<false>(st, a, rl, lds, blockIdx.x == 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave != 0) pose_free_work();  // beside the one wave that solves
+    __builtin_amdgcn_sched_barrier(0);
+    gn_prologue_solve<false>(st, a, lds, blockIdx.x == 0);
+    if (wave == 0) pose_free_work();
+    __builtin_amdgcn_sched_barrier(0);
     MMF_STAMP(8);
     float K[9], kt[3];
 #pragma unroll
@@ -499,7 +516,35 @@ __global__ __launch_bounds__(kBlock) void gn_final_kernel(OdomState* st, GnIterA
     }
     GnRecLoads rl;
     gn_records_issue(st, a, rl);
-    gn_prologue<true>(st, a, rl, lds, true);
+    gn_prologue_sums<true>(st, a, rl, lds, true);
+    gn_prologue_solve<true>(st, a, lds, true);
+}
+
+// the same, and the result goes to the host in the same launch (odom_publish_kernel's two waves behind the solve: the copy
+// into the host's pinned state + sequence number, Model::computeFusionWeight of the new pose for an early fuse pass)
+__global__ __launch_bounds__(kBlock) void gn_final_publish_kernel(OdomState* st, GnIterArgs a, BatchDelta bd, PublishTargets to,
+                                                                  unsigned seq) {
+    __shared__ GnLds lds;
+    if (gridDim.x > 1) {
+        const long long d = bd.d[blockIdx.x];
+        st = batch_shift(st, d);
+        a.rec_in = batch_shift(a.rec_in, d);
+    }
+    GnRecLoads rl;
+    gn_records_issue(st, a, rl);
+    gn_prologue_sums<true>(st, a, rl, lds, true);
+    gn_prologue_solve<true>(st, a, lds, true);  // ends with a workgroup barrier: the state lane 0 stored is visible to the workgroup
+    if (threadIdx.x >= 64) {
+        if (threadIdx.x == 64) odom_fusion_weight(st);
+        return;
+    }
+    OdomState* host = to.host[blockIdx.x];
+    const unsigned* src = reinterpret_cast<const unsigned*>(st);
+    unsigned* dst = reinterpret_cast<unsigned*>(host);
+    constexpr unsigned kWords = offsetof(OdomState, publish_seq) / 4;
+    for (unsigned i = threadIdx.x; i < kWords; i += 64) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();  // executed by the one copying wave as a whole: every lane's stores are out before lane 0 publishes
+    if (threadIdx.x == 0) __hip_atomic_store(&host->publish_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace mmf

@@ -1404,6 +1404,9 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     }
     o->so3_prefetched = false;
 
+    GnIterArgs final_args;
+    bool final_pending = false;
+    std::memset(&final_args, 0, sizeof(final_args));
     if (fused_chain) {
         int it = 0;
         unsigned prev_groups = 0;
@@ -1478,7 +1481,13 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         a.rec_in = o->gn_rec[(it + 1) & 1], a.rec_out = nullptr;
         a.intr = level_intr(o->fx, o->fy, o->cx, o->cy, 0);
         a.ifx = 1.0 / (double)a.intr.fx, a.ify = 1.0 / (double)a.intr.fy;
-        q.launch(gn_final_kernel, dim3(ny), dim3(kBlock), o->state, a, bd);
+        final_args = a;
+        // the chain's last solve shares a launch with the hand-over of the result to the host (below), unless the chain is
+        // being timed as such (its closing event lies between the two)
+        if (o->timing)
+            q.launch(gn_final_kernel, dim3(ny), dim3(kBlock), o->state, a, bd);
+        else
+            final_pending = true;
     }
     bool first_level = true;
     bool end_folded = fused_chain;  // odom_end ran in the finishing lane of the frame's last rgb_step (or in gn_final_kernel)
@@ -1635,7 +1644,10 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         if (so3)
             for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(om->last_next_image[i], om->next_image[i]);
     }
-    hipLaunchKernelGGL(odom_publish_kernel, dim3(ny), dim3(128), 0, c->stream, o->state, to, seq, bd);
+    if (final_pending)
+        hipLaunchKernelGGL(gn_final_publish_kernel, dim3(ny), dim3(kBlock), 0, c->stream, o->state, final_args, bd, to, seq);
+    else
+        hipLaunchKernelGGL(odom_publish_kernel, dim3(ny), dim3(128), 0, c->stream, o->state, to, seq, bd);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }

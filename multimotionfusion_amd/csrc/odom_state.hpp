@@ -129,13 +129,23 @@ __host__ __device__ inline void inverse4f(const float* m, float* inv) {
     inv[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
 }
 
+// 1 / d for the pivots and determinants of the one-lane tail: the hardware's reciprocal estimate and two Newton steps
+// (full double precision for normal numbers; 0 and non-finite d end in NaN or infinity like a division) instead of the
+// twelve-instruction IEEE division sequence -- the lane that runs it is the critical path of a whole launch.
+__device__ __forceinline__ double tail_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+}
+
 __device__ inline void inverse3d(const double* m, double* inv) {
 #pragma clang fp contract(fast)
     const double c00 = m[4] * m[8] - m[5] * m[7];
     const double c01 = m[5] * m[6] - m[3] * m[8];
     const double c02 = m[3] * m[7] - m[4] * m[6];
     const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-    const double id = 1.0 / det;
+    const double id = tail_rcp(det);
     inv[0] = c00 * id;
     inv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
     inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
@@ -270,7 +280,7 @@ __device__ inline void ldlt_solve_recip(const double* A, const double* b, double
         double d = A[j * N + j];
         for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k] * D[k];
         D[j] = d;
-        iD[j] = 1.0 / d;
+        iD[j] = tail_rcp(d);
         for (int i = j + 1; i < N; ++i) {
             double s = A[i * N + j];
             for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k] * D[k];
