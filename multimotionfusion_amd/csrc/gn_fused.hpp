@@ -39,7 +39,7 @@ constexpr int kGnMaxWaves = 8;      // a workgroup is 256 .. 512 threads: the ho
 struct GnIterArgs {
     IcpArgs ia;
     RgbResidualArgs ra;  // the correspondence pass's images; `corres` is not used
-    const float* cloud;  // AoS float3 of the model's depth (rgbStep)
+    const float4* cloud4;  // {X, Y, Z, 1/Z} of the model's depth (rgbStep's point and the quotient it divides by)
     float fx, fy, sobel_scale;
     LevelIntr intr;      // this level's intrinsics: the prologue prepares THIS launch's K R K^-1
     int it;              // index of the launch in the chain; 0: nothing to solve yet
@@ -61,6 +61,7 @@ struct GnLds {
     float sf[13];    // Rprev[9], tprev[3], icp_weight
     int wsum[kGnMaxWaves][2];
     unsigned bar[4];
+    float wtab[256];  // rgbStep's weight by |diff| for this pass's sigma
 };
 
 __device__ __forceinline__ float uniform_f(float v) {
@@ -212,7 +213,7 @@ __device__ __forceinline__ void gn_batch_shift(OdomState*& st, GnIterArgs& a, co
     a.ia.prev_packed = batch_shift(a.ia.prev_packed, d), a.ia.err_map = batch_shift(a.ia.err_map, d);
     a.ra.last_depth = batch_shift(a.ra.last_depth, d), a.ra.next_depth = batch_shift(a.ra.next_depth, d);
     a.ra.last_image = batch_shift(a.ra.last_image, d), a.ra.err_map = batch_shift(a.ra.err_map, d);
-    a.cloud = batch_shift(a.cloud, d);
+    a.cloud4 = batch_shift(a.cloud4, d);
     a.rec_in = batch_shift(a.rec_in, d), a.rec_out = batch_shift(a.rec_out, d);
 }
 
@@ -356,14 +357,15 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
     };
     float d0s[PX];
     uint8_t lis[PX];
-    f3pk cl[PX], gv[PX], gn[PX];
+    f3pk gv[PX], gn[PX];
+    float4 cl[PX];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < PX; ++p) {  // addresses clamped, masks applied afterwards
         const int gu = inb[p] ? u0s[p] : 0, gvv = inb[p] ? v0s[p] : 0;
         d0s[p] = a.ra.last_depth[(size_t)gvv * a.ra.ld_stride + gu];
         lis[p] = a.ra.last_image[(size_t)gvv * a.ra.li_stride + gu];
-        cl[p] = *reinterpret_cast<const f3pk*>(a.cloud + (size_t)(gvv * cols + gu) * 3);  // rgbStep's point (reduce.cu:522)
+        cl[p] = a.cloud4[(size_t)gvv * cols + gu];  // rgbStep's point (reduce.cu:522) and 1 / Z
     }
     __builtin_amdgcn_sched_barrier(0);
     MMF_STAMP(9);
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
         sq += vy;
         ph.c[p].diff = hit ? (float)idiff : 0.f;
         ph.c[p].valid = hit ? 1 : 0;
-        ph.X[p] = cl[p].x, ph.Y[p] = cl[p].y, ph.Z[p] = cl[p].z;
+        ph.X[p] = cl[p].x, ph.Y[p] = cl[p].y, ph.Z[p] = cl[p].z, ph.invz[p] = cl[p].w;
         ph.gx[p] = valxs[p], ph.gy[p] = valys[p];
     }
     if (ERR && a.ra.err_map && live) store_px<PX>(a.ra.err_map + (size_t)i * a.ra.err_stride + j0, perr);
@@ -451,7 +453,19 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
     __builtin_amdgcn_sched_barrier(0);
     MMF_STAMP(11);
 
-    // ---- the count barrier: wave 0 polls the 16 shards until every workgroup of this model has arrived ----
+    // the ICP sums are complete: their reduction over the wave goes here, into the wait for the other workgroups
+    {
+        float s32[32];
+#pragma unroll
+        for (int k = 0; k < 29; ++k) s32[k] = L::hsum(isum[k]);
+        s32[29] = s32[30] = s32[31] = 0.f;
+        const float t = wave_sum_transposed(s32);
+        if ((lane & 1) == 0) lds.wave[wave][lane >> 1] = t;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the count barrier: wave 0 polls the 16 shards until every workgroup of this model has arrived, then decides
+    //      sigma (RGBDOdometry.cpp:373-385) and lays out the pass's 256 weights ----
     if (wave == 0) {
         const unsigned long long* acc = st->gn_acc[a.it % 3];
         unsigned c = 0, s2 = 0, ok = 0;
@@ -467,27 +481,28 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
             }
             for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
         }
-        if (lane == 63) lds.bar[0] = c, lds.bar[1] = s2, lds.bar[2] = ok;
+        c = (unsigned)__builtin_amdgcn_readlane((int)c, 63), s2 = (unsigned)__builtin_amdgcn_readlane((int)s2, 63);
+        // sigmaVal of residual_decide without its double-precision square root and division: tmpError = sqrt(sum) / count is
+        // zero exactly when sum is (count <= 2^19: no underflow), and NaN -- not zero -- for 0 / 0
+        const float sigma_val = ((int)s2 == 0 && (int)c != 0) ? 1.0f : (float)(int)c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds.wtab[lane * 4 + q] = rgb_weight(sigma_val, (float)(lane * 4 + q));
+        if (lane == 63) lds.bar[2] = ok, lds.bar[3] = __builtin_bit_cast(unsigned, sigma_val);
     }
     __syncthreads();
     MMF_STAMP(12);
     if (!lds.bar[2] && blockIdx.x == 0 && tid == 0) st->gn_fault = 1;  // a workgroup of this launch never arrived
-    const ResidualDecision dec = residual_decide((int)lds.bar[0], (int)lds.bar[1], 0, 0.f);  // RGBDOdometry.cpp:373-385
+    const float sigmaVal = __builtin_bit_cast(float, lds.bar[3]);
 
     // ---- photometric: rgbStep's rows (reduce.cu:504-535) ----
     float psum[29];
 #pragma unroll
     for (int k = 0; k < 29; ++k) psum[k] = 0.f;
-    rgb_rows<PX>(a.sobel_scale, a.fx, a.fy, dec.sigmaVal, live, ph, psum);
+    rgb_rows<PX>(a.sobel_scale, a.fx, a.fy, sigmaVal, live, ph, psum, lds.wtab, true);
 
-    // ---- both sum sets over the workgroup -> one 256-byte record ----
+    // ---- their sums over the wave; both sum sets over the workgroup -> one 256-byte record ----
     {
         float s32[32];
-#pragma unroll
-        for (int k = 0; k < 29; ++k) s32[k] = L::hsum(isum[k]);
-        s32[29] = s32[30] = s32[31] = 0.f;
-        const float t = wave_sum_transposed(s32);
-        if ((lane & 1) == 0) lds.wave[wave][lane >> 1] = t;
 #pragma unroll
         for (int k = 0; k < 29; ++k) s32[k] = psum[k];
         s32[29] = s32[30] = s32[31] = 0.f;

@@ -326,21 +326,26 @@ __global__ __launch_bounds__(256) void derivative_kernel(const uint8_t* __restri
 }
 
 // cudafuncs.cu:729-747 (projectPointsKernel); AoS float3 output, dense
+// cloud4 (optional): the same point as {X, Y, Z, 1 / Z} in one 16-byte record -- rgbStep divides by Z for every
+// correspondence of every Gauss-Newton iteration (reduce.cu:523); the quotient is the same float each time, so the
+// one-launch chain gathers it (one aligned 16-byte load) instead of dividing
 __device__ __forceinline__ void project_points_px(int x, int y, const float* __restrict__ depth, int d_stride, int cols,
                                                              int rows, float* __restrict__ cloud, float inv_fx,
-                                                             float inv_fy, float cx, float cy) {
+                                                             float inv_fy, float cx, float cy, float4* __restrict__ cloud4 = nullptr) {
     if (x >= cols || y >= rows) return;
     const float z = depth[(size_t)y * d_stride + x];
     float* c = cloud + ((size_t)y * cols + x) * 3;
-    c[0] = (float)((x - cx) * z * inv_fx);
-    c[1] = (float)((y - cy) * z * inv_fy);
+    const float X = (float)((x - cx) * z * inv_fx), Y = (float)((y - cy) * z * inv_fy);
+    c[0] = X;
+    c[1] = Y;
     c[2] = z;
+    if (cloud4) cloud4[(size_t)y * cols + x] = make_float4(X, Y, z, 1.0f / z);
 }
 __global__ __launch_bounds__(256) void project_points_kernel(const float* __restrict__ depth, int d_stride, int cols,
                                                              int rows, float* __restrict__ cloud, float inv_fx,
-                                                             float inv_fy, float cx, float cy) {
+                                                             float inv_fy, float cx, float cy, float4* __restrict__ cloud4) {
     MMF_PIXEL_XY();
-    project_points_px(x, y, depth, d_stride, cols, rows, cloud, inv_fx, inv_fy, cx, cy);
+    project_points_px(x, y, depth, d_stride, cols, rows, cloud, inv_fx, inv_fy, cx, cy, cloud4);
 }
 
 }  // namespace mmf

@@ -653,9 +653,9 @@ extern "C" int mmf_vertices_to_depth(mmf_ctx* c, const float* vmap_rgba, int col
 }
 
 static int launch_project(mmf_ctx* c, const float* depth, int d_stride, int cols, int rows, LevelIntr in,
-                          float* cloud) {
+                          float* cloud, float* cloud4 = nullptr) {
     hipLaunchKernelGGL(project_points_kernel, tile_grid(cols, rows), tile_block(), 0, c->stream, depth, d_stride, cols,
-                       rows, cloud, 1.0f / in.fx, 1.0f / in.fy, in.cx, in.cy);
+                       rows, cloud, 1.0f / in.fx, 1.0f / in.fy, in.cx, in.cy, reinterpret_cast<float4*>(cloud4));
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }
@@ -758,6 +758,7 @@ struct mmf_odom {
     uint8_t *last_image[MMF_NUM_PYRS], *next_image[MMF_NUM_PYRS], *last_next_image[MMF_NUM_PYRS];
     int16_t *dIdx[MMF_NUM_PYRS], *dIdy[MMF_NUM_PYRS];
     float* cloud[MMF_NUM_PYRS];
+    float* cloud4[MMF_NUM_PYRS];  // the same points as {X, Y, Z, 1/Z} (16-byte records: what gn_iter_kernel gathers)
     mmf_dataterm* corres[MMF_NUM_PYRS];
     float* prev_packed[MMF_NUM_PYRS];  // model vertex + normal, pixel interleaved 24-byte records (the ICP gather side)
     // reduction scratch of the Gauss-Newton loop and the two error images, inside the slab: every odometry object has
@@ -835,7 +836,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     const size_t n0 = (size_t)width * height;
     size_t o_vt = carve(4 * n0 * 4), o_nt = carve(4 * n0 * 4);
     size_t o_vgp[3], o_ngp[3], o_vc[3], o_nc[3], o_ld[3], o_nd[3], o_dp[3], o_li[3], o_ni[3], o_lni[3], o_dx[3],
-        o_dy[3], o_cl[3], o_co[3], o_pp[3];
+        o_dy[3], o_cl[3], o_c4[3], o_co[3], o_pp[3];
     for (int i = 0; i < MMF_NUM_PYRS; ++i) {
         const size_t n = (size_t)(width >> i) * (height >> i);
         o_vgp[i] = carve(3 * n * 4);
@@ -851,6 +852,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
         o_dx[i] = carve(n * 2);
         o_dy[i] = carve(n * 2);
         o_cl[i] = carve(3 * n * 4);
+        o_c4[i] = carve(4 * n * 4);
         o_co[i] = carve(n * sizeof(mmf_dataterm));
         o_pp[i] = carve(n * 6 * sizeof(float));
     }
@@ -883,6 +885,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
         o->dIdx[i] = (int16_t*)(base + o_dx[i]);
         o->dIdy[i] = (int16_t*)(base + o_dy[i]);
         o->cloud[i] = (float*)(base + o_cl[i]);
+        o->cloud4[i] = (float*)(base + o_c4[i]);
         o->corres[i] = (mmf_dataterm*)(base + o_co[i]);
         o->prev_packed[i] = (float*)(base + o_pp[i]);
     }
@@ -1151,7 +1154,7 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             for (int k = 0; k < 9; ++k) t.f[k] = R[k];
             t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
             PrepJob& p = pb.add(PREP_PROJECT, cols, rows);
-            p.src0 = o->last_depth[lvl], p.dst0 = o->cloud[lvl];
+            p.src0 = o->last_depth[lvl], p.dst0 = o->cloud[lvl], p.dst1 = o->cloud4[lvl];
             intr_f(p, lvl, false, 0.f);
         }
         if (in_img) {
@@ -1421,7 +1424,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
             const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, i);
             if (!o->prep_batched) {  // :332-334
                 MMF_HIP_TRY(q.flush());
-                int rc = launch_project(c, o->last_depth[i], cols, cols, rows, in, o->cloud[i]);
+                int rc = launch_project(c, o->last_depth[i], cols, cols, rows, in, o->cloud[i], o->cloud4[i]);
                 if (rc) return rc;
             }
             if (first && !fold_first_level)  // the SO3 loop ran in between: seed resultRt from its result now
@@ -1440,7 +1443,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                                           last_l0 ? rgb_err_dev : nullptr, 0);
                 a.ra.intr = in;
                 a.ia = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
-                a.cloud = o->cloud[i];
+                a.cloud4 = reinterpret_cast<const float4*>(o->cloud4[i]);
                 a.fx = in.fx, a.fy = in.fy, a.sobel_scale = o->sobel_scale;
                 a.intr = in;
                 a.ifx = 1.0 / (double)in.fx, a.ify = 1.0 / (double)in.fy;
@@ -1498,7 +1501,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, i);
         if (rgb && !o->prep_batched) {  // :332-334
             MMF_HIP_TRY(q.flush());
-            int rc = launch_project(c, o->last_depth[i], cols, cols, rows, in, o->cloud[i]);
+            int rc = launch_project(c, o->last_depth[i], cols, cols, rows, in, o->cloud[i], o->cloud4[i]);
             if (rc) return rc;
         }
         if (!begin_folded)

@@ -25,7 +25,7 @@ enum PrepOp : int {
     PREP_V2D,             // src0 RGBA32F vertices -> dst0 depth                f = {cutoff}
     PREP_INTENSITY,       // src0 interleaved u8 (stride scols bytes, `channels`) -> dst0
     PREP_DERIV,           // src0 u8 -> dst0 dIdx, dst1 dIdy
-    PREP_PROJECT,         // src0 depth -> dst0 AoS cloud                     f = {1/fx, 1/fy, cx, cy}
+    PREP_PROJECT,         // src0 depth -> dst0 AoS cloud, dst1 {X, Y, Z, 1/Z} records   f = {1/fx, 1/fy, cx, cy}
 };
 
 struct PrepJob {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
             derivative_px(x, y, (const uint8_t*)src0, cols, cols, rows, (int16_t*)J.dst0, cols, (int16_t*)J.dst1, cols);
             break;
         case PREP_PROJECT:
-            project_points_px(x, y, (const float*)src0, cols, cols, rows, (float*)J.dst0, J.f[0], J.f[1], J.f[2], J.f[3]);
+            project_points_px(x, y, (const float*)src0, cols, cols, rows, (float*)J.dst0, J.f[0], J.f[1], J.f[2], J.f[3], (float4*)J.dst1);
             break;
         default: break;
     }

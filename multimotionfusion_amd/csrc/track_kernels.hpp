@@ -462,6 +462,7 @@ struct RgbLane {
     mmf_dataterm c[PX];
     float X[PX], Y[PX], Z[PX];
     int gx[PX], gy[PX];
+    float invz[PX];  // 1.0f / Z when the caller has it (gn_iter_kernel gathers it beside the point), see rgb_rows
 };
 // COMPACT: the lane's PX records are CorresPk (8 bytes, PX / 2 loads); i0 = index of its first record
 template <int PX, bool COMPACT>
@@ -489,17 +490,25 @@ __device__ __forceinline__ void rgb_gather(const RgbStepArgs& a, const int4 (&ra
         l.gy[p] = a.dIdy[(size_t)l.c[p].one_y * a.d_stride + l.c[p].one_x];
     }
 }
+// rgbStep's weight of a correspondence (reduce.cu:506-514): a function of sigma (one value per pass) and of |diff|, an integer
+// in [0, 255] -- so a pass needs at most 256 different weights (rgb_weight_table: gn_iter_kernel keeps them in LDS, one
+// division per entry instead of one per pixel)
+__device__ __forceinline__ float rgb_weight(float sigma, float absdiff) {
+    float w = sigma + absdiff;
+    w = w > FLT_EPSILON ? 1.0f / w : 1.0f;
+    if (sigma == -1) w = 1;
+    return w;
+}
+
 template <int PX>
 __device__ __forceinline__ void rgb_rows(float sobel_scale, float fx, float fy, float sigma, bool live, const RgbLane<PX>& l,
-                                         float (&sum)[29]) {
+                                         float (&sum)[29], const float* wtab = nullptr, bool have_invz = false) {
 #pragma unroll
     for (int p = 0; p < PX; ++p) {  // branch free
         const bool found = live && l.c[p].valid != 0;
-        float w = sigma + fabsf(l.c[p].diff);
-        w = w > FLT_EPSILON ? 1.0f / w : 1.0f;
-        if (sigma == -1) w = 1;
+        const float w = wtab ? wtab[(int)fabsf(l.c[p].diff)] : rgb_weight(sigma, fabsf(l.c[p].diff));
         const float X = l.X[p], Y = l.Y[p], Z = l.Z[p];
-        const float invz = 1.0f / Z;  // (float)(1.0 / Z): double rounding is innocuous for division
+        const float invz = have_invz ? l.invz[p] : 1.0f / Z;  // (float)(1.0 / Z): double rounding is innocuous for division
         const float dI_dx = w * sobel_scale * l.gx[p];
         const float dI_dy = w * sobel_scale * l.gy[p];
         const float v0 = dI_dx * fx * invz;
