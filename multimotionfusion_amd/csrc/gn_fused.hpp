@@ -553,13 +553,7 @@ __global__ __launch_bounds__(kBlock) void gn_final_publish_kernel(OdomState* st,
         if (threadIdx.x == 64) odom_fusion_weight(st);
         return;
     }
-    OdomState* host = to.host[blockIdx.x];
-    const unsigned* src = reinterpret_cast<const unsigned*>(st);
-    unsigned* dst = reinterpret_cast<unsigned*>(host);
-    constexpr unsigned kWords = offsetof(OdomState, publish_seq) / 4;
-    for (unsigned i = threadIdx.x; i < kWords; i += 64) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();  // executed by the one copying wave as a whole: every lane's stores are out before lane 0 publishes
-    if (threadIdx.x == 0) __hip_atomic_store(&host->publish_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    odom_publish_wave(st, to.host[blockIdx.x], seq, threadIdx.x);
 }
 
 }  // namespace mmf

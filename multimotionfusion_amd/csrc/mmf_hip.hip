@@ -736,6 +736,20 @@ static bool graphs_enabled() {
     return on;
 }
 
+// the side streams' chains alone (MMF_GRAPHS_SIDE) / the end-of-frame model-side preparation alone (MMF_GRAPHS_SPEC)
+static bool env_flag(const char* name) {
+    const char* v = std::getenv(name);
+    return v && v[0] && v[0] != '0';
+}
+static bool side_graphs_enabled() {
+    static const bool on = graphs_enabled() || env_flag("MMF_GRAPHS_SIDE");
+    return on;
+}
+static bool spec_graphs_enabled() {
+    static const bool on = graphs_enabled() || env_flag("MMF_GRAPHS_SPEC");
+    return on;
+}
+
 struct mmf_odom {
     mmf_ctx* ctx = nullptr;
     GraphCache gn_graphs;    // the Gauss-Newton chain of odom_enqueue_tracking (launch_graph.hpp)
@@ -773,6 +787,8 @@ struct mmf_odom {
     OdomState* host_result = nullptr;  // pinned, device visible: odom_publish_kernel writes it, the host polls publish_seq
     OdomState* host_result_dev = nullptr;
     unsigned publish_seq = 0;          // sequence number of the last chain enqueued
+    bool defer_publish = false;        // set by the orchestrator: the hand-over to the host + the fusion weight ride on the
+    FrameRider rider;                  // frame's next resolve launch (frame_rider.hpp) instead of ending the chain
     bool have_tmp = false;  // vmaps_tmp filled by an initICP* call (ordering contract)
     // The reference COPIES its inputs at each init* call (RGBDOdometry.cpp:125,130; Model.cpp:359-388).
     // An owner that guarantees the images stay untouched until getIncrementalTransformation returns
@@ -1647,7 +1663,11 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         if (so3)
             for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(om->last_next_image[i], om->next_image[i]);
     }
-    if (final_pending)
+    o->rider = FrameRider();
+    if (final_pending && o->defer_publish && ny == 1) {
+        hipLaunchKernelGGL(gn_final_kernel, dim3(ny), dim3(kBlock), 0, c->stream, o->state, final_args, bd);
+        o->rider.st = o->state, o->rider.host = o->host_result_dev, o->rider.seq = seq;
+    } else if (final_pending)
         hipLaunchKernelGGL(gn_final_publish_kernel, dim3(ny), dim3(kBlock), 0, c->stream, o->state, final_args, bd, to, seq);
     else
         hipLaunchKernelGGL(odom_publish_kernel, dim3(ny), dim3(128), 0, c->stream, o->state, to, seq, bd);
@@ -1910,6 +1930,7 @@ struct mmf_model {
     const float* weight_dev = nullptr;  // fusion_weight) for a fuse pass; `weighting` is then the multiplier
     const float* t_inv_dev = nullptr;  // set by the orchestrator around projections it enqueues before the tracked pose has
                                        // reached the host: the device copy of inverse(pose) (OdomState::pose_inv)
+    FrameRider rider;  // set by the orchestrator for the predict() right behind a chain: carried by its resolve launch
     float pose[16];
     unsigned count = 0;  // host copy of the number of surfels in set[cur]
     // After clean() the new count is on its way to host_totals (asynchronous copy on the stream); until a host
@@ -2215,11 +2236,14 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     if (launch_count)
         hipLaunchKernelGGL(splat_kernel, grid1d(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
                            m->keys, m->count_pending ? m->totals : nullptr);
-    if (fill_rgb && fill_depth)
-        hipLaunchKernelGGL(splat_resolve_fill_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys,
-                           m->image, m->vertexConf, m->normalRadius, m->time_tex, fill_depth, fill_rgb, lost ? 1 : 0,
-                           (lost || frame_to_frame_rgb) ? 1 : 0, m->fill_vertex, m->fill_normal, m->fill_image);
-    else
+    if (fill_rgb && fill_depth) {
+        const FrameRider rider = m->rider;
+        m->rider = FrameRider();
+        hipLaunchKernelGGL(splat_resolve_fill_kernel, dim3(splat_tile_grid(m->width, m->height) + (rider.st ? 1u : 0u)), dim3(256), 0,
+                           c->stream, m->set[m->cur], a, m->keys, m->image, m->vertexConf, m->normalRadius, m->time_tex, fill_depth,
+                           fill_rgb, lost ? 1 : 0, (lost || frame_to_frame_rgb) ? 1 : 0, m->fill_vertex, m->fill_normal,
+                           m->fill_image, rider);
+    } else
         hipLaunchKernelGGL(splat_resolve_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->image,
                            m->vertexConf, m->normalRadius, m->time_tex);
     MMF_HIP_TRY(hipGetLastError());

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/mmf_math.h"
+#include "frame_rider.hpp"
 
 namespace mmf {
 
@@ -616,10 +617,11 @@ struct SplatTexel {
 // (x, y) -- threads run along x, the images are row-major -- gets its key.  Returns false outside the image.
 constexpr int kSplatTile = 16;
 __device__ __forceinline__ bool splat_tile_key(unsigned long long* __restrict__ keys, int cols, int rows, int& px, int& py,
-                                               unsigned long long& k) {
+                                               unsigned long long& k, unsigned first_block = 0) {
     __shared__ unsigned long long tile[kSplatTile][kSplatTile + 1];
     const int tiles_x = (cols + kSplatTile - 1) / kSplatTile;
-    const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
+    const int bid = (int)(blockIdx.x - first_block);
+    const int bx = bid % tiles_x, by = bid / tiles_x;
     const int t = threadIdx.x;
     {
         const int cx = t >> 4, cy = t & 15;  // loading: threads run along y
@@ -1169,11 +1171,16 @@ __global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, Sp
                                                                  const float* __restrict__ depth_fil,
                                                                  const uint8_t* __restrict__ rgb, int passthrough_geom,
                                                                  int passthrough_rgb, float4* __restrict__ vertex_out,
-                                                                 float4* __restrict__ normal_out, uchar4* __restrict__ image_out) {
+                                                                 float4* __restrict__ normal_out, uchar4* __restrict__ image_out,
+                                                                 FrameRider rider) {
+    if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
+        frame_rider_run(rider);
+        return;
+    }
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
-    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k)) return;
+    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, rider.st ? 1u : 0u)) return;
     const int i = py * a.cols + px;
     const SplatTexel t = splat_resolve_px(i, k, s, a);
     image[i] = t.image;

@@ -13,6 +13,8 @@
 #include "grid_reduce.hpp"
 #include "icp_kernels.hpp"
 #include "odom_state.hpp"
+#include "pose_algebra.hpp"
+#include "frame_rider.hpp"
 
 namespace mmf {
 
@@ -869,34 +871,15 @@ __global__ void gn_level_begin_kernel(OdomState* st, int first_level, LevelIntr 
 struct PublishTargets {
     OdomState* host[kMaxBatch];
 };
-// A second wave evaluates Model::computeFusionWeight (Model.cpp:876-891) of the tracked pose against lastPose = the pose the
-// chain started from (Model.cpp:412) with weightMultiplier 1 (the multiplier is the last factor: the fuse pass applies
-// it) for a fuse pass enqueued before the host has the pose: the JacobiSVD is a few microseconds on one lane, beside the
-// copy instead of in front of the frame's next kernel, and nothing the host waits for.
-__device__ __forceinline__ void odom_fusion_weight(OdomState* st) {
-    float last[16];
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) last[r * 4 + c] = st->Rprev[r * 3 + c];
-        last[r * 4 + 3] = st->tprev[r];
-    }
-    last[12] = last[13] = last[14] = 0.f, last[15] = 1.f;
-    float inv[16];
-    for (int k = 0; k < 16; ++k) inv[k] = st->pose_inv[k];
-    st->fusion_weight = mmf::host::compute_fusion_weight(inv, last, 1.0f);
-}
+// A second wave evaluates Model::computeFusionWeight for a fuse pass enqueued before the host has the pose (frame_rider.hpp):
+// a few microseconds on one lane, beside the copy.
 __global__ __launch_bounds__(128) void odom_publish_kernel(OdomState* st, PublishTargets to, unsigned seq, BatchDelta bd) {
     if (gridDim.x > 1) st = batch_shift(st, bd.d[blockIdx.x]);
     if (threadIdx.x >= 64) {
         if (threadIdx.x == 64) odom_fusion_weight(st);
         return;
     }
-    OdomState* host = to.host[blockIdx.x];
-    const unsigned* src = reinterpret_cast<const unsigned*>(st);
-    unsigned* dst = reinterpret_cast<unsigned*>(host);
-    constexpr unsigned kWords = offsetof(OdomState, publish_seq) / 4;
-    for (unsigned i = threadIdx.x; i < kWords; i += 64) dst[i] = src[i];
-    __threadfence_system();  // executed by the one copying wave as a whole: every lane's stores are out before lane 0 publishes
-    if (threadIdx.x == 0) __hip_atomic_store(&host->publish_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    odom_publish_wave(st, to.host[blockIdx.x], seq, threadIdx.x);
 }
 
 __global__ void odom_end_kernel(OdomState* st, BatchDelta bd) {
