@@ -739,6 +739,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 const float trans[3] = {pose[3], pose[7], pose[11]};
                 const float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
                 fm->odom->exclusive_chain = tracked.size() == 1;  // several chains side by side: no in-launch barriers
+                // the predict() enqueued right behind this chain (below) carries the hand-over to the host (frame_rider.hpp)
+                static const bool no_rider = std::getenv("MMF_NO_RIDER") != nullptr;  // A/B aid
+                fm->odom->defer_publish = tracked.size() == 1 && !fr->bootstrap && !have_init && !g.rgb_only && fm->fill_in && !no_rider;
                 rc = odom_enqueue_tracking(fm->odom, trans, rot, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom, g.so3,
                                            fm->icp_error, fm->rgb_error);
                 if (rc) return rc;
@@ -761,7 +764,10 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 f->inputs_free_recorded = true;
                 inputs_free_early = true;
                 m->t_inv_dev = fm->odom->state->pose_inv;
+                m->rider = fm->odom->rider;
+                fm->odom->rider = FrameRider();
                 rc = fusion_predict_model(f, fm);
+                MMF_REQUIRE(rc != MMF_OK || m->rider.st == nullptr, "mmf_fusion_process_frame: the tracking result was not handed over");
                 if (rc == MMF_OK) rc = mmf_model_predict_indices(m, f->tick, g.max_depth_processed, g.time_delta);
                 fm->early_done = rc == MMF_OK;
                 // Without a segmentation the mask of the frame is known (all zeros) and nothing the host decides lies

@@ -736,20 +736,6 @@ static bool graphs_enabled() {
     return on;
 }
 
-// the side streams' chains alone (MMF_GRAPHS_SIDE) / the end-of-frame model-side preparation alone (MMF_GRAPHS_SPEC)
-static bool env_flag(const char* name) {
-    const char* v = std::getenv(name);
-    return v && v[0] && v[0] != '0';
-}
-static bool side_graphs_enabled() {
-    static const bool on = graphs_enabled() || env_flag("MMF_GRAPHS_SIDE");
-    return on;
-}
-static bool spec_graphs_enabled() {
-    static const bool on = graphs_enabled() || env_flag("MMF_GRAPHS_SPEC");
-    return on;
-}
-
 struct mmf_odom {
     mmf_ctx* ctx = nullptr;
     GraphCache gn_graphs;    // the Gauss-Newton chain of odom_enqueue_tracking (launch_graph.hpp)
