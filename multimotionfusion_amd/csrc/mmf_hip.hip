@@ -14,7 +14,10 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -1639,6 +1642,9 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         mmf_odom* om = batch ? batch->o[m] : o;
         to.host[m] = om->host_result_dev;
         om->publish_seq = seq;
+        // a follower of a batch takes the LEADER's counter: whatever its own earlier chains left in the pinned flag, it is not
+        // this chain's number before this chain has written it
+        om->host_result->publish_seq = ~seq;
         om->pending_icp = icp, om->pending_so3 = so3 != 0;
         om->track_stream = c->stream;
         om->result_of = o;
