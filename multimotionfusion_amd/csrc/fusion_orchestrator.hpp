@@ -172,6 +172,24 @@ static int fusion_model_create(mmf_fusion* f, int id, float conf, int fill_in, b
     FusionModel* fm = new (std::nothrow) FusionModel();
     MMF_REQUIRE(fm != nullptr, "mmf_fusion: out of host memory");
     int rc = MMF_OK;
+    // a rigid body another rank owns (ownership is by id: fusion_owner_of) is bookkeeping here: id, thresholds, pose,
+    // statistics -- no surfel store, no odometry slab, no stream.  (The global model's odometry holds the sensor side of
+    // every rank: it is always the real thing.)
+    if (f->shard_world > 1 && id != 0 && id % f->shard_world != f->shard_rank) {
+        fm->lane = f->ctx;
+        rc = model_create_bookkeeping(f->ctx, f->width, f->height, f->cx, f->cy, f->fx, f->fy, (unsigned char)id, conf, &fm->model);
+        if (rc == MMF_OK) rc = odom_create_bookkeeping(f->ctx, f->width, f->height, f->cx, f->cy, f->fx, f->fy, &fm->odom);
+        if (rc != MMF_OK) {
+            const std::string keep = g_last_error;
+            fusion_model_destroy(fm);
+            return fail(rc, keep);
+        }
+        fm->fill_in = fill_in;
+        identity16(fm->last_pose);
+        if (f->cfg.pose_logging) fm->pose_log.reserve(1000);  // Model.cpp:177
+        *out = fm;
+        return MMF_OK;
+    }
     if (own_lane) {
         rc = mmf_ctx_create(f->ctx->device, nullptr, 1, &fm->lane);
         fm->own_lane = rc == MMF_OK;
@@ -353,7 +371,22 @@ static inline bool fusion_owns(const mmf_fusion* f, size_t index) { return index
 
 extern "C" int mmf_fusion_set_shard(mmf_fusion* f, int rank, int world) {
     MMF_REQUIRE(f && world >= 1 && rank >= 0 && rank < world, "mmf_fusion_set_shard: bad argument");
+    MMF_REQUIRE(f->models.size() == 1 && f->inactive.empty(), "mmf_fusion_set_shard: call it before the first object model is spawned");
     f->shard_rank = rank, f->shard_world = world;
+    // models created ahead of their use (preallocateModels): the ones this rank will not own shrink to bookkeeping
+    for (FusionModel*& fm : f->preallocated) {
+        const int id = (int)fm->model->id;
+        const bool is_light = fm->model->slab == nullptr, want_light = world > 1 && id % world != rank;
+        if (is_light == want_light) continue;
+        FusionModel* again = nullptr;
+        const float conf = fm->model->conf_threshold;
+        const int fill_in = fm->fill_in;
+        fusion_model_destroy(fm);
+        fm = nullptr;
+        int rc = fusion_model_create(f, id, conf, fill_in, true, &again);
+        if (rc) return rc;
+        fm = again;
+    }
     return MMF_OK;
 }
 extern "C" int mmf_fusion_owns_model(mmf_fusion* f, int index) {
@@ -1298,7 +1331,7 @@ extern "C" int mmf_fusion_get_pose(mmf_fusion* f, float pose[16]) {
 static int model_reset_store(mmf_model* m) {
     if (int rc = model_resolve_count(m)) return rc;  // lets an in-flight count land before it is dropped
     m->count = 0, m->count_pending = false, m->count_bound = 0;
-    MMF_HIP_TRY(hipMemsetAsync(m->totals, 0, 16, m->ctx->stream));
+    if (m->slab) MMF_HIP_TRY(hipMemsetAsync(m->totals, 0, 16, m->ctx->stream));  // (no slab: another rank's model)
     identity16(m->pose);
     m->max_depth = FLT_MAX;
     return MMF_OK;

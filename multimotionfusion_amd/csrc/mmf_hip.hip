@@ -907,6 +907,21 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     return MMF_OK;
 }
 
+// The odometry of a model ANOTHER rank tracks (fusion_orchestrator.hpp: a shard rank's bookkeeping copies): the host
+// struct only -- statistics as they arrive with the pose exchange -- no slab, no events, nothing a kernel could be given.
+static int odom_create_bookkeeping(mmf_ctx* c, int width, int height, float cx, float cy, float fx, float fy, mmf_odom** out) {
+    mmf_odom* o = new (std::nothrow) mmf_odom();
+    MMF_REQUIRE(o != nullptr, "mmf_odom_create: out of host memory");
+    o->ctx = c;
+    o->width = width, o->height = height;
+    o->cx = cx, o->cy = cy, o->fx = fx, o->fy = fy;
+    std::memset(&o->stats, 0, sizeof(o->stats));
+    std::memset(&o->timing_acc, 0, sizeof(o->timing_acc));
+    o->stats.lastICPCount = o->stats.lastRGBCount = o->stats.lastSO3Count = (float)(width * height);
+    *out = o;
+    return MMF_OK;
+}
+
 extern "C" void mmf_odom_destroy(mmf_odom* o) {
     if (!o) return;
     (void)hipSetDevice(o->ctx->device);
@@ -2052,6 +2067,23 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     std::memset(m->host_totals, 0, 64);
     MMF_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&m->host_totals_dev), m->host_totals, 0));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = m;
+    return MMF_OK;
+}
+
+// The model of a rigid body another rank owns: id, thresholds and pose on the host, no surfel store, no images
+// (mmf_fusion_set_shard; the round-2 advisor's finding: every rank allocated every model's stores)
+static int model_create_bookkeeping(mmf_ctx* c, int width, int height, float cx, float cy, float fx, float fy, unsigned char id,
+                                    float conf_threshold, mmf_model** out) {
+    mmf_model* m = new (std::nothrow) mmf_model();
+    MMF_REQUIRE(m != nullptr, "mmf_model_create: out of host memory");
+    m->ctx = c;
+    m->width = width, m->height = height;
+    m->cx = cx, m->cy = cy, m->fx = fx, m->fy = fy;
+    m->id = id;
+    m->conf_threshold = conf_threshold;
+    m->capacity = 0;
+    for (int i = 0; i < 16; ++i) m->pose[i] = (i % 5 == 0) ? 1.f : 0.f;
     *out = m;
     return MMF_OK;
 }

@@ -191,3 +191,46 @@ def test_two_ranks_over_rccl(tmp_path):
     a, b = np.load(out + ".0.npy"), np.load(out + ".1.npy")
     assert np.array_equal(a, b)  # after the all-gather both ranks hold every model's pose
     assert np.abs(a[-32:-16].reshape(4, 4) - np.eye(4)).max() > 1e-4  # the camera moved
+
+
+def test_a_rank_holds_no_store_for_models_it_does_not_own(gpu_ctx):
+    """Round-2 advisor finding: every rank allocated the surfel stores, odometry slabs and streams of ALL models.  A model
+    another rank owns is id, thresholds, pose and statistics on the host now: three object models cost rank 0 of 4 nothing on
+    the device, and an unsharded process several hundred MB."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h, n = 320, 240, 5
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=1)
+    objs = synth.make_objects(3, seed=2)
+    traj = synth.object_trajectories(objs, n, seed=2)
+    frames = [synth.render(poses[i], w, h, seed=i, objects=objs, object_poses=[t[i] for t in traj]) for i in range(n)]
+
+    def used_by_the_objects(shard):
+        g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1)
+        if shard:
+            g.setShard(0, 4)
+        keep = []
+        torch.cuda.synchronize()
+        before = torch.cuda.mem_get_info()[0]
+        for i in range(n):
+            ids = frames[i]["ids"]
+            keep.append((dev(frames[i]["rgb"]), dev(frames[i]["depth"]), dev(np.where(ids <= min(i, 3), ids, 0).astype(np.uint8))))
+            if i == 0:  # (the frame buffers above are the same in both runs; the global model's first frame too)
+                g.processFrame(keep[-1][0], keep[-1][1], timestamp=i, mask=keep[-1][2])
+                torch.cuda.synchronize()
+                before = torch.cuda.mem_get_info()[0]
+                continue
+            g.processFrame(keep[-1][0], keep[-1][1], timestamp=i, mask=keep[-1][2], hasNewLabel=1 <= i <= 3)
+        torch.cuda.synchronize()
+        after = torch.cuda.mem_get_info()[0]
+        owned = [g.ownsModel(k) for k in range(len(g.getModels()))]
+        poses_ok = all(np.isfinite(m.getPose()).all() for m in g.getModels())
+        g.close()
+        return before - after, owned, poses_ok
+
+    full, owned_full, ok_full = used_by_the_objects(False)
+    lean, owned_lean, ok_lean = used_by_the_objects(True)
+    assert owned_full == [True] * 4 and owned_lean == [True, False, False, False] and ok_full and ok_lean
+    frame_bytes = 4 * w * h * 8  # the frames uploaded after the first one, in both runs
+    assert full > 3 * 100e6  # three object models with stores, odometry slabs, streams
+    assert lean < frame_bytes + 16e6, (full, lean)
