@@ -130,20 +130,17 @@ __global__ __launch_bounds__(256) void copy_maps_kernel(int rows, int cols, cons
 }
 
 // cudafuncs.cu:366-417 (resizeMapKernel<normalize>): float2 loads cover the 2x2 footprint
+// The value of destination pixel (x, y); `in` = the three source planes (srows rows each).  false: one of the four x taps is
+// NaN -- the kernel then writes NaN to the x plane ONLY (the other two keep what they held), which every reader treats
+// as "invalid" by looking at x first.
 template <bool NORMALIZE>
-__device__ __forceinline__ void resize_map_px(int x, int y, int drows, int dcols, int srows, const float* __restrict__ in,
-                                                         int i_stride, float* __restrict__ out, int o_stride) {
-    if (x >= dcols || y >= drows) return;
+__device__ __forceinline__ bool resize_map_value(int x, int y, int srows, const float* __restrict__ in, int i_stride, f3& n) {
     const int xs = x * 2, ys = y * 2;
     const float x00 = in[(size_t)(ys + 0) * i_stride + xs + 0];
     const float x01 = in[(size_t)(ys + 0) * i_stride + xs + 1];
     const float x10 = in[(size_t)(ys + 1) * i_stride + xs + 0];
     const float x11 = in[(size_t)(ys + 1) * i_stride + xs + 1];
-    if ((x00 != x00) || (x01 != x01) || (x10 != x10) || (x11 != x11)) {
-        out[(size_t)y * o_stride + x] = qnan();
-        return;
-    }
-    f3 n;
+    if ((x00 != x00) || (x01 != x01) || (x10 != x10) || (x11 != x11)) return false;
     n.x = (x00 + x01 + x10 + x11) / 4;
     const float y00 = in[(size_t)(ys + srows + 0) * i_stride + xs + 0];
     const float y01 = in[(size_t)(ys + srows + 0) * i_stride + xs + 1];
@@ -156,6 +153,17 @@ __device__ __forceinline__ void resize_map_px(int x, int y, int drows, int dcols
     const float z11 = in[(size_t)(ys + 2 * srows + 1) * i_stride + xs + 1];
     n.z = (z00 + z01 + z10 + z11) / 4;
     if (NORMALIZE) n = normalized(n);
+    return true;
+}
+template <bool NORMALIZE>
+__device__ __forceinline__ void resize_map_px(int x, int y, int drows, int dcols, int srows, const float* __restrict__ in,
+                                                         int i_stride, float* __restrict__ out, int o_stride) {
+    if (x >= dcols || y >= drows) return;
+    f3 n;
+    if (!resize_map_value<NORMALIZE>(x, y, srows, in, i_stride, n)) {
+        out[(size_t)y * o_stride + x] = qnan();
+        return;
+    }
     out[(size_t)y * o_stride + x] = n.x;
     out[(size_t)(y + drows) * o_stride + x] = n.y;
     out[(size_t)(y + 2 * drows) * o_stride + x] = n.z;
@@ -174,10 +182,8 @@ __device__ __forceinline__ float binom5(int k) { return k == 2 ? 6.f : ((k == 1 
 
 // cudafuncs.cu:333-364 (pyrDownKernelGaussF), quirks kept: int `count`, the window is
 // [max(0,2x-2), min(2x+3, cols-1)) and the weight index is mirrored from the clipped end (:358)
-__device__ __forceinline__ void pyrdown_gauss_f_px(int x, int y, const float* __restrict__ src, int s_stride, int scols,
-                                                              int srows, float* __restrict__ dst, int d_stride,
-                                                              int dcols, int drows) {
-    if (x >= dcols || y >= drows) return;
+__device__ __forceinline__ float pyrdown_gauss_f_value(int x, int y, const float* __restrict__ src, int s_stride, int scols,
+                                                                int srows) {
     const int tx = min(2 * x + 3, scols - 1);
     const int ty = min(2 * y + 3, srows - 1);
     // All 25 taps are loaded from clamped addresses BEFORE any is consumed, and the accumulation is
@@ -207,7 +213,13 @@ __device__ __forceinline__ void pyrdown_gauss_f_px(int x, int y, const float* __
             count = use ? (int)((float)count + w) : count;
         }
     }
-    dst[(size_t)y * d_stride + x] = (float)(sum / (float)count);
+    return (float)(sum / (float)count);
+}
+__device__ __forceinline__ void pyrdown_gauss_f_px(int x, int y, const float* __restrict__ src, int s_stride, int scols,
+                                                              int srows, float* __restrict__ dst, int d_stride,
+                                                              int dcols, int drows) {
+    if (x >= dcols || y >= drows) return;
+    dst[(size_t)y * d_stride + x] = pyrdown_gauss_f_value(x, y, src, s_stride, scols, srows);
 }
 __global__ __launch_bounds__(256) void pyrdown_gauss_f_kernel(const float* __restrict__ src, int s_stride, int scols,
                                                               int srows, float* __restrict__ dst, int d_stride,
@@ -329,17 +341,21 @@ __global__ __launch_bounds__(256) void derivative_kernel(const uint8_t* __restri
 // cloud4 (optional): the same point as {X, Y, Z, 1 / Z} in one 16-byte record -- rgbStep divides by Z for every
 // correspondence of every Gauss-Newton iteration (reduce.cu:523); the quotient is the same float each time, so the
 // one-launch chain gathers it (one aligned 16-byte load) instead of dividing
-__device__ __forceinline__ void project_points_px(int x, int y, const float* __restrict__ depth, int d_stride, int cols,
-                                                             int rows, float* __restrict__ cloud, float inv_fx,
-                                                             float inv_fy, float cx, float cy, float4* __restrict__ cloud4 = nullptr) {
-    if (x >= cols || y >= rows) return;
-    const float z = depth[(size_t)y * d_stride + x];
+// (the pixel's depth in a register: prep_batch.hpp computes it in the same job)
+__device__ __forceinline__ void project_points_store(int x, int y, float z, int cols, float* __restrict__ cloud, float inv_fx,
+                                                                float inv_fy, float cx, float cy, float4* __restrict__ cloud4) {
     float* c = cloud + ((size_t)y * cols + x) * 3;
     const float X = (float)((x - cx) * z * inv_fx), Y = (float)((y - cy) * z * inv_fy);
     c[0] = X;
     c[1] = Y;
     c[2] = z;
     if (cloud4) cloud4[(size_t)y * cols + x] = make_float4(X, Y, z, 1.0f / z);
+}
+__device__ __forceinline__ void project_points_px(int x, int y, const float* __restrict__ depth, int d_stride, int cols,
+                                                             int rows, float* __restrict__ cloud, float inv_fx,
+                                                             float inv_fy, float cx, float cy, float4* __restrict__ cloud4 = nullptr) {
+    if (x >= cols || y >= rows) return;
+    project_points_store(x, y, depth[(size_t)y * d_stride + x], cols, cloud, inv_fx, inv_fy, cx, cy, cloud4);
 }
 __global__ __launch_bounds__(256) void project_points_kernel(const float* __restrict__ depth, int d_stride, int cols,
                                                              int rows, float* __restrict__ cloud, float inv_fx,

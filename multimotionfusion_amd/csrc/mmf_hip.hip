@@ -1154,6 +1154,10 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     // staging images, which this path does not need as copies: 3*N*(1 + 1/4 + 1/16) floats each
     float* uv[3] = {o->vmaps_tmp, o->vmaps_tmp + 3 * n0, o->vmaps_tmp + 3 * n0 + 3 * (n0 / 4)};
     float* un[3] = {o->nmaps_tmp, o->nmaps_tmp + 3 * n0, o->nmaps_tmp + 3 * n0 + 3 * (n0 / 4)};
+    // The coarsest level's model-side products (transformed + packed maps, point cloud) are computed in the SAME stage as
+    // its pyramid step, from the level above (PREP_RESIZE_TP, PREP_PYR_PROJECT): the model side is three dependent launches
+    // instead of four.  MMF_PREP_MERGE=0: the four-stage form (A/B aid).
+    static const bool merge_last = []() { const char* e = std::getenv("MMF_PREP_MERGE"); return !e || std::atoi(e) != 0; }();
     auto intr_f = [&](PrepJob& j, int lvl, bool cutoff_too, float cutoff) {
         const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, lvl);
         j.f[0] = 1.f / in.fx, j.f[1] = 1.f / in.fy, j.f[2] = in.cx, j.f[3] = in.cy;
@@ -1166,7 +1170,7 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     };
     auto level_jobs = [&](PrepBuilder& pb, int lvl) {  // jobs whose inputs are the level-lvl images
         const int cols = W >> lvl, rows = H >> lvl;
-        if (model_side) {
+        if (model_side && !(merge_last && lvl == MMF_NUM_PYRS - 1)) {
             PrepJob& t = pb.add(PREP_TRANSFORM_PACK, cols, rows);
             t.src0 = uv[lvl], t.src1 = un[lvl];
             t.dst0 = o->vmaps_g_prev[lvl], t.dst1 = o->nmaps_g_prev[lvl], t.dst2 = o->prev_packed[lvl];
@@ -1193,7 +1197,20 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     };
     auto down_jobs = [&](PrepBuilder& pb, int lvl, const float* depth_src) {  // level lvl-1 -> lvl of every pyramid
         if (in_img) pyr(pb, PREP_PYRDOWN_U8, o->next_image[lvl - 1], o->next_image[lvl], lvl);
-        if (model_side) {
+        if (model_side && merge_last && lvl == MMF_NUM_PYRS - 1) {
+            pyr(pb, PREP_PYRDOWN_U8, o->last_image[lvl - 1], o->last_image[lvl], lvl);
+            const int cols = W >> lvl, rows = H >> lvl;
+            PrepJob& t = pb.add(PREP_RESIZE_TP, cols, rows);
+            t.src0 = uv[lvl - 1], t.src1 = un[lvl - 1], t.scols = W >> (lvl - 1), t.srows = H >> (lvl - 1);
+            t.dst0 = o->vmaps_g_prev[lvl], t.dst1 = o->nmaps_g_prev[lvl], t.dst2 = o->prev_packed[lvl];
+            const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+            for (int k = 0; k < 9; ++k) t.f[k] = R[k];
+            t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
+            PrepJob& p = pb.add(PREP_PYR_PROJECT, cols, rows);
+            p.src0 = o->last_depth[lvl - 1], p.scols = W >> (lvl - 1), p.srows = H >> (lvl - 1);
+            p.dst0 = o->cloud[lvl], p.dst1 = o->cloud4[lvl], p.dst2 = o->last_depth[lvl];
+            intr_f(p, lvl, false, 0.f);
+        } else if (model_side) {
             pyr(pb, PREP_PYRDOWN_F, o->last_depth[lvl - 1], o->last_depth[lvl], lvl);
             pyr(pb, PREP_PYRDOWN_U8, o->last_image[lvl - 1], o->last_image[lvl], lvl);
             pyr(pb, PREP_RESIZE_V, uv[lvl - 1], uv[lvl], lvl);

@@ -26,6 +26,10 @@ enum PrepOp : int {
     PREP_INTENSITY,       // src0 interleaved u8 (stride scols bytes, `channels`) -> dst0
     PREP_DERIV,           // src0 u8 -> dst0 dIdx, dst1 dIdy
     PREP_PROJECT,         // src0 depth -> dst0 AoS cloud, dst1 {X, Y, Z, 1/Z} records   f = {1/fx, 1/fy, cx, cy}
+    // The coarsest level's products straight from the level above (the pyramid step's value stays in a register), so that the
+    // chain of stages ends one launch earlier:
+    PREP_RESIZE_TP,       // PREP_RESIZE_V + PREP_RESIZE_N + PREP_TRANSFORM_PACK: src0 vmap, src1 nmap (scols x srows) -> dst0, dst1, dst2   f = {R[9], t[3]}
+    PREP_PYR_PROJECT,     // PREP_PYRDOWN_F + PREP_PROJECT: src0 depth (scols x srows) -> dst2 depth, dst0 cloud, dst1 records   f = {1/fx, 1/fy, cx, cy}
 };
 
 struct PrepJob {
@@ -51,25 +55,18 @@ struct PrepBatch {
 };
 
 // transform_maps_px + pack_prev_kernel in one pass (same arithmetic; an invalid pixel's record is all NaN)
-__device__ __forceinline__ void transform_pack_px(int x, int y, int rows, int cols, const float* __restrict__ vsrc,
-                                                  const float* __restrict__ nsrc, m33 R, f3 t, float* __restrict__ vdst,
-                                                  float* __restrict__ ndst, float* __restrict__ packed) {
-    if (x >= cols || y >= rows) return;
-    f3 vs, vd = make_f3(qnan(), qnan(), qnan());
-    vs.x = vsrc[(size_t)y * cols + x];
-    if (!(vs.x != vs.x)) {
-        vs.y = vsrc[(size_t)(y + rows) * cols + x];
-        vs.z = vsrc[(size_t)(y + 2 * rows) * cols + x];
+// (v_ok / n_ok: the source vertex / normal is valid, i.e. its x is not NaN)
+__device__ __forceinline__ void transform_pack_store(int x, int y, int rows, int cols, bool v_ok, f3 vs, bool n_ok, f3 ns, m33 R, f3 t,
+                                                     float* __restrict__ vdst, float* __restrict__ ndst, float* __restrict__ packed) {
+    f3 vd = make_f3(qnan(), qnan(), qnan());
+    if (v_ok) {
         vd = R * vs + t;
         vdst[(size_t)(y + rows) * cols + x] = vd.y;
         vdst[(size_t)(y + 2 * rows) * cols + x] = vd.z;
     }
     vdst[(size_t)y * cols + x] = vd.x;
-    f3 ns, nd = make_f3(qnan(), qnan(), qnan());
-    ns.x = nsrc[(size_t)y * cols + x];
-    if (!(ns.x != ns.x)) {
-        ns.y = nsrc[(size_t)(y + rows) * cols + x];
-        ns.z = nsrc[(size_t)(y + 2 * rows) * cols + x];
+    f3 nd = make_f3(qnan(), qnan(), qnan());
+    if (n_ok) {
         nd = R * ns;
         ndst[(size_t)(y + rows) * cols + x] = nd.y;
         ndst[(size_t)(y + 2 * rows) * cols + x] = nd.z;
@@ -79,6 +76,25 @@ __device__ __forceinline__ void transform_pack_px(int x, int y, int rows, int co
     o[0] = make_float2(vd.x, vd.y);
     o[1] = make_float2(vd.z, nd.x);
     o[2] = make_float2(nd.y, nd.z);
+}
+__device__ __forceinline__ void transform_pack_px(int x, int y, int rows, int cols, const float* __restrict__ vsrc,
+                                                  const float* __restrict__ nsrc, m33 R, f3 t, float* __restrict__ vdst,
+                                                  float* __restrict__ ndst, float* __restrict__ packed) {
+    if (x >= cols || y >= rows) return;
+    f3 vs = make_f3(0.f, 0.f, 0.f), ns = vs;
+    vs.x = vsrc[(size_t)y * cols + x];
+    const bool v_ok = !(vs.x != vs.x);
+    if (v_ok) {
+        vs.y = vsrc[(size_t)(y + rows) * cols + x];
+        vs.z = vsrc[(size_t)(y + 2 * rows) * cols + x];
+    }
+    ns.x = nsrc[(size_t)y * cols + x];
+    const bool n_ok = !(ns.x != ns.x);
+    if (n_ok) {
+        ns.y = nsrc[(size_t)(y + rows) * cols + x];
+        ns.z = nsrc[(size_t)(y + 2 * rows) * cols + x];
+    }
+    transform_pack_store(x, y, rows, cols, v_ok, vs, n_ok, ns, R, t, vdst, ndst, packed);
 }
 
 __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
@@ -127,6 +143,25 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
         case PREP_PROJECT:
             project_points_px(x, y, (const float*)src0, cols, cols, rows, (float*)J.dst0, J.f[0], J.f[1], J.f[2], J.f[3], (float4*)J.dst1);
             break;
+        case PREP_RESIZE_TP: {
+            if (x >= cols || y >= rows) break;
+            m33 R;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R.m[k] = J.f[k];
+            f3 vs = make_f3(0.f, 0.f, 0.f), ns = vs;
+            const bool v_ok = resize_map_value<false>(x, y, J.srows, (const float*)src0, J.scols, vs);
+            const bool n_ok = resize_map_value<true>(x, y, J.srows, (const float*)src1, J.scols, ns);
+            transform_pack_store(x, y, rows, cols, v_ok, vs, n_ok, ns, R, make_f3(J.f[9], J.f[10], J.f[11]), (float*)J.dst0,
+                                 (float*)J.dst1, (float*)J.dst2);
+            break;
+        }
+        case PREP_PYR_PROJECT: {
+            if (x >= cols || y >= rows) break;
+            const float z = pyrdown_gauss_f_value(x, y, (const float*)src0, J.scols, J.scols, J.srows);
+            ((float*)J.dst2)[(size_t)y * cols + x] = z;
+            project_points_store(x, y, z, cols, (float*)J.dst0, J.f[0], J.f[1], J.f[2], J.f[3], (float4*)J.dst1);
+            break;
+        }
         default: break;
     }
 }
