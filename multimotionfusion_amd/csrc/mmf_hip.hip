@@ -2255,6 +2255,12 @@ extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cut
     return MMF_OK;
 }
 
+// splat_kernel's launch: a fixed number of workgroups that deal the surfels out among their waves (surfel_kernels.hpp)
+static dim3 splat_grid(size_t bound) {
+    static const unsigned wgs = []() { const char* e = std::getenv("MMF_SPLAT_WGS"); return e ? (unsigned)std::max(1, std::atoi(e)) : 512u; }();
+    const size_t one_per_thread = (bound + 255) / 256;
+    return dim3((unsigned)std::max<size_t>(1, std::min<size_t>(one_per_thread, wgs)));
+}
 // ModelProjection::combinedPredict(ACTIVE) (ModelProjection.cpp:187-269); Model.h:210-214
 // fill_rgb / fill_depth != nullptr: Model::performFillIn in the same pass as the resolve (the orchestrator's predict)
 static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, int max_time, int time_delta,
@@ -2275,7 +2281,7 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     // and let the kernel read the count on the device instead of waiting for it
     const unsigned launch_count = m->count_pending ? m->count_bound : m->count;
     if (launch_count)
-        hipLaunchKernelGGL(splat_kernel, grid1d(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
+        hipLaunchKernelGGL(splat_kernel, splat_grid(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
                            m->keys, m->count_pending ? m->totals : nullptr);
     if (fill_rgb && fill_depth) {
         const FrameRider rider = m->rider;
@@ -2312,7 +2318,7 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
     a.time = time, a.maxTime = max_time, a.timeDelta = time_delta;
     if (int rc0 = model_resolve_count(m)) return rc0;
     if (m->count)
-        hipLaunchKernelGGL(splat_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
+        hipLaunchKernelGGL(splat_kernel, splat_grid(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
                            m->keys, nullptr);
     hipLaunchKernelGGL(splat_depth_resolve_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys,
                        m->synth_depth);

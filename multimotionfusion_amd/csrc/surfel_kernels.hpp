@@ -556,55 +556,69 @@ __device__ __forceinline__ bool splat_fragment(const SplatFrag& f, const SplatAr
 // changed nothing).  Here the wave's sprite ROWS are laid end to end (inclusive scan of the sprite heights), lane l takes
 // rows l, l + 64, ..., finds the row's surfel by a binary search in the wave's scan and reads that surfel's set-up from
 // LDS.  The per-fragment arithmetic is the same function as before, and atomicMin does not care about the order.
+//
+// Round 3: the launch is a FIXED number of waves that deal the surfels out among themselves, `per` at a time per wave with
+// per = ceil(count / waves) <= 64 read on the device.  The grid used to be one thread per surfel of the BOUND the launch
+// is sized by -- after a fuse pass that is count + width x height: an object model of 4 000 surfels, seen from close up
+// (sprites of 40 x 40 pixels), ran as 1 215 workgroups of which 16 held all the fragments, 17-21 us at 640x480, longer
+// than the global model's 300 k surfels.  With every wave of the launch holding a few of those sprites' rows: 3-4 us.
 __global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, SplatArgs a_in,
                                                     unsigned long long* __restrict__ keys,
                                                     const unsigned* __restrict__ count_dev) {
     const SplatArgs a = with_device_pose(a_in);
     __shared__ SplatFrag frag_lds[256];
     __shared__ int row_end[256];  // inclusive scan of the sprite heights inside each wave
-    const int id = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
     if (count_dev != nullptr) count = min((unsigned)count, *count_dev);
-    SplatFrag f;
-    f.ok = false;
-    if (id < count) f = splat_setup(s.pos[id], s.col[id], s.nrm[id], a);
-    int rows_here = f.ok ? f.y1 - f.y0 + 1 : 0;
-    if (rows_here < 0) rows_here = 0;
-    int scan = rows_here;
+    const int nwaves = (int)gridDim.x * 4, wave_id = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int per = min(64, max(1, (count + nwaves - 1) / nwaves));  // surfels of one wave's pass
+    for (int base = wave_id * per; base < count; base += nwaves * per) {  // wave uniform
+        const int id = base + lane;
+        SplatFrag f;
+        f.ok = false;
+        if (lane < per && id < count) f = splat_setup(s.pos[id], s.col[id], s.nrm[id], a);
+        int rows_here = f.ok ? f.y1 - f.y0 + 1 : 0;
+        if (rows_here < 0) rows_here = 0;
+        int scan = rows_here;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up(scan, d);
-        if (lane >= d) scan += up;
-    }
-    const int total = __shfl(scan, 63);
-    if (total == 0) return;  // wave uniform
-    frag_lds[threadIdx.x] = f;
-    row_end[threadIdx.x] = scan;
-    // one wave writes and reads its own 64 entries: no workgroup barrier needed, only the LDS writes drained
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    for (int t = lane; t < total; t += 64) {
-        int lo = 0, hi = 63;  // first surfel of the wave with row_end > t
-#pragma unroll
-        for (int step = 0; step < 6; ++step) {
-            const int mid = (lo + hi) >> 1;
-            const bool right = row_end[wbase + mid] <= t;
-            lo = right ? mid + 1 : lo;
-            hi = right ? hi : mid;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(scan, d);
+            if (lane >= d) scan += up;
         }
-        const SplatFrag& g = frag_lds[wbase + lo];
-        const int row_first = lo ? row_end[wbase + lo - 1] : 0;
-        const int py = g.y0 + (t - row_first);
-        const unsigned sid = (unsigned)(blockIdx.x * 256 + wbase + lo);
-        for (int px = g.x0; px <= g.x1; ++px) {
-            float z;
-            unsigned d24;
-            if (!splat_fragment(g, a, px, py, z, d24)) continue;
-            // the key image is stored TRANSPOSED (x * rows + y), like the index map's
-            atomicMin(&keys[(size_t)px * a.rows + py], ((unsigned long long)d24 << 32) | sid);
+        const int total = __shfl(scan, 63);
+        if (total == 0) continue;  // wave uniform
+        // one wave writes and reads its own 64 entries: no workgroup barrier needed, only the previous pass's reads and
+        // these writes drained
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        frag_lds[threadIdx.x] = f;
+        row_end[threadIdx.x] = scan;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < total; t += 64) {
+            int lo = 0, hi = 63;  // first surfel of the wave with row_end > t
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const int mid = (lo + hi) >> 1;
+                const bool right = row_end[wbase + mid] <= t;
+                lo = right ? mid + 1 : lo;
+                hi = right ? hi : mid;
+            }
+            const SplatFrag& g = frag_lds[wbase + lo];
+            const int row_first = lo ? row_end[wbase + lo - 1] : 0;
+            const int py = g.y0 + (t - row_first);
+            const unsigned sid = (unsigned)(base + lo);
+            for (int px = g.x0; px <= g.x1; ++px) {
+                float z;
+                unsigned d24;
+                if (!splat_fragment(g, a, px, py, z, d24)) continue;
+                // the key image is stored TRANSPOSED (x * rows + y), like the index map's
+                atomicMin(&keys[(size_t)px * a.rows + py], ((unsigned long long)d24 << 32) | sid);
+            }
         }
     }
 }
+
 
 struct SplatTexel {
     uchar4 image;
