@@ -64,6 +64,8 @@ struct mmf_fusion {
     // thresholds, poses handed in through mmf_fusion_set_model_pose) -- their owners run on other GPUs
     int shard_rank = 0, shard_world = 1;
     double t_tracking_s = 0, t_frame_s = 0;  // host wall clock of the last processFrame: tracking phase, whole call
+    double trace_us[6] = {0, 0, 0, 0, 0, 0};  // MMF_HOST_TRACE
+    long trace_calls = 0;
     float* depth_filtered = nullptr;  // = filtered[cur]
     uint8_t* mask = nullptr;          // textures[MASK]: all zeros unless enableMultipleModels
     bool mask_is_zero = false;
@@ -598,6 +600,11 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     mmf_ctx* c = f->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     const auto t_begin = std::chrono::steady_clock::now();
+    // MMF_HOST_TRACE=1: where the calling thread is, in us after the call began, at six points of the call (averages over 100 calls)
+    static const bool host_trace = std::getenv("MMF_HOST_TRACE") != nullptr;
+    auto stamp = [&](int i) {
+        if (host_trace) f->trace_us[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+    };
     f->t_tracking_s = 0;
     const mmf_fusion_config& g = f->cfg;
     const float weight_multiplier = fr->weight_multiplier;
@@ -863,6 +870,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 if (rc) return rc;
                 next_prefetched = true;
             }
+            stamp(0);
             // a host frame announced for the next call: staged and sent up now, while the GPU tracks and the host would only wait
             rc = fusion_stage_host_next(f);
             if (rc) return rc;
@@ -883,6 +891,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 }
             }
             f->t_tracking_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_track).count();
+            stamp(1);
             if (fr->bootstrap) {  // :397-400
                 MMF_REQUIRE(fr->in_pose != nullptr, "mmf_fusion_process_frame: bootstrap needs in_pose");
                 float pose[16], np[16];
@@ -969,6 +978,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
         }
 
+        stamp(2);
         for (size_t k = 0; k < f->models.size(); ++k) {  // predict() (:675), then :791-816, model by model
             FusionModel* fm = f->models[k];
             if (!fusion_owns(f, k)) continue;
@@ -991,11 +1001,13 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             fm->early_fused = false;
         }
     }
+    stamp(3);
     for (size_t k = 0; k < f->models.size(); ++k) {  // predict() (:821)
         if (!fusion_owns(f, k)) continue;
         rc = fusion_predict_model(f, f->models[k]);
         if (rc) return rc;
     }
+    stamp(4);
     f->tick++;  // :825
 
     // :829-846: pose log (camera->world for the first model, object->world for the others)
@@ -1059,6 +1071,14 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             only->spec_f2f = g.frame_to_frame_rgb;
             only->spec_valid = true;
         }
+    }
+    stamp(5);
+    if (host_trace && ++f->trace_calls % 100 == 0) {
+        std::fprintf(stderr, "host us from call start: chains enqueued %.0f, poses here %.0f, segmentation handled %.0f, per-model passes enqueued %.0f, "
+                             "final predicts enqueued %.0f, end %.0f\n",
+                     f->trace_us[0] / 100, f->trace_us[1] / 100, f->trace_us[2] / 100, f->trace_us[3] / 100, f->trace_us[4] / 100,
+                     f->trace_us[5] / 100);
+        for (double& a : f->trace_us) a = 0;
     }
     f->t_frame_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return MMF_OK;
