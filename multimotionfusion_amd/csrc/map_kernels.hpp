@@ -182,8 +182,9 @@ __device__ __forceinline__ float binom5(int k) { return k == 2 ? 6.f : ((k == 1 
 
 // cudafuncs.cu:333-364 (pyrDownKernelGaussF), quirks kept: int `count`, the window is
 // [max(0,2x-2), min(2x+3, cols-1)) and the weight index is mirrored from the clipped end (:358)
-__device__ __forceinline__ float pyrdown_gauss_f_value(int x, int y, const float* __restrict__ src, int s_stride, int scols,
-                                                                int srows) {
+// `at(yy, xx)`: the source pixel (a plain image, or a value derived from another image in the same job: prep_batch.hpp)
+template <typename At>
+__device__ __forceinline__ float pyrdown_gauss_f_taps(int x, int y, int scols, int srows, At at) {
     const int tx = min(2 * x + 3, scols - 1);
     const int ty = min(2 * y + 3, srows - 1);
     // All 25 taps are loaded from clamped addresses BEFORE any is consumed, and the accumulation is
@@ -193,8 +194,7 @@ __device__ __forceinline__ float pyrdown_gauss_f_value(int x, int y, const float
 #pragma unroll
     for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx)
-            tap[dy][dx] = src[(size_t)min(max(2 * y - 2 + dy, 0), srows - 1) * s_stride + min(max(2 * x - 2 + dx, 0), scols - 1)];
+        for (int dx = 0; dx < 5; ++dx) tap[dy][dx] = at(min(max(2 * y - 2 + dy, 0), srows - 1), min(max(2 * x - 2 + dx, 0), scols - 1));
     __builtin_amdgcn_sched_barrier(0);
     float sum = 0;
     int count = 0;
@@ -215,6 +215,10 @@ __device__ __forceinline__ float pyrdown_gauss_f_value(int x, int y, const float
     }
     return (float)(sum / (float)count);
 }
+__device__ __forceinline__ float pyrdown_gauss_f_value(int x, int y, const float* __restrict__ src, int s_stride, int scols,
+                                                                int srows) {
+    return pyrdown_gauss_f_taps(x, y, scols, srows, [&](int yy, int xx) { return src[(size_t)yy * s_stride + xx]; });
+}
 __device__ __forceinline__ void pyrdown_gauss_f_px(int x, int y, const float* __restrict__ src, int s_stride, int scols,
                                                               int srows, float* __restrict__ dst, int d_stride,
                                                               int dcols, int drows) {
@@ -229,18 +233,15 @@ __global__ __launch_bounds__(256) void pyrdown_gauss_f_kernel(const float* __res
 }
 
 // cudafuncs.cu:534-564 (pyrDownKernelIntensityGauss)
-__device__ __forceinline__ void pyrdown_uchar_gauss_px(int x, int y, const uint8_t* __restrict__ src, int s_stride,
-                                                                  int scols, int srows, uint8_t* __restrict__ dst,
-                                                                  int d_stride, int dcols, int drows) {
-    if (x >= dcols || y >= drows) return;
+template <typename At>
+__device__ __forceinline__ uint8_t pyrdown_uchar_gauss_taps(int x, int y, int scols, int srows, At at) {
     const int tx = min(2 * x + 3, scols - 1);
     const int ty = min(2 * y + 3, srows - 1);
     uint8_t tap[5][5];  // all taps in flight before the first use, see pyrdown_gauss_f_kernel
 #pragma unroll
     for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx)
-            tap[dy][dx] = src[(size_t)min(max(2 * y - 2 + dy, 0), srows - 1) * s_stride + min(max(2 * x - 2 + dx, 0), scols - 1)];
+        for (int dx = 0; dx < 5; ++dx) tap[dy][dx] = at(min(max(2 * y - 2 + dy, 0), srows - 1), min(max(2 * x - 2 + dx, 0), scols - 1));
     __builtin_amdgcn_sched_barrier(0);
     float sum = 0;
     int count = 0;
@@ -260,7 +261,14 @@ __device__ __forceinline__ void pyrdown_uchar_gauss_px(int x, int y, const uint8
         }
     }
     const float q = sum / (float)count;
-    dst[(size_t)y * d_stride + x] = (q != q) ? (uint8_t)0 : (uint8_t)(unsigned)q;
+    return (q != q) ? (uint8_t)0 : (uint8_t)(unsigned)q;
+}
+__device__ __forceinline__ void pyrdown_uchar_gauss_px(int x, int y, const uint8_t* __restrict__ src, int s_stride,
+                                                                  int scols, int srows, uint8_t* __restrict__ dst,
+                                                                  int d_stride, int dcols, int drows) {
+    if (x >= dcols || y >= drows) return;
+    dst[(size_t)y * d_stride + x] =
+        pyrdown_uchar_gauss_taps(x, y, scols, srows, [&](int yy, int xx) { return src[(size_t)yy * s_stride + xx]; });
 }
 __global__ __launch_bounds__(256) void pyrdown_uchar_gauss_kernel(const uint8_t* __restrict__ src, int s_stride,
                                                                   int scols, int srows, uint8_t* __restrict__ dst,
@@ -270,11 +278,11 @@ __global__ __launch_bounds__(256) void pyrdown_uchar_gauss_kernel(const uint8_t*
 }
 
 // cudafuncs.cu:602-613 (verticesToDepthKernel)
+__device__ __forceinline__ float vertex_depth_value(float z, float cutoff) { return (z > cutoff || z <= 0) ? qnan() : z; }
 __device__ __forceinline__ void vertices_to_depth_px(int x, int y, const float4* __restrict__ vmap_rgba, int cols, int rows,
                                                                 float* __restrict__ dst, int d_stride, float cutoff) {
     if (x >= cols || y >= rows) return;
-    const float z = vmap_rgba[(size_t)y * cols + x].z;
-    dst[(size_t)y * d_stride + x] = (z > cutoff || z <= 0) ? qnan() : z;
+    dst[(size_t)y * d_stride + x] = vertex_depth_value(vmap_rgba[(size_t)y * cols + x].z, cutoff);
 }
 __global__ __launch_bounds__(256) void vertices_to_depth_kernel(const float4* __restrict__ vmap_rgba, int cols, int rows,
                                                                 float* __restrict__ dst, int d_stride, float cutoff) {
@@ -283,13 +291,14 @@ __global__ __launch_bounds__(256) void vertices_to_depth_kernel(const float4* __
 }
 
 // cudafuncs.cu:624-637 (bgr2IntensityKernel): channel order as uploaded
+__device__ __forceinline__ uint8_t intensity_value(const uint8_t* __restrict__ p) {
+    return (uint8_t)(int)((float)p[0] * 0.114f + (float)p[1] * 0.299f + (float)p[2] * 0.587f);
+}
 __device__ __forceinline__ void image_to_intensity_px(int x, int y, const uint8_t* __restrict__ img, int i_stride,
                                                                  int channels, int cols, int rows,
                                                                  uint8_t* __restrict__ dst, int d_stride) {
     if (x >= cols || y >= rows) return;
-    const uint8_t* p = img + (size_t)y * i_stride + (size_t)x * channels;
-    const int value = (int)((float)p[0] * 0.114f + (float)p[1] * 0.299f + (float)p[2] * 0.587f);
-    dst[(size_t)y * d_stride + x] = (uint8_t)value;
+    dst[(size_t)y * d_stride + x] = intensity_value(img + (size_t)y * i_stride + (size_t)x * channels);
 }
 __global__ __launch_bounds__(256) void image_to_intensity_kernel(const uint8_t* __restrict__ img, int i_stride,
                                                                  int channels, int cols, int rows,

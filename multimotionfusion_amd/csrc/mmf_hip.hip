@@ -1158,6 +1158,9 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     // its pyramid step, from the level above (PREP_RESIZE_TP, PREP_PYR_PROJECT): the model side is three dependent launches
     // instead of four.  MMF_PREP_MERGE=0: the four-stage form (A/B aid).
     static const bool merge_last = []() { const char* e = std::getenv("MMF_PREP_MERGE"); return !e || std::atoi(e) != 0; }();
+    // ... and level 0 and the first pyramid step are computed straight from the prediction's images (PREP_TEX_*): two
+    // dependent launches.  MMF_PREP_MERGE=1: only the last stage merged (A/B aid).
+    static const bool merge_first = []() { const char* e = std::getenv("MMF_PREP_MERGE"); return !e || std::atoi(e) >= 2; }();
     auto intr_f = [&](PrepJob& j, int lvl, bool cutoff_too, float cutoff) {
         const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, lvl);
         j.f[0] = 1.f / in.fx, j.f[1] = 1.f / in.fy, j.f[2] = in.cx, j.f[3] = in.cy;
@@ -1170,7 +1173,22 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     };
     auto level_jobs = [&](PrepBuilder& pb, int lvl) {  // jobs whose inputs are the level-lvl images
         const int cols = W >> lvl, rows = H >> lvl;
-        if (model_side && !(merge_last && lvl == MMF_NUM_PYRS - 1)) {
+        if (model_side && merge_first && lvl == 0) {  // from the prediction's images
+            const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+            PrepJob& t = pb.add(PREP_TEX_TP, cols, rows);
+            t.src0 = pred_vertex, t.src1 = pred_normal, t.sel = sel, t.alt0 = alt_vertex, t.alt1 = alt_normal;
+            t.dst0 = o->vmaps_g_prev[0], t.dst1 = o->nmaps_g_prev[0], t.dst2 = o->prev_packed[0];
+            for (int k = 0; k < 9; ++k) t.f[k] = R[k];
+            t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
+            PrepJob& p = pb.add(PREP_TEX_PROJECT, cols, rows);
+            p.src0 = pred_vertex, p.sel = sel, p.alt0 = alt_vertex;
+            p.dst0 = o->cloud[0], p.dst1 = o->cloud4[0], p.dst2 = o->last_depth[0];
+            intr_f(p, 0, false, 0.f);
+            p.f[4] = o->max_depth_rgb;
+            PrepJob& il = pb.add(PREP_INTENSITY, W, H);
+            il.src0 = pred_image, il.dst0 = o->last_image[0], il.scols = W * pred_channels, il.channels = pred_channels;
+            il.sel = sel, il.alt0 = alt_image;
+        } else if (model_side && !(merge_last && lvl == MMF_NUM_PYRS - 1)) {
             PrepJob& t = pb.add(PREP_TRANSFORM_PACK, cols, rows);
             t.src0 = uv[lvl], t.src1 = un[lvl];
             t.dst0 = o->vmaps_g_prev[lvl], t.dst1 = o->nmaps_g_prev[lvl], t.dst2 = o->prev_packed[lvl];
@@ -1197,7 +1215,18 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     };
     auto down_jobs = [&](PrepBuilder& pb, int lvl, const float* depth_src) {  // level lvl-1 -> lvl of every pyramid
         if (in_img) pyr(pb, PREP_PYRDOWN_U8, o->next_image[lvl - 1], o->next_image[lvl], lvl);
-        if (model_side && merge_last && lvl == MMF_NUM_PYRS - 1) {
+        if (model_side && merge_first && lvl == 1) {  // from the prediction's images
+            const int cols = W >> 1, rows = H >> 1;
+            PrepJob& d = pb.add(PREP_TEX_PYR_F, cols, rows);
+            d.src0 = pred_vertex, d.sel = sel, d.alt0 = alt_vertex, d.scols = W, d.srows = H;
+            d.dst0 = o->last_depth[1], d.f[0] = o->max_depth_rgb;
+            PrepJob& u = pb.add(PREP_TEX_PYR_U8, cols, rows);
+            u.src0 = pred_image, u.sel = sel, u.alt0 = alt_image, u.scols = W, u.srows = H, u.channels = pred_channels;
+            u.dst0 = o->last_image[1];
+            PrepJob& r = pb.add(PREP_TEX_RESIZE, cols, rows);
+            r.src0 = pred_vertex, r.src1 = pred_normal, r.sel = sel, r.alt0 = alt_vertex, r.alt1 = alt_normal, r.scols = W, r.srows = H;
+            r.dst0 = uv[1], r.dst1 = un[1];
+        } else if (model_side && merge_last && lvl == MMF_NUM_PYRS - 1) {
             pyr(pb, PREP_PYRDOWN_U8, o->last_image[lvl - 1], o->last_image[lvl], lvl);
             const int cols = W >> lvl, rows = H >> lvl;
             PrepJob& t = pb.add(PREP_RESIZE_TP, cols, rows);
@@ -1235,7 +1264,7 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             PrepJob& in = pb.add(PREP_INTENSITY, W, H);
             in.src0 = rgb, in.dst0 = o->next_image[0], in.scols = W * rgb_channels, in.channels = rgb_channels;
         }
-        if (model_side) {
+        if (model_side && !merge_first) {
             PrepJob& v = pb.add(PREP_V2D, W, H);
             v.src0 = pred_vertex, v.dst0 = o->last_depth[0], v.f[0] = o->max_depth_rgb;
             v.sel = sel, v.alt0 = alt_vertex;

@@ -30,6 +30,14 @@ enum PrepOp : int {
     // chain of stages ends one launch earlier:
     PREP_RESIZE_TP,       // PREP_RESIZE_V + PREP_RESIZE_N + PREP_TRANSFORM_PACK: src0 vmap, src1 nmap (scols x srows) -> dst0, dst1, dst2   f = {R[9], t[3]}
     PREP_PYR_PROJECT,     // PREP_PYRDOWN_F + PREP_PROJECT: src0 depth (scols x srows) -> dst2 depth, dst0 cloud, dst1 records   f = {1/fx, 1/fy, cx, cy}
+    // Level 0 and the first pyramid step straight from the prediction's RGBA32F / RGBA8 images (what PREP_V2D, PREP_INTENSITY
+    // and PREP_COPY_MAPS would have written to memory first stays in registers), so that the chain of stages STARTS one launch
+    // later: the model side is two dependent launches.  Same per-pixel functions on the same values: same bits.
+    PREP_TEX_TP,          // PREP_COPY_MAPS + PREP_TRANSFORM_PACK: src0, src1 prediction -> dst0, dst1, dst2   f = {R[9], t[3]}
+    PREP_TEX_PROJECT,     // PREP_V2D + PREP_PROJECT: src0 vertices -> dst2 depth, dst0 cloud, dst1 records   f = {1/fx, 1/fy, cx, cy, cutoff}
+    PREP_TEX_PYR_F,       // PREP_V2D + PREP_PYRDOWN_F: src0 vertices (scols x srows) -> dst0 depth   f = {cutoff}
+    PREP_TEX_PYR_U8,      // PREP_INTENSITY + PREP_PYRDOWN_U8: src0 image (scols x srows pixels of `channels` bytes) -> dst0
+    PREP_TEX_RESIZE,      // PREP_COPY_MAPS + PREP_RESIZE_V + PREP_RESIZE_N: src0, src1 prediction (scols x srows) -> dst0 vmap, dst1 nmap
 };
 
 struct PrepJob {
@@ -153,6 +161,86 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
             const bool n_ok = resize_map_value<true>(x, y, J.srows, (const float*)src1, J.scols, ns);
             transform_pack_store(x, y, rows, cols, v_ok, vs, n_ok, ns, R, make_f3(J.f[9], J.f[10], J.f[11]), (float*)J.dst0,
                                  (float*)J.dst1, (float*)J.dst2);
+            break;
+        }
+        case PREP_TEX_TP: {
+            if (x >= cols || y >= rows) break;
+            m33 R;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R.m[k] = J.f[k];
+            const float4 v = ((const float4*)src0)[(size_t)y * cols + x], n = ((const float4*)src1)[(size_t)y * cols + x];
+            const bool ok = !(v.z == 0);  // copy_maps_px: an empty texel is an invalid vertex AND an invalid normal
+            const f3 vs = ok ? make_f3(v.x, v.y, v.z) : make_f3(qnan(), qnan(), qnan());
+            const f3 ns = ok ? make_f3(n.x, n.y, n.z) : make_f3(qnan(), qnan(), qnan());
+            transform_pack_store(x, y, rows, cols, !(vs.x != vs.x), vs, !(ns.x != ns.x), ns, R, make_f3(J.f[9], J.f[10], J.f[11]),
+                                 (float*)J.dst0, (float*)J.dst1, (float*)J.dst2);
+            break;
+        }
+        case PREP_TEX_PROJECT: {
+            if (x >= cols || y >= rows) break;
+            const float z = vertex_depth_value(((const float4*)src0)[(size_t)y * cols + x].z, J.f[4]);
+            ((float*)J.dst2)[(size_t)y * cols + x] = z;
+            project_points_store(x, y, z, cols, (float*)J.dst0, J.f[0], J.f[1], J.f[2], J.f[3], (float4*)J.dst1);
+            break;
+        }
+        case PREP_TEX_PYR_F: {
+            if (x >= cols || y >= rows) break;
+            const float4* tex = (const float4*)src0;
+            const int scols = J.scols;
+            const float cutoff = J.f[0];
+            ((float*)J.dst0)[(size_t)y * cols + x] = pyrdown_gauss_f_taps(
+                x, y, scols, J.srows, [&](int yy, int xx) { return vertex_depth_value(tex[(size_t)yy * scols + xx].z, cutoff); });
+            break;
+        }
+        case PREP_TEX_PYR_U8: {
+            if (x >= cols || y >= rows) break;
+            const uint8_t* img = (const uint8_t*)src0;
+            const int ch = J.channels;
+            const size_t stride = (size_t)J.scols * ch;
+            ((uint8_t*)J.dst0)[(size_t)y * cols + x] = pyrdown_uchar_gauss_taps(
+                x, y, J.scols, J.srows, [&](int yy, int xx) { return intensity_value(img + (size_t)yy * stride + (size_t)xx * ch); });
+            break;
+        }
+        case PREP_TEX_RESIZE: {
+            if (x >= cols || y >= rows) break;
+            const float4* vt = (const float4*)src0;
+            const float4* nt = (const float4*)src1;
+            const int scols = J.scols;
+            float4 v[4], n[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t at = (size_t)(2 * y + (k >> 1)) * scols + 2 * x + (k & 1);
+                v[k] = vt[at], n[k] = nt[at];
+            }
+            float vx[4], vy[4], vz[4], nx[4], ny[4], nz[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // copy_maps_px
+                const bool ok = !(v[k].z == 0);
+                vx[k] = ok ? v[k].x : qnan(), vy[k] = ok ? v[k].y : qnan(), vz[k] = ok ? v[k].z : qnan();
+                nx[k] = ok ? n[k].x : qnan(), ny[k] = ok ? n[k].y : qnan(), nz[k] = ok ? n[k].z : qnan();
+            }
+            float* vd = (float*)J.dst0;
+            float* nd = (float*)J.dst1;
+            // resize_map_px<false> / <true>: x00 + x01 + x10 + x11 in that order
+            if ((vx[0] != vx[0]) || (vx[1] != vx[1]) || (vx[2] != vx[2]) || (vx[3] != vx[3])) {
+                vd[(size_t)y * cols + x] = qnan();
+            } else {
+                vd[(size_t)y * cols + x] = (vx[0] + vx[1] + vx[2] + vx[3]) / 4;
+                vd[(size_t)(y + rows) * cols + x] = (vy[0] + vy[1] + vy[2] + vy[3]) / 4;
+                vd[(size_t)(y + 2 * rows) * cols + x] = (vz[0] + vz[1] + vz[2] + vz[3]) / 4;
+            }
+            if ((nx[0] != nx[0]) || (nx[1] != nx[1]) || (nx[2] != nx[2]) || (nx[3] != nx[3])) {
+                nd[(size_t)y * cols + x] = qnan();
+            } else {
+                f3 m;
+                m.x = (nx[0] + nx[1] + nx[2] + nx[3]) / 4;
+                m.y = (ny[0] + ny[1] + ny[2] + ny[3]) / 4;
+                m.z = (nz[0] + nz[1] + nz[2] + nz[3]) / 4;
+                m = normalized(m);
+                nd[(size_t)y * cols + x] = m.x;
+                nd[(size_t)(y + rows) * cols + x] = m.y;
+                nd[(size_t)(y + 2 * rows) * cols + x] = m.z;
+            }
             break;
         }
         case PREP_PYR_PROJECT: {
