@@ -81,7 +81,12 @@ struct mmf_fusion {
     // clean / fill-in read one while frame t+1's filter writes the other.
     float* filtered[2] = {nullptr, nullptr};
     int cur = 0;
-    mmf_odom* so3_odom = nullptr;  // whose state holds the prefetched SO3 pre-alignment of the next frame
+    // The next frame's SO3 pre-alignment runs in one of two states of its own (by the parity of the frame it is for): no
+    // chain reads or writes them, so it can run while the current frame's chain is still at work; the chain's first launch
+    // copies the result into every tracked model's state (BeginArgs::so3_stage).
+    OdomState* so3_stage[2] = {nullptr, nullptr};
+    int so3_stage_ready = -1;               // which of the two holds the pre-alignment of the upcoming frame; -1: none
+    const uint8_t* image_pre_rgb = nullptr;  // the image side of this frame (intensity pyramid, gradients, SO3) is enqueued already
     GraphCache depth_chain_graphs, image_chain_graphs;  // the two launch chains of a prefetch (launch_graph.hpp)
     hipStream_t side = nullptr;   // depth chain: filter, depth pyramid, vertex / normal maps
     hipStream_t side2 = nullptr;  // image chain: intensity pyramid, gradients, SO3 pre-alignment
@@ -329,6 +334,7 @@ extern "C" void mmf_fusion_destroy(mmf_fusion* f) {
     }
     if (f->up_stream) (void)hipStreamDestroy(f->up_stream);
     if (f->ev_up_begin) (void)hipEventDestroy(f->ev_up_begin);
+    (void)hipFree(f->so3_stage[0]);
     if (f->ev_inputs_free) (void)hipEventDestroy(f->ev_inputs_free);
     if (f->ev_frame_ready) (void)hipEventDestroy(f->ev_frame_ready);
     if (f->ev_prefetch_done) (void)hipEventDestroy(f->ev_prefetch_done);
@@ -589,6 +595,7 @@ static int fusion_spawn(mmf_fusion* f, FusionModel** out) {
 }
 
 static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* depth, int tick_at_use);
+static int fusion_prefetch_image(mmf_fusion* f, const uint8_t* rgb, int tick_at_use);
 static int fusion_stage_host_next(mmf_fusion* f);
 
 static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
@@ -621,13 +628,16 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     }
     const bool track = f->tick > 1 && (fr->bootstrap || !fr->in_pose);  // :299 "regular execution"
     // a prefetched SO3 pre-alignment only counts for the frame it was computed for, and only when that frame is tracked
-    mmf_odom* const so3_pre = f->so3_odom;  // the odometry the prefetch ran the SO3 loop in (the one model this process runs)
-    f->so3_odom = nullptr;
-    if (so3_pre && (!prefetched || !track || (have_init && !fr->icp_refine))) so3_pre->so3_prefetched = false;
-    if (so3_pre != global->odom) global->odom->so3_prefetched = false;
+    const int so3_ready = f->so3_stage_ready;
+    f->so3_stage_ready = -1;
+    f->image_pre_rgb = nullptr;
+    const OdomState* const so3_stage =
+        (so3_ready >= 0 && prefetched && track && !(have_init && !fr->icp_refine)) ? f->so3_stage[so3_ready] : nullptr;
+    for (FusionModel* fm : f->models) fm->odom->so3_prefetched = false, fm->odom->so3_stage = nullptr;
     if (prefetched) {  // the filter (:262) and the input-side preparation already ran on the side stream
         f->cur ^= 1;
         f->depth_filtered = f->filtered[f->cur];
+        odom_adopt_gradients(global->odom);
     } else {
         rc = mmf_filter_depth(c, depth, f->width, f->height, g.depth_cutoff, f->depth_filtered);  // :262
         if (rc) return rc;
@@ -679,8 +689,33 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                                           nullptr, 4, identity, nullptr, nullptr, nullptr, nullptr,
                                           PREP_INPUT_IMAGE | PREP_INPUT_DEPTH);
                 if (rc) return rc;
+                odom_adopt_gradients(global->odom);
             }
             if (!one_pass) MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
+            // Round 3: the IMAGE side of the next frame -- intensity pyramid, gradients, SO3 pre-alignment: sixteen launches --
+            // depends on nothing the chains read or write (the image ring and the gradients are double buffered, the
+            // pre-alignment runs in a state of its own), so it need not wait behind the pose, where its enqueue was the longest
+            // part of the host's tail (93 us) and its stream the last thing the next frame's chain waited for.
+            //   MMF_EARLY_IMAGE=start (default): enqueued HERE, before this frame's chain: the GPU is still working off the
+            //     last frame's tail then, and the image side runs beside that, not beside the latency-bound chain;
+            //   =chain: after the chain's enqueue, while the host would only wait (runs beside the chain: +5..35 us on it);
+            //   =off: at the end of the call with the depth side.
+            // so3_stage: this frame's own pre-alignment ran ahead as well -- inside the chain it reads the LAST frame's level-2
+            // image, the half of the image ring the next frame's pyramid is written to.
+            static const int early_image = []() {
+                const char* e = std::getenv("MMF_EARLY_IMAGE");
+                return !e ? 2 : (std::strcmp(e, "off") == 0 ? 0 : (std::strcmp(e, "chain") == 0 ? 1 : 2));
+            }();
+            const bool image_early_ok = fr->next_rgb && fr->next_depth && f->side2 && g.so3 && so3_stage != nullptr &&
+                                        !(f->host_next.slot >= 0 && f->up_dev[0] != nullptr);  // (not a frame still being uploaded)
+            if (early_image == 2 && image_early_ok) {
+                // the ring as it will be once this frame's chain is enqueued (RGBDOdometry.cpp:469-473; odom_enqueue_tracking)
+                mmf_odom* go = global->odom;
+                for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(go->last_next_image[i], go->next_image[i]);
+                rc = fusion_prefetch_image(f, fr->next_rgb, f->tick + 1);
+                for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(go->last_next_image[i], go->next_image[i]);
+                if (rc) return rc;
+            }
             std::vector<FusionModel*> tracked;
             for (size_t k = 0; k < n_models; ++k) {  // :312-387, enqueue only
                 FusionModel* fm = f->models[k];
@@ -727,11 +762,8 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 fm->tracking = true;
                 tracked.push_back(fm);
             }
-            if (so3_pre && so3_pre->so3_prefetched) {  // ... in a model that is not tracked here on its own after all
-                bool used = tracked.size() == 1 && tracked[0]->odom == so3_pre;
-                used = used || (!tracked.empty() && tracked[0]->odom == so3_pre);  // the leader of a batch
-                if (!used) so3_pre->so3_prefetched = false;
-            }
+            if (so3_stage)  // every chain enqueued below starts from the prefetched pre-alignment
+                for (FusionModel* fm : tracked) fm->odom->so3_prefetched = true, fm->odom->so3_stage = so3_stage;
             // ONE chain of launches for all tracked models (gridDim.y = model) when every level runs on the fused
             // producer path and no model went through a pose-initialisation round on its own stream; else one chain
             // per model on the model's stream.  Either way nothing waits here.
@@ -764,6 +796,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 }
                 rc = stages.launch(st, graphs_enabled() ? &lead->odom->prep_graphs : nullptr);
                 if (rc) return rc;
+                // (a PREP_ALL collect above prepared this frame's image side as well; NOT when the pending gradients are the
+                // next frame's, from the image side enqueued ahead a few lines up)
+                if (one_pass && !prefetched) odom_adopt_gradients(global->odom);
                 batch_ok = odom_batchable(lead->odom, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom);
                 if (batch_ok) {
                     TrackBatch tb;
@@ -798,6 +833,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     collect_prep(stages, fm, (fm == global && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE);
                     rc = stages.launch(fm->lane->stream, graphs_enabled() ? &fm->odom->prep_graphs : nullptr);
                     if (rc) return rc;
+                    if (fm == global && one_pass && !prefetched) odom_adopt_gradients(global->odom);  // (PREP_ALL: this frame's image side as well)
                 } else if (k > 0) {  // prepared on the leader's stream
                     MMF_HIP_TRY(hipEventRecord(fm->ev_done, tracked[0]->lane->stream));
                     MMF_HIP_TRY(hipStreamWaitEvent(fm->lane->stream, fm->ev_done, 0));
@@ -860,6 +896,10 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // here, while the chains run and the host would only wait, instead of at the end of the call.  Correct (an
             // event behind the chain orders it) but 20 % SLOWER: the side streams then sit on a barrier packet for the
             // whole chain, and a dependent chain on another queue runs slower next to parked queues (308 -> 370-450 us).
+            if (early_image == 1 && image_early_ok && !tracked.empty()) {  // (see above)
+                rc = fusion_prefetch_image(f, fr->next_rgb, f->tick + 1);
+                if (rc) return rc;
+            }
             static const bool early = std::getenv("MMF_PREFETCH_EARLY") != nullptr;
             if (early && fr->next_rgb && fr->next_depth && !tracked.empty() && tracked[0]->lane->stream == c->stream &&
                 (tracked.size() == 1 || batch_ok)) {
@@ -1264,19 +1304,55 @@ extern "C" int mmf_fusion_predict(mmf_fusion* f) {
 // NEXT frame, enqueued on a second stream so that they run while the current frame is still being fused.
 // rgb / depth must stay unchanged until the mmf_fusion_process_frame call that consumes them (same pointers).
 // `tick_at_use`: the tick of the processFrame call these buffers are for
+static int fusion_prefetch_init(mmf_fusion* f) {
+    if (f->side != nullptr) return MMF_OK;
+    MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+    MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking));
+    MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch_done, hipEventDisableTiming));
+    MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch2_done, hipEventDisableTiming));
+    MMF_HIP_TRY(hipMalloc(&f->side_partials, sizeof(float) * kMaxGrid * kPartialStride));
+    MMF_HIP_TRY(hipMalloc(&f->side_ticket, sizeof(unsigned) * kTicketWords));
+    MMF_HIP_TRY(hipMemsetAsync(f->side_ticket, 0, sizeof(unsigned) * kTicketWords, f->side2));
+    MMF_HIP_TRY(hipMalloc(&f->so3_stage[0], 2 * sizeof(OdomState)));
+    f->so3_stage[1] = f->so3_stage[0] + 1;
+    MMF_HIP_TRY(hipMemsetAsync(f->so3_stage[0], 0, 2 * sizeof(OdomState), f->side2));
+    return MMF_OK;
+}
+
+// The image side of the frame the call with tick `tick_at_use` will be given: intensity pyramid + gradients into the
+// free halves of their double buffers, then the SO3 pre-alignment (this frame's against the last frame's level-2 image:
+// no model, no pose) in the staging state of that tick's parity.  Second side stream; needs the streams to exist.
+static int fusion_prefetch_image(mmf_fusion* f, const uint8_t* rgb, int tick_at_use) {
+    const mmf_fusion_config& g = f->cfg;
+    mmf_odom* odom = f->models[0]->odom;
+    float identity[16];
+    identity16(identity);
+    hipStream_t img_stream = f->side2;
+    // without the pre-alignment the image ring does not advance (RGBDOdometry.cpp:469-473 sits under `if (so3)`): the
+    // pyramid about to be overwritten is the one the chains read
+    if (!g.so3 && f->inputs_free_recorded) MMF_HIP_TRY(hipStreamWaitEvent(img_stream, f->ev_inputs_free, 0));
+    Enqueuer qi(img_stream, graphs_enabled() ? &f->image_chain_graphs : nullptr);
+    int rc = odom_prepare_batched(odom, nullptr, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity, nullptr,
+                                  nullptr, nullptr, nullptr, PREP_INPUT_IMAGE, img_stream, &qi);
+    if (rc) return rc;
+    f->so3_stage_ready = -1;
+    if (g.so3 && tick_at_use > 1) {  // a model exists: the frame will be tracked, SO3 first
+        const int s = tick_at_use & 1;
+        rc = odom_prefetch_so3(odom, qi, f->side_partials, f->side_ticket, f->so3_stage[s]);
+        if (rc) return rc;
+        f->so3_stage_ready = s;
+    }
+    MMF_HIP_TRY(qi.flush());
+    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch2_done, img_stream));
+    f->image_pre_rgb = rgb;
+    return MMF_OK;
+}
+
 static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* depth, int tick_at_use) {
     mmf_ctx* c = f->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     mmf_odom* odom = f->models[0]->odom;
-    if (f->side == nullptr) {  // first use
-        MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
-        MMF_HIP_TRY(hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking));
-        MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch_done, hipEventDisableTiming));
-        MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_prefetch2_done, hipEventDisableTiming));
-        MMF_HIP_TRY(hipMalloc(&f->side_partials, sizeof(float) * kMaxGrid * kPartialStride));
-        MMF_HIP_TRY(hipMalloc(&f->side_ticket, sizeof(unsigned) * kTicketWords));
-        MMF_HIP_TRY(hipMemsetAsync(f->side_ticket, 0, sizeof(unsigned) * kTicketWords, f->side2));
-    }
+    if (int rc0 = fusion_prefetch_init(f)) return rc0;
     f->pre_valid = false;  // an earlier prefetch is simply overwritten: same streams, same order
     if (f->host_next.slot >= 0 && f->up_dev[0] && rgb == f->up_dev[f->host_next.slot] + (size_t)f->width * f->height * 4) {
         // the hinted frame comes from host memory (mmf_fusion_process_frame_host_next): behind its upload
@@ -1284,16 +1360,13 @@ static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* 
         MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_up[f->host_next.slot], 0));
         MMF_HIP_TRY(hipStreamWaitEvent(f->side2, f->ev_up[f->host_next.slot], 0));
     }
-    if (f->inputs_free_recorded) {
-        MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_inputs_free, 0));
-        MMF_HIP_TRY(hipStreamWaitEvent(f->side2, f->ev_inputs_free, 0));
-    }
+    if (f->inputs_free_recorded) MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_inputs_free, 0));
     const mmf_fusion_config& g = f->cfg;
     float identity[16];
     identity16(identity);
-    // depth chain (first side stream): filter, depth pyramid, vertex and normal maps.  Enqueued FIRST: it is five
-    // launches that start with the 40 us filter, while the image chain below is fifteen short ones -- behind those the
-    // filter started ~100 us later (one host enqueue per launch) and the next frame waited for it.
+    // depth chain (first side stream): filter, depth pyramid, vertex and normal maps -- what the chains' ICP term reads,
+    // hence behind ev_inputs_free.  Enqueued before the image chain when that is still to come: it is five launches that
+    // start with the 40 us filter, the image chain fifteen short ones.
     float* target = f->filtered[1 - f->cur];
     Enqueuer qd(f->side, graphs_enabled() ? &f->depth_chain_graphs : nullptr);
     int rc = filter_depth_on(c, qd, depth, f->width, f->height, g.depth_cutoff, target);
@@ -1303,37 +1376,10 @@ static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* 
     if (rc) return rc;
     MMF_HIP_TRY(qd.flush());
     MMF_HIP_TRY(hipEventRecord(f->ev_prefetch_done, f->side));
-    hipStream_t img_stream = f->side2;
-    Enqueuer qi(img_stream, graphs_enabled() ? &f->image_chain_graphs : nullptr);
-    // image chain (second side stream): intensity pyramid + gradients, then the SO3 pre-alignment, which needs
-    // nothing but this frame's and the last frame's level-2 images
-    rc = odom_prepare_batched(odom, nullptr, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity, nullptr,
-                              nullptr, nullptr, nullptr, PREP_INPUT_IMAGE, img_stream, &qi);
-    if (rc) return rc;
-    odom->so3_prefetched = false;
-    if (g.so3 && tick_at_use > 1) {  // a model exists: the frame will be tracked, SO3 first
-        // Every model's odometry runs the same pre-alignment on the same two images (RGBDOdometry.cpp:239-310 has no model
-        // input).  It is computed in the state of the model that will consume it: the global model's, or -- when this
-        // process runs exactly one other model (a rank of the shard) -- that model's, whose sensor-side pointers alias
-        // the global odometry's.
-        mmf_odom* target = odom;
-        int owned = 0;
-        for (size_t k = 0; k < f->models.size(); ++k)
-            if (fusion_owns(f, k)) {
-                ++owned;
-                target = f->models[k]->odom;
-            }
-        if (owned != 1) target = odom;
-        if (target != odom) {
-            odom_alias_sensor_side(target, odom);
-            target->so3_prefetched = false;
-        }
-        rc = odom_prefetch_so3(target, qi, f->side_partials, f->side_ticket);
+    if (f->image_pre_rgb != rgb) {  // (else: enqueued while the chains ran)
+        rc = fusion_prefetch_image(f, rgb, tick_at_use);
         if (rc) return rc;
-        f->so3_odom = target;
     }
-    MMF_HIP_TRY(qi.flush());
-    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch2_done, img_stream));
     f->pre_valid = true, f->pre_rgb = rgb, f->pre_depth = depth;
     return MMF_OK;
 }
@@ -1380,13 +1426,13 @@ extern "C" int mmf_fusion_reset(mmf_fusion* f) {
         if (rc) return rc;
         fm->model->conf_threshold = fm->model->id == 0 ? f->cfg.conf_global_init : f->cfg.conf_object_init;
         identity16(fm->last_pose);
-        fm->odom->so3_prefetched = false;
+        fm->odom->so3_prefetched = false, fm->odom->so3_stage = nullptr;
         fm->odom->have_tmp = false;
         fm->unseen = 0;
         fm->pose_log.clear();
     }
     for (FusionModel* fm : all) fm->spec_valid = false;
-    f->so3_odom = nullptr;
+    f->so3_stage_ready = -1, f->image_pre_rgb = nullptr;
     f->tick = 1;
     return MMF_OK;
 }

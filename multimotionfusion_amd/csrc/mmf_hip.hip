@@ -790,6 +790,12 @@ struct mmf_odom {
     // last_depth (both come from the same prediction, RGBDOdometry.cpp:179 -- see odom_populate_rgbd)
     bool prep_batched = false;
     bool so3_prefetched = false;  // this frame's SO3 pre-alignment already ran (odom_prefetch_so3)
+    const OdomState* so3_stage = nullptr;  // ... in this state (nullptr: in this odometry's own)
+    // The gradient images are double buffered: the batched image-side preparation writes grad_w_*, the chain reads dIdx /
+    // dIdy, and odom_adopt_gradients swaps the two when a prepared frame becomes the frame that is tracked -- so that the
+    // NEXT frame's image side can be prepared while this frame's chain still reads its gradients.
+    int16_t *grad_w_dx[MMF_NUM_PYRS], *grad_w_dy[MMF_NUM_PYRS];
+    bool grad_pending = false;  // grad_w_* hold a prepared frame's gradients
     // The one-launch-per-iteration chain has a barrier inside every launch: its workgroups must all become resident.  Two
     // such launches from different streams can each hold part of the GPU and wait for the rest forever, so an owner that
     // keeps several chains in flight at once (the orchestrator without batching) clears this and gets the two-launch chain.
@@ -841,7 +847,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     const size_t n0 = (size_t)width * height;
     size_t o_vt = carve(4 * n0 * 4), o_nt = carve(4 * n0 * 4);
     size_t o_vgp[3], o_ngp[3], o_vc[3], o_nc[3], o_ld[3], o_nd[3], o_dp[3], o_li[3], o_ni[3], o_lni[3], o_dx[3],
-        o_dy[3], o_cl[3], o_c4[3], o_co[3], o_pp[3];
+        o_dy[3], o_dx2[3], o_dy2[3], o_cl[3], o_c4[3], o_co[3], o_pp[3];
     for (int i = 0; i < MMF_NUM_PYRS; ++i) {
         const size_t n = (size_t)(width >> i) * (height >> i);
         o_vgp[i] = carve(3 * n * 4);
@@ -856,6 +862,8 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
         o_lni[i] = carve(n);
         o_dx[i] = carve(n * 2);
         o_dy[i] = carve(n * 2);
+        o_dx2[i] = carve(n * 2);
+        o_dy2[i] = carve(n * 2);
         o_cl[i] = carve(3 * n * 4);
         o_c4[i] = carve(4 * n * 4);
         o_co[i] = carve(n * sizeof(mmf_dataterm));
@@ -889,6 +897,8 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
         o->last_next_image[i] = (uint8_t*)(base + o_lni[i]);
         o->dIdx[i] = (int16_t*)(base + o_dx[i]);
         o->dIdy[i] = (int16_t*)(base + o_dy[i]);
+        o->grad_w_dx[i] = (int16_t*)(base + o_dx2[i]);
+        o->grad_w_dy[i] = (int16_t*)(base + o_dy2[i]);
         o->cloud[i] = (float*)(base + o_cl[i]);
         o->cloud4[i] = (float*)(base + o_c4[i]);
         o->corres[i] = (mmf_dataterm*)(base + o_co[i]);
@@ -1201,7 +1211,7 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
         }
         if (in_img) {
             PrepJob& d = pb.add(PREP_DERIV, cols, rows);
-            d.src0 = o->next_image[lvl], d.dst0 = o->dIdx[lvl], d.dst1 = o->dIdy[lvl];
+            d.src0 = o->next_image[lvl], d.dst0 = o->grad_w_dx[lvl], d.dst1 = o->grad_w_dy[lvl];  // (odom_adopt_gradients)
         }
         if (in_depth) {
             PrepJob& nm = pb.add(PREP_NMAP, cols, rows);
@@ -1296,6 +1306,13 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
         level_jobs(pb, 2);
     }
     if (model_side) o->prep_batched = true;
+    if (in_img) o->grad_pending = true;
+}
+// the gradients the batched preparation wrote last become the ones the chain reads
+static void odom_adopt_gradients(mmf_odom* o) {
+    if (!o->grad_pending) return;
+    o->grad_pending = false;
+    for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(o->dIdx[i], o->grad_w_dx[i]), std::swap(o->dIdy[i], o->grad_w_dy[i]);
 }
 
 static int odom_prepare_batched(mmf_odom* o, const float* depth_filtered, float depth_cutoff, const uint8_t* rgb,
@@ -1332,8 +1349,9 @@ static IcpArgs odom_icp_args(mmf_odom* o, int level, float* err_map) {
 
 // the ten launches of the SO3 pre-alignment (RGBDOdometry.cpp:239-310): last frame's image against this frame's
 // at level 2 -- no model, no pose
-static int odom_enqueue_so3(mmf_odom* o, Enqueuer& q, float* partials = nullptr, unsigned* ticket = nullptr) {
+static int odom_enqueue_so3(mmf_odom* o, Enqueuer& q, float* partials = nullptr, unsigned* ticket = nullptr, OdomState* state = nullptr) {
     if (!partials) partials = o->gn_partials_f, ticket = o->gn_ticket;
+    if (!state) state = o->state;
     const int lvl = 2, cols = o->width >> lvl, rows = o->height >> lvl;
     So3Args a;
     a.last_image = o->last_next_image[lvl];
@@ -1344,18 +1362,16 @@ static int odom_enqueue_so3(mmf_odom* o, Enqueuer& q, float* partials = nullptr,
     a.intr = level_intr(o->fx, o->fy, o->cx, o->cy, 2);
     a.cols_magic = (unsigned)((1ull << 32) / (unsigned)cols) + 1u;
     const int grid = reduce_grid(cols * rows, kBlock);
-    for (int i = 0; i < 10; ++i) q.launch((so3_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), o->state, a, partials, ticket);
+    for (int i = 0; i < 10; ++i) q.launch((so3_kernel<FINISH_GN>), dim3(grid), dim3(kBlock), state, a, partials, ticket);
     return MMF_OK;
 }
 
 // the SO3 pre-alignment of the NEXT frame ahead of its tracking, on `stream` (after that frame's intensity
 // pyramid): its begin part, then the ten launches; getIncrementalTransformation then skips both
-static int odom_prefetch_so3(mmf_odom* o, Enqueuer& q, float* partials, unsigned* ticket) {
-    q.launch(so3_begin_kernel, dim3(1), dim3(64), o->state, level_intr(o->fx, o->fy, o->cx, o->cy, 2));
-    int rc = odom_enqueue_so3(o, q, partials, ticket);
-    if (rc) return rc;
-    o->so3_prefetched = true;
-    return MMF_OK;
+// `stage`: the state the pre-alignment runs in (its images are o's); the caller tells the consumer (mmf_odom::so3_stage)
+static int odom_prefetch_so3(mmf_odom* o, Enqueuer& q, float* partials, unsigned* ticket, OdomState* stage) {
+    q.launch(so3_begin_kernel, dim3(1), dim3(64), stage, level_intr(o->fx, o->fy, o->cx, o->cy, 2));
+    return odom_enqueue_so3(o, q, partials, ticket, stage);
 }
 
 // RGBDOdometry::getIncrementalTransformation (RGBDOdometry.cpp:217-477), device resident:
@@ -1454,6 +1470,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     b.icp_weight = icp_weight;
     b.so3_intr = level_intr(o->fx, o->fy, o->cx, o->cy, 2);
     b.so3_prefetched = (so3 && o->so3_prefetched) ? 1 : 0;
+    b.so3_stage = b.so3_prefetched ? o->so3_stage : nullptr;
     // nothing runs between the beginning and the first level's begin unless the SO3 loop does: one launch
     const bool fold_first_level = !so3 || o->so3_prefetched;
     b.fold_level_begin = fold_first_level ? 1 : 0;
@@ -1472,6 +1489,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         if (rc) return rc;
     }
     o->so3_prefetched = false;
+    o->so3_stage = nullptr;
 
     GnIterArgs final_args;
     bool final_pending = false;

@@ -772,6 +772,10 @@ struct BeginArgs {
     int so3_prefetched;  // the SO3 pre-alignment of this frame already ran (so3_begin_kernel + the so3 launches)
     int fold_level_begin;  // nothing runs between this kernel and the first gn_level_begin: do it here
     LevelIntr first_intr;  // intrinsics of the first (coarsest) level
+    // so3_prefetched: where the pre-alignment sits complete -- a state of its own that no chain touches (the orchestrator's
+    // staging states: the next frame's pre-alignment runs while this frame's chain is still at work), or nullptr = in the
+    // leader's state
+    const OdomState* so3_stage;
 };
 
 // the SO3 part of the beginning (RGBDOdometry.cpp:239-255): depends on the two images only, so the orchestrator
@@ -849,6 +853,8 @@ __global__ void odom_begin_kernel(OdomState* st, BeginArgs a, BatchDelta bd, Beg
     for (int k = 0; k < kResShards; ++k) st->gn_acc[0][kResStride * k] = 0ull;  // the first gn_iter_kernel launch adds here
     if (!a.so3_prefetched)
         so3_begin(st, a.so3_intr, a.so3);
+    else if (a.so3_stage)
+        so3_share(st, a.so3_stage);
     else if (blockIdx.x > 0)
         so3_share(st, leader);  // the prefetched pre-alignment sits complete in the leader's state (nobody writes it here)
     if (a.fold_level_begin) gn_level_begin(st, 1, a.first_intr);
