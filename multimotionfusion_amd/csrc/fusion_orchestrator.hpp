@@ -843,9 +843,12 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 const float trans[3] = {pose[3], pose[7], pose[11]};
                 const float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
                 fm->odom->exclusive_chain = tracked.size() == 1;  // several chains side by side: no in-launch barriers
-                // the predict() enqueued right behind this chain (below) carries the hand-over to the host (frame_rider.hpp)
-                static const bool no_rider = std::getenv("MMF_NO_RIDER") != nullptr;  // A/B aid
-                fm->odom->defer_publish = tracked.size() == 1 && !fr->bootstrap && !have_init && !g.rgb_only && fm->fill_in && !no_rider;
+                // MMF_RIDER=1: the predict() enqueued right behind this chain (below) carries the hand-over to the host
+                // (frame_rider.hpp).  Off by default: with the next frame's image side out of the host's tail the model's stream
+                // is what a frame waits for, and there the rider costs more than it saves (2 651-2 669 against 2 696-2 706
+                // frames/s without it: its system-scope stores hold the resolve launch open).
+                static const bool rider = std::getenv("MMF_RIDER") != nullptr;
+                fm->odom->defer_publish = rider && tracked.size() == 1 && !fr->bootstrap && !have_init && !g.rgb_only && fm->fill_in;
                 rc = odom_enqueue_tracking(fm->odom, trans, rot, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom, g.so3,
                                            fm->icp_error, fm->rgb_error);
                 if (rc) return rc;
