@@ -787,6 +787,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     MMF_HIP_TRY(hipStreamWaitEvent(st, tracked[k]->ev_done, 0));
                 }
                 PrepStages stages;
+                stages.set_critical(true);  // the model's stream
                 for (size_t k = 0; k < tracked.size(); ++k) {
                     if (tracked[k]->spec_hit) {
                         tracked[k]->odom->depth_l0 = f->depth_filtered;
@@ -830,6 +831,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     fm->odom->depth_l0 = f->depth_filtered;  // (or just above)
                 } else if (!batched) {  // (a failed batch has prepared every model already)
                     PrepStages stages;
+                stages.set_critical(true);  // the model's stream
                     collect_prep(stages, fm, (fm == global && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE);
                     rc = stages.launch(fm->lane->stream, graphs_enabled() ? &fm->odom->prep_graphs : nullptr);
                     if (rc) return rc;
@@ -1102,6 +1104,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 MMF_HIP_TRY(hipGetLastError());
             }
             PrepStages stages;
+                stages.set_critical(true);  // the model's stream
             const uint8_t* pi = (const uint8_t*)((g.frame_to_frame_rgb && only->fill_in) ? m->fill_image : m->image);
             mmf_model_get_pose(only->model, only->spec_pose);
             odom_prepare_collect(stages, only->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,

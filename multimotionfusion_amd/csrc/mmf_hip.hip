@@ -1098,6 +1098,7 @@ extern "C" int mmf_odom_init_first_rgb(mmf_odom* o, const uint8_t* rgb, size_t s
 // ---- the whole per-frame preparation in four launches (prep_batch.hpp) -------------------------
 struct PrepBuilder {  // the jobs of one stage (possibly of several models); launched kMaxPrepJobs at a time
     std::vector<PrepJob> jobs;
+    bool critical = false;  // PrepBatch::critical
     PrepJob& add(int op, int cols, int rows) {
         if (jobs.capacity() < 96) jobs.reserve(96);  // references handed out stay valid while a stage is being filled
         jobs.emplace_back();
@@ -1112,6 +1113,7 @@ struct PrepBuilder {  // the jobs of one stage (possibly of several models); lau
         for (size_t first = 0; first < jobs.size(); first += kMaxPrepJobs) {
             PrepBatch b;
             b.njobs = 0;
+            b.critical = critical ? 1 : 0;
             int blocks = 0;
             for (size_t k = first; k < jobs.size() && b.njobs < kMaxPrepJobs; ++k) {
                 PrepJob& j = b.job[b.njobs++];
@@ -1127,6 +1129,9 @@ struct PrepBuilder {  // the jobs of one stage (possibly of several models); lau
 };
 struct PrepStages {  // the four dependent launches of a frame's preparation
     PrepBuilder stage[4];
+    void set_critical(bool on) {
+        for (PrepBuilder& pb : stage) pb.critical = on;
+    }
     int launch(Enqueuer& q) {  // recorded; the caller flushes
         for (PrepBuilder& pb : stage)
             if (int rc = pb.launch(q)) return rc;

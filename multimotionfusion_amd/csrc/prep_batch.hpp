@@ -59,6 +59,7 @@ struct PrepJob {
 constexpr int kMaxPrepJobs = 24;  // 24 x 144 B of kernel arguments; longer job lists go out as several launches
 struct PrepBatch {
     int njobs;
+    int critical;  // 1: on the model's stream (what a frame waits for): its waves ask for issue priority over side-stream work
     PrepJob job[kMaxPrepJobs];
 };
 
@@ -106,6 +107,7 @@ __device__ __forceinline__ void transform_pack_px(int x, int y, int rows, int co
 }
 
 __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
+    if (b.critical) __builtin_amdgcn_s_setprio(3);
     int j = 0;
     for (int k = 1; k < b.njobs; ++k) j = (int)blockIdx.x >= b.job[k].first_block ? k : j;  // wave uniform
     const PrepJob& J = b.job[j];

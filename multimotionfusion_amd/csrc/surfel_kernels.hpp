@@ -24,6 +24,15 @@
 #include "../../include/mmf_math.h"
 #include "frame_rider.hpp"
 
+// The surfel passes run on the model's stream, which is what a frame waits for, while the next frame's bilateral filter
+// (ALU bound on every CU for ~42 us) runs beside them on a side stream: their waves ask for issue priority over the
+// filter's (s_setprio; the default is 0, the lowest).
+#ifndef MMF_NO_PRIO
+#define MMF_MODEL_STREAM_PRIORITY() __builtin_amdgcn_s_setprio(3)
+#else
+#define MMF_MODEL_STREAM_PRIORITY() do {} while (0)
+#endif
+
 namespace mmf {
 
 struct v3 {
@@ -422,6 +431,7 @@ struct IndexArgs {
 
 __global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, IndexArgs a_in,
                                                         unsigned long long* __restrict__ keys) {
+    MMF_MODEL_STREAM_PRIORITY();
     const IndexArgs a = with_device_pose(a_in);
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= count) return;
@@ -452,6 +462,7 @@ __global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexAr
                                                             unsigned long long* __restrict__ keys,
                                                             unsigned* __restrict__ index, float4* __restrict__ vertConf,
                                                             float4* __restrict__ colorTime, float4* __restrict__ normRad) {
+    MMF_MODEL_STREAM_PRIORITY();
     const IndexArgs a = with_device_pose(a_in);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.cols * a.rows) return;
@@ -565,6 +576,7 @@ __device__ __forceinline__ bool splat_fragment(const SplatFrag& f, const SplatAr
 __global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, SplatArgs a_in,
                                                     unsigned long long* __restrict__ keys,
                                                     const unsigned* __restrict__ count_dev) {
+    MMF_MODEL_STREAM_PRIORITY();
     const SplatArgs a = with_device_pose(a_in);
     __shared__ SplatFrag frag_lds[256];
     __shared__ int row_end[256];  // inclusive scan of the sprite heights inside each wave
@@ -688,6 +700,7 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatAr
                                                             uchar4* __restrict__ image, float4* __restrict__ vertexConf,
                                                             float4* __restrict__ normalRadius,
                                                             unsigned short* __restrict__ time_out) {
+    MMF_MODEL_STREAM_PRIORITY();
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
@@ -743,6 +756,7 @@ __global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restric
                                                         const unsigned* __restrict__ index, const float4* __restrict__ vertConf,
                                                         const float4* __restrict__ normRad, FuseArgs a_in, SurfelSoA meas,
                                                         unsigned* __restrict__ new_flags, unsigned* __restrict__ winner) {
+    MMF_MODEL_STREAM_PRIORITY();
     FuseArgs a = a_in;
     if (a_in.pose_dev) {
 #pragma unroll
@@ -864,6 +878,7 @@ __global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restric
 // update.vert:38-111, in place (each surfel only touches itself); resets winner[] for the next frame
 __global__ __launch_bounds__(256) void fuse_update_kernel(SurfelSoA s, int count, SurfelSoA meas, int time,
                                                           unsigned* __restrict__ winner) {
+    MMF_MODEL_STREAM_PRIORITY();
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
     const unsigned w = winner[k];
@@ -1055,6 +1070,7 @@ __global__ __launch_bounds__(256) void clean_flag_kernel(SurfelSoA s, SurfelSoA 
                                                          const float* __restrict__ depth_in, const uint8_t* __restrict__ mask,
                                                          unsigned* __restrict__ keep, float2* __restrict__ conf_time,
                                                          unsigned* __restrict__ block_sums) {
+    MMF_MODEL_STREAM_PRIORITY();
     const CleanArgs a = with_device_pose(a_in);
     const int e = blockIdx.x * 256 + threadIdx.x;
     unsigned k = 0u;
@@ -1076,6 +1092,7 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
                                                             const float2* __restrict__ conf_time, SurfelSoA dst,
                                                             int capacity, unsigned* __restrict__ total_out,
                                                             unsigned* __restrict__ total_host, unsigned seq) {
+    MMF_MODEL_STREAM_PRIORITY();
     __shared__ unsigned wave_part[4], wave_kept[4];
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1187,6 +1204,7 @@ __global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, Sp
                                                                  int passthrough_rgb, float4* __restrict__ vertex_out,
                                                                  float4* __restrict__ normal_out, uchar4* __restrict__ image_out,
                                                                  FrameRider rider) {
+    MMF_MODEL_STREAM_PRIORITY();
     if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
         frame_rider_run(rider);
         return;
