@@ -595,7 +595,7 @@ static int fusion_spawn(mmf_fusion* f, FusionModel** out) {
 }
 
 static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* depth, int tick_at_use);
-static int fusion_prefetch_image(mmf_fusion* f, const uint8_t* rgb, int tick_at_use);
+static int fusion_prefetch_image(mmf_fusion* f, const uint8_t* rgb, int tick_at_use, bool ahead);
 static int fusion_stage_host_next(mmf_fusion* f);
 
 static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
@@ -643,6 +643,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
         if (rc) return rc;
     }
     f->frame_rgb = rgb, f->frame_depth = depth;
+    f->inputs_free_recorded = false;  // (set again by the branches below that record ev_inputs_free)
     if (!g.enable_multiple_models && !f->mask_is_zero) {  // :268-275: everything is background
         MMF_HIP_TRY(hipMemsetAsync(f->mask, 0, (size_t)f->width * f->height, c->stream));
         f->mask_is_zero = true;
@@ -712,7 +713,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 // the ring as it will be once this frame's chain is enqueued (RGBDOdometry.cpp:469-473; odom_enqueue_tracking)
                 mmf_odom* go = global->odom;
                 for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(go->last_next_image[i], go->next_image[i]);
-                rc = fusion_prefetch_image(f, fr->next_rgb, f->tick + 1);
+                rc = fusion_prefetch_image(f, fr->next_rgb, f->tick + 1, true);
                 for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(go->last_next_image[i], go->next_image[i]);
                 if (rc) return rc;
             }
@@ -867,11 +868,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 FusionModel* fm = tracked[0];
                 mmf_model* m = fm->model;
                 // "nothing enqueued so far reads the odometries' sensor-side buffers or the other filtered-depth buffer" holds
-                // HERE, behind the one chain of this process; the passes enqueued next do not read them either.  (Recorded
-                // behind them, the event kept the next frame's side-stream work waiting until the clean pass had run.)
-                MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, fm->lane->stream));
-                f->inputs_free_recorded = true;
-                inputs_free_early = true;
+                // HERE, behind the one chain of this process; the passes enqueued next do not read them either.  No event
+                // says so any more (see below: the host knows when it has the pose; a marker behind the chain cost the
+                // model's stream ~4 us in front of the frame's first projection).
                 m->t_inv_dev = fm->odom->state->pose_inv;
                 m->rider = fm->odom->rider;
                 fm->odom->rider = FrameRider();
@@ -902,7 +901,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // event behind the chain orders it) but 20 % SLOWER: the side streams then sit on a barrier packet for the
             // whole chain, and a dependent chain on another queue runs slower next to parked queues (308 -> 370-450 us).
             if (early_image == 1 && image_early_ok && !tracked.empty()) {  // (see above)
-                rc = fusion_prefetch_image(f, fr->next_rgb, f->tick + 1);
+                rc = fusion_prefetch_image(f, fr->next_rgb, f->tick + 1, true);
                 if (rc) return rc;
             }
             static const bool early = std::getenv("MMF_PREFETCH_EARLY") != nullptr;
@@ -946,11 +945,10 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 std::memcpy(global->last_pose, np, sizeof(np));
             }
             // from here on nothing enqueued reads the odometries' sensor-side buffers or the other filtered-depth
-            // buffer (every lane's tracking has been awaited): the next frame's prefetch may start
-            if (!inputs_free_early) {
-                MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
-                f->inputs_free_recorded = true;
-            }
+            // buffer, and the HOST knows it: every chain's result has been received, so every chain -- and whatever its
+            // stream held before it, e.g. this frame's own image-side preparation -- has run.  The next frame's side-stream
+            // work, enqueued from here on, needs no event to wait for (inputs_free_recorded stays false).
+            (void)inputs_free_early;
             if (one_pass) MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
 
             if (g.enable_multiple_models) {  // :407-622
@@ -1328,15 +1326,16 @@ static int fusion_prefetch_init(mmf_fusion* f) {
 // The image side of the frame the call with tick `tick_at_use` will be given: intensity pyramid + gradients into the
 // free halves of their double buffers, then the SO3 pre-alignment (this frame's against the last frame's level-2 image:
 // no model, no pose) in the staging state of that tick's parity.  Second side stream; needs the streams to exist.
-static int fusion_prefetch_image(mmf_fusion* f, const uint8_t* rgb, int tick_at_use) {
+// ahead: enqueued at the start of a frame whose own image side was prepared on this same stream (nothing to wait for);
+// else behind ev_inputs_free where a frame recorded it (the first frame's intensity pyramid and an untracked frame's
+// preparation are written on the fusion's stream; after a tracked frame the host has the poses: everything is done)
+static int fusion_prefetch_image(mmf_fusion* f, const uint8_t* rgb, int tick_at_use, bool ahead) {
     const mmf_fusion_config& g = f->cfg;
     mmf_odom* odom = f->models[0]->odom;
     float identity[16];
     identity16(identity);
     hipStream_t img_stream = f->side2;
-    // without the pre-alignment the image ring does not advance (RGBDOdometry.cpp:469-473 sits under `if (so3)`): the
-    // pyramid about to be overwritten is the one the chains read
-    if (!g.so3 && f->inputs_free_recorded) MMF_HIP_TRY(hipStreamWaitEvent(img_stream, f->ev_inputs_free, 0));
+    if (!ahead && f->inputs_free_recorded) MMF_HIP_TRY(hipStreamWaitEvent(img_stream, f->ev_inputs_free, 0));
     Enqueuer qi(img_stream, graphs_enabled() ? &f->image_chain_graphs : nullptr);
     int rc = odom_prepare_batched(odom, nullptr, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity, nullptr,
                                   nullptr, nullptr, nullptr, PREP_INPUT_IMAGE, img_stream, &qi);
@@ -1383,7 +1382,7 @@ static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* 
     MMF_HIP_TRY(qd.flush());
     MMF_HIP_TRY(hipEventRecord(f->ev_prefetch_done, f->side));
     if (f->image_pre_rgb != rgb) {  // (else: enqueued while the chains ran)
-        rc = fusion_prefetch_image(f, rgb, tick_at_use);
+        rc = fusion_prefetch_image(f, rgb, tick_at_use, false);
         if (rc) return rc;
     }
     f->pre_valid = true, f->pre_rgb = rgb, f->pre_depth = depth;
