@@ -621,8 +621,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     bool prefetched = false;
     bool next_prefetched = false;  // mmf_frame::next_* has been enqueued
     if (f->pre_valid) {  // whatever was prefetched has to be complete before this frame touches the same buffers
-        MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch_done, 0));
-        MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch2_done, 0));
+        MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_prefetch_done, 0));  // (recorded behind BOTH side streams' work)
         prefetched = f->pre_rgb == rgb && f->pre_depth == depth;
         f->pre_valid = false;
     }
@@ -692,7 +691,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 if (rc) return rc;
                 odom_adopt_gradients(global->odom);
             }
-            if (!one_pass) MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
+            // (waited for by the other models' streams only: one model and no segmentation = no marker on the model's stream)
+            const bool lanes_wait = g.enable_multiple_models || n_models > 1;
+            if (!one_pass && lanes_wait) MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
             // Round 3: the IMAGE side of the next frame -- intensity pyramid, gradients, SO3 pre-alignment: sixteen launches --
             // depends on nothing the chains read or write (the image ring and the gradients are double buffered, the
             // pre-alignment runs in a state of its own), so it need not wait behind the pose, where its enqueue was the longest
@@ -949,7 +950,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // stream held before it, e.g. this frame's own image-side preparation -- has run.  The next frame's side-stream
             // work, enqueued from here on, needs no event to wait for (inputs_free_recorded stays false).
             (void)inputs_free_early;
-            if (one_pass) MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
+            if (one_pass && lanes_wait) MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
 
             if (g.enable_multiple_models) {  // :407-622
                 mmf_segmentation seg_cb;
@@ -1380,11 +1381,13 @@ static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* 
                               nullptr, nullptr, nullptr, PREP_INPUT_DEPTH, f->side, &qd);
     if (rc) return rc;
     MMF_HIP_TRY(qd.flush());
-    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch_done, f->side));
-    if (f->image_pre_rgb != rgb) {  // (else: enqueued while the chains ran)
+    if (f->image_pre_rgb != rgb) {  // (else: enqueued at the start of the frame)
         rc = fusion_prefetch_image(f, rgb, tick_at_use, false);
         if (rc) return rc;
     }
+    // ONE event for the consumer: the first side stream takes in the second's (one wait less on the model's stream)
+    MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_prefetch2_done, 0));
+    MMF_HIP_TRY(hipEventRecord(f->ev_prefetch_done, f->side));
     f->pre_valid = true, f->pre_rgb = rgb, f->pre_depth = depth;
     return MMF_OK;
 }
