@@ -540,6 +540,11 @@ static void odom_alias_sensor_side(mmf_odom* o, const mmf_odom* primary) {
     o->depth_l0 = primary->depth_l0;
 }
 
+// the covered thumbnail samples of a model's latest prediction (thumbnail_count_px)
+static const int* fusion_thumb_count(const mmf_model* m) {
+    return reinterpret_cast<const int*>(&m->totals[4 + (m->tex_gen & 1)]);
+}
+
 // Model::combinedPredict(ACTIVE) + Model::performFillIn of one model (the body of predict(), :863-875)
 static int fusion_predict_model(mmf_fusion* f, FusionModel* fm) {
     const mmf_fusion_config& g = f->cfg;
@@ -751,13 +756,8 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 }
                 if (!do_icp) continue;  // no refinement, use the initial pose directly (:382-385)
                 // Model::performTracking (Model.cpp:409-433) with Model::initICP (:390-407).  requiresFillIn (:380,
-                // :877-895) is decided on the device: the preparation jobs pick their sources from the flag
-                const mmf_model* m = fm->model;
-                if (fm->fill_in && !fm->spec_hit) {
-                    hipLaunchKernelGGL(thumbnail_flag_kernel, dim3(1), dim3(256), 0, fm->lane->stream, m->image, m->width,
-                                       m->height, 0.75f, reinterpret_cast<int*>(&m->totals[3]));
-                    MMF_HIP_TRY(hipGetLastError());
-                }
+                // :877-895) is decided on the device: the preparation jobs pick their sources by the count of covered
+                // thumbnail samples the prediction's resolve pass left behind (surfel_kernels.hpp: thumbnail_count_px)
                 float pose[16];
                 mmf_model_get_pose(fm->model, pose);
                 std::memcpy(fm->last_pose, pose, sizeof(pose));  // lastPose = pose (Model.cpp:412)
@@ -777,8 +777,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 mmf_model_get_pose(fm->model, pose);
                 odom_prepare_collect(stages, fm->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
                                      (const float*)m->normalRadius, pi, 4, pose,
-                                     fm->fill_in ? reinterpret_cast<const int*>(&m->totals[3]) : nullptr, (const float*)m->fill_vertex,
-                                     (const float*)m->fill_normal, (const uint8_t*)m->fill_image, side);
+                                     fm->fill_in ? fusion_thumb_count(m) : nullptr, (const float*)m->fill_vertex,
+                                     (const float*)m->fill_normal, (const uint8_t*)m->fill_image, side, (m->width / 20) * (m->height / 20),
+                                     0.75f);
             };
             bool batch_ok = batched;
             if (batched) {
@@ -1097,19 +1098,16 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
         if (owned == 1) {
             const mmf_model* m = only->model;
             hipStream_t st = only->lane->stream;
-            if (only->fill_in) {  // requiresFillIn (:380, :877-895) of the next frame: decided on the device from this prediction
-                hipLaunchKernelGGL(thumbnail_flag_kernel, dim3(1), dim3(256), 0, st, m->image, m->width, m->height, 0.75f,
-                                   reinterpret_cast<int*>(&m->totals[3]));
-                MMF_HIP_TRY(hipGetLastError());
-            }
+            // (requiresFillIn (:380, :877-895) of the next frame: decided on the device from the count this prediction's resolve left)
             PrepStages stages;
                 stages.set_critical(true);  // the model's stream
             const uint8_t* pi = (const uint8_t*)((g.frame_to_frame_rgb && only->fill_in) ? m->fill_image : m->image);
             mmf_model_get_pose(only->model, only->spec_pose);
             odom_prepare_collect(stages, only->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
                                  (const float*)m->normalRadius, pi, 4, only->spec_pose,
-                                 only->fill_in ? reinterpret_cast<const int*>(&m->totals[3]) : nullptr, (const float*)m->fill_vertex,
-                                 (const float*)m->fill_normal, (const uint8_t*)m->fill_image, PREP_MODEL_SIDE);
+                                 only->fill_in ? fusion_thumb_count(m) : nullptr, (const float*)m->fill_vertex,
+                                 (const float*)m->fill_normal, (const uint8_t*)m->fill_image, PREP_MODEL_SIDE,
+                                 (m->width / 20) * (m->height / 20), 0.75f);
             rc = stages.launch(st, graphs_enabled() ? &only->odom->prep_graphs : nullptr);
             if (rc) return rc;
             only->spec_tex_gen = m->tex_gen;

@@ -1160,7 +1160,7 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
                                  const uint8_t* pred_image, int pred_channels, const float pose[16],
                                  const int* sel = nullptr, const float* alt_vertex = nullptr,
                                  const float* alt_normal = nullptr, const uint8_t* alt_image = nullptr,
-                                 int side = PREP_ALL) {
+                                 int side = PREP_ALL, int sel_total = 0, float sel_ratio = 0.f) {
     const bool in_img = (side & PREP_INPUT_IMAGE) != 0, in_depth = (side & PREP_INPUT_DEPTH) != 0;
     const bool model_side = (side & PREP_MODEL_SIDE) != 0;
     const int W = o->width, H = o->height;
@@ -1312,6 +1312,10 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     }
     if (model_side) o->prep_batched = true;
     if (in_img) o->grad_pending = true;
+    if (sel && sel_total)  // *sel is a count (PrepJob::sel_total)
+        for (PrepBuilder& pb : stages.stage)
+            for (PrepJob& j : pb.jobs)
+                if (j.sel == sel) j.sel_total = sel_total, j.sel_ratio = sel_ratio;
 }
 // the gradients the batched preparation wrote last become the ones the chain reads
 static void odom_adopt_gradients(mmf_odom* o) {
@@ -2307,6 +2311,8 @@ extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cut
     return MMF_OK;
 }
 
+// the two thumbnail counters of thumbnail_count_px (surfel_kernels.hpp): the count of the latest prediction is [tex_gen & 1]
+static unsigned* model_thumb_counts(mmf_model* m) { return &m->totals[4]; }
 // splat_kernel's launch: a fixed number of workgroups that deal the surfels out among their waves (surfel_kernels.hpp)
 static dim3 splat_grid(size_t bound) {
     static const unsigned wgs = []() { const char* e = std::getenv("MMF_SPLAT_WGS"); return e ? (unsigned)std::max(1, std::atoi(e)) : 512u; }();
@@ -2341,10 +2347,10 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
         hipLaunchKernelGGL(splat_resolve_fill_kernel, dim3(splat_tile_grid(m->width, m->height) + (rider.st ? 1u : 0u)), dim3(256), 0,
                            c->stream, m->set[m->cur], a, m->keys, m->image, m->vertexConf, m->normalRadius, m->time_tex, fill_depth,
                            fill_rgb, lost ? 1 : 0, (lost || frame_to_frame_rgb) ? 1 : 0, m->fill_vertex, m->fill_normal,
-                           m->fill_image, rider);
+                           m->fill_image, rider, model_thumb_counts(m), (int)(m->tex_gen & 1));
     } else
         hipLaunchKernelGGL(splat_resolve_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->image,
-                           m->vertexConf, m->normalRadius, m->time_tex);
+                           m->vertexConf, m->normalRadius, m->time_tex, model_thumb_counts(m), (int)(m->tex_gen & 1));
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }

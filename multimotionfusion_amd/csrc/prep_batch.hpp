@@ -53,6 +53,10 @@ struct PrepJob {
     // alt0 / alt1 instead of src0 / src1 (the fill-in decision, Model.cpp:380, taken on the device)
     const int* sel;
     const void *alt0, *alt1;
+    // sel_total != 0: *sel is a COUNT of covered thumbnail samples out of sel_total, and the alt_* sources are read when
+    // count / total < sel_ratio (requiresFillIn, MultiMotionFusion.cpp:877-895: surfel_kernels.hpp: thumbnail_count_px)
+    int sel_total;
+    float sel_ratio;
     float f[12];
 };
 
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
     const int by = local / J.gx, bx = local - by * J.gx;
     const int x = bx * kTileX + threadIdx.x, y = by * kTileY + threadIdx.y;
     const int cols = J.cols, rows = J.rows;
-    const bool alt = J.sel != nullptr && *J.sel != 0;  // wave uniform
+    const bool alt = J.sel != nullptr && (J.sel_total ? ((float)*J.sel / (float)J.sel_total < J.sel_ratio) : *J.sel != 0);  // wave uniform
     const void* src0 = alt ? J.alt0 : J.src0;
     const void* src1 = alt ? J.alt1 : J.src1;
     switch (J.op) {

@@ -669,6 +669,21 @@ __host__ __device__ inline unsigned splat_tile_grid(int cols, int rows) {
     return (unsigned)(((cols + kSplatTile - 1) / kSplatTile) * ((rows + kSplatTile - 1) / kSplatTile));
 }
 
+// requiresFillIn's thumbnail test (MultiMotionFusion.cpp:877-895: how many of the (cols / 20) x (rows / 20) samples of the
+// predicted image have all three channels > 0) counted by the pass that WRITES the image, instead of a launch of its own on
+// the model's stream: `thumb` = two counters; the resolve of generation g adds to thumb[g & 1] (one atomic per wave with
+// hits) and zeroes thumb[(g + 1) & 1] for the next one.  The preparation jobs that choose between the prediction and the
+// fill-in images read the count and apply the ratio themselves (prep_batch.hpp: PrepJob::sel_total).
+__device__ __forceinline__ void thumbnail_count_px(int px, int py, int cols, int rows, uchar4 p, unsigned* __restrict__ thumb, int gen) {
+    if (thumb == nullptr) return;
+    const int dc = cols / 20, dr = rows / 20;
+    const int i = px * dc / cols, j = py * dr / rows;  // the one sample this pixel can be
+    const bool sample = dc > 0 && dr > 0 && texel((i + 0.5f) / dc, cols) == px && texel((j + 0.5f) / dr, rows) == py;
+    const unsigned long long hits = __ballot(sample && p.x > 0 && p.y > 0 && p.z > 0);
+    if (hits != 0ull && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(hits)) atomicAdd(&thumb[gen & 1], (unsigned)__popcll(hits));
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) thumb[(gen + 1) & 1] = 0u;
+}
+
 // the splat images' texel i = (px, py) from the depth-test winner k
 __device__ __forceinline__ SplatTexel splat_resolve_px(int i, unsigned long long k, const SurfelSoA& s, const SplatArgs& a) {
     SplatTexel t;
@@ -699,7 +714,8 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatAr
                                                             unsigned long long* __restrict__ keys,
                                                             uchar4* __restrict__ image, float4* __restrict__ vertexConf,
                                                             float4* __restrict__ normalRadius,
-                                                            unsigned short* __restrict__ time_out) {
+                                                            unsigned short* __restrict__ time_out, unsigned* __restrict__ thumb,
+                                                            int gen) {
     MMF_MODEL_STREAM_PRIORITY();
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
@@ -710,6 +726,7 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatAr
     image[i] = t.image;
     vertexConf[i] = t.vertexConf, normalRadius[i] = t.normalRadius;
     time_out[i] = t.time;
+    thumbnail_count_px(px, py, a.cols, a.rows, t.image, thumb, gen);
 }
 
 // depth_splat.frag (ModelProjection::synthesizeDepth): the winner's corrected_pos.z, 0 where cleared
@@ -1203,7 +1220,7 @@ __global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, Sp
                                                                  const uint8_t* __restrict__ rgb, int passthrough_geom,
                                                                  int passthrough_rgb, float4* __restrict__ vertex_out,
                                                                  float4* __restrict__ normal_out, uchar4* __restrict__ image_out,
-                                                                 FrameRider rider) {
+                                                                 FrameRider rider, unsigned* __restrict__ thumb, int gen) {
     MMF_MODEL_STREAM_PRIORITY();
     if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
         frame_rider_run(rider);
@@ -1220,6 +1237,7 @@ __global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, Sp
     time_out[i] = t.time;
     fill_in_px(i, t.vertexConf, t.normalRadius, t.image, depth_fil, rgb, a.cols, a.rows, a.c, passthrough_geom, passthrough_rgb,
                vertex_out, normal_out, image_out);
+    thumbnail_count_px(px, py, a.cols, a.rows, t.image, thumb, gen);
 }
 
 // requiresFillIn: number of (cols/20 x rows/20) thumbnail samples with all three channels > 0
