@@ -2391,7 +2391,6 @@ extern "C" int mmf_model_fuse(mmf_model* m, int time, const uint8_t* rgb, const 
     if (int rc0 = model_resolve_count(m)) return rc0;
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
-    const int npix = m->width * m->height;
     FuseArgs a;
     std::memcpy(a.pose.m, m->pose, sizeof(m->pose));
     a.c = make_cam(m, true);
@@ -2402,7 +2401,7 @@ extern "C" int mmf_model_fuse(mmf_model* m, int time, const uint8_t* rgb, const 
     a.maskID = m->id;
     a.maxDepth = depth_cutoff < m->max_depth ? depth_cutoff : m->max_depth;  // std::min(depthCutoff, maxDepth) (Model.cpp:928)
     a.count = (int)m->count;
-    hipLaunchKernelGGL(fuse_data_kernel, grid1d(npix), dim3(256), 0, c->stream, rgb, depth_raw, depth_filtered, mask,
+    hipLaunchKernelGGL(fuse_data_kernel, grid1d((size_t)((m->width + 1) / 2) * ((m->height + 1) / 2)), dim3(256), 0, c->stream, rgb, depth_raw, depth_filtered, mask,
                        m->index, m->vertConf, m->normRad, a, m->meas, m->flags_b, m->winner);
     if (m->count)
         hipLaunchKernelGGL(fuse_update_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count,

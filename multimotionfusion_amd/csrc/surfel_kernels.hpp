@@ -780,16 +780,28 @@ __global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restric
         for (int k = 0; k < 16; ++k) a.pose.m[k] = a_in.pose_dev[k];
         a.weighting = *a_in.weight_dev * a_in.weight_mult;  // (computeFusionWeight's last operation)
     }
-    const int d = blockIdx.x * 256 + threadIdx.x;
+    // One thread per 2 x 2 block of pixels: data.vert:116 keeps one pixel in four -- (int)x and (int)y both of the frame's
+    // parity, i.e. one lattice point per block ((int)(uv_coord(i, n) * n) == i for every i: the error of that product is
+    // ~1e-5) -- so a thread per PIXEL left every other wave empty and the rest half empty.  The thread clears its block's
+    // four flags and carries on with the block's lattice pixel, in the pixel's own draw-order slot d: same results.
     const int cols = a.cols, rows = a.rows;
-    if (d >= cols * rows) return;
-    const int i = d / rows, j = d - i * rows;
+    const int hr = (rows + 1) / 2, hc = (cols + 1) / 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= hc * hr) return;
+    const int ia = t / hr, jb = t - ia * hr;  // column-major like the draw order
+    const int tm = ((int)(float)a.time) % 2;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+            if (2 * ia + u < cols && 2 * jb + v < rows) new_flags[(2 * ia + u) * rows + 2 * jb + v] = 0u;
+    const int i = 2 * ia + tm, j = 2 * jb + tm;
+    if (i >= cols || j >= rows) return;
+    const int d = i * rows + j;
     const Cam& c = a.c;
     const float tx = uv_coord(i, cols), ty = uv_coord(j, rows);
     const float x = tx * cols, y = ty * rows;
-    new_flags[d] = 0u;
-    const int tm = ((int)(float)a.time) % 2;
-    // the quarter-rate test of data.vert:116 first: it needs no memory, and three of four threads leave here
+    // the quarter-rate test of data.vert:116 (true by construction; kept as the shader has it)
     if (!(((int)x) % 2 == tm && ((int)y) % 2 == tm)) return;
     const v3 vPosLocal = get_vertex(depth_raw, cols, rows, tx, ty, x, y, c);
     const int pxi = texel(tx, cols), pyi = texel(ty, rows);
