@@ -520,3 +520,41 @@ def test_process_frame_sequence_in_other_tracking_modes(gpu_ctx, orc, mode):
         ng, no = g.getBackgroundModel().lastCount(), o.surfels.shape[0]
         assert abs(ng - no) <= max(8, 0.002 * no), (mode, i, ng, no)
     g.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_hints_of_every_kind_leave_no_trace(gpu_ctx, seed):
+    """40 frames at 640x480 with the next frame announced correctly, wrongly, or not at all in a random pattern (and the
+    host never waiting between calls): the next frame's image side runs at the start of the current frame, its depth side
+    behind the chain -- every ordering between the three streams gets its turn.  Poses and the final map must be those of
+    the run without any hint, bit for bit."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h, n = 640, 480, 40
+    K = synth.intrinsics(w, h)
+    base = synth.trajectory(10, seed=13)
+    order = [i if i < 10 else 18 - i for i in range(18)]  # there and back again: small steps between neighbours
+    frames = [synth.render(base[k], w, h, seed=k) for k in range(10)]
+    rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+    seq = [order[i % len(order)] for i in range(n)]
+    rng = np.random.default_rng(seed)
+    kinds = rng.integers(0, 4, size=n)  # 0, 1: right hint; 2: wrong hint; 3: none
+
+    def run(hints):
+        g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+        out = []
+        for i in range(n):
+            nxt = None
+            if hints and i + 1 < n and kinds[i] != 3:
+                k = seq[i + 1] if kinds[i] < 2 else (seq[i + 1] + 3) % 10
+                nxt = (rgb[k], depth[k])
+            g.processFrame(rgb[seq[i]], depth[seq[i]], timestamp=i, next=nxt)
+            out.append(g.getCurrPose().copy())
+        m = g.getBackgroundModel().downloadMap()
+        g.close()
+        return out, m
+
+    ref, ref_map = run(False)
+    got, got_map = run(True)
+    for i in range(n):
+        assert np.array_equal(ref[i], got[i]), (i, int(kinds[i - 1]) if i else None)
+    assert np.array_equal(ref_map.view(np.uint32), got_map.view(np.uint32))
