@@ -713,8 +713,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 const char* e = std::getenv("MMF_EARLY_IMAGE");
                 return !e ? 2 : (std::strcmp(e, "off") == 0 ? 0 : (std::strcmp(e, "chain") == 0 ? 1 : 2));
             }();
-            const bool image_early_ok = fr->next_rgb && fr->next_depth && f->side2 && g.so3 && so3_stage != nullptr &&
-                                        !(f->host_next.slot >= 0 && f->up_dev[0] != nullptr);  // (not a frame still being uploaded)
+            const bool next_from_host = f->host_next.slot >= 0 && f->up_dev[0] != nullptr;  // (a frame still being uploaded)
+            const bool image_early_any = fr->next_rgb && fr->next_depth && f->side2 && g.so3 && so3_stage != nullptr;
+            const bool image_early_ok = image_early_any && !next_from_host;
             if (early_image == 2 && image_early_ok) {
                 // the ring as it will be once this frame's chain is enqueued (RGBDOdometry.cpp:469-473; odom_enqueue_tracking)
                 mmf_odom* go = global->odom;
@@ -920,6 +921,13 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // a host frame announced for the next call: staged and sent up now, while the GPU tracks and the host would only wait
             rc = fusion_stage_host_next(f);
             if (rc) return rc;
+            // ... and its image side behind the upload (an announced HOST frame cannot have it at the start of the call: its
+            // copy into pinned memory has only just begun then), beside the chain instead of behind the pose
+            if (early_image != 0 && image_early_any && next_from_host && !tracked.empty() && f->host_next.staged) {
+                MMF_HIP_TRY(hipStreamWaitEvent(f->side2, f->ev_up[f->host_next.slot], 0));
+                rc = fusion_prefetch_image(f, fr->next_rgb, f->tick + 1, true);
+                if (rc) return rc;
+            }
             for (size_t k = 0; k < n_models; ++k) {  // the results, model by model
                 FusionModel* fm = f->models[k];
                 float pose[16];
