@@ -229,7 +229,7 @@ def main():
 
     from multimotionfusion_amd import shard, synth
     from multimotionfusion_amd.cudafuncs import Context, _p
-    from multimotionfusion_amd.fusion import MultiMotionFusion
+    from multimotionfusion_amd.fusion import HostFrame, MultiMotionFusion
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -766,6 +766,7 @@ def main():
         # ---- host FrameData hand-over: the same static sequence with the upload inside processFrame, the way the reference's
         # front-end hands frames over (FrameData in host memory, MultiMotionFusion.cpp:221, 261); the reader is one frame ahead
         # (GUI/MainController.cpp:547-590), so the next frame is announced with each call (mmf_fusion_process_frame_host_next)
+        host_frames = [HostFrame(fr["rgb"], fr["depth"]) for fr in frames]  # (addresses taken once, as a C++ caller has them)
         def host_loop(announce):
             g = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], icp_weight=ICP_WEIGHT)
             n_steps, t1 = 90, 0.0
@@ -777,8 +778,8 @@ def main():
                 if i and k == 0:
                     g.reset()
                 kn = (i + 1) % len(frames)
-                nxt = (frames[kn]["rgb"], frames[kn]["depth"]) if announce and kn != 0 else None
-                g.processFrameHost(frames[k]["rgb"], frames[k]["depth"], timestamp=i, next=nxt)
+                nxt = host_frames[kn] if announce and kn != 0 else None
+                g.processFrameHost(host_frames[k], timestamp=i, next=nxt)
             torch.cuda.synchronize()
             fps = n_steps / (time.perf_counter() - t1)
             g.close()

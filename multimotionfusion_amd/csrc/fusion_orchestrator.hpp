@@ -106,19 +106,24 @@ struct mmf_fusion {
     static constexpr int kUp = 3;
     uint8_t* up_pin[kUp] = {nullptr, nullptr, nullptr};
     uint8_t* up_dev[kUp] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_up[kUp] = {nullptr, nullptr, nullptr};  // upload stream: slot k is on the device
+    hipEvent_t ev_up[kUp] = {nullptr, nullptr, nullptr};      // upload stream: slot k is on the device
+    hipEvent_t ev_up_rgb[kUp] = {nullptr, nullptr, nullptr};  // ... its colour image is (sent first: the image side needs only that)
     bool up_recorded[kUp] = {false, false, false};
     hipStream_t up_stream = nullptr;
     hipEvent_t ev_up_begin = nullptr;  // fusion stream -> upload stream
     int up_cur = 0;
+    // the last call waited on the host for a pose that came off the fusion's stream: everything enqueued before that call is
+    // done, a slot of the ring can be refilled without an event from the fusion's stream (a marker on the stream a frame waits for)
+    bool host_caught_up = false;
     // the NEXT call's host frame, handed in as a hint: staged and uploaded while the host would only wait for this
     // frame's pose (fusion_stage_host_next), its sensor-side preparation enqueued like a device-side hint's
     struct HostNext {
         const uint8_t* rgb = nullptr;
         const float* depth = nullptr;
         int slot = -1;
-        bool pending = false;  // handed to the staging thread, not yet joined
-        bool staged = false;   // on its way to (or on) the device in `slot`
+        bool pending = false;     // handed to the staging thread, not yet joined
+        bool rgb_staged = false;  // its colour image is on its way (ev_up_rgb[slot] recorded)
+        bool staged = false;      // all of it is on its way to (or on) the device in `slot`
     } host_next;
     // The copy of an announced frame into its pinned slot (2.15 MB at 640x480: ~150 us of one core) and the enqueue of its
     // upload run on a thread of their own, started when the call that announces the frame begins: on the calling thread the
@@ -128,6 +133,8 @@ struct mmf_fusion {
         std::mutex mu;
         std::condition_variable cv;
         bool stop = false, busy = false;
+        bool rgb_done = false;  // the job's colour image has been copied and its upload enqueued
+        bool after_begin = true;  // the upload waits for ev_up_begin
         int slot = 0;
         const uint8_t* rgb = nullptr;
         const float* depth = nullptr;
@@ -331,6 +338,7 @@ extern "C" void mmf_fusion_destroy(mmf_fusion* f) {
         if (f->up_pin[i]) (void)hipHostFree(f->up_pin[i]);
         (void)hipFree(f->up_dev[i]);
         if (f->ev_up[i]) (void)hipEventDestroy(f->ev_up[i]);
+        if (f->ev_up_rgb[i]) (void)hipEventDestroy(f->ev_up_rgb[i]);
     }
     if (f->up_stream) (void)hipStreamDestroy(f->up_stream);
     if (f->ev_up_begin) (void)hipEventDestroy(f->ev_up_begin);
@@ -602,6 +610,13 @@ static int fusion_spawn(mmf_fusion* f, FusionModel** out) {
 static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* depth, int tick_at_use);
 static int fusion_prefetch_image(mmf_fusion* f, const uint8_t* rgb, int tick_at_use, bool ahead);
 static int fusion_stage_host_next(mmf_fusion* f);
+// a stream waits for an event only when the event has not happened yet (a wait is a barrier packet on the queue either way)
+static hipError_t fusion_wait_unless_done(hipStream_t s, hipEvent_t e) {
+    if (hipEventQuery(e) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    return hipStreamWaitEvent(s, e, 0);
+}
+static int fusion_stage_host_rgb(mmf_fusion* f);
 
 static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     MMF_REQUIRE(f != nullptr && fr != nullptr, "mmf_fusion_process_frame: null argument");
@@ -648,6 +663,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     }
     f->frame_rgb = rgb, f->frame_depth = depth;
     f->inputs_free_recorded = false;  // (set again by the branches below that record ev_inputs_free)
+    f->host_caught_up = false;
     if (!g.enable_multiple_models && !f->mask_is_zero) {  // :268-275: everything is background
         MMF_HIP_TRY(hipMemsetAsync(f->mask, 0, (size_t)f->width * f->height, c->stream));
         f->mask_is_zero = true;
@@ -919,12 +935,13 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             }
             stamp(0);
             // a host frame announced for the next call: staged and sent up now, while the GPU tracks and the host would only wait
-            rc = fusion_stage_host_next(f);
+            // (its colour image first; the depth image is joined where the depth side is enqueued, behind the pose)
+            rc = fusion_stage_host_rgb(f);
             if (rc) return rc;
             // ... and its image side behind the upload (an announced HOST frame cannot have it at the start of the call: its
             // copy into pinned memory has only just begun then), beside the chain instead of behind the pose
-            if (early_image != 0 && image_early_any && next_from_host && !tracked.empty() && f->host_next.staged) {
-                MMF_HIP_TRY(hipStreamWaitEvent(f->side2, f->ev_up[f->host_next.slot], 0));
+            if (early_image != 0 && image_early_any && next_from_host && !tracked.empty() && f->host_next.rgb_staged) {
+                MMF_HIP_TRY(fusion_wait_unless_done(f->side2, f->ev_up_rgb[f->host_next.slot]));
                 rc = fusion_prefetch_image(f, fr->next_rgb, f->tick + 1, true);
                 if (rc) return rc;
             }
@@ -942,6 +959,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     }
                     mmf_model_set_pose(fm->model, pose);
                     fm->tracking = false;
+                    if (fm->lane->stream == c->stream) f->host_caught_up = true;
                 }
             }
             f->t_tracking_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_track).count();
@@ -1168,22 +1186,35 @@ static int fusion_up_init(mmf_fusion* f) {
         MMF_HIP_TRY(hipHostMalloc((void**)&f->up_pin[i], total, hipHostMallocDefault));
         MMF_HIP_TRY(hipMalloc((void**)&f->up_dev[i], total));
         MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_up[i], hipEventDisableTiming));
+        MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_up_rgb[i], hipEventDisableTiming));
     }
     MMF_HIP_TRY(hipStreamCreateWithFlags(&f->up_stream, hipStreamNonBlocking));
     MMF_HIP_TRY(hipEventCreateWithFlags(&f->ev_up_begin, hipEventDisableTiming));
     return MMF_OK;
 }
-// host -> pinned -> device of rgb + depth into `slot`, on the upload stream; ev_up[slot] marks the arrival
-static int fusion_up_stage(mmf_fusion* f, int slot, const uint8_t* rgb_host, const float* depth_host) {
+// host -> pinned -> device of rgb, then depth, into `slot`, on the upload stream; ev_up_rgb[slot] / ev_up[slot] mark the
+// arrivals.  The colour image goes first: the next frame's image side (intensity pyramid, gradients, SO3) needs only that
+// and runs beside the chain, the depth side is enqueued behind the pose.  after_begin: see mmf_fusion::host_caught_up.
+static int fusion_up_stage(mmf_fusion* f, int slot, const uint8_t* rgb_host, const float* depth_host, bool after_begin,
+                           mmf_fusion::Stager* announce) {
     const size_t npix = (size_t)f->width * f->height;
     // the staging buffer's previous upload must have left it (round-2 advisor finding: nothing made sure of that)
     if (f->up_recorded[slot]) MMF_HIP_TRY(hipEventSynchronize(f->ev_up[slot]));
-    std::memcpy(f->up_pin[slot], depth_host, npix * 4);
     std::memcpy(f->up_pin[slot] + npix * 4, rgb_host, npix * 3);
     // the device copy's last readers are frames enqueued before this call (ev_up_begin: recorded when the call began --
     // NOT now: by now this frame's whole tracking chain sits on the fusion's stream and the upload is meant to overlap it)
-    MMF_HIP_TRY(hipStreamWaitEvent(f->up_stream, f->ev_up_begin, 0));
-    MMF_HIP_TRY(hipMemcpyAsync(f->up_dev[slot], f->up_pin[slot], npix * 7, hipMemcpyHostToDevice, f->up_stream));
+    if (after_begin) MMF_HIP_TRY(hipStreamWaitEvent(f->up_stream, f->ev_up_begin, 0));
+    MMF_HIP_TRY(hipMemcpyAsync(f->up_dev[slot] + npix * 4, f->up_pin[slot] + npix * 4, npix * 3, hipMemcpyHostToDevice, f->up_stream));
+    MMF_HIP_TRY(hipEventRecord(f->ev_up_rgb[slot], f->up_stream));
+    if (announce) {
+        {
+            std::lock_guard<std::mutex> lock(announce->mu);
+            announce->rgb_done = true;
+        }
+        announce->cv.notify_all();
+    }
+    std::memcpy(f->up_pin[slot], depth_host, npix * 4);
+    MMF_HIP_TRY(hipMemcpyAsync(f->up_dev[slot], f->up_pin[slot], npix * 4, hipMemcpyHostToDevice, f->up_stream));
     MMF_HIP_TRY(hipEventRecord(f->ev_up[slot], f->up_stream));
     f->up_recorded[slot] = true;
     return MMF_OK;
@@ -1199,22 +1230,23 @@ static void fusion_stager_main(mmf_fusion* f) {
         const int slot = s.slot;
         const uint8_t* rgb = s.rgb;
         const float* depth = s.depth;
+        const bool after_begin = s.after_begin;
         lock.unlock();
-        const int rc = fusion_up_stage(f, slot, rgb, depth);
+        const int rc = fusion_up_stage(f, slot, rgb, depth, after_begin, &s);
         const std::string err = rc ? std::string(mmf_last_error()) : std::string();  // (the error text is per thread)
         lock.lock();
-        s.rc = rc, s.error = err, s.busy = false;
+        s.rc = rc, s.error = err, s.busy = false, s.rgb_done = true;
         s.cv.notify_all();
     }
 }
 // hands the announced frame to the staging thread (started on first use)
-static int fusion_stage_host_begin(mmf_fusion* f) {
+static int fusion_stage_host_begin(mmf_fusion* f, bool after_begin) {
     mmf_fusion::HostNext& hn = f->host_next;
     mmf_fusion::Stager& s = f->stager;
     if (!s.thread.joinable()) s.thread = std::thread(fusion_stager_main, f);
     {
         std::lock_guard<std::mutex> lock(s.mu);
-        s.slot = hn.slot, s.rgb = hn.rgb, s.depth = hn.depth, s.busy = true;
+        s.slot = hn.slot, s.rgb = hn.rgb, s.depth = hn.depth, s.busy = true, s.rgb_done = false, s.after_begin = after_begin;
     }
     s.cv.notify_all();
     hn.pending = true;
@@ -1231,7 +1263,18 @@ static int fusion_stage_host_next(mmf_fusion* f) {
     std::unique_lock<std::mutex> lock(s.mu);
     s.cv.wait(lock, [&] { return !s.busy; });
     if (s.rc) return fail(s.rc, s.error);
-    hn.staged = true;
+    hn.staged = hn.rgb_staged = true;
+    return MMF_OK;
+}
+// ... only its colour image's (ev_up_rgb[slot] recorded): what the image side enqueued beside the chain waits for
+static int fusion_stage_host_rgb(mmf_fusion* f) {
+    mmf_fusion::HostNext& hn = f->host_next;
+    if (!hn.pending || hn.rgb_staged) return MMF_OK;
+    mmf_fusion::Stager& s = f->stager;
+    std::unique_lock<std::mutex> lock(s.mu);
+    s.cv.wait(lock, [&] { return s.rgb_done; });
+    if (!s.busy && s.rc) return MMF_OK;  // (the join reports it)
+    hn.rgb_staged = true;
     return MMF_OK;
 }
 
@@ -1251,18 +1294,26 @@ extern "C" int mmf_fusion_process_frame_host_next(mmf_fusion* f, const uint8_t* 
     const size_t o_depth = 0, o_rgb = npix * 4, o_mask = npix * 7;
     mmf_fusion::HostNext& hn = f->host_next;
     if (int rc = fusion_stage_host_next(f)) return rc;  // (nothing of an earlier announcement is still being staged)
-    MMF_HIP_TRY(hipEventRecord(f->ev_up_begin, c->stream));
+    // what a refilled slot's upload has to wait for: the work enqueued before this call -- nothing, when the last call
+    // ended with the host holding a pose from the fusion's stream (every lane joins that stream at the end of a frame)
+    static const bool host_knows = std::getenv("MMF_HOST_UP_EVENTS") == nullptr;
+    const bool after_begin = !(host_knows && f->host_caught_up);
+    if (after_begin) MMF_HIP_TRY(hipEventRecord(f->ev_up_begin, c->stream));
     int slot;
     if (hn.staged && hn.rgb == rgb_host && hn.depth == depth_host) {  // announced by the previous call: already on its way
         slot = hn.slot;
     } else {
         if (hn.staged || hn.pending) f->pre_rgb = nullptr, f->pre_depth = nullptr;  // what was prepared belongs to a frame that never came
         slot = f->up_cur;                                                          // (its device buffer is about to be reused)
-        if (int rc = fusion_up_stage(f, slot, rgb_host, depth_host)) return rc;
+        if (int rc = fusion_up_stage(f, slot, rgb_host, depth_host, after_begin, nullptr)) return rc;
     }
     hn = mmf_fusion::HostNext();
     f->up_cur = (slot + 1) % mmf_fusion::kUp;
-    MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_up[slot], 0));
+    // (an announced frame arrived during the last call as a rule: then the fusion's stream gets no barrier packet)
+    if (host_knows)
+        MMF_HIP_TRY(fusion_wait_unless_done(c->stream, f->ev_up[slot]));
+    else
+        MMF_HIP_TRY(hipStreamWaitEvent(c->stream, f->ev_up[slot], 0));
     mmf_frame fr;
     std::memset(&fr, 0, sizeof(fr));
     fr.rgb = f->up_dev[slot] + o_rgb, fr.depth = (const float*)(f->up_dev[slot] + o_depth), fr.timestamp = timestamp;
@@ -1279,7 +1330,7 @@ extern "C" int mmf_fusion_process_frame_host_next(mmf_fusion* f, const uint8_t* 
     if (next_rgb_host && next_depth_host) {
         hn.rgb = next_rgb_host, hn.depth = next_depth_host, hn.slot = f->up_cur;
         fr.next_rgb = f->up_dev[hn.slot] + o_rgb, fr.next_depth = (const float*)(f->up_dev[hn.slot] + o_depth);
-        if (int rc = fusion_stage_host_begin(f)) return rc;  // staged and sent up beside this call's own work
+        if (int rc = fusion_stage_host_begin(f, after_begin)) return rc;  // staged and sent up beside this call's own work
     }
     int rc = fusion_process_frame_impl(f, &fr);
     if (rc) return rc;
@@ -1369,8 +1420,11 @@ static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* 
     if (f->host_next.slot >= 0 && f->up_dev[0] && rgb == f->up_dev[f->host_next.slot] + (size_t)f->width * f->height * 4) {
         // the hinted frame comes from host memory (mmf_fusion_process_frame_host_next): behind its upload
         if (int rc0 = fusion_stage_host_next(f)) return rc0;
-        MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_up[f->host_next.slot], 0));
-        MMF_HIP_TRY(hipStreamWaitEvent(f->side2, f->ev_up[f->host_next.slot], 0));
+        if (hipEventQuery(f->ev_up[f->host_next.slot]) != hipSuccess) {  // (as a rule it arrived long ago: no barrier packets)
+            (void)hipGetLastError();
+            MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_up[f->host_next.slot], 0));
+            MMF_HIP_TRY(hipStreamWaitEvent(f->side2, f->ev_up[f->host_next.slot], 0));
+        }
     }
     if (f->inputs_free_recorded) MMF_HIP_TRY(hipStreamWaitEvent(f->side, f->ev_inputs_free, 0));
     const mmf_fusion_config& g = f->cfg;

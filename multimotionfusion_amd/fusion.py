@@ -12,6 +12,17 @@ from .model import Model
 from .odometry import RGBDOdometry
 
 
+class HostFrame:
+    """One frame in host memory (FrameData::rgb / depth as numpy arrays) with the arrays' addresses taken once: numpy's
+    `.ctypes.data` costs ~2 us per access, 9 us per call for the four pointers of a frame and its successor."""
+    __slots__ = ("rgb", "depth", "rgb_ptr", "depth_ptr")
+
+    def __init__(self, rgb, depth):
+        assert rgb.dtype == np.uint8 and depth.dtype == np.float32 and rgb.flags.c_contiguous and depth.flags.c_contiguous
+        self.rgb, self.depth = rgb, depth  # (kept alive with the addresses)
+        self.rgb_ptr, self.depth_ptr = rgb.ctypes.data, depth.ctypes.data
+
+
 class MultiMotionFusion:
     def __init__(self, ctx: Context, width, height, cx, cy, fx, fy, **overrides):
         self.ctx, self.width, self.height = ctx, width, height
@@ -141,22 +152,20 @@ class MultiMotionFusion:
     def scheduleDeactivation(self, model_id):
         check(self.ctx.lib.mmf_fusion_schedule_deactivation(self.handle, int(model_id)))
 
-    def processFrameHost(self, rgb, depth, timestamp=0, mask=None, hasNewLabel=False, inPose=None, weightMultiplier=1.0,
+    def processFrameHost(self, rgb, depth=None, timestamp=0, mask=None, hasNewLabel=False, inPose=None, weightMultiplier=1.0,
                          bootstrap=False, next=None):
         """processFrame(const FrameData&) with HOST numpy arrays: staged through pinned buffers and uploaded inside.
         next = (rgb, depth) of the NEXT call (C-contiguous uint8 / float32 arrays, the very objects that call will pass):
-        uploaded and prepared during this one (mmf_fusion_process_frame_host_next)."""
-        assert rgb.dtype == np.uint8 and depth.dtype == np.float32 and rgb.flags.c_contiguous and depth.flags.c_contiguous
+        uploaded and prepared during this one (mmf_fusion_process_frame_host_next).  A frame may also be handed in as a
+        HostFrame (rgb=HostFrame, next=HostFrame): the arrays' addresses are then taken once, not per call."""
+        cur = rgb if isinstance(rgb, HostFrame) else HostFrame(rgb, depth)
+        nxt = None if next is None else (next if isinstance(next, HostFrame) else HostFrame(*next))
         m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
         pose = np.ascontiguousarray(np.asarray(inPose, np.float32).reshape(16)) if inPose is not None else None
-        nr = nd = None
-        if next is not None:
-            nr, nd = next
-            assert nr.dtype == np.uint8 and nd.dtype == np.float32 and nr.flags.c_contiguous and nd.flags.c_contiguous
         check(self.ctx.lib.mmf_fusion_process_frame_host_next(
-            self.handle, rgb.ctypes.data, depth.ctypes.data, m.ctypes.data if m is not None else None, int(bool(hasNewLabel)),
+            self.handle, cur.rgb_ptr, cur.depth_ptr, m.ctypes.data if m is not None else None, int(bool(hasNewLabel)),
             int(timestamp), fptr(pose) if pose is not None else None, float(weightMultiplier), int(bool(bootstrap)),
-            nr.ctypes.data if nr is not None else None, nd.ctypes.data if nd is not None else None))
+            nxt.rgb_ptr if nxt is not None else None, nxt.depth_ptr if nxt is not None else None))
 
     def predict(self):
         check(self.ctx.lib.mmf_fusion_predict(self.handle))

@@ -98,6 +98,32 @@ def test_host_frames_announced_one_call_ahead_give_the_same_bits(gpu_ctx):
     b.close()
 
 
+def test_announced_host_frames_around_a_dictated_pose(gpu_ctx):
+    """The upload of an announced frame waits for an event from the fusion's stream only when the last call did not end
+    with the host holding a tracked pose (a dictated pose: no wait for the GPU in that call) -- both ways give the bits of
+    device-resident frames; frames handed in as HostFrame objects (addresses taken once)."""
+    import numpy as np
+    import torch
+    from multimotionfusion_amd import synth
+    from multimotionfusion_amd.fusion import HostFrame, MultiMotionFusion
+    w, h, n = 320, 240, 10
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=29)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    host = [HostFrame(f["rgb"], f["depth"]) for f in frames]
+    dev = [(torch.from_numpy(f["rgb"]).cuda(), torch.from_numpy(f["depth"]).cuda()) for f in frames]
+    a = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    b = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+    for i in range(n):
+        dictated = a.getCurrPose().copy() if i in (4, 5) else None  # two calls in a row that track nothing
+        a.processFrame(*dev[i], timestamp=i, inPose=dictated, next=dev[i + 1] if i + 1 < n else None)
+        b.processFrameHost(host[i], timestamp=i, inPose=dictated, next=host[i + 1] if i + 1 < n else None)
+        assert np.array_equal(a.getCurrPose(), b.getCurrPose()), i
+    assert np.array_equal(a.getBackgroundModel().downloadMap().view(np.uint32), b.getBackgroundModel().downloadMap().view(np.uint32))
+    a.close()
+    b.close()
+
+
 def test_runtime_setters_take_effect_at_the_next_frame(gpu_ctx):
     """setFastOdom / setPyramid / setSo3 / setIcpWeight / setRgbOnly change the NEXT processFrame like a GUI checkbox
     (MultiMotionFusion.cpp:1064-1116): iteration counts and the tracker's mode follow them."""

@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimotionfusion_amd import synth  # noqa: E402
 from multimotionfusion_amd.cudafuncs import Context  # noqa: E402
-from multimotionfusion_amd.fusion import MultiMotionFusion  # noqa: E402
+from multimotionfusion_amd.fusion import HostFrame, MultiMotionFusion  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 W, H, nf = 640, 480, 30
@@ -19,6 +19,7 @@ poses = synth.trajectory(nf, seed=1)
 frames = [synth.render(p, W, H, seed=i) for i, p in enumerate(poses)]
 ctx = Context(0)
 dev = [(torch.from_numpy(f["rgb"]).cuda(), torch.from_numpy(f["depth"]).cuda()) for f in frames]
+host = [HostFrame(f["rgb"], f["depth"]) for f in frames]
 import gc  # noqa: E402
 gc.collect()
 gc.disable()
@@ -34,8 +35,7 @@ for mode in ("device", "host", "device", "host"):
             g.reset()
         last = (i + 1) % nf == 0
         if mode == "host":
-            nxt = None if last else (frames[k + 1]["rgb"], frames[k + 1]["depth"])
-            g.processFrameHost(frames[k]["rgb"], frames[k]["depth"], timestamp=i, next=nxt)
+            g.processFrameHost(host[k], timestamp=i, next=None if last else host[k + 1])
         else:
             nxt = None if last else dev[k + 1]
             g.processFrame(dev[k][0], dev[k][1], timestamp=i, next=nxt)
