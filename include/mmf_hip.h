@@ -506,6 +506,10 @@ int mmf_debug_expf(mmf_ctx *ctx, const float *x_dev, int n, float *out_mmf_dev, 
 /* test / A-B hook: 1 = run the Gauss-Newton chain as one launch per iteration where it applies (the default), 0 = always as
  * producer + step launches, -1 = what the environment says (MMF_GN_FUSED=0 turns it off).  Process wide. */
 int mmf_debug_set_gn_fused(int on);
+/* test / A-B hook: 1 = enqueue the reference's first predict() of a frame (MultiMotionFusion.cpp:675) although nothing
+ * inside this library reads its images before the frame's second predict() (:821) overwrites them, 0 = leave it out (the
+ * default), -1 = what the environment says (MMF_MID_PREDICT=1 turns it on).  Process wide. */
+int mmf_debug_set_mid_predict(int on);
 /* Model::computeFusionWeight (Model.cpp:876-891) for pose / lastPose (host 4x4), exported for tests */
 int mmf_compute_fusion_weight(const float pose[16], const float last_pose[16], float multiplier, float *out);
 

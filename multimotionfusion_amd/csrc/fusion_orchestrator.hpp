@@ -562,6 +562,23 @@ static int fusion_predict_model(mmf_fusion* f, FusionModel* fm) {
     return mmf_model_combined_predict(fm->model, g.max_depth_processed, f->tick, f->tick, g.time_delta);
 }
 
+// The reference predicts twice per frame: behind the tracking (:675) and at the end (:821).  The first prediction's images
+// feed loop closure (ferns, :682) and the segmentation (:700-790), neither of which runs inside this library -- the
+// segmentation result is handed in with the frame, a caller sees the images only between calls -- and the fuse / clean
+// passes read their own index maps, not the prediction.  Its images are overwritten by the second prediction before
+// anything can read them, so it is not enqueued (bit-identical poses, maps and images: every oracle parity test runs this
+// way, and tests/test_gpu_fusion.py compares the two).  MMF_MID_PREDICT=1 runs it as the reference does.
+static std::atomic<int> g_mid_predict{-1};  // -1: MMF_MID_PREDICT decides (default off); 0 / 1: mmf_debug_set_mid_predict
+extern "C" int mmf_debug_set_mid_predict(int on) {
+    g_mid_predict.store(on < 0 ? -1 : (on ? 1 : 0));
+    return MMF_OK;
+}
+static bool fusion_mid_predict() {
+    static const bool env_on = std::getenv("MMF_MID_PREDICT") != nullptr;
+    const int forced = g_mid_predict.load();
+    return forced < 0 ? env_on : forced != 0;
+}
+
 // predictIndices -> fuse -> predictIndices -> clean of one model (:791-816 per model; models never read each
 // other's surfels, so running the four passes model by model on the model's own stream gives the same maps as
 // the reference's pass-by-pass loops over the list)
@@ -893,7 +910,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 m->t_inv_dev = fm->odom->state->pose_inv;
                 m->rider = fm->odom->rider;
                 fm->odom->rider = FrameRider();
-                rc = fusion_predict_model(f, fm);
+                rc = (fusion_mid_predict() || m->rider.st != nullptr) ? fusion_predict_model(f, fm) : MMF_OK;
                 MMF_REQUIRE(rc != MMF_OK || m->rider.st == nullptr, "mmf_fusion_process_frame: the tracking result was not handed over");
                 if (rc == MMF_OK) rc = mmf_model_predict_indices(m, f->tick, g.max_depth_processed, g.time_delta);
                 fm->early_done = rc == MMF_OK;
@@ -1059,7 +1076,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             }
             const bool early = fm->early_done;  // its predict + predictIndices are already enqueued
             fm->early_done = false;
-            if (!early) {
+            if (!early && fusion_mid_predict()) {
                 rc = fusion_predict_model(f, fm);
                 if (rc) return rc;
             }

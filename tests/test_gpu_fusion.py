@@ -558,3 +558,44 @@ def test_hints_of_every_kind_leave_no_trace(gpu_ctx, seed):
     for i in range(n):
         assert np.array_equal(ref[i], got[i]), (i, int(kinds[i - 1]) if i else None)
     assert np.array_equal(ref_map.view(np.uint32), got_map.view(np.uint32))
+
+
+def test_the_first_prediction_of_a_frame_is_never_read(gpu_ctx):
+    """The reference predicts behind the tracking (MultiMotionFusion.cpp:675) and again at the end of the frame (:821).  The
+    library leaves the first one out -- its images feed only loop closure and the segmentation, which run outside, and the
+    second one overwrites them before a caller can look.  With it enqueued as the reference does (mmf_debug_set_mid_predict)
+    every pose, the map and every image a caller can read between calls are the same bits; frames without fusion
+    (dictated pose, rgb-only tracking) included."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h, n = 320, 240, 9
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=31)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+    names = ("image", "vertexConf", "normalRadius", "time", "fillVertex", "fillNormal", "fillImage")
+
+    def run(mid, rgb_only):
+        assert gpu_ctx.lib.mmf_debug_set_mid_predict(mid) == 0
+        try:
+            g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+            g.setRgbOnly(rgb_only)
+            out = []
+            for i in range(n):
+                dictated = g.getCurrPose().copy() if i == 5 else None
+                g.processFrame(rgb[i], depth[i], timestamp=i, inPose=dictated, next=(rgb[i + 1], depth[i + 1]) if i + 1 < n else None)
+                m = g.getBackgroundModel()
+                out.append((g.getCurrPose().copy(), [m.texture(k).cpu().numpy().copy() for k in names]))
+            surfels = g.getBackgroundModel().downloadMap()
+            g.close()
+            return out, surfels
+        finally:
+            gpu_ctx.lib.mmf_debug_set_mid_predict(-1)
+
+    for rgb_only in (False, True):
+        ref, ref_map = run(1, rgb_only)
+        got, got_map = run(0, rgb_only)
+        for i in range(n):
+            assert np.array_equal(ref[i][0], got[i][0]), i
+            for k, a, b in zip(names, ref[i][1], got[i][1]):
+                assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (i, k)
+        assert np.array_equal(ref_map.view(np.uint32), got_map.view(np.uint32))
