@@ -1,12 +1,14 @@
 // frame_rider.hpp -- tracker work that nothing on the model's stream waits for, carried by one extra workgroup of the
-// frame's first resolve pass.
+// frame's first projection pass.
 //
 // The chain's last launch used to end with (a) the copy of the odometry state into the host's pinned struct + the
 // sequence number the host spins on and (b) Model::computeFusionWeight of the new pose for the early fuse pass
 // (Model.cpp:876-891): one wave each, 3.5 us and 3.8 us behind the 5.6 us of the solve (rocprofv3: 13.0 us for the
-// launch, 9.2 without the weight), and the frame's first splat waited for both.  The early predict() that follows the
-// chain (MultiMotionFusion.cpp:675) reads neither: its resolve launch (7 us) gets one more workgroup that does both
-// while the image is resolved.  The first reader of the weight is fuse_data_kernel, three launches later.
+// launch, 9.2 without the weight), and the frame's first projection waited for both.  That projection -- the first
+// predictIndices (MultiMotionFusion.cpp:792), index_map_kernel; or the resolve of predict() (:675) when that is enqueued --
+// reads neither: its launch gets one more workgroup, dispatched first, that does both while the surfels are projected.
+// The first reader of the weight is fuse_data_kernel, two launches later; the host has the pose ~2 us EARLIER than from
+// the end of the 13 us launch.
 #pragma once
 #include "odom_state.hpp"
 #include "pose_algebra.hpp"

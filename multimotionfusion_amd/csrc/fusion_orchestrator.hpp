@@ -882,12 +882,11 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 const float trans[3] = {pose[3], pose[7], pose[11]};
                 const float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
                 fm->odom->exclusive_chain = tracked.size() == 1;  // several chains side by side: no in-launch barriers
-                // MMF_RIDER=1: the predict() enqueued right behind this chain (below) carries the hand-over to the host
-                // (frame_rider.hpp).  Off by default: with the next frame's image side out of the host's tail the model's stream
-                // is what a frame waits for, and there the rider costs more than it saves (2 651-2 669 against 2 696-2 706
-                // frames/s without it: its system-scope stores hold the resolve launch open).
-                static const bool rider = std::getenv("MMF_RIDER") != nullptr;
-                fm->odom->defer_publish = rider && tracked.size() == 1 && !fr->bootstrap && !have_init && !g.rgb_only && fm->fill_in;
+                // The frame's first projection, enqueued right behind this chain (below), carries the hand-over to the host and
+                // the fusion weight on one extra workgroup (frame_rider.hpp): the chain's last launch is the solve alone (13 ->
+                // 5.7 us on the stream a frame waits for).  MMF_RIDER=0: both at the end of the chain's last launch.
+                static const bool rider = []() { const char* e = std::getenv("MMF_RIDER"); return !e || e[0] != '0'; }();
+                fm->odom->defer_publish = rider && tracked.size() == 1 && !fr->bootstrap && !have_init && !g.rgb_only && f->tracking_ok;
                 rc = odom_enqueue_tracking(fm->odom, trans, rot, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom, g.so3,
                                            fm->icp_error, fm->rgb_error);
                 if (rc) return rc;
@@ -910,9 +909,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 m->t_inv_dev = fm->odom->state->pose_inv;
                 m->rider = fm->odom->rider;
                 fm->odom->rider = FrameRider();
-                rc = (fusion_mid_predict() || m->rider.st != nullptr) ? fusion_predict_model(f, fm) : MMF_OK;
-                MMF_REQUIRE(rc != MMF_OK || m->rider.st == nullptr, "mmf_fusion_process_frame: the tracking result was not handed over");
+                rc = fusion_mid_predict() ? fusion_predict_model(f, fm) : MMF_OK;
                 if (rc == MMF_OK) rc = mmf_model_predict_indices(m, f->tick, g.max_depth_processed, g.time_delta);
+                MMF_REQUIRE(rc != MMF_OK || m->rider.st == nullptr, "mmf_fusion_process_frame: the tracking result was not handed over");
                 fm->early_done = rc == MMF_OK;
                 // Without a segmentation the mask of the frame is known (all zeros) and nothing the host decides lies
                 // between tracking and fusion: fuse -> predictIndices -> clean (:791-816) follow at once, with the pose and

@@ -2302,9 +2302,11 @@ extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cut
     MMF_HIP_TRY(hipSetDevice(c->device));
     const size_t npix = (size_t)m->width * m->height;
     const IndexArgs a = model_index_args(m, time, depth_cutoff, time_delta);
-    if (m->count)
-        hipLaunchKernelGGL(index_map_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
-                           m->keys);
+    const FrameRider rider = m->rider;  // (frame_rider.hpp: the tracking result's hand-over, when this is the frame's first projection)
+    m->rider = FrameRider();
+    if (m->count || rider.st)
+        hipLaunchKernelGGL(index_map_kernel, dim3((unsigned)((m->count + 255) / 256) + (rider.st ? 1u : 0u)), dim3(256), 0, c->stream,
+                           m->set[m->cur], (int)m->count, a, m->keys, rider);
     hipLaunchKernelGGL(index_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->index,
                        m->vertConf, m->colorTime, m->normRad);
     MMF_HIP_TRY(hipGetLastError());

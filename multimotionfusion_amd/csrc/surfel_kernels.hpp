@@ -430,10 +430,14 @@ struct IndexArgs {
 };
 
 __global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, IndexArgs a_in,
-                                                        unsigned long long* __restrict__ keys) {
+                                                        unsigned long long* __restrict__ keys, FrameRider rider) {
     MMF_MODEL_STREAM_PRIORITY();
+    if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
+        frame_rider_run(rider);
+        return;
+    }
     const IndexArgs a = with_device_pose(a_in);
-    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int id = (int)(blockIdx.x - (rider.st ? 1u : 0u)) * 256 + threadIdx.x;
     if (id >= count) return;
     const float4 p = s.pos[id];
     const float ts = s.col[id].w;
