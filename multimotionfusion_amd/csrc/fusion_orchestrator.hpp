@@ -586,10 +586,13 @@ static int fusion_fuse_clean_model(mmf_fusion* f, FusionModel* fm, float weighti
     const mmf_fusion_config& g = f->cfg;
     int rc = indices_done ? MMF_OK : mmf_model_predict_indices(fm->model, f->tick, g.max_depth_processed, g.time_delta);
     if (rc) return rc;
-    rc = mmf_model_fuse(fm->model, f->tick, f->frame_rgb, f->mask, f->frame_depth, f->depth_filtered, g.max_depth_processed,
-                        weighting);
+    // (the fuse's update pass projects the surfels for the predictIndices behind it: MMF_FUSE_INDEX=0 keeps the two apart)
+    static const bool merged = []() { const char* e = std::getenv("MMF_FUSE_INDEX"); return !e || e[0] != '0'; }();
+    const IndexArgs ia = model_index_args(fm->model, f->tick, g.max_depth_processed, g.time_delta);
+    rc = model_fuse(fm->model, f->tick, f->frame_rgb, f->mask, f->frame_depth, f->depth_filtered, g.max_depth_processed, weighting,
+                    merged ? &ia : nullptr);
     if (rc) return rc;
-    rc = mmf_model_predict_indices(fm->model, f->tick, g.max_depth_processed, g.time_delta);
+    rc = model_predict_indices(fm->model, f->tick, g.max_depth_processed, g.time_delta, merged);
     if (rc) return rc;
     return mmf_model_clean(fm->model, f->tick, g.time_delta, g.max_depth_processed, f->depth_filtered, f->mask, g.outlier_coeff);
 }

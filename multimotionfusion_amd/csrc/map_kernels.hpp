@@ -28,6 +28,14 @@ __device__ __forceinline__ void create_vmap_px(int x, int y, const float* __rest
         vmap[(size_t)y * v_stride + x] = qnan();
     }
 }
+// the vertex create_vmap_px stores for depth z at pixel (x, y); false: none (the x plane gets NaN)
+__device__ __forceinline__ bool vmap_value(int x, int y, float z, float fx_inv, float fy_inv, float cx, float cy, float cutoff, f3& v) {
+    if (!(z != 0 && z < cutoff)) return false;
+    v.x = z * (x - cx) * fx_inv;
+    v.y = z * (y - cy) * fy_inv;
+    v.z = z;
+    return true;
+}
 __global__ __launch_bounds__(256) void create_vmap_kernel(const float* __restrict__ depth, int d_stride, int cols,
                                                           int rows, float* __restrict__ vmap, int v_stride,
                                                           float fx_inv, float fy_inv, float cx, float cy,
@@ -61,6 +69,39 @@ __device__ __forceinline__ void create_nmap_px(int x, int y, int rows, int cols,
         nmap[(size_t)(y + 2 * rows) * n_stride + x] = r.z;
     } else {
         nmap[(size_t)y * n_stride + x] = qnan();
+    }
+}
+// create_vmap_px and create_nmap_px of one pixel in one pass over the depth image: the two neighbours' vertices are
+// computed from their depths (the same expressions that give them their own vmap entries) instead of being read back
+__device__ __forceinline__ void create_vmap_nmap_px(int x, int y, const float* __restrict__ depth, int cols, int rows,
+                                                    float* __restrict__ vmap, float* __restrict__ nmap, float fx_inv, float fy_inv,
+                                                    float cx, float cy, float cutoff) {
+    if (x >= cols || y >= rows) return;
+    const float z00 = depth[(size_t)y * cols + x];
+    const float z01 = depth[(size_t)y * cols + min(x + 1, cols - 1)];
+    const float z10 = depth[(size_t)min(y + 1, rows - 1) * cols + x];
+    f3 v00, v01, v10;
+    const bool ok00 = vmap_value(x, y, z00, fx_inv, fy_inv, cx, cy, cutoff, v00);
+    if (ok00) {
+        vmap[(size_t)y * cols + x] = v00.x;
+        vmap[(size_t)(y + rows) * cols + x] = v00.y;
+        vmap[(size_t)(y + 2 * rows) * cols + x] = v00.z;
+    } else {
+        vmap[(size_t)y * cols + x] = qnan();
+    }
+    if (x == cols - 1 || y == rows - 1) {
+        nmap[(size_t)y * cols + x] = qnan();
+        return;
+    }
+    const bool ok01 = vmap_value(x + 1, y, z01, fx_inv, fy_inv, cx, cy, cutoff, v01);
+    const bool ok10 = vmap_value(x, y + 1, z10, fx_inv, fy_inv, cx, cy, cutoff, v10);
+    if (ok00 && ok01 && ok10) {
+        const f3 r = normalized(cross(v01 - v00, v10 - v00));
+        nmap[(size_t)y * cols + x] = r.x;
+        nmap[(size_t)(y + rows) * cols + x] = r.y;
+        nmap[(size_t)(y + 2 * rows) * cols + x] = r.z;
+    } else {
+        nmap[(size_t)y * cols + x] = qnan();
     }
 }
 __global__ __launch_bounds__(256) void create_nmap_kernel(int rows, int cols, const float* __restrict__ vmap,

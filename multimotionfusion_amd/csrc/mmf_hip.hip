@@ -1176,6 +1176,9 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     // ... and level 0 and the first pyramid step are computed straight from the prediction's images (PREP_TEX_*): two
     // dependent launches.  MMF_PREP_MERGE=1: only the last stage merged (A/B aid).
     static const bool merge_first = []() { const char* e = std::getenv("MMF_PREP_MERGE"); return !e || std::atoi(e) >= 2; }();
+    // The sensor frame's normal map of a level is computed in the same job as its vertex map, from the depth image
+    // (PREP_VMAP_NMAP): the depth side is three dependent launches instead of four.  MMF_PREP_VN=0: apart (A/B aid).
+    static const bool merge_vn = []() { const char* e = std::getenv("MMF_PREP_VN"); return !e || e[0] != '0'; }();
     auto intr_f = [&](PrepJob& j, int lvl, bool cutoff_too, float cutoff) {
         const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, lvl);
         j.f[0] = 1.f / in.fx, j.f[1] = 1.f / in.fy, j.f[2] = in.cx, j.f[3] = in.cy;
@@ -1218,14 +1221,14 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             PrepJob& d = pb.add(PREP_DERIV, cols, rows);
             d.src0 = o->next_image[lvl], d.dst0 = o->grad_w_dx[lvl], d.dst1 = o->grad_w_dy[lvl];  // (odom_adopt_gradients)
         }
-        if (in_depth) {
+        if (in_depth && !merge_vn) {
             PrepJob& nm = pb.add(PREP_NMAP, cols, rows);
             nm.src0 = o->vmaps_curr[lvl], nm.dst0 = o->nmaps_curr[lvl];
         }
     };
     auto vmap_job = [&](PrepBuilder& pb, int lvl, const float* depth) {
-        PrepJob& j = pb.add(PREP_VMAP, W >> lvl, H >> lvl);
-        j.src0 = depth, j.dst0 = o->vmaps_curr[lvl];
+        PrepJob& j = pb.add(merge_vn ? PREP_VMAP_NMAP : PREP_VMAP, W >> lvl, H >> lvl);
+        j.src0 = depth, j.dst0 = o->vmaps_curr[lvl], j.dst1 = o->nmaps_curr[lvl];
         intr_f(j, lvl, true, depth_cutoff);
     };
     auto down_jobs = [&](PrepBuilder& pb, int lvl, const float* depth_src) {  // level lvl-1 -> lvl of every pyramid
@@ -2295,7 +2298,8 @@ static IndexArgs model_index_args(mmf_model* m, int time, float depth_cutoff, in
 }
 
 // ModelProjection::predictIndices (ModelProjection.cpp:94-143)
-extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cutoff, int time_delta) {
+// projected: the surfels are in the key image already (model_fuse with then_index); only the resolve is left
+static int model_predict_indices(mmf_model* m, int time, float depth_cutoff, int time_delta, bool projected) {
     MMF_REQUIRE(m != nullptr, "mmf_model_predict_indices: null model");
     if (int rc0 = model_resolve_count(m)) return rc0;
     mmf_ctx* c = m->ctx;
@@ -2304,13 +2308,16 @@ extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cut
     const IndexArgs a = model_index_args(m, time, depth_cutoff, time_delta);
     const FrameRider rider = m->rider;  // (frame_rider.hpp: the tracking result's hand-over, when this is the frame's first projection)
     m->rider = FrameRider();
-    if (m->count || rider.st)
+    if (!projected && (m->count || rider.st))
         hipLaunchKernelGGL(index_map_kernel, dim3((unsigned)((m->count + 255) / 256) + (rider.st ? 1u : 0u)), dim3(256), 0, c->stream,
                            m->set[m->cur], (int)m->count, a, m->keys, rider);
     hipLaunchKernelGGL(index_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->index,
                        m->vertConf, m->colorTime, m->normRad);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
+}
+extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cutoff, int time_delta) {
+    return model_predict_indices(m, time, depth_cutoff, time_delta, false);
 }
 
 // the two thumbnail counters of thumbnail_count_px (surfel_kernels.hpp): the count of the latest prediction is [tex_gen & 1]
@@ -2387,8 +2394,10 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
 }
 
 // Model::fuse (Model.cpp:893-1048): data association + update; `weighting` = computeFusionWeight()
-extern "C" int mmf_model_fuse(mmf_model* m, int time, const uint8_t* rgb, const uint8_t* mask, const float* depth_raw,
-                              const float* depth_filtered, float depth_cutoff, float weighting) {
+// then_index: the update pass also projects every surfel into the key image with these arguments -- the first half of
+// the predictIndices that follows a fuse (fuse_update_index_kernel); the caller continues with model_predict_indices(projected)
+static int model_fuse(mmf_model* m, int time, const uint8_t* rgb, const uint8_t* mask, const float* depth_raw,
+                      const float* depth_filtered, float depth_cutoff, float weighting, const IndexArgs* then_index) {
     MMF_REQUIRE(m && rgb && mask && depth_raw && depth_filtered, "mmf_model_fuse: null argument");
     if (int rc0 = model_resolve_count(m)) return rc0;
     mmf_ctx* c = m->ctx;
@@ -2405,11 +2414,18 @@ extern "C" int mmf_model_fuse(mmf_model* m, int time, const uint8_t* rgb, const 
     a.count = (int)m->count;
     hipLaunchKernelGGL(fuse_data_kernel, grid1d((size_t)((m->width + 1) / 2) * ((m->height + 1) / 2)), dim3(256), 0, c->stream, rgb, depth_raw, depth_filtered, mask,
                        m->index, m->vertConf, m->normRad, a, m->meas, m->flags_b, m->winner);
-    if (m->count)
+    if (m->count && then_index)
+        hipLaunchKernelGGL(fuse_update_index_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count,
+                           m->meas, time, m->winner, *then_index, m->keys);
+    else if (m->count)
         hipLaunchKernelGGL(fuse_update_kernel, grid1d(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count,
                            m->meas, time, m->winner);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
+}
+extern "C" int mmf_model_fuse(mmf_model* m, int time, const uint8_t* rgb, const uint8_t* mask, const float* depth_raw,
+                              const float* depth_filtered, float depth_cutoff, float weighting) {
+    return model_fuse(m, time, rgb, mask, depth_raw, depth_filtered, depth_cutoff, weighting, nullptr);
 }
 
 // Model::clean (Model.cpp:1050-1182); must follow mmf_model_fuse + mmf_model_predict_indices of the same frame

@@ -37,6 +37,7 @@ enum PrepOp : int {
     PREP_TEX_PROJECT,     // PREP_V2D + PREP_PROJECT: src0 vertices -> dst2 depth, dst0 cloud, dst1 records   f = {1/fx, 1/fy, cx, cy, cutoff}
     PREP_TEX_PYR_F,       // PREP_V2D + PREP_PYRDOWN_F: src0 vertices (scols x srows) -> dst0 depth   f = {cutoff}
     PREP_TEX_PYR_U8,      // PREP_INTENSITY + PREP_PYRDOWN_U8: src0 image (scols x srows pixels of `channels` bytes) -> dst0
+    PREP_VMAP_NMAP,       // PREP_VMAP + PREP_NMAP of the same level: src0 depth -> dst0 vmap, dst1 nmap   f = {1/fx, 1/fy, cx, cy, cutoff}
     PREP_TEX_RESIZE,      // PREP_COPY_MAPS + PREP_RESIZE_V + PREP_RESIZE_N: src0, src1 prediction (scols x srows) -> dst0 vmap, dst1 nmap
 };
 
@@ -126,6 +127,10 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
         case PREP_VMAP:
             create_vmap_px(x, y, (const float*)src0, cols, cols, rows, (float*)J.dst0, cols, J.f[0], J.f[1], J.f[2], J.f[3],
                            J.f[4]);
+            break;
+        case PREP_VMAP_NMAP:
+            create_vmap_nmap_px(x, y, (const float*)src0, cols, rows, (float*)J.dst0, (float*)J.dst1, J.f[0], J.f[1], J.f[2], J.f[3],
+                                J.f[4]);
             break;
         case PREP_NMAP: create_nmap_px(x, y, rows, cols, (const float*)src0, cols, (float*)J.dst0, cols); break;
         case PREP_TRANSFORM_PACK: {

@@ -429,18 +429,9 @@ struct IndexArgs {
     int time, timeDelta;
 };
 
-__global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, IndexArgs a_in,
-                                                        unsigned long long* __restrict__ keys, FrameRider rider) {
-    MMF_MODEL_STREAM_PRIORITY();
-    if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
-        frame_rider_run(rider);
-        return;
-    }
-    const IndexArgs a = with_device_pose(a_in);
-    const int id = (int)(blockIdx.x - (rider.st ? 1u : 0u)) * 256 + threadIdx.x;
-    if (id >= count) return;
-    const float4 p = s.pos[id];
-    const float ts = s.col[id].w;
+// index.vert: surfel `id` (position p, timestamp ts) into the key image
+__device__ __forceinline__ void index_map_project(const IndexArgs& a, int id, float4 p, float ts,
+                                                  unsigned long long* __restrict__ keys) {
     const v3 h = m4point(a.t_inv, V3(p.x, p.y, p.z));
     if (h.z > a.maxDepth || h.z < 0 || (float)a.time - ts > (float)a.timeDelta) return;
     const float xn = ((((a.c.fx * h.x) / h.z) + a.c.cx) - (a.cols * 0.5f)) / (a.cols * 0.5f);
@@ -457,6 +448,19 @@ __global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, 
     // look-ups of fuse_data_kernel / clean_flag_kernel (row-major storage made each of those a
     // one-cache-line-per-lane access: 47 us for clean_flag_kernel at 640x480)
     atomicMin(&keys[px * a.rows + py], k);
+}
+
+__global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, IndexArgs a_in,
+                                                        unsigned long long* __restrict__ keys, FrameRider rider) {
+    MMF_MODEL_STREAM_PRIORITY();
+    if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
+        frame_rider_run(rider);
+        return;
+    }
+    const IndexArgs a = with_device_pose(a_in);
+    const int id = (int)(blockIdx.x - (rider.st ? 1u : 0u)) * 256 + threadIdx.x;
+    if (id >= count) return;
+    index_map_project(a, id, s.pos[id], s.col[id].w, keys);
 }
 
 // linear over the transposed images (it never needs a pixel's coordinates)
@@ -909,16 +913,11 @@ __global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restric
 }
 
 // update.vert:38-111, in place (each surfel only touches itself); resets winner[] for the next frame
-__global__ __launch_bounds__(256) void fuse_update_kernel(SurfelSoA s, int count, SurfelSoA meas, int time,
-                                                          unsigned* __restrict__ winner) {
-    MMF_MODEL_STREAM_PRIORITY();
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= count) return;
-    const unsigned w = winner[k];
-    if (w == kNoWinner) return;
-    winner[k] = kNoWinner;
+// surfel k merged with its winning measurement w, in place
+__device__ __forceinline__ void fuse_update_one(SurfelSoA s, int k, unsigned w, SurfelSoA meas, int time, float4& op, float4& oc) {
     const float4 np = meas.pos[w], nc = meas.col[w], nn = meas.nrm[w];
-    float4 op = s.pos[k], oc = s.col[k], on = s.nrm[k];
+    float4 on = s.nrm[k];
+    op = s.pos[k], oc = s.col[k];
     const float c_k = op.w, av = np.w;
     if (nn.w < (1.0f + 0.5f) * on.w) {
         op.x = ((c_k * op.x) + (av * np.x)) / (c_k + av);
@@ -944,6 +943,39 @@ __global__ __launch_bounds__(256) void fuse_update_kernel(SurfelSoA s, int count
         s.pos[k] = op;
         s.col[k] = oc;
     }
+}
+
+__global__ __launch_bounds__(256) void fuse_update_kernel(SurfelSoA s, int count, SurfelSoA meas, int time,
+                                                          unsigned* __restrict__ winner) {
+    MMF_MODEL_STREAM_PRIORITY();
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const unsigned w = winner[k];
+    if (w == kNoWinner) return;
+    winner[k] = kNoWinner;
+    float4 op, oc;
+    fuse_update_one(s, k, w, meas, time, op, oc);
+}
+
+// fuse_update_kernel and the predictIndices that follows it (MultiMotionFusion.cpp:800-808) in one pass over the surfels: the
+// projection takes the surfel from the registers the update left it in
+__global__ __launch_bounds__(256) void fuse_update_index_kernel(SurfelSoA s, int count, SurfelSoA meas, int time,
+                                                                unsigned* __restrict__ winner, IndexArgs a_in,
+                                                                unsigned long long* __restrict__ keys) {
+    MMF_MODEL_STREAM_PRIORITY();
+    const IndexArgs a = with_device_pose(a_in);
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const unsigned w = winner[k];
+    float4 op, oc;
+    if (w == kNoWinner) {
+        op = s.pos[k];
+        oc.w = s.col[k].w;
+    } else {
+        winner[k] = kNoWinner;
+        fuse_update_one(s, k, w, meas, time, op, oc);
+    }
+    index_map_project(a, k, op, oc.w, keys);
 }
 
 // ---- clean: copy_unstable.vert:53-150 ---------------------------------------------------------------
