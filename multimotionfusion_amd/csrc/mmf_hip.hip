@@ -1440,6 +1440,7 @@ static bool gn_geometry(int level, int n, GnGeometry* out) {
     return false;
 }
 static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom);
+static unsigned fused_max_models();
 
 static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float rot[9], int rgb_only, float icp_weight,
                                  int pyramid, int fast_odom, int so3, float* icp_err_dev, float* rgb_err_dev,
@@ -1465,10 +1466,10 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
 
     const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};  // :312-314
     // both terms on and every level fits: ONE launch per iteration (gn_fused.hpp) instead of producer + step
-    // (more than two models: the batched two-launch chain is faster -- 8 models 1.56 ms against 2.0 -- because a model's
-    // workgroups hold their CUs at the count barrier while the next models' wait for a place)
+    // (more than three models: the batched two-launch chain is as fast (four) or faster -- 8 models 1.40 ms against 1.60 --
+    // because a model's workgroups hold their CUs at the count barrier while the next models' wait for a place)
     const bool fused_chain = odom_fused_chain_ok(o, rgb_only, icp_weight, pyramid, fast_odom) &&
-                             (ny == 1 || (ny <= 2 && odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom)));
+                             (ny == 1 || (ny <= fused_max_models() && odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom)));
     int first_iter_level = MMF_NUM_PYRS - 1;  // the coarsest level that runs iterations
     while (first_iter_level > 0 && !iterations[first_iter_level]) --first_iter_level;
 
@@ -1782,6 +1783,10 @@ static std::atomic<int> g_gn_fused{-1};  // -1: MMF_GN_FUSED decides (default on
 extern "C" int mmf_debug_set_gn_fused(int on) {
     g_gn_fused.store(on < 0 ? -1 : (on ? 1 : 0));
     return MMF_OK;
+}
+static unsigned fused_max_models() {  // MMF_GN_FUSED_MAX: up to how many models one one-launch chain carries
+    static const unsigned n = []() { const char* e = std::getenv("MMF_GN_FUSED_MAX"); return e ? (unsigned)std::max(1, std::atoi(e)) : 3u; }();
+    return n;
 }
 static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom) {
     static const bool env_enabled = []() {
