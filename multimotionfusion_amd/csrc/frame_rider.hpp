@@ -19,6 +19,7 @@ struct FrameRider {
     OdomState* st = nullptr;    // nullptr: nothing rides
     OdomState* host = nullptr;  // pinned, device visible: the copy the host polls
     unsigned seq = 0;
+    unsigned what = 3;  // bit 0: the hand-over to the host, bit 1: the fusion weight (the projection's two launches carry one each)
 };
 
 // Model::computeFusionWeight (Model.cpp:876-891) of the tracked pose against lastPose = the pose the chain started from
@@ -41,17 +42,26 @@ __device__ __forceinline__ void odom_publish_wave(const OdomState* st, OdomState
     const unsigned* src = reinterpret_cast<const unsigned*>(st);
     unsigned* dst = reinterpret_cast<unsigned*>(host);
     constexpr unsigned kWords = offsetof(OdomState, publish_seq) / 4;
-    for (unsigned i = lane; i < kWords; i += 64) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr unsigned kRounds = (kWords + 63) / 64;
+    // all of a lane's words are loaded before any is stored: as a load-store loop this was kRounds dependent round trips
+    unsigned v[kRounds];
+#pragma unroll
+    for (unsigned r = 0; r < kRounds; ++r)
+        v[r] = __hip_atomic_load(src + min(lane + 64 * r, kWords - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (unsigned r = 0; r < kRounds; ++r)
+        if (lane + 64 * r < kWords) dst[lane + 64 * r] = v[r];
     __threadfence_system();
     if (lane == 0) __hip_atomic_store(&host->publish_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // the riding workgroup (>= 128 threads): wave 0 publishes, lane 0 of wave 1 evaluates the weight
 __device__ __forceinline__ void frame_rider_run(const FrameRider& r) {
-    if (threadIdx.x < 64)
-        odom_publish_wave(r.st, r.host, r.seq, threadIdx.x);
-    else if (threadIdx.x == 64)
-        odom_fusion_weight(r.st);
+    if (threadIdx.x < 64) {
+        if (r.what & 1u) odom_publish_wave(r.st, r.host, r.seq, threadIdx.x);
+    } else if (threadIdx.x == 64) {
+        if (r.what & 2u) odom_fusion_weight(r.st);
+    }
 }
 
 }  // namespace mmf

@@ -2302,6 +2302,10 @@ static IndexArgs model_index_args(mmf_model* m, int time, float depth_cutoff, in
     return a;
 }
 
+static bool split_rider() {  // MMF_RIDER_SPLIT=0: hand-over and weight both on the first launch (A/B aid)
+    static const bool on = []() { const char* e = std::getenv("MMF_RIDER_SPLIT"); return !e || e[0] != '0'; }();
+    return on;
+}
 // ModelProjection::predictIndices (ModelProjection.cpp:94-143)
 // projected: the surfels are in the key image already (model_fuse with then_index); only the resolve is left
 static int model_predict_indices(mmf_model* m, int time, float depth_cutoff, int time_delta, bool projected) {
@@ -2311,13 +2315,18 @@ static int model_predict_indices(mmf_model* m, int time, float depth_cutoff, int
     MMF_HIP_TRY(hipSetDevice(c->device));
     const size_t npix = (size_t)m->width * m->height;
     const IndexArgs a = model_index_args(m, time, depth_cutoff, time_delta);
-    const FrameRider rider = m->rider;  // (frame_rider.hpp: the tracking result's hand-over, when this is the frame's first projection)
+    // frame_rider.hpp: when this is the frame's first projection, its first launch carries the tracking result's hand-over
+    // to the host and its second the fusion weight (each a few microseconds on one extra workgroup, shorter than its carrier)
+    FrameRider publish = m->rider, weight = m->rider;
+    publish.what = split_rider() ? 1u : 3u, weight.what = 2u;
+    if (!split_rider()) weight = FrameRider();
     m->rider = FrameRider();
-    if (!projected && (m->count || rider.st))
-        hipLaunchKernelGGL(index_map_kernel, dim3((unsigned)((m->count + 255) / 256) + (rider.st ? 1u : 0u)), dim3(256), 0, c->stream,
-                           m->set[m->cur], (int)m->count, a, m->keys, rider);
-    hipLaunchKernelGGL(index_resolve_kernel, grid1d(npix), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->index,
-                       m->vertConf, m->colorTime, m->normRad);
+    MMF_REQUIRE(!(projected && publish.st), "mmf_model_predict_indices: a tracking result to hand over, but no projection launch to carry it");
+    if (!projected && (m->count || publish.st))
+        hipLaunchKernelGGL(index_map_kernel, dim3((unsigned)((m->count + 255) / 256) + (publish.st ? 1u : 0u)), dim3(256), 0, c->stream,
+                           m->set[m->cur], (int)m->count, a, m->keys, publish);
+    hipLaunchKernelGGL(index_resolve_kernel, dim3((unsigned)((npix + 255) / 256) + (weight.st ? 1u : 0u)), dim3(256), 0, c->stream,
+                       m->set[m->cur], a, m->keys, m->index, m->vertConf, m->colorTime, m->normRad, weight);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }

@@ -469,10 +469,15 @@ __global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, 
 __global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexArgs a_in,
                                                             unsigned long long* __restrict__ keys,
                                                             unsigned* __restrict__ index, float4* __restrict__ vertConf,
-                                                            float4* __restrict__ colorTime, float4* __restrict__ normRad) {
+                                                            float4* __restrict__ colorTime, float4* __restrict__ normRad,
+                                                            FrameRider rider) {
     MMF_MODEL_STREAM_PRIORITY();
+    if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
+        frame_rider_run(rider);
+        return;
+    }
     const IndexArgs a = with_device_pose(a_in);
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(blockIdx.x - (rider.st ? 1u : 0u)) * 256 + threadIdx.x;
     if (i >= a.cols * a.rows) return;
     const unsigned long long k = keys[i];
     if (k != kEmptyKey) keys[i] = kEmptyKey;
