@@ -17,7 +17,7 @@ import pandas as pd
 
 PER_LEVEL = ("gn_iter_kernel", "track_producer_kernel", "rgb_step_kernel")
 PER_KERNEL = ("index_map_kernel", "index_resolve_kernel", "splat_kernel", "splat_resolve_fill_kernel", "fuse_data_kernel",
-              "fuse_update_kernel", "clean_flag_kernel", "clean_scatter_kernel", "prep_batch_kernel", "bilateral_filter2_kernel",
+              "fuse_update_kernel", "fuse_update_index_kernel", "clean_flag_kernel", "clean_scatter_kernel", "prep_batch_kernel", "bilateral_filter2_kernel",
               "so3_kernel", "gn_final_kernel", "odom_publish_kernel")
 
 
