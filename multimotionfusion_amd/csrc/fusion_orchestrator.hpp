@@ -563,9 +563,9 @@ static int fusion_predict_model(mmf_fusion* f, FusionModel* fm) {
 }
 
 // The reference predicts twice per frame: behind the tracking (:675) and at the end (:821).  The first prediction's images
-// feed loop closure (ferns, :682) and the segmentation (:700-790), neither of which runs inside this library -- the
-// segmentation result is handed in with the frame, a caller sees the images only between calls -- and the fuse / clean
-// passes read their own index maps, not the prediction.  Its images are overwritten by the second prediction before
+// feed loop closure (closeLoops: ferns, :682, and the model-to-model odometry, :714-760), which does not run inside this
+// library; the segmentation (:412) comes before it and reads the previous frame's prediction (as a segmentation callback
+// does here), a caller sees the images only between calls, and the fuse / clean passes read their own index maps.  Its images are overwritten by the second prediction before
 // anything can read them, so it is not enqueued (bit-identical poses, maps and images: every oracle parity test runs this
 // way, and tests/test_gpu_fusion.py compares the two).  MMF_MID_PREDICT=1 runs it as the reference does.
 static std::atomic<int> g_mid_predict{-1};  // -1: MMF_MID_PREDICT decides (default off); 0 / 1: mmf_debug_set_mid_predict
