@@ -335,11 +335,18 @@ __global__ __launch_bounds__(256) void vertices_to_depth_kernel(const float4* __
 __device__ __forceinline__ uint8_t intensity_value(const uint8_t* __restrict__ p) {
     return (uint8_t)(int)((float)p[0] * 0.114f + (float)p[1] * 0.299f + (float)p[2] * 0.587f);
 }
+// the same from the three low bytes of one RGBA8 texel (one 4-byte load instead of three byte loads)
+__device__ __forceinline__ uint8_t intensity_value_rgba(unsigned texel) {
+    return (uint8_t)(int)((float)(texel & 0xFFu) * 0.114f + (float)((texel >> 8) & 0xFFu) * 0.299f + (float)((texel >> 16) & 0xFFu) * 0.587f);
+}
 __device__ __forceinline__ void image_to_intensity_px(int x, int y, const uint8_t* __restrict__ img, int i_stride,
                                                                  int channels, int cols, int rows,
                                                                  uint8_t* __restrict__ dst, int d_stride) {
     if (x >= cols || y >= rows) return;
-    dst[(size_t)y * d_stride + x] = intensity_value(img + (size_t)y * i_stride + (size_t)x * channels);
+    if (channels == 4 && (i_stride & 3) == 0)  // (wave uniform; hipMalloc'd images are 256-byte aligned)
+        dst[(size_t)y * d_stride + x] = intensity_value_rgba(*reinterpret_cast<const unsigned*>(img + (size_t)y * i_stride + (size_t)x * 4));
+    else
+        dst[(size_t)y * d_stride + x] = intensity_value(img + (size_t)y * i_stride + (size_t)x * channels);
 }
 __global__ __launch_bounds__(256) void image_to_intensity_kernel(const uint8_t* __restrict__ img, int i_stride,
                                                                  int channels, int cols, int rows,

@@ -1096,6 +1096,10 @@ extern "C" int mmf_odom_init_first_rgb(mmf_odom* o, const uint8_t* rgb, size_t s
 }
 
 // ---- the whole per-frame preparation in four launches (prep_batch.hpp) -------------------------
+static size_t prep_big_job() {  // pixels from which a job's workgroups take four tiles each; MMF_PREP_BIG=0: never
+    static const size_t n = []() { const char* e = std::getenv("MMF_PREP_BIG"); return e ? (std::atol(e) > 0 ? (size_t)std::atol(e) : ~(size_t)0) : (size_t)200000; }();
+    return n;
+}
 struct PrepBuilder {  // the jobs of one stage (possibly of several models); launched kMaxPrepJobs at a time
     std::vector<PrepJob> jobs;
     bool critical = false;  // PrepBatch::critical
@@ -1107,6 +1111,7 @@ struct PrepBuilder {  // the jobs of one stage (possibly of several models); lau
         j.op = op;
         j.cols = cols, j.rows = rows;
         j.gx = (cols + kTileX - 1) / kTileX;
+        j.reps = (size_t)cols * rows >= prep_big_job() ? 4 : 1;  // (PrepJob::reps)
         return j;
     }
     int launch(Enqueuer& q) {
@@ -1119,7 +1124,7 @@ struct PrepBuilder {  // the jobs of one stage (possibly of several models); lau
                 PrepJob& j = b.job[b.njobs++];
                 j = jobs[k];
                 j.first_block = blocks;
-                blocks += j.gx * ((j.rows + kTileY - 1) / kTileY);
+                blocks += j.gx * ((j.rows + kTileY * j.reps - 1) / (kTileY * j.reps));
             }
             q.launch(prep_batch_kernel, dim3(blocks), tile_block(), b);
         }
@@ -1300,7 +1305,11 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             pyr(pb, PREP_PYRDOWN_F, o->depth_pyr[1], o->depth_pyr[2], 2);
             vmap_job(pb, 1, o->depth_pyr[1]);
         }
-        level_jobs(pb, 0);
+        // The model side's level-0 products come straight from the prediction's images (merge_first) and nothing of the
+        // preparation reads them: they go into the LAST of its two launches, beside the small jobs of levels 1 and 2, and the
+        // first launch is the three quarter-size pyramid jobs alone (MMF_PREP_L0_LATE=0: in the first, as before).
+        static const bool l0_late = []() { const char* e = std::getenv("MMF_PREP_L0_LATE"); return !e || e[0] != '0'; }();
+        level_jobs(model_side && merge_first && merge_last && l0_late && !in_img && !in_depth ? stages.stage[2] : pb, 0);
         down_jobs(pb, 1, nullptr);
     }
     {   // stage 3: level 1 -> level 2

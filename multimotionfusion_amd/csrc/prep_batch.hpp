@@ -44,6 +44,8 @@ enum PrepOp : int {
 struct PrepJob {
     int op;
     int gx;           // 64-pixel tiles per row of this job's grid
+    int reps;         // 64 x 4 tiles a workgroup handles, one below the other (a full-size job as 1 200 workgroups of one
+                      // tile each is bound by the dispatcher: ~3 ns per workgroup, longer than the work)
     int first_block;  // first workgroup of the launch that belongs to this job
     int cols, rows;   // destination size in pixels (all internal buffers are dense: stride = cols)
     int scols, srows; // source size where it differs (pyramid steps), or the source byte stride (PREP_INTENSITY)
@@ -111,18 +113,9 @@ __device__ __forceinline__ void transform_pack_px(int x, int y, int rows, int co
     transform_pack_store(x, y, rows, cols, v_ok, vs, n_ok, ns, R, t, vdst, ndst, packed);
 }
 
-__global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
-    if (b.critical) __builtin_amdgcn_s_setprio(3);
-    int j = 0;
-    for (int k = 1; k < b.njobs; ++k) j = (int)blockIdx.x >= b.job[k].first_block ? k : j;  // wave uniform
-    const PrepJob& J = b.job[j];
-    const int local = (int)blockIdx.x - J.first_block;
-    const int by = local / J.gx, bx = local - by * J.gx;
-    const int x = bx * kTileX + threadIdx.x, y = by * kTileY + threadIdx.y;
+// pixel (x, y) of job J
+__device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, const void* src1, int x, int y) {
     const int cols = J.cols, rows = J.rows;
-    const bool alt = J.sel != nullptr && (J.sel_total ? ((float)*J.sel / (float)J.sel_total < J.sel_ratio) : *J.sel != 0);  // wave uniform
-    const void* src0 = alt ? J.alt0 : J.src0;
-    const void* src1 = alt ? J.alt1 : J.src1;
     switch (J.op) {
         case PREP_VMAP:
             create_vmap_px(x, y, (const float*)src0, cols, cols, rows, (float*)J.dst0, cols, J.f[0], J.f[1], J.f[2], J.f[3],
@@ -208,8 +201,15 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
             const uint8_t* img = (const uint8_t*)src0;
             const int ch = J.channels;
             const size_t stride = (size_t)J.scols * ch;
-            ((uint8_t*)J.dst0)[(size_t)y * cols + x] = pyrdown_uchar_gauss_taps(
-                x, y, J.scols, J.srows, [&](int yy, int xx) { return intensity_value(img + (size_t)yy * stride + (size_t)xx * ch); });
+            if (ch == 4) {  // an RGBA8 prediction image: one load per tap
+                const unsigned* tex = (const unsigned*)img;
+                const int scols = J.scols;
+                ((uint8_t*)J.dst0)[(size_t)y * cols + x] = pyrdown_uchar_gauss_taps(
+                    x, y, scols, J.srows, [&](int yy, int xx) { return intensity_value_rgba(tex[(size_t)yy * scols + xx]); });
+            } else {
+                ((uint8_t*)J.dst0)[(size_t)y * cols + x] = pyrdown_uchar_gauss_taps(
+                    x, y, J.scols, J.srows, [&](int yy, int xx) { return intensity_value(img + (size_t)yy * stride + (size_t)xx * ch); });
+            }
             break;
         }
         case PREP_TEX_RESIZE: {
@@ -263,6 +263,20 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
         }
         default: break;
     }
+}
+
+__global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
+    if (b.critical) __builtin_amdgcn_s_setprio(3);
+    int j = 0;
+    for (int k = 1; k < b.njobs; ++k) j = (int)blockIdx.x >= b.job[k].first_block ? k : j;  // wave uniform
+    const PrepJob& J = b.job[j];
+    const int local = (int)blockIdx.x - J.first_block;
+    const int by = local / J.gx, bx = local - by * J.gx;
+    const int x = bx * kTileX + threadIdx.x;
+    const bool alt = J.sel != nullptr && (J.sel_total ? ((float)*J.sel / (float)J.sel_total < J.sel_ratio) : *J.sel != 0);  // wave uniform
+    const void* src0 = alt ? J.alt0 : J.src0;
+    const void* src1 = alt ? J.alt1 : J.src1;
+    for (int r = 0; r < J.reps; ++r) prep_job_px(J, src0, src1, x, (by * J.reps + r) * kTileY + threadIdx.y);
 }
 
 }  // namespace mmf
