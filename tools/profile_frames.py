@@ -51,7 +51,8 @@ for i in range(n):
         k = i % nf
         if i and k == 0:
             g.reset()
-        g.processFrame(rgb[k], depth[k], timestamp=i, next=(rgb[(i + 1) % nf], depth[(i + 1) % nf]) if (i + 1) % nf != 0 else None)
+        hint = (i + 1) % nf != 0 and prefetch  # (prefetch 0: the headline loop without the next-frame hint -- nothing on the side streams)
+        g.processFrame(rgb[k], depth[k], timestamp=i, next=(rgb[(i + 1) % nf], depth[(i + 1) % nf]) if hint else None)
         continue
     if models > 1:
         kn = frame_of(i + 1)

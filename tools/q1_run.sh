@@ -7,7 +7,7 @@ for cfg in "$@"; do
   n=$((n+1))
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_q
   export $cfg
-  rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_q -o p -- python3 $GRAFT_REPO_ROOT/tools/profile_frames.py 120 640x480 1 1 headline > $GRAFT_REPO_ROOT/gpurun_out/prof_q.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_q -o p -- python3 $GRAFT_REPO_ROOT/tools/profile_frames.py 120 640x480 1 ${MMF_Q1_HINT:-1} headline > $GRAFT_REPO_ROOT/gpurun_out/prof_q.log 2>&1
   unset ${cfg%%=*}
   echo "== $cfg" > $GRAFT_REPO_ROOT/gpurun_out/q1_$n.txt
   python3 $GRAFT_REPO_ROOT/tools/q1_sum.py $(ls $GRAFT_REPO_ROOT/gpurun_out/prof_q/*kernel_trace.csv | head -1) >> $GRAFT_REPO_ROOT/gpurun_out/q1_$n.txt
