@@ -7,6 +7,11 @@
 // (inputs -> level 0 -> level 1 -> level 2), so every stage of the chain runs as ONE launch whose
 // workgroups pick their job from a table by block index.  The jobs call the same per-pixel functions
 // (map_kernels.hpp) as the stand-alone kernels, so the results are bit-identical.
+//
+// Round 3: the chains got shorter by computing a stage's input in the job that needs it instead of storing it first -- the
+// model side (prediction -> pyramids, global-frame maps, point clouds) is TWO dependent launches (PREP_TEX_*, PREP_RESIZE_TP,
+// PREP_PYR_PROJECT), the depth side of the sensor frame THREE (PREP_VMAP_NMAP), its image side four; a launch on the
+// model's stream costs ~4.5 us before it does anything, which is most of what a small stage takes.
 #pragma once
 #include "icp_kernels.hpp"
 #include "map_kernels.hpp"
