@@ -401,11 +401,13 @@ __global__ __launch_bounds__(256) void derivative_kernel(const uint8_t* __restri
 // (the pixel's depth in a register: prep_batch.hpp computes it in the same job)
 __device__ __forceinline__ void project_points_store(int x, int y, float z, int cols, float* __restrict__ cloud, float inv_fx,
                                                                 float inv_fy, float cx, float cy, float4* __restrict__ cloud4) {
-    float* c = cloud + ((size_t)y * cols + x) * 3;
     const float X = (float)((x - cx) * z * inv_fx), Y = (float)((y - cy) * z * inv_fy);
-    c[0] = X;
-    c[1] = Y;
-    c[2] = z;
+    if (cloud) {  // (the AoS copy: three 12-byte-strided stores per pixel; the chains read the records)
+        float* c = cloud + ((size_t)y * cols + x) * 3;
+        c[0] = X;
+        c[1] = Y;
+        c[2] = z;
+    }
     if (cloud4) cloud4[(size_t)y * cols + x] = make_float4(X, Y, z, 1.0f / z);
 }
 __device__ __forceinline__ void project_points_px(int x, int y, const float* __restrict__ depth, int d_stride, int cols,

@@ -453,7 +453,7 @@ extern "C" int mmf_rgb_step(mmf_ctx* c, const mmf_dataterm* corres_dev, float si
     a.icp_partials = nullptr;
     a.icp_records = 0;
     a.corres = corres_dev;
-    a.cloud = cloud_dev;
+    a.cloud = cloud_dev, a.cloud4 = nullptr;
     a.fx = fx;
     a.fy = fy;
     a.dIdx = dIdx;
@@ -1181,6 +1181,10 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     // ... and level 0 and the first pyramid step are computed straight from the prediction's images (PREP_TEX_*): two
     // dependent launches.  MMF_PREP_MERGE=1: only the last stage merged (A/B aid).
     static const bool merge_first = []() { const char* e = std::getenv("MMF_PREP_MERGE"); return !e || std::atoi(e) >= 2; }();
+    // The model maps in the global frame go out as the packed records (and {X, Y, Z, 1/Z} point records) the chains gather
+    // from; the planar copies and the AoS cloud of the first-generation kernels (25 -> 14 MB written per frame at level 0)
+    // only for the first-generation ICP kernel (MMF_ICP_VARIANT 1xxxxxx) or on request: MMF_PREP_PLANAR=1.
+    static const bool planar = []() { const char* e = std::getenv("MMF_PREP_PLANAR"); return (e && e[0] != '0') || icp_default_variant(0) / 1000000 == 1; }();
     // The sensor frame's normal map of a level is computed in the same job as its vertex map, from the depth image
     // (PREP_VMAP_NMAP): the depth side is three dependent launches instead of four.  MMF_PREP_VN=0: apart (A/B aid).
     static const bool merge_vn = []() { const char* e = std::getenv("MMF_PREP_VN"); return !e || e[0] != '0'; }();
@@ -1200,12 +1204,12 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
             PrepJob& t = pb.add(PREP_TEX_TP, cols, rows);
             t.src0 = pred_vertex, t.src1 = pred_normal, t.sel = sel, t.alt0 = alt_vertex, t.alt1 = alt_normal;
-            t.dst0 = o->vmaps_g_prev[0], t.dst1 = o->nmaps_g_prev[0], t.dst2 = o->prev_packed[0];
+            t.dst0 = planar ? o->vmaps_g_prev[0] : nullptr, t.dst1 = planar ? o->nmaps_g_prev[0] : nullptr, t.dst2 = o->prev_packed[0];
             for (int k = 0; k < 9; ++k) t.f[k] = R[k];
             t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
             PrepJob& p = pb.add(PREP_TEX_PROJECT, cols, rows);
             p.src0 = pred_vertex, p.sel = sel, p.alt0 = alt_vertex;
-            p.dst0 = o->cloud[0], p.dst1 = o->cloud4[0], p.dst2 = o->last_depth[0];
+            p.dst0 = planar ? o->cloud[0] : nullptr, p.dst1 = o->cloud4[0], p.dst2 = o->last_depth[0];
             intr_f(p, 0, false, 0.f);
             p.f[4] = o->max_depth_rgb;
             PrepJob& il = pb.add(PREP_INTENSITY, W, H);
@@ -1214,12 +1218,12 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
         } else if (model_side && !(merge_last && lvl == MMF_NUM_PYRS - 1)) {
             PrepJob& t = pb.add(PREP_TRANSFORM_PACK, cols, rows);
             t.src0 = uv[lvl], t.src1 = un[lvl];
-            t.dst0 = o->vmaps_g_prev[lvl], t.dst1 = o->nmaps_g_prev[lvl], t.dst2 = o->prev_packed[lvl];
+            t.dst0 = planar ? o->vmaps_g_prev[lvl] : nullptr, t.dst1 = planar ? o->nmaps_g_prev[lvl] : nullptr, t.dst2 = o->prev_packed[lvl];
             const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
             for (int k = 0; k < 9; ++k) t.f[k] = R[k];
             t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
             PrepJob& p = pb.add(PREP_PROJECT, cols, rows);
-            p.src0 = o->last_depth[lvl], p.dst0 = o->cloud[lvl], p.dst1 = o->cloud4[lvl];
+            p.src0 = o->last_depth[lvl], p.dst0 = planar ? o->cloud[lvl] : nullptr, p.dst1 = o->cloud4[lvl];
             intr_f(p, lvl, false, 0.f);
         }
         if (in_img) {
@@ -1254,13 +1258,13 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             const int cols = W >> lvl, rows = H >> lvl;
             PrepJob& t = pb.add(PREP_RESIZE_TP, cols, rows);
             t.src0 = uv[lvl - 1], t.src1 = un[lvl - 1], t.scols = W >> (lvl - 1), t.srows = H >> (lvl - 1);
-            t.dst0 = o->vmaps_g_prev[lvl], t.dst1 = o->nmaps_g_prev[lvl], t.dst2 = o->prev_packed[lvl];
+            t.dst0 = planar ? o->vmaps_g_prev[lvl] : nullptr, t.dst1 = planar ? o->nmaps_g_prev[lvl] : nullptr, t.dst2 = o->prev_packed[lvl];
             const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
             for (int k = 0; k < 9; ++k) t.f[k] = R[k];
             t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
             PrepJob& p = pb.add(PREP_PYR_PROJECT, cols, rows);
             p.src0 = o->last_depth[lvl - 1], p.scols = W >> (lvl - 1), p.srows = H >> (lvl - 1);
-            p.dst0 = o->cloud[lvl], p.dst1 = o->cloud4[lvl], p.dst2 = o->last_depth[lvl];
+            p.dst0 = planar ? o->cloud[lvl] : nullptr, p.dst1 = o->cloud4[lvl], p.dst2 = o->last_depth[lvl];
             intr_f(p, lvl, false, 0.f);
         } else if (model_side) {
             pyr(pb, PREP_PYRDOWN_F, o->last_depth[lvl - 1], o->last_depth[lvl], lvl);
@@ -1689,7 +1693,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 a.icp_partials = o->gn_partials_icp;
                 a.icp_records = (unsigned)icp_records;
                 a.corres = o->corres[i];
-                a.cloud = o->cloud[i];
+                a.cloud = nullptr, a.cloud4 = reinterpret_cast<const float4*>(o->cloud4[i]);
                 a.fx = in.fx;
                 a.fy = in.fy;
                 a.dIdx = o->dIdx[i];
@@ -1962,6 +1966,8 @@ extern "C" int mmf_odom_buffer(mmf_odom* o, const char* name, int level, void** 
     else if (s == "next_depth") p = o->next_depth[level], b = n * 4;
     else if (s == "depth_pyr") p = o->depth_pyr[level], b = n * 4;
     else if (s == "cloud") p = o->cloud[level], b = 3 * n * 4;
+    else if (s == "cloud4") p = o->cloud4[level], b = 4 * n * 4;         // {X, Y, Z, 1/Z} per pixel
+    else if (s == "prev_packed") p = o->prev_packed[level], b = 6 * n * 4;  // {vertex, normal} per pixel
     else if (s == "last_image") p = o->last_image[level], b = n;
     else if (s == "next_image") p = o->next_image[level], b = n;
     else if (s == "last_next_image") p = o->last_next_image[level], b = n;

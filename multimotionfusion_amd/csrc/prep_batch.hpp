@@ -79,20 +79,25 @@ struct PrepBatch {
 // (v_ok / n_ok: the source vertex / normal is valid, i.e. its x is not NaN)
 __device__ __forceinline__ void transform_pack_store(int x, int y, int rows, int cols, bool v_ok, f3 vs, bool n_ok, f3 ns, m33 R, f3 t,
                                                      float* __restrict__ vdst, float* __restrict__ ndst, float* __restrict__ packed) {
+    // (vdst / ndst: the planar copies, or null -- the chains gather from the packed records only)
     f3 vd = make_f3(qnan(), qnan(), qnan());
     if (v_ok) {
         vd = R * vs + t;
-        vdst[(size_t)(y + rows) * cols + x] = vd.y;
-        vdst[(size_t)(y + 2 * rows) * cols + x] = vd.z;
+        if (vdst) {
+            vdst[(size_t)(y + rows) * cols + x] = vd.y;
+            vdst[(size_t)(y + 2 * rows) * cols + x] = vd.z;
+        }
     }
-    vdst[(size_t)y * cols + x] = vd.x;
+    if (vdst) vdst[(size_t)y * cols + x] = vd.x;
     f3 nd = make_f3(qnan(), qnan(), qnan());
     if (n_ok) {
         nd = R * ns;
-        ndst[(size_t)(y + rows) * cols + x] = nd.y;
-        ndst[(size_t)(y + 2 * rows) * cols + x] = nd.z;
+        if (ndst) {
+            ndst[(size_t)(y + rows) * cols + x] = nd.y;
+            ndst[(size_t)(y + 2 * rows) * cols + x] = nd.z;
+        }
     }
-    ndst[(size_t)y * cols + x] = nd.x;
+    if (ndst) ndst[(size_t)y * cols + x] = nd.x;
     float2* o = reinterpret_cast<float2*>(packed + 6 * ((size_t)y * cols + x));
     o[0] = make_float2(vd.x, vd.y);
     o[1] = make_float2(vd.z, nd.x);

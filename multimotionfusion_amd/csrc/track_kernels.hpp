@@ -421,7 +421,8 @@ struct RgbStepArgs {
     const float* icp_partials;     // GN mode, when the ICP term is on: records of icp_kernel
     unsigned icp_records;
     const mmf_dataterm* corres;
-    const float* cloud;  // AoS float3, dense
+    const float* cloud;    // AoS float3, dense (the stand-alone entry's argument) ...
+    const float4* cloud4;  // ... or, when non-null, the {X, Y, Z, 1/Z} records the preparation writes for the chains
     float fx, fy;
     const int16_t *dIdx, *dIdy;
     int d_stride;
@@ -486,8 +487,13 @@ __device__ __forceinline__ void rgb_gather(const RgbStepArgs& a, const int4 (&ra
         } else {
             *reinterpret_cast<int4*>(&l.c[p]) = raws[p];
         }
-        const float* cp = a.cloud + (size_t)(l.c[p].zero_y * a.cols + l.c[p].zero_x) * 3;
-        l.X[p] = cp[0], l.Y[p] = cp[1], l.Z[p] = cp[2];
+        if (a.cloud4) {  // (uniform; the same three floats either way)
+            const float4 cp = a.cloud4[(size_t)(l.c[p].zero_y * a.cols + l.c[p].zero_x)];
+            l.X[p] = cp.x, l.Y[p] = cp.y, l.Z[p] = cp.z;
+        } else {
+            const float* cp = a.cloud + (size_t)(l.c[p].zero_y * a.cols + l.c[p].zero_x) * 3;
+            l.X[p] = cp[0], l.Y[p] = cp[1], l.Z[p] = cp[2];
+        }
         l.gx[p] = a.dIdx[(size_t)l.c[p].one_y * a.d_stride + l.c[p].one_x];
         l.gy[p] = a.dIdy[(size_t)l.c[p].one_y * a.d_stride + l.c[p].one_x];
     }
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     if (gridDim.y > 1) {  // model blockIdx.y (see BatchDelta)
         const long long d = bd.d[blockIdx.y];
         st = batch_shift(st, d);
-        a.corres = batch_shift(a.corres, d), a.cloud = batch_shift(a.cloud, d);
+        a.corres = batch_shift(a.corres, d), a.cloud = batch_shift(a.cloud, d), a.cloud4 = batch_shift(a.cloud4, d);
         a.icp_partials = batch_shift(a.icp_partials, d), a.residual_partials = batch_shift(a.residual_partials, d);
         partials = batch_shift(partials, d), ticket = batch_shift(ticket, d);
     }

@@ -105,8 +105,8 @@ class RGBDOdometry:
         check(self.ctx.lib.mmf_odom_download(self.handle, name.encode(), level, C.c_void_p(host.ctypes.data),
                                              nbytes.value))
         cols, rows = self.width >> level, self.height >> level
-        if name == "cloud":
-            return host.view(np.float32).reshape(rows, cols, 3)
+        if name in ("cloud", "cloud4", "prev_packed"):  # per-pixel records
+            return host.view(np.float32).reshape(rows, cols, {"cloud": 3, "cloud4": 4, "prev_packed": 6}[name])
         if name == "corres":
             return host.reshape(rows, cols, 16)
         dt, planes = self._DTYPES[name]

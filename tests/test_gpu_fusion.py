@@ -126,13 +126,29 @@ def test_batched_preparation_matches_the_separate_kernels(gpu_ctx):
     ref.getIncrementalTransformation(pose0[:3, 3], pose0[:3, :3], False, 10.0, True, False, True)  # gradients, clouds
     for lvl in range(3):
         rows = h >> lvl
-        for name in ("vmaps_curr", "nmaps_curr", "vmaps_g_prev", "nmaps_g_prev"):
+        for name in ("vmaps_curr", "nmaps_curr"):
             a, b = batched.download(name, lvl), ref.download(name, lvl)
             valid = ~np.isnan(b[:rows])
             assert_bit_equal(np.isnan(a[:rows]), np.isnan(b[:rows]), f"{name}[{lvl}] validity")
             for p in range(3):
                 assert_bit_equal(a[p * rows:(p + 1) * rows][valid], b[p * rows:(p + 1) * rows][valid], f"{name}[{lvl}] plane {p}")
-        for name in ("last_depth", "last_image", "dIdx", "dIdy", "cloud") + (("depth_pyr",) if lvl else ()):
+        # the model maps in the global frame: the batched preparation writes the packed {vertex, normal} records only (what
+        # the chains gather from); the separate kernels write planar maps and pack them -- records and planes must agree
+        pk, pk_ref = batched.download("prev_packed", lvl), ref.download("prev_packed", lvl)
+        for first in (0, 3):  # (an invalid vector is NaN in x; what its y and z hold is not defined: every reader tests x)
+            ok = ~np.isnan(pk_ref[..., first])
+            assert_bit_equal(np.isnan(pk[..., first]), ~ok, f"prev_packed[{lvl}] validity of vector {first // 3}")
+            assert_bit_equal(pk[..., first:first + 3][ok], pk_ref[..., first:first + 3][ok], f"prev_packed[{lvl}] vector {first // 3}")
+        for name, first in (("vmaps_g_prev", 0), ("nmaps_g_prev", 3)):
+            b = ref.download(name, lvl)
+            valid = ~np.isnan(b[:rows])
+            assert_bit_equal(np.isnan(pk[..., first]), np.isnan(b[:rows]), f"{name}[{lvl}] validity")
+            for p in range(3):
+                assert_bit_equal(pk[..., first + p][valid], b[p * rows:(p + 1) * rows][valid], f"{name}[{lvl}] plane {p}")
+        cl4, cl4_ref = batched.download("cloud4", lvl), ref.download("cloud4", lvl)
+        assert_bit_equal(cl4, cl4_ref, f"cloud4[{lvl}]")
+        assert_bit_equal(cl4[..., :3], ref.download("cloud", lvl), f"cloud4[{lvl}] against the AoS cloud")
+        for name in ("last_depth", "last_image", "dIdx", "dIdy") + (("depth_pyr",) if lvl else ()):
             assert_bit_equal(batched.download(name, lvl), ref.download(name, lvl), f"{name}[{lvl}]")
     ref.close()
     g.close()
