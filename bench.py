@@ -2,7 +2,7 @@
 """bench.py -- frames/sec of MultiMotionFusion::processFrame on MI355X, the roofline figure of the dominant
 Gauss-Newton kernel and a CPU baseline (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus 1 --steps 600 --warmup 30
   python bench.py --gpus N ...            (starts its N ranks itself through torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
@@ -183,8 +183,8 @@ def pingpong(i, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-frames", type=int, default=40)
     ap.add_argument("--extras", action="store_true", default=True, help="also time the SURVEY 8(f) kernels beside the path: descriptor "
