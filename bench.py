@@ -739,7 +739,7 @@ def main():
             o_mask = [up(np.where(f["ids"] < m, f["ids"], 0).astype(np.uint8)) for f in oframes]
             g = MultiMotionFusion(ctx, W, H, Ko["cx"], Ko["cy"], Ko["fx"], Ko["fy"], icp_weight=ICP_WEIGHT, enable_multiple_models=1,
                                   preallocated_models=m - 1)
-            n_steps, track_s = 60, 0.0
+            n_steps, track_s = 120, 0.0
             for i in range(m + 10 + n_steps):
                 if i == m + 10:
                     torch.cuda.synchronize()
@@ -769,7 +769,7 @@ def main():
         host_frames = [HostFrame(fr["rgb"], fr["depth"]) for fr in frames]  # (addresses taken once, as a C++ caller has them)
         def host_loop(announce):
             g = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], icp_weight=ICP_WEIGHT)
-            n_steps, t1 = 90, 0.0
+            n_steps, t1 = 300, 0.0
             for i in range(10 + n_steps):
                 if i == 10:
                     torch.cuda.synchronize()
