@@ -5,8 +5,10 @@
 // sequence number the host spins on and (b) Model::computeFusionWeight of the new pose for the early fuse pass
 // (Model.cpp:876-891): one wave each, 3.5 us and 3.8 us behind the 5.6 us of the solve (rocprofv3: 13.0 us for the
 // launch, 9.2 without the weight), and the frame's first projection waited for both.  That projection -- the first
-// predictIndices (MultiMotionFusion.cpp:792), index_map_kernel; or the resolve of predict() (:675) when that is enqueued --
-// reads neither: its launch gets one more workgroup, dispatched first, that does both while the surfels are projected.
+// predictIndices (MultiMotionFusion.cpp:792): index_map_kernel, then index_resolve_kernel -- reads neither: each of its two
+// launches gets one more workgroup, dispatched first: the hand-over on the first, the weight on the second.
+// (The resolve of a prediction used to be a carrier too; the weight's local arrays gave that whole kernel a scratch frame
+// and 82 registers instead of 37.)
 // The first reader of the weight is fuse_data_kernel, two launches later; the host has the pose ~2 us EARLIER than from
 // the end of the 13 us launch.
 #pragma once

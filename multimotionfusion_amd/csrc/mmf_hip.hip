@@ -2379,13 +2379,11 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     if (launch_count)
         hipLaunchKernelGGL(splat_kernel, splat_grid(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
                            m->keys, m->count_pending ? m->totals : nullptr);
-    if (fill_rgb && fill_depth) {
-        const FrameRider rider = m->rider;
-        m->rider = FrameRider();
-        hipLaunchKernelGGL(splat_resolve_fill_kernel, dim3(splat_tile_grid(m->width, m->height) + (rider.st ? 1u : 0u)), dim3(256), 0,
+    if (fill_rgb && fill_depth) {  // (a pending frame rider stays for the predictIndices that follows: frame_rider.hpp)
+        hipLaunchKernelGGL(splat_resolve_fill_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0,
                            c->stream, m->set[m->cur], a, m->keys, m->image, m->vertexConf, m->normalRadius, m->time_tex, fill_depth,
                            fill_rgb, lost ? 1 : 0, (lost || frame_to_frame_rgb) ? 1 : 0, m->fill_vertex, m->fill_normal,
-                           m->fill_image, rider, model_thumb_counts(m), (int)(m->tex_gen & 1));
+                           m->fill_image, model_thumb_counts(m), (int)(m->tex_gen & 1));
     } else
         hipLaunchKernelGGL(splat_resolve_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->image,
                            m->vertexConf, m->normalRadius, m->time_tex, model_thumb_counts(m), (int)(m->tex_gen & 1));

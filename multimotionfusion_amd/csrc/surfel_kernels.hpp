@@ -1056,7 +1056,9 @@ __device__ __forceinline__ unsigned clean_flag_one(int e, SurfelSoA s, SurfelSoA
             }
         }
         unsigned cur[9];
-        float4 vcs[9], cts[9];
+        float4 vcs[9];
+        float2 cts[9];  // {init time, timestamp}: the half of the colour / time texel the tests below read (18 registers less:
+                        // 104 -> 86, five waves per SIMD instead of four)
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -1064,7 +1066,7 @@ __device__ __forceinline__ unsigned clean_flag_one(int e, SurfelSoA s, SurfelSoA
                 const size_t t = (size_t)min(cx0 + d, cols - 1) * rows + min(cy0 + e2, rows - 1);  // transposed
                 cur[d * 3 + e2] = index[t];
                 vcs[d * 3 + e2] = vertConf[t];
-                cts[d * 3 + e2] = colorTime[t];
+                cts[d * 3 + e2] = reinterpret_cast<const float2*>(colorTime + t)[1];
             }
 #pragma unroll
         for (int d = 0; d < 3; ++d)
@@ -1072,12 +1074,13 @@ __device__ __forceinline__ unsigned clean_flag_one(int e, SurfelSoA s, SurfelSoA
             for (int e2 = 0; e2 < 3; ++e2) {
                 const int mult = mx[d] * my[e2];
                 if (mult > 0 && cur[d * 3 + e2] > 0U) {
-                    const float4 vc = vcs[d * 3 + e2], ct = cts[d * 3 + e2];
+                    const float4 vc = vcs[d * 3 + e2];
+                    const float2 ct = cts[d * 3 + e2];  // (.x = colorTime.z, .y = colorTime.w)
                     const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
-                    if (ct.z < vcol.z && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
+                    if (ct.x < vcol.z && vc.w > a.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
                         sqrtf(dx * dx + dy * dy) < vnrm.w * 1.4f)
                         count += mult;
-                    if (ct.w == (float)a.time && vc.w > a.confThreshold && vc.z > localPos.z &&
+                    if (ct.y == (float)a.time && vc.w > a.confThreshold && vc.z > localPos.z &&
                         vc.z - localPos.z > 0.01f && fabsf(localNorm.z) > 0.85f)
                         zCount += mult;
                 }
@@ -1131,9 +1134,12 @@ __device__ __forceinline__ unsigned clean_flag_one(int e, SurfelSoA s, SurfelSoA
     return test ? 1u : 0u;
 }
 
+#ifndef MMF_CLEAN_WAVES
+#define MMF_CLEAN_WAVES 5  // waves per SIMD the register allocation aims for (96 registers; the default allocation takes 104: four)
+#endif
 // keep[e] for every candidate, and -- so that the compaction needs no separate scan launches -- the
 // number of kept candidates of each 256-candidate workgroup in block_sums[blockIdx.x]
-__global__ __launch_bounds__(256) void clean_flag_kernel(SurfelSoA s, SurfelSoA meas, const unsigned* __restrict__ new_flags,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MMF_CLEAN_WAVES))) void clean_flag_kernel(SurfelSoA s, SurfelSoA meas, const unsigned* __restrict__ new_flags,
                                                          CleanArgs a_in, const unsigned* __restrict__ index,
                                                          const float4* __restrict__ vertConf,
                                                          const float4* __restrict__ colorTime,
@@ -1273,16 +1279,12 @@ __global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, Sp
                                                                  const uint8_t* __restrict__ rgb, int passthrough_geom,
                                                                  int passthrough_rgb, float4* __restrict__ vertex_out,
                                                                  float4* __restrict__ normal_out, uchar4* __restrict__ image_out,
-                                                                 FrameRider rider, unsigned* __restrict__ thumb, int gen) {
+                                                                 unsigned* __restrict__ thumb, int gen) {
     MMF_MODEL_STREAM_PRIORITY();
-    if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
-        frame_rider_run(rider);
-        return;
-    }
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
-    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, rider.st ? 1u : 0u)) return;
+    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k)) return;
     const int i = py * a.cols + px;
     const SplatTexel t = splat_resolve_px(i, k, s, a);
     image[i] = t.image;
