@@ -58,11 +58,14 @@ __device__ __forceinline__ void odom_publish_wave(const OdomState* st, OdomState
 }
 
 // the riding workgroup (>= 128 threads): wave 0 publishes, lane 0 of wave 1 evaluates the weight
+// PARTS: what this carrier's code can do at all (bit 0 hand-over, bit 1 weight) -- the weight's SVD is 60 registers that a
+// carrier which never computes it need not reserve for every one of its waves
+template <unsigned PARTS = 3u>
 __device__ __forceinline__ void frame_rider_run(const FrameRider& r) {
     if (threadIdx.x < 64) {
-        if (r.what & 1u) odom_publish_wave(r.st, r.host, r.seq, threadIdx.x);
+        if ((PARTS & 1u) && (r.what & 1u)) odom_publish_wave(r.st, r.host, r.seq, threadIdx.x);
     } else if (threadIdx.x == 64) {
-        if (r.what & 2u) odom_fusion_weight(r.st);
+        if ((PARTS & 2u) && (r.what & 2u)) odom_fusion_weight(r.st);
     }
 }
 

@@ -2317,10 +2317,6 @@ static IndexArgs model_index_args(mmf_model* m, int time, float depth_cutoff, in
     return a;
 }
 
-static bool split_rider() {  // MMF_RIDER_SPLIT=0: hand-over and weight both on the first launch (A/B aid)
-    static const bool on = []() { const char* e = std::getenv("MMF_RIDER_SPLIT"); return !e || e[0] != '0'; }();
-    return on;
-}
 // ModelProjection::predictIndices (ModelProjection.cpp:94-143)
 // projected: the surfels are in the key image already (model_fuse with then_index); only the resolve is left
 static int model_predict_indices(mmf_model* m, int time, float depth_cutoff, int time_delta, bool projected) {
@@ -2333,8 +2329,7 @@ static int model_predict_indices(mmf_model* m, int time, float depth_cutoff, int
     // frame_rider.hpp: when this is the frame's first projection, its first launch carries the tracking result's hand-over
     // to the host and its second the fusion weight (each a few microseconds on one extra workgroup, shorter than its carrier)
     FrameRider publish = m->rider, weight = m->rider;
-    publish.what = split_rider() ? 1u : 3u, weight.what = 2u;
-    if (!split_rider()) weight = FrameRider();
+    publish.what = 1u, weight.what = 2u;
     m->rider = FrameRider();
     MMF_REQUIRE(!(projected && publish.st), "mmf_model_predict_indices: a tracking result to hand over, but no projection launch to carry it");
     if (!projected && (m->count || publish.st))

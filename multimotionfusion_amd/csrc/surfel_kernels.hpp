@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, 
                                                         unsigned long long* __restrict__ keys, FrameRider rider) {
     MMF_MODEL_STREAM_PRIORITY();
     if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
-        frame_rider_run(rider);
+        frame_rider_run<1u>(rider);
         return;
     }
     const IndexArgs a = with_device_pose(a_in);
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexAr
                                                             FrameRider rider) {
     MMF_MODEL_STREAM_PRIORITY();
     if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
-        frame_rider_run(rider);
+        frame_rider_run<2u>(rider);
         return;
     }
     const IndexArgs a = with_device_pose(a_in);
