@@ -4,29 +4,40 @@
 // The reference runs an iteration as computeRgbResidual -> icpStep -> rgbStep -> host solve, each a launch pair plus a
 // device synchronise.  The two-launch chain of track_kernels.hpp (producer launch, then rgb_step_kernel whose last
 // workgroup sums the records and solves) cost ~16 us per iteration at 640x480, two thirds of it latency that is not
-// memory traffic: the second kernel boundary, the re-read of the correspondence records, the write-through drain +
-// ticket of the in-launch finish and the cold read of the state the finishing lane had just written.  Here:
+// memory traffic.  Here a workgroup is ONE SOLVER WAVE plus four (or more) PIXEL WAVES, one workgroup per CU:
 //
-//   * prologue, in EVERY workgroup: sum the partial records of the previous launch (plain loads, a kernel boundary lies
-//     between), combine A = A_rgb + w^2 A_icp, solve the 6x6 system in double and update the pose -- redundantly, on
-//     identical inputs, so every workgroup holds the new pose without any hand-off inside the launch.  The
-//     pose-independent image loads of the pixel phase are issued BEFORE the prologue and land while it runs;
-//   * photometric correspondence search (reduce.cu:722-865) for four pixels per lane, correspondences kept in
+//   * solver wave, in EVERY workgroup: reads the previous launch's 58 sums (64-bit fixed-point
+//     integers in sixteen shards, OdomState::gn_sum: plain loads, a kernel boundary lies between), combines A = A_rgb + w^2 A_icp, solves the
+//     6x6 system in double and updates the pose -- redundantly, on identical inputs, so every workgroup holds the new pose
+//     without any hand-off inside the launch.  It has no pixels: while it solves, the pixel waves' image loads land and
+//     they decide what the correspondence search can decide without the pose; once the pose is out, nothing of the pixel
+//     phase waits for the solver's share of it (round 3 gave the solver wave pixels as well: the workgroup then waited
+//     for that wave's pose-free work, and at 640x480 a fifth wave shared its SIMD);
+//   * pixel waves: photometric correspondence search (reduce.cu:722-865) for PX pixels per lane, correspondences kept in
 //     registers (no DataTerm records are written or re-read), the point-cloud gather of rgbStep issued with the
-//     depth / intensity gathers of the search (same target pixel);
+//     depth / intensity gathers of the search (same target pixel); ICP projection and gathers (reduce.cu:231-397);
 //   * the weight of rgbStep's rows needs sigma = the number of correspondences of THIS pass over the whole image
-//     (RGBDOdometry.cpp:373-385, reduce.cu:506-514): every workgroup adds {1 arrival, count, sum diff^2} to a sharded
-//     64-bit counter (integer atomics: exact, order independent) and carries on with the ICP rows of its pixels
-//     (reduce.cu:231-397) -- by the time those are done the other workgroups have arrived, so the one poll that follows
-//     finds the totals complete.  The grid is at most kGnMaxGroups workgroups per model, all co-resident;
-//   * rgbStep's Jacobian rows (reduce.cu:504-535) from the registers, both 29-sum sets reduced over the workgroup and
-//     stored as ONE 256-byte partial record (plain stores): the next launch's prologue -- or gn_final_kernel -- sums them.
+//     (RGBDOdometry.cpp:373-385, reduce.cu:506-514): the solver wave adds the workgroup's {1 arrival, count, sum diff^2} to
+//     a sharded 64-bit counter (integer atomics: exact, order independent), polls until every workgroup of the launch has
+//     arrived, decides sigma and lays out the pass's 256 possible weights in LDS, while the pixel waves compute their ICP
+//     rows and reduce them.  The grid is at most kGnMaxGroups workgroups per model, all co-resident (the host checks the
+//     occupancy: odom_fused_chain_ok);
+//   * rgbStep's Jacobian rows (reduce.cu:504-535) from the registers, both 29-sum sets reduced over the workgroup in float
+//     and added to the launch's sums as fixed-point integers by atomics (exact, order independent): the next
+//     launch -- or gn_final_kernel -- reads 7.4 KB of totals instead of a 256-byte record per workgroup (round 3: 61 KB
+//     fetched by every workgroup, 0.8 us of a 640x480 launch).
 //
+// PX = 1, 2, 4 or 5 pixels per lane, chosen by the host per level (gn_geometry) so that a launch has at most one
+// workgroup per CU with exactly four pixel waves wherever the level allows: 640x480 = 240 workgroups x 256 lanes x 5.
 // Per-pixel arithmetic is the very code of the two-launch chain (icp_project_v / icp_rows_v, rgb_rows), so Jacobian rows,
-// counts and error images keep their bits; only the order in which workgroup partials are summed differs (fixed by the
-// launch geometry, so results stay reproducible run to run).
+// counts and error images keep their bits; only the order in which partials are summed differs (fixed by the launch
+// geometry, so results stay reproducible run to run).
 #pragma once
 #include "track_kernels.hpp"
+
+#ifndef MMF_ABL
+#define MMF_ABL 0  // diagnostic builds only (tools/gn_floor_probe.sh): 64 = the dependent phases alone, no pixel work
+#endif
 
 namespace mmf {
 
@@ -34,7 +45,7 @@ constexpr int kGnRec = 64;          // floats per workgroup record: [0, 32) ICP 
 constexpr int kGnMaxGroups = 512;   // workgroups per model per launch: all resident at once, <= 32 arrivals per shard
 constexpr int kGnArriveShift = 58;  // counter word: arrivals << 58 | count << 40 | sum diff^2 (per shard: < 2^6, 2^18, 2^40)
 constexpr int kGnMaxPolls = 1 << 17;
-constexpr int kGnMaxWaves = 8;      // a workgroup is 256 .. 512 threads: the host sizes it so that a launch has <= one workgroup per CU
+constexpr int kGnMaxWaves = 8;      // the solver wave + up to seven pixel waves (the host sizes it: one workgroup per CU)
 
 struct GnIterArgs {
     IcpArgs ia;
@@ -43,19 +54,17 @@ struct GnIterArgs {
     float fx, fy, sobel_scale;
     LevelIntr intr;      // this level's intrinsics: the prologue prepares THIS launch's K R K^-1
     int it;              // index of the launch in the chain; 0: nothing to solve yet
-    unsigned prev_groups;  // partial records the previous launch wrote
-    const float* rec_in;
-    float* rec_out;
     double ifx, ify;  // 1.0 / (double)intr.fx, 1.0 / (double)intr.fy
     int poll_sleep;  // s_sleep(1) repetitions between two polls of the count barrier
-    int lanes;       // lanes of a workgroup that take pixels (<= blockDim.x, the rest only help with the reductions)
+    int lanes;       // pixel lanes of a workgroup (<= blockDim.x - 64; the rest only help with the reductions)
+    int max_polls;   // kGnMaxPolls (a test forces a time-out with 0: mmf_debug_force_gn_fault)
 };
 
 struct GnLds {
-    float group[16][kGnRec + 4];
-    float total[kGnRec];
+    double dtot[kGnRec];  // the previous launch's totals: [0, 29) ICP, [29, 58) photometric
     float wave[kGnMaxWaves][kGnRec];
     double sol[42];
+    double xch[12];  // gn_solve_rows: the rows of the new running transform
     float pose[24];  // Rcurr[9], tcurr[3], krkinv[9], kt[3]
     double sd[16];   // the running transform the solve starts from
     float sf[13];    // Rprev[9], tprev[3], icp_weight
@@ -64,145 +73,254 @@ struct GnLds {
     float wtab[256];  // rgbStep's weight by |diff| for this pass's sigma
 };
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the
+// wave (s_waitcnt vmcnt(0)): gathers in flight across a barrier would be waited for in front of it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float uniform_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
-// {count, sum diff^2} of launch `it` (all its workgroups have finished)
-__device__ __forceinline__ void gn_read_counts(const OdomState* st, int it, int& count, int& sigma) {
-    unsigned c = 0, s = 0;
-    for (int k = 0; k < kResShards; ++k) {
-        const unsigned long long v = st->gn_acc[it % 3][kResStride * k];
-        c += (unsigned)(v >> kResCountShift) & 0x3FFFFu;
-        s += (unsigned)v;  // the sum wraps at 2^32 like the reference's int
-    }
-    count = (int)c, sigma = (int)s;
-}
+#ifdef MMF_STAMPS  // the pixel phases are stamped by the first lane of the first pixel wave
+#define MMF_STAMP_PX(i)                                                                        \
+    do {                                                                                       \
+        if (g_mmf_dbg && threadIdx.x == 64) g_mmf_dbg[blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define MMF_STAMP_PX(i) \
+    do {                \
+    } while (0)
+#endif
 
-// Sums the previous launch's records, solves, leaves the new pose in lds.pose.  Two halves so that the caller can place
-// pose-independent work between the issue of the loads and their first use.  All threads call both; the second ends with a
-// barrier.
-struct GnRecLoads {
-    static constexpr int U = 20;  // 16 x 20 = 320 records per pass: the 300 of a 640x480 launch in one round trip
-    v4u r[U];
-    double sd;  // lane t < 16 of the first wave: element t of the running transform
-    float sf;   // lane 16 + k: Rprev[k], tprev[k - 9], icp_weight (k = 12)
+// ---- the previous launch's sums and the solve's state (one wave) ----
+// sigma of a pass as rgbStep uses it (residual_decide's sigmaVal without its double-precision square root and division:
+// tmpError = sqrt(sum) / count is zero exactly when sum is (count <= 2^19: no underflow), and NaN -- not zero -- for 0 / 0)
+__device__ __forceinline__ float gn_sigma_val(unsigned count, unsigned sumsq) {
+    return ((int)sumsq == 0 && (int)count != 0) ? 1.0f : (float)(int)count;
+}
+// binary exponent of the photometric sums' fixed-point scale: their rows carry w = 1 / (sigma + |d|), so the scale follows
+// sigma^2; a function of the pass's sigma alone, which every workgroup of the launch and the next launch's readers know
+__device__ __forceinline__ int gn_rgb_exp(float sigma_val) {
+    const float s = sigma_val > 1.0f ? sigma_val : 1.0f;  // (also NaN -> 1)
+    return kGnSumRgbExp0 + 2 * ((int)((__builtin_bit_cast(unsigned, s) >> 23) & 0xFFu) - 127);
+}
+struct GnSumLoads {
+    long long q[kGnSumShards];    // lane k < 58: sum k of every shard
+    unsigned long long cnt;  // lane t < 16: shard t of the previous launch's {arrivals, count, sum diff^2}
+    double sd;               // lane t < 16: element t of the running transform
+    float sf;                // lane 16 + k: Rprev[k], tprev[k - 9], icp_weight (k = 12)
 };
-// The loads the critical path of the launch starts with: issued before anything else.  The solve's state is fetched by
-// 29 lanes, one word each (lane-dependent addresses: a uniform load hipcc sinks into the one lane's branch that uses it,
-// where it is a cold ~1 us round trip in the middle of the solve).
-__device__ __forceinline__ void gn_records_issue(const OdomState* st, const GnIterArgs& a, GnRecLoads& rl) {
-    if (a.it == 0 || threadIdx.x >= 256) return;  // uniform per wave; the first four waves fetch the records
-    const auto rsrc = partials_rsrc(a.rec_in, a.prev_groups * (kGnRec / kPartialStride));
-    const int q = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+// every lane loads (lane-dependent addresses: a uniform load hipcc sinks into the one lane's branch that uses it, where it
+// is a cold ~1 us round trip in the middle of the solve)
+__device__ __forceinline__ void gn_sums_issue(const OdomState* st, const GnIterArgs& a, GnSumLoads& sl, int lane) {
+    const int prev = (a.it + 2) % 3, k = lane < 58 ? lane : 57;
 #pragma unroll
-    for (int u = 0; u < GnRecLoads::U; ++u)  // reads past the last record return zero
-        rl.r[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((u * 16 + r0) * kGnRec + q * 4) * sizeof(float)), 0, 0);
-    const int t = threadIdx.x;
-    rl.sd = st->gn_rt[a.it & 1][t & 15];
-    const int k = t < 16 ? 0 : (t > 28 ? 12 : t - 16);
-    const float* fsrc = k < 9 ? &st->Rprev[k] : (k < 12 ? &st->tprev[k - 9] : &st->icp_weight);
-    rl.sf = *fsrc;
+    for (int x = 0; x < kGnSumShards; ++x) sl.q[x] = st->gn_sum[prev][x][k];
+    sl.cnt = st->gn_acc[prev][kResStride * (lane & 15)];
+    sl.sd = st->gn_rt[a.it & 1][lane & 15];
+    const int j = lane < 16 ? 0 : (lane > 28 ? 12 : lane - 16);
+    const float* fsrc = j < 9 ? &st->Rprev[j] : (j < 12 ? &st->tprev[j - 9] : &st->icp_weight);
+    sl.sf = *fsrc;
+}
+// the totals as doubles -> lds.dtot, the state -> lds.sd / lds.sf; returns the previous pass's {count, sum diff^2}
+__device__ __forceinline__ void gn_totals_to_lds(const GnSumLoads& sl, GnLds& lds, int lane, unsigned& count, unsigned& sumsq) {
+    unsigned c = lane < kResShards ? (unsigned)(sl.cnt >> kResCountShift) & 0x3FFFFu : 0u;
+    unsigned s2 = lane < kResShards ? (unsigned)sl.cnt : 0u;  // wraps at 2^32 like the reference's int
+    c = wave_sum_to_lane63(c), s2 = wave_sum_to_lane63(s2);
+    count = (unsigned)__builtin_amdgcn_readlane((int)c, 63), sumsq = (unsigned)__builtin_amdgcn_readlane((int)s2, 63);
+    const int e = lane < 29 ? kGnSumIcpExp : gn_rgb_exp(gn_sigma_val(count, sumsq));
+    long long q = sl.q[0];
+#pragma unroll
+    for (int x = 1; x < kGnSumShards; ++x) q += sl.q[x];
+    if (lane < 58) lds.dtot[lane] = __builtin_ldexp((double)q, -e);
+    if (lane < 16) lds.sd[lane] = sl.sd;
+    else if (lane < 29) lds.sf[lane - 16] = sl.sf;
+}
+// lane k < 58 adds sum k of this workgroup (float) to the launch's sums; false: the value does not fit the fixed-point range
+__device__ __forceinline__ bool gn_sum_add(OdomState* st, int it, int lane, float v, int rgb_exp) {
+    const double d = __builtin_ldexp((double)v, lane < 29 ? kGnSumIcpExp : rgb_exp);  // exact
+    const bool ok = __builtin_fabs(d) < 9007199254740992.0;  // 2^53 per workgroup: 512 of them fit 2^62 (a NaN fails too)
+    const long long q = ok ? (long long)__builtin_rint(d) : 0ll;
+    if (lane < 58)
+        (void)__hip_atomic_fetch_add(&st->gn_sum[it % 3][blockIdx.x % kGnSumShards][lane], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return ok || lane >= 58;
 }
 
-// lead: this workgroup also stores the running transform for the next launch.  FINAL: the chain's last solve
-// (gn_final_kernel): everything the host reads goes to the state, then odom_end.
-// Part 1 ends with the workgroup's first barrier (the record sums are in LDS); part 2 is the one wave's work up to the pose
-// and ends with the second.  Between the two the other waves are free: the caller gives them pose-independent work.
-template <bool FINAL>
-__device__ __forceinline__ void gn_prologue_sums(OdomState* st, const GnIterArgs& a, GnRecLoads& rl, GnLds& lds, bool lead) {
-    const int tid = threadIdx.x;
-    if (a.it == 0) {  // nothing to solve yet: the pose the beginning left in the state
-        if (tid < 9)
-            lds.pose[tid] = st->Rcurr[tid];
-        else if (tid < 12)
-            lds.pose[tid] = st->tcurr[tid - 9];
-        else if (tid < 21)
-            lds.pose[tid] = st->krkinv[tid - 12];
-        else if (tid < 24)
-            lds.pose[tid] = st->kt[tid - 21];
-        if (lead && tid >= 64 && tid < 80) st->gn_rt[1][tid - 64] = st->resultRt[tid - 64];
-        return;
-    }
-    if (tid < 256) {
-        const auto rsrc = partials_rsrc(a.rec_in, a.prev_groups * (kGnRec / kPartialStride));
-        const int q = tid & 15, r0 = tid >> 4;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < GnRecLoads::U; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + __builtin_bit_cast(float, (unsigned)rl.r[u][j]);
-        for (unsigned base = 16 * GnRecLoads::U; base < a.prev_groups; base += 16 * GnRecLoads::U) {  // more than 320 records
-#pragma unroll
-            for (int u = 0; u < GnRecLoads::U; ++u)
-                rl.r[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((base + u * 16 + r0) * kGnRec + q * 4) * sizeof(float)), 0, 0);
-#pragma unroll
-            for (int u = 0; u < GnRecLoads::U; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = acc[j] + __builtin_bit_cast(float, (unsigned)rl.r[u][j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lds.group[r0][q * 4 + j] = acc[j];
-        if (tid < 16) lds.sd[tid] = rl.sd;
-        else if (tid < 29) lds.sf[tid - 16] = rl.sf;
-    }
-    __syncthreads();
-    if (!FINAL) MMF_STAMP(3);
+// it == 0: nothing to solve yet, the pose the beginning left in the state.  One wave.
+__device__ __forceinline__ void gn_first_pose(OdomState* st, GnLds& lds, bool lead, int lane) {
+    if (lane < 9)
+        lds.pose[lane] = st->Rcurr[lane];
+    else if (lane < 12)
+        lds.pose[lane] = st->tcurr[lane - 9];
+    else if (lane < 21)
+        lds.pose[lane] = st->krkinv[lane - 12];
+    else if (lane < 24)
+        lds.pose[lane] = st->kt[lane - 21];
+    if (lead && lane >= 32 && lane < 48) st->gn_rt[1][lane - 32] = st->resultRt[lane - 32];
 }
 
-template <bool FINAL>
-__device__ __forceinline__ void gn_prologue_solve(OdomState* st, const GnIterArgs& a, GnLds& lds, bool lead) {
-    const int tid = threadIdx.x;
-    if (a.it == 0) {
-        __syncthreads();
-        return;
+// The solve and pose update of gn_solve_core (RGBDOdometry.cpp:435-460 + OdometryProvider.h:69-89, RGBDOdometry.cpp:348-358)
+// for a whole wave instead of one lane.  On one lane it is ~330 dependent double-precision instructions at ~12 cycles each:
+// 1.8 us of every launch with nothing beside it (tools/gn_iter_probe.py: barrier A -> barrier B 2.4 us).  Here EVERY lane
+// runs the 6x6 LDL^T (same instructions on the same operands: no divergence, the solution sits in every lane's registers),
+// then lanes 0..2 take one ROW each of what follows -- the Rodrigues rotation, the 3x4 product with the running transform,
+// the isometry inverse and Rprev product, the 3x3 inverse, K R K^-1 and K t -- and exchange rows through LDS (in-order
+// within a wave) or v_readlane.  Same formulas in the same order per element; contraction may differ (~1e-16 relative
+// before the casts to float).  A, b: the combined system (LDS, 42 doubles); rt_old: the running transform (LDS, 16);
+// sf: Rprev[9], tprev[3] (LDS); xch: 12 doubles of LDS for the exchange; pose: Rcurr[9], tcurr[3], krkinv[9], kt[3] (LDS).
+// Returns this lane's row of the new running transform in nr[4] (lanes >= 3 repeat row 0).
+__device__ __forceinline__ void gn_solve_rows(const double* A_lds, const double* rt_old, const float* sf, const LevelIntr& in,
+                                              double ifx, double ify, int lane, double* xch, float* pose, double (&nr)[4]) {
+#pragma clang fp contract(fast)
+    double A[36], b[6], result[6];
+    for (int k = 0; k < 36; ++k) A[k] = A_lds[k];
+    for (int k = 0; k < 6; ++k) b[k] = A_lds[36 + k];
+    MMF_SOLVE_STAMP(1);
+    if (MMF_ABL & 256) {
+        for (int k = 0; k < 6; ++k) result[k] = b[k] * 1e-12 + A[k * 7] * 1e-14;
+    } else
+    ldlt_solve_recip<6>(A, b, result);
+    MMF_SOLVE_STAMP(2);
+    const int r = lane < 3 ? lane : 0;
+    // R = cc I + cb v v^T + ca [v]x (OdometryProvider.h:32-67; small increments: rodrigues_increment's series in y = |r|^2)
+    double vx = result[3], vy = result[4], vz = result[5];
+    const double y = vx * vx + vy * vy + vz * vz;
+    double ca = 0.0, cb = 0.0, cc = 1.0;
+    if (!(y < 0.015625)) {  // |r| >= 1/8 or not a number (wave-uniform): the literal form
+        const double theta = sqrt(y);
+        if (theta >= DBL_EPSILON) {
+            const double itheta = theta ? 1. / theta : 0.;
+            vx *= itheta, vy *= itheta, vz *= itheta;
+            cc = cos(theta), ca = sin(theta), cb = 1. - cc;
+        }
+    } else if (!(MMF_ABL & 512) && y >= DBL_EPSILON * DBL_EPSILON) {
+        ca = 1.0 + y * (-1.0 / 6 + y * (1.0 / 120 + y * (-1.0 / 5040 + y * (1.0 / 362880 + y * (-1.0 / 39916800 + y * (1.0 / 6227020800.0))))));
+        cb = 0.5 + y * (-1.0 / 24 + y * (1.0 / 720 + y * (-1.0 / 40320 + y * (1.0 / 3628800 + y * (-1.0 / 479001600 + y * (1.0 / 87178291200.0))))));
+        cc = 1.0 - cb * y;
     }
-    // From here to the pose one wave works alone (its LDS accesses execute in program order: no workgroup barriers):
-    // the 64 totals, RGBDOdometry.cpp:431-435 with one element of the combined system per lane, the solve on lane 0.
-    if (tid < 64) {
-        float s = lds.group[0][tid];
-#pragma unroll
-        for (int g = 1; g < 16; ++g) s = s + lds.group[g][tid];
-        lds.total[tid] = s;
-        __builtin_amdgcn_wave_barrier();
-        const double w = (double)lds.sf[12];
-        if (tid < 42) lds.sol[tid] = combine_element(FINAL ? st : nullptr, tid, w, lds.total + 32, lds.total);
-        __builtin_amdgcn_wave_barrier();
-        if (!FINAL) MMF_STAMP(4);
-        if (tid == 0) {
-            double A[36], b[6], rt[16];
-            float Rprev[9], tprev[3];
-            for (int k = 0; k < 36; ++k) A[k] = lds.sol[k];
-            for (int k = 0; k < 6; ++k) b[k] = lds.sol[36 + k];
-            for (int k = 0; k < 16; ++k) rt[k] = lds.sd[k];
-            for (int k = 0; k < 9; ++k) Rprev[k] = lds.sf[k];
-            for (int k = 0; k < 3; ++k) tprev[k] = lds.sf[9 + k];
-            GnPose np;
-            gn_solve_core(A, b, rt, Rprev, tprev, a.intr, np, a.ifx, a.ify);
-            for (int k = 0; k < 9; ++k) lds.pose[k] = np.Rcurr[k], lds.pose[12 + k] = np.krkinv[k];
-            for (int k = 0; k < 3; ++k) lds.pose[9 + k] = np.tcurr[k], lds.pose[21 + k] = np.kt[k];
-            if (FINAL) {
-                int count, sigma;
-                gn_read_counts(st, a.it - 1, count, sigma);
-                const ResidualDecision dec = residual_decide(count, sigma, 0, 0.f);
-                st->sigma = sigma;
-                st->rgbCount = count;
-                st->sigmaVal = dec.sigmaVal;
-                st->st.lastRGBError = dec.tmpError;
-                st->st.lastRGBCount = (float)count;
-                st->st.lastICPError = sqrtf(lds.total[27]) / lds.total[28];  // RGBDOdometry.cpp:412-413
-                st->st.lastICPCount = lds.total[28];
-                st->st.iterations_run = a.it;
-                for (int k = 0; k < 16; ++k) st->resultRt[k] = rt[k];
-                for (int k = 0; k < 9; ++k) st->Rcurr[k] = np.Rcurr[k], st->krkinv[k] = np.krkinv[k];
-                for (int k = 0; k < 3; ++k) st->tcurr[k] = np.tcurr[k], st->kt[k] = np.kt[k];
-                odom_end(st);
-            } else if (lead) {
-                for (int k = 0; k < 16; ++k) st->gn_rt[(a.it + 1) & 1][k] = rt[k];
-            }
+    {
+        const double vr = r == 0 ? vx : (r == 1 ? vy : vz);
+        // row r of [v]x: (0, -vz, vy), (vz, 0, -vx), (-vy, vx, 0)
+        const double e0 = r == 0 ? 0.0 : (r == 1 ? vz : -vy), e1 = r == 0 ? -vz : (r == 1 ? 0.0 : vx), e2 = r == 0 ? vy : (r == 1 ? -vx : 0.0);
+        const double u0 = (r == 0 ? cc : 0.0) + cb * (vr * vx) + ca * e0;
+        const double u1 = (r == 1 ? cc : 0.0) + cb * (vr * vy) + ca * e1;
+        const double u2 = (r == 2 ? cc : 0.0) + cb * (vr * vz) + ca * e2;
+        const double res = r == 0 ? result[0] : (r == 1 ? result[1] : result[2]);
+        // resultRt <- [Rup | result(0..2); 0 0 0 1] * resultRt: the translation column multiplies the last row as in the
+        // reference's full 4x4 product (a non-finite solution poisons the whole matrix, gn_solve_core)
+        for (int c = 0; c < 4; ++c) nr[c] = u0 * rt_old[c] + u1 * rt_old[4 + c] + u2 * rt_old[8 + c] + res * rt_old[12 + c];
+    }
+    if (lane < 3)
+        for (int c = 0; c < 4; ++c) xch[r * 4 + c] = nr[c];
+    __builtin_amdgcn_wave_barrier();  // (a wave's LDS accesses execute in program order)
+    MMF_SOLVE_STAMP(14);
+    double N[12];
+    for (int k = 0; k < 12; ++k) N[k] = xch[k];
+    {  // currentT = [Rprev|tprev] * rgbOdom.inverse(); isometry inverse = (R^T, -R^T t): row r of Rcurr, tcurr[r]
+#pragma clang fp contract(off)
+        float RoT[9], to[3], ti[3];
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) RoT[j * 3 + i] = (float)N[i * 4 + j];
+            to[i] = (float)N[i * 4 + 3];
+        }
+        for (int i = 0; i < 3; ++i) ti[i] = -RoT[i * 3 + 0] * to[0] + -RoT[i * 3 + 1] * to[1] + -RoT[i * 3 + 2] * to[2];
+        const float p0 = sf[r * 3 + 0], p1 = sf[r * 3 + 1], p2 = sf[r * 3 + 2];
+        float rc[3], tc = 0.f;
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.f;  // matmul<3, float>: s = 0; s += a * b
+            acc += p0 * RoT[0 * 3 + j];
+            acc += p1 * RoT[1 * 3 + j];
+            acc += p2 * RoT[2 * 3 + j];
+            rc[j] = acc;
+        }
+        tc += p0 * ti[0];
+        tc += p1 * ti[1];
+        tc += p2 * ti[2];
+        tc = tc + sf[9 + r];
+        if (lane < 3) {
+            for (int j = 0; j < 3; ++j) pose[r * 3 + j] = rc[j];
+            pose[9 + r] = tc;
         }
     }
-    __syncthreads();
+    {  // rgb_prepare: row r of (resultRt^-1)'s rotation, K R, (K R) K^-1, K t
+        const int ca1 = r == 2 ? 0 : r + 1, cb2 = r == 0 ? 2 : r - 1;  // columns (r + 1) % 3 and (r + 2) % 3 of the 3x3 block
+        const double a0 = xch[0 * 4 + ca1], a1 = xch[1 * 4 + ca1], a2 = xch[2 * 4 + ca1];
+        const double b0 = xch[0 * 4 + cb2], b1 = xch[1 * 4 + cb2], b2 = xch[2 * 4 + cb2];
+        const double c00 = N[5] * N[10] - N[6] * N[9], c01 = N[6] * N[8] - N[4] * N[10], c02 = N[4] * N[9] - N[5] * N[8];
+        const double det = N[0] * c00 + N[1] * c01 + N[2] * c02;
+        const double id = (MMF_ABL & 1024) ? 1.0 + det * 1e-12 : tail_rcp(det);
+        // inverse[r][j] = (m[(j+1)%3][(r+1)%3] m[(j+2)%3][(r+2)%3] - m[(j+1)%3][(r+2)%3] m[(j+2)%3][(r+1)%3]) / det
+        const double i0 = (a1 * b2 - b1 * a2) * id, i1 = (a2 * b0 - b2 * a0) * id, i2 = (a0 * b1 - b0 * a1) * id;
+        const double t3 = -(i0 * N[3] + i1 * N[7] + i2 * N[11]);
+        auto from_lane2 = [](double v) {
+            const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 2), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 2);
+            return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        };
+        const double r20 = from_lane2(i0), r21 = from_lane2(i1), r22 = from_lane2(i2), t32 = from_lane2(t3);
+        const double fx = in.fx, fy = in.fy, cx = in.cx, cy = in.cy;
+        const double fr = r == 0 ? fx : (r == 1 ? fy : 1.0), cr = r == 0 ? cx : (r == 1 ? cy : 0.0);
+        const double k0 = fr * i0 + cr * r20, k1 = fr * i1 + cr * r21, k2 = fr * i2 + cr * r22;
+        const double ia = ifx != 0.0 ? ifx : 1.0 / fx, ib = ify != 0.0 ? ify : 1.0 / fy;
+        const double qa = k0 * ia, qb = k1 * ib;
+        if (lane < 3) {
+            pose[12 + r * 3 + 0] = (float)qa;
+            pose[12 + r * 3 + 1] = (float)qb;
+            pose[12 + r * 3 + 2] = (float)(k2 - qa * cx - qb * cy);
+            pose[21 + r] = (float)(fr * t3 + cr * t32);
+        }
+    }
+    MMF_SOLVE_STAMP(15);
+}
+
+// One wave, lds.dtot / lds.sd / lds.sf complete (gn_totals_to_lds by the same wave): RGBDOdometry.cpp:431-435 with one
+// element of the combined system per lane, the solve; leaves the new pose in lds.pose (the caller's next barrier hands it to
+// the workgroup).  lead: this workgroup also stores the running transform for the next launch.  FINAL: the chain's last
+// solve (gn_final_kernel), on one lane: everything the host reads goes to the state, then odom_end.
+template <bool FINAL>
+__device__ __forceinline__ void gn_solve_wave(OdomState* st, const GnIterArgs& a, GnLds& lds, bool lead, int lane, unsigned prev_count,
+                                              unsigned prev_sumsq) {
+    __builtin_amdgcn_wave_barrier();
+    const double w = (double)lds.sf[12];
+    if (lane < 42) lds.sol[lane] = combine_element_d(FINAL ? st : nullptr, lane, w, lds.dtot + 29, lds.dtot);
+    __builtin_amdgcn_wave_barrier();
+    if (!FINAL) MMF_STAMP(4);
+    if (!FINAL) {
+        double nr[4];
+        gn_solve_rows(lds.sol, lds.sd, lds.sf, a.intr, a.ifx, a.ify, lane, lds.xch, lds.pose, nr);
+        if (lead && lane < 4) {  // the running transform for the next launch: rows 0..2 new, the last row as it was
+            double* dst = st->gn_rt[(a.it + 1) & 1] + lane * 4;
+            for (int c = 0; c < 4; ++c) dst[c] = lane < 3 ? nr[c] : lds.sd[12 + c];
+        }
+        return;
+    }
+    if (lane == 0) {
+        double A[36], b[6], rt[16];
+        float Rprev[9], tprev[3];
+        for (int k = 0; k < 36; ++k) A[k] = lds.sol[k];
+        for (int k = 0; k < 6; ++k) b[k] = lds.sol[36 + k];
+        for (int k = 0; k < 16; ++k) rt[k] = lds.sd[k];
+        for (int k = 0; k < 9; ++k) Rprev[k] = lds.sf[k];
+        for (int k = 0; k < 3; ++k) tprev[k] = lds.sf[9 + k];
+        GnPose np;
+        gn_solve_core(A, b, rt, Rprev, tprev, a.intr, np, a.ifx, a.ify);
+        for (int k = 0; k < 9; ++k) lds.pose[k] = np.Rcurr[k], lds.pose[12 + k] = np.krkinv[k];
+        for (int k = 0; k < 3; ++k) lds.pose[9 + k] = np.tcurr[k], lds.pose[21 + k] = np.kt[k];
+        const int count = (int)prev_count, sigma = (int)prev_sumsq;
+        const ResidualDecision dec = residual_decide(count, sigma, 0, 0.f);
+        st->sigma = sigma;
+        st->rgbCount = count;
+        st->sigmaVal = dec.sigmaVal;
+        st->st.lastRGBError = dec.tmpError;
+        st->st.lastRGBCount = (float)count;
+        st->st.lastICPError = sqrtf((float)lds.dtot[27]) / (float)lds.dtot[28];  // RGBDOdometry.cpp:412-413
+        st->st.lastICPCount = (float)lds.dtot[28];
+        st->st.iterations_run = a.it;
+        for (int k = 0; k < 16; ++k) st->resultRt[k] = rt[k];
+        for (int k = 0; k < 9; ++k) st->Rcurr[k] = np.Rcurr[k], st->krkinv[k] = np.krkinv[k];
+        for (int k = 0; k < 3; ++k) st->tcurr[k] = np.tcurr[k], st->kt[k] = np.kt[k];
+        odom_end(st);
+    }
 }
 
 // model blockIdx.y of a batched launch: everything model-side moves by the distance between the slabs
@@ -214,12 +332,35 @@ __device__ __forceinline__ void gn_batch_shift(OdomState*& st, GnIterArgs& a, co
     a.ra.last_depth = batch_shift(a.ra.last_depth, d), a.ra.next_depth = batch_shift(a.ra.next_depth, d);
     a.ra.last_image = batch_shift(a.ra.last_image, d), a.ra.err_map = batch_shift(a.ra.err_map, d);
     a.cloud4 = batch_shift(a.cloud4, d);
-    a.rec_in = batch_shift(a.rec_in, d), a.rec_out = batch_shift(a.rec_out, d);
 }
 
-// PX consecutive int16 of one row as one load
+// ---- PX consecutive values of one row.  4 and 2: one aligned load (the host checks the rows' alignment); 5: a 16-byte
+//      load at 4-byte alignment plus one dword (a wave still reads one contiguous 1280-byte run); else element by element ----
+typedef float gn_f4 __attribute__((ext_vector_type(4)));
+typedef gn_f4 gn_f4u __attribute__((aligned(4)));
 template <int PX>
-__device__ __forceinline__ void load_i16(const int16_t* __restrict__ p, int (&out)[PX]) {
+__device__ __forceinline__ void gn_load_f32(const float* __restrict__ p, float (&out)[PX]) {
+    if constexpr (PX == 4 || PX == 2 || PX == 1) {
+        load_px<PX>(p, out);
+    } else {
+        static_assert(PX == 5, "pixels per lane");
+        const gn_f4u t = *reinterpret_cast<const gn_f4u*>(p);
+        out[0] = t.x, out[1] = t.y, out[2] = t.z, out[3] = t.w;
+        out[4] = p[4];
+    }
+}
+template <int PX>
+__device__ __forceinline__ void gn_store_f32(float* __restrict__ p, const float (&v)[PX]) {
+    if constexpr (PX == 4 || PX == 2 || PX == 1) {
+        store_px<PX>(p, v);
+    } else {
+        const gn_f4u t = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<gn_f4u*>(p) = t;
+        p[4] = v[4];
+    }
+}
+template <int PX>
+__device__ __forceinline__ void gn_load_i16(const int16_t* __restrict__ p, int (&out)[PX]) {
     if constexpr (PX == 4) {
         const short4 t = *reinterpret_cast<const short4*>(p);
         out[0] = t.x, out[1] = t.y, out[2] = t.z, out[3] = t.w;
@@ -227,64 +368,136 @@ __device__ __forceinline__ void load_i16(const int16_t* __restrict__ p, int (&ou
         const short2 t = *reinterpret_cast<const short2*>(p);
         out[0] = t.x, out[1] = t.y;
     } else {
-        out[0] = *p;
+#pragma unroll
+        for (int k = 0; k < PX; ++k) out[k] = p[k];
     }
 }
 
-// PX pixels per lane (4, 2 or 1: the host picks it per level so that a launch has a few hundred workgroups whatever the
-// level's size).  ERR: the launch also writes the two error images (the last level-0 iteration, RGBDOdometry.cpp:367,408).
-// Needs cols % 4 == 0, 16-byte aligned rows, the packed model maps; blockDim.x = 256 .. 512 (a multiple of 64) >= a.lanes.
+// ---- the solver wave (wave 0 of every workgroup) ----
+__device__ __forceinline__ void gn_solver_wave(OdomState* st, const GnIterArgs& a, GnLds& lds, bool lead, int lane, int npw) {
+    GnSumLoads sl;
+    if (a.it > 0) gn_sums_issue(st, a, sl, lane);
+    if (lead) {  // what the launch after this one adds to starts from zero (nobody else touches those buffers during this launch)
+        if (lane < kResShards) st->gn_acc[(a.it + 1) % 3][kResStride * lane] = 0ull;
+#pragma unroll
+        for (int x = 0; x < kGnSumShards; ++x) st->gn_sum[(a.it + 1) % 3][x][lane] = 0ll;
+    }
+    MMF_STAMP(0);
+    if (a.it > 0) {
+        unsigned pc, ps;
+        gn_totals_to_lds(sl, lds, lane, pc, ps);
+        MMF_STAMP(3);
+        gn_solve_wave<false>(st, a, lds, lead, lane, pc, ps);
+    } else {
+        gn_first_pose(st, lds, lead, lane);
+    }
+    lds_barrier();  // B: the pose is in LDS
+    MMF_STAMP(8);
+    lds_barrier();  // C: every pixel wave's {count, sum diff^2} is in LDS
+
+    // one arrival per workgroup
+    {
+        unsigned c = (lane >= 1 && lane <= npw) ? (unsigned)lds.wsum[lane][0] : 0u;
+        unsigned s2 = (lane >= 1 && lane <= npw) ? (unsigned)lds.wsum[lane][1] : 0u;
+        c = wave_sum_to_lane63(c), s2 = wave_sum_to_lane63(s2);
+        if (lane == 63) {
+            const unsigned long long word = (1ull << kGnArriveShift) | ((unsigned long long)c << kResCountShift) | (unsigned long long)s2;
+            (void)__hip_atomic_fetch_add(&st->gn_acc[a.it % 3][kResStride * (blockIdx.x % kResShards)], word, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    MMF_STAMP(10);
+    // The pixel waves compute and reduce their ICP rows now; polling starts when they are done (barrier C2).  By then the other
+    // workgroups have arrived and the first poll finds the totals complete: 240 workgroups polling 16 lines from the moment
+    // they arrive queue in front of the very atomics they wait for (measured: level 0 +2.3 us).
+    lds_barrier();  // C2
+    // the count barrier: poll the 16 shards until every workgroup of this model has arrived, then decide sigma
+    // (RGBDOdometry.cpp:373-385) and lay out the pass's 256 weights
+    float sigma_val;
+    unsigned ok = 0;
+    {
+        const unsigned long long* acc = st->gn_acc[a.it % 3];
+        unsigned c = 0, s2 = 0;
+        for (int poll = 0; poll < a.max_polls; ++poll) {
+            const unsigned long long v = lane < kResShards ? __hip_atomic_load(acc + kResStride * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            unsigned arr = wave_sum_to_lane63((unsigned)(v >> kGnArriveShift));
+            c = wave_sum_to_lane63((unsigned)(v >> kResCountShift) & 0x3FFFFu);
+            s2 = wave_sum_to_lane63((unsigned)v);  // wraps at 2^32 like the reference's int
+            arr = (unsigned)__builtin_amdgcn_readlane((int)arr, 63);
+            if (arr == gridDim.x) {
+                ok = 1;
+                break;
+            }
+            for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+        }
+        c = (unsigned)__builtin_amdgcn_readlane((int)c, 63), s2 = (unsigned)__builtin_amdgcn_readlane((int)s2, 63);
+        sigma_val = gn_sigma_val(c, s2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds.wtab[lane * 4 + q] = rgb_weight(sigma_val, (float)(lane * 4 + q));
+        if (lane == 63) lds.bar[3] = __builtin_bit_cast(unsigned, sigma_val);
+    }
+    lds_barrier();  // D: sigma and the weights; the pixel waves' ICP sums
+    MMF_STAMP(12);
+    lds_barrier();  // E: the pixel waves' photometric sums
+    {  // the workgroup's 58 sums -> the launch's (lane k: ICP sum k, lane 29 + k: photometric sum k)
+        const int col = lane < 29 ? lane : (lane < 58 ? 32 + (lane - 29) : 63);
+        float v = lds.wave[1][col];
+        for (int wv = 2; wv <= npw; ++wv) v = v + lds.wave[wv][col];  // fixed order: the launch geometry decides the sum, not the timing
+        const bool fits = gn_sum_add(st, a.it, lane, v, gn_rgb_exp(sigma_val));
+        // 1: a workgroup of this launch never arrived (ANY workgroup that gives up says so: the one that arrives last sees a
+        // full count although the early ones built their rows from a partial sigma); 2: a sum left the fixed-point range.
+        // Either way the host re-runs the frame's tracking on the two-launch chain (odom_finish_tracking).
+        const bool all_fit = __builtin_amdgcn_ballot_w64(!fits) == 0ull;
+        if ((!ok || !all_fit) && lane == 0) __hip_atomic_store(&st->gn_fault, ok ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    MMF_STAMP(13);
+}
+
+// ---- the pixel waves (waves 1 .. npw).  PX pixels per lane; needs cols % PX == 0 and cols % 4 == 0, 16-byte aligned rows
+//      (PX = 4, 2), the packed model maps.  ERR: the launch also writes the two error images (the last level-0 iteration,
+//      RGBDOdometry.cpp:367,408). ----
 template <int PX, bool ERR>
-__global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st, GnIterArgs a, BatchDelta bd) {
-    __shared__ GnLds lds;
-    if (gridDim.y > 1) gn_batch_shift(st, a, bd);
+__device__ __forceinline__ void gn_pixel_waves(OdomState* st, const GnIterArgs& a, GnLds& lds, int ptid, int lane, int wave) {
     const OdomState* __restrict__ stc = st;  // what this launch only reads: scalar loads
-    MMF_STAMP(5);
-    using T = typename std::conditional<PX == 1, float, v2f>::type;
+    using T = typename std::conditional<PX % 2 == 0, v2f, float>::type;
     using L = lanevec<T>;
     constexpr int W = L::W, NV = PX / W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cols = a.ra.cols, rows = a.ra.rows, N = cols * rows;
-    const int nwaves = blockDim.x >> 6;
-    int k0 = (blockIdx.x * a.lanes + tid) * PX;
-    const bool live = tid < a.lanes && k0 < N;  // the other lanes stay active for the reductions: pixel 0, masked
+    int k0 = (blockIdx.x * a.lanes + ptid) * PX;
+    const bool live = ptid < a.lanes && k0 < N;  // the other lanes stay active for the reductions: pixel 0, masked
     k0 = live ? k0 : 0;
     const int i = (int)__umulhi((unsigned)k0, a.ra.cols_magic), j0 = k0 - i * cols;
-    const int jq = j0 & ~3, p0 = j0 & 3;  // the lane's pixels are [p0, p0 + PX) of the 4-pixel group at column jq
-
-    // ---- the launch's critical path starts with the previous launch's records and the solve's state ----
-    GnRecLoads rl;
-    gn_records_issue(st, a, rl);
-    __builtin_amdgcn_sched_barrier(0);
+    // the 4x4 windows of the lane's pixels cover columns [j0 - 2, j0 + PX + 1]: three aligned words from column jb
+    const int jb = (j0 - 2) & ~3, sb = j0 - 2 - jb;  // sb = 0 .. 3: byte of column j0 - 2 in the first word
 
     // ---- loads that do not depend on the pose: the photometric pass's images, the current vertex / normal maps ----
     unsigned ww[4][3];
-    const bool has_l = jq >= 4, has_r = jq + 4 < cols;
+    bool win[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) win[k] = jb + 4 * k >= 0 && jb + 4 * k < cols;
 #pragma unroll
     for (int dr = -2; dr <= 1; ++dr) {
         const int u = min(max(i + dr, 0), rows - 1);
-        const uint8_t* rowp = a.ra.next_image + (size_t)u * a.ra.ni_stride + jq;
-        ww[dr + 2][1] = *reinterpret_cast<const unsigned*>(rowp);
-        ww[dr + 2][0] = *reinterpret_cast<const unsigned*>(rowp - (has_l ? 4 : 0));
-        ww[dr + 2][2] = *reinterpret_cast<const unsigned*>(rowp + (has_r ? 4 : 0));
+        const uint8_t* rowp = a.ra.next_image + (size_t)u * a.ra.ni_stride;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ww[dr + 2][k] = *reinterpret_cast<const unsigned*>(rowp + (win[k] ? jb + 4 * k : (j0 & ~3)));
     }
-    const unsigned own = *reinterpret_cast<const unsigned*>(a.ra.next_image + (size_t)i * a.ra.ni_stride + jq);
     int valxs[PX], valys[PX];
     float d1s[PX];
-    load_i16<PX>(a.ra.dIdx + (size_t)i * a.ra.d_stride + j0, valxs);
-    load_i16<PX>(a.ra.dIdy + (size_t)i * a.ra.d_stride + j0, valys);
-    load_px<PX>(a.ra.next_depth + (size_t)i * a.ra.nd_stride + j0, d1s);
+    gn_load_i16<PX>(a.ra.dIdx + (size_t)i * a.ra.d_stride + j0, valxs);
+    gn_load_i16<PX>(a.ra.dIdy + (size_t)i * a.ra.d_stride + j0, valys);
+    gn_load_f32<PX>(a.ra.next_depth + (size_t)i * a.ra.nd_stride + j0, d1s);
     float cur[6][PX];
     {
         const float* pv = a.ia.vmap_curr.base + (size_t)i * a.ia.vmap_curr.stride + j0;
         const float* pn = a.ia.nmap_curr.base + (size_t)i * a.ia.nmap_curr.stride + j0;
         const size_t sv = (size_t)rows * a.ia.vmap_curr.stride, sn = (size_t)rows * a.ia.nmap_curr.stride;
-        load_px<PX>(pv, cur[0]);
-        load_px<PX>(pv + sv, cur[1]);
-        load_px<PX>(pv + 2 * sv, cur[2]);
-        load_px<PX>(pn, cur[3]);
-        load_px<PX>(pn + sn, cur[4]);
-        load_px<PX>(pn + 2 * sn, cur[5]);
+        gn_load_f32<PX>(pv, cur[0]);
+        gn_load_f32<PX>(pv + sv, cur[1]);
+        gn_load_f32<PX>(pv + 2 * sv, cur[2]);
+        gn_load_f32<PX>(pn, cur[3]);
+        gn_load_f32<PX>(pn + sn, cur[4]);
+        gn_load_f32<PX>(pn + 2 * sn, cur[5]);
     }
     // the model pose of the frame (constant over the chain)
     IcpPose P;
@@ -293,46 +506,51 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
 #pragma unroll
     for (int k = 0; k < 3; ++k) P.tprev[k] = stc->tprev[k];
     __builtin_amdgcn_sched_barrier(0);
-    MMF_STAMP(0);
 
-    // the counters of the launch after this one start from zero (nobody else touches that buffer during this launch)
-    if (blockIdx.x == 0 && tid >= 64 && tid < 64 + kResShards) st->gn_acc[(a.it + 1) % 3][kResStride * (tid - 64)] = 0ull;
-
-    // what the correspondence search can decide without the pose (reduce.cu:773-797): the 4x4 "all neighbours > 0"
-    // windows from the twelve words, the gradient test -- done by the waves that wait for the solve, beside it
+    // ---- beside the solve: what the correspondence search can decide without the pose (reduce.cu:773-797): the 4x4
+    //      "all neighbours > 0" windows from the twelve words, the gradient test; the lane's own intensities ----
     bool cand[PX];
-    auto pose_free_work = [&]() {
-    unsigned nz[3] = {0x80808080u, 0x80808080u, 0x80808080u};
+    int own[PX];
+    {
+        unsigned nz[3] = {0x80808080u, 0x80808080u, 0x80808080u};
 #pragma unroll
-    for (int dr = -2; dr <= 1; ++dr) {
-        const bool rowin = (i + dr) >= 0 && (i + dr) < rows;
+        for (int dr = -2; dr <= 1; ++dr) {
+            const bool rowin = (i + dr) >= 0 && (i + dr) < rows;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) nz[k] &= rowin ? nonzero_bytes(ww[dr + 2][k]) : 0x80808080u;
+            for (int k = 0; k < 3; ++k) nz[k] &= rowin ? nonzero_bytes(ww[dr + 2][k]) : 0x80808080u;
+        }
+        // bit b: column jb + b is non-zero in all four rows (columns outside the image count as set: reduce.cu:777-787 clips its loops)
+        const unsigned okw = (win[0] ? byte_flags_to_bits(nz[0]) : 0xFu) | ((win[1] ? byte_flags_to_bits(nz[1]) : 0xFu) << 4) |
+                             ((win[2] ? byte_flags_to_bits(nz[2]) : 0xFu) << 8);
+        const unsigned long long lo = (unsigned long long)ww[2][0] | ((unsigned long long)ww[2][1] << 32);
+        const unsigned long long hi = (unsigned long long)ww[2][1] | ((unsigned long long)ww[2][2] << 32);
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const int x = j0 + p;
+            const bool valid = live && x < cols - 5 && i < rows - 1 && ((okw >> (sb + p)) & 0xFu) == 0xFu;
+            const float mTwo = (float)((valxs[p] * valxs[p]) + (valys[p] * valys[p]));
+            cand[p] = valid && mTwo >= a.ra.min_scale && !(d1s[p] != d1s[p]);
+            const int b = sb + 2 + p;  // byte of column x in the row's three words (2 .. 9)
+            own[p] = (int)(((b < 8 ? lo : hi) >> (8 * (b < 8 ? b : b - 4))) & 0xFFull);
+        }
     }
-    const unsigned okw = (has_l ? byte_flags_to_bits(nz[0]) : 0xFu) | (byte_flags_to_bits(nz[1]) << 4) |
-                         ((has_r ? byte_flags_to_bits(nz[2]) : 0xFu) << 8);
-#pragma unroll
-    for (int p = 0; p < PX; ++p) {
-        const int x = j0 + p;
-        const bool valid = live && x < cols - 5 && i < rows - 1 && ((okw >> (p0 + p + 2)) & 0xFu) == 0xFu;
-        const float mTwo = (float)((valxs[p] * valxs[p]) + (valys[p] * valys[p]));
-        cand[p] = valid && mTwo >= a.ra.min_scale && !(d1s[p] != d1s[p]);
-    }
     __builtin_amdgcn_sched_barrier(0);
-    };
-    gn_prologue_sums<false>(st, a, rl, lds, blockIdx.x == 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (wave != 0) pose_free_work();  // beside the one wave that solves
-    __builtin_amdgcn_sched_barrier(0);
-    gn_prologue_solve<false>(st, a, lds, blockIdx.x == 0);
-    if (wave == 0) pose_free_work();
-    __builtin_amdgcn_sched_barrier(0);
-    MMF_STAMP(8);
+    lds_barrier();  // B: the pose is in LDS
     float K[9], kt[3];
 #pragma unroll
     for (int k = 0; k < 9; ++k) P.Rcurr[k] = uniform_f(lds.pose[k]), K[k] = uniform_f(lds.pose[12 + k]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) P.tcurr[k] = uniform_f(lds.pose[9 + k]), kt[k] = uniform_f(lds.pose[21 + k]);
+
+    if (MMF_ABL & 64) {  // the dependent phases alone: no pixel work between the pose and the record
+        if (lane == 63) lds.wsum[wave][0] = (int)(P.Rcurr[0] == 123.f), lds.wsum[wave][1] = (int)(K[0] == 123.f) + (int)cand[0] + own[0];
+        lds_barrier();  // C
+        if ((lane & 1) == 0) lds.wave[wave][lane >> 1] = 0.f, lds.wave[wave][32 + (lane >> 1)] = 0.f;
+        lds_barrier();  // C2
+        lds_barrier();  // D
+        lds_barrier();  // E
+        return;
+    }
 
     // ---- photometric correspondence search: warp (reduce.cu:799-812), then its gathers at once ----
     bool inb[PX];
@@ -368,7 +586,7 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
         cl[p] = a.cloud4[(size_t)gvv * cols + gu];  // rgbStep's point (reduce.cu:522) and 1 / Z
     }
     __builtin_amdgcn_sched_barrier(0);
-    MMF_STAMP(9);
+    MMF_STAMP_PX(9);
 
     // ---- ICP: projection into the model's camera (reduce.cu:257-273) while those are in flight, then its gathers ----
     IcpProj<T> pr[NV];
@@ -392,15 +610,15 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- photometric: accept / reject (reduce.cu:813-836), the workgroup's {count, sum diff^2}, arrival ----
+    // ---- photometric: accept / reject (reduce.cu:813-836), the wave's {count, sum diff^2} ----
     RgbLane<PX> ph;
     int cnt = 0, sq = 0;
     float perr[PX];
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
         const bool hit = inb[p] && d0s[p] > 0 && fabsf(td1s[p] - d0s[p]) <= a.ra.max_depth_delta && lis[p] != 0;
-        const int idiff = (int)((own >> (8 * (p0 + p))) & 0xFFu) - (int)lis[p];  // == (float)next - (float)last, exactly
-        const int vy = hit ? idiff * idiff : 0;                                   // == (int)(diff * diff)
+        const int idiff = own[p] - (int)lis[p];  // == (float)next - (float)last, exactly
+        const int vy = hit ? idiff * idiff : 0;   // == (int)(diff * diff)
         perr[p] = hit ? 0.001f * vy : 0.0f;
         cnt += hit ? 1 : 0;
         sq += vy;
@@ -409,23 +627,14 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
         ph.X[p] = cl[p].x, ph.Y[p] = cl[p].y, ph.Z[p] = cl[p].z, ph.invz[p] = cl[p].w;
         ph.gx[p] = valxs[p], ph.gy[p] = valys[p];
     }
-    if (ERR && a.ra.err_map && live) store_px<PX>(a.ra.err_map + (size_t)i * a.ra.err_stride + j0, perr);
-#ifdef MMF_STAMPS
-    MMF_STAMP(6);
-#endif
+    if (ERR && a.ra.err_map && live) gn_store_f32<PX>(a.ra.err_map + (size_t)i * a.ra.err_stride + j0, perr);
+    MMF_STAMP_PX(6);
     cnt = wave_sum_to_lane63(cnt);
     sq = wave_sum_to_lane63(sq);
     if (lane == 63) lds.wsum[wave][0] = cnt, lds.wsum[wave][1] = sq;
-    __syncthreads();
-    if (tid == 0) {  // one arrival per workgroup
-        unsigned c = 0, s2 = 0;
-        for (int wv = 0; wv < nwaves; ++wv) c += (unsigned)lds.wsum[wv][0], s2 += (unsigned)lds.wsum[wv][1];
-        const unsigned long long word = (1ull << kGnArriveShift) | ((unsigned long long)c << kResCountShift) | (unsigned long long)s2;
-        (void)__hip_atomic_fetch_add(&st->gn_acc[a.it % 3][kResStride * (blockIdx.x % kResShards)], word, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-    }
+    lds_barrier();  // C: the solver wave adds the workgroup's counts to the launch's and waits for the others
     __builtin_amdgcn_sched_barrier(0);
-    MMF_STAMP(10);
+    MMF_STAMP_PX(7);
 
     // ---- ICP: Jacobian rows (reduce.cu:275-368) while the other workgroups arrive ----
     T isum[29];
@@ -449,12 +658,10 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
             for (int e = 0; e < W; ++e) ierr[h * W + e] = er[e];
         }
     }
-    if (ERR && a.ia.err_map && live) store_px<PX>(a.ia.err_map + (size_t)i * a.ia.err_stride + j0, ierr);
+    if (ERR && a.ia.err_map && live) gn_store_f32<PX>(a.ia.err_map + (size_t)i * a.ia.err_stride + j0, ierr);
     __builtin_amdgcn_sched_barrier(0);
-    MMF_STAMP(11);
-
-    // the ICP sums are complete: their reduction over the wave goes here, into the wait for the other workgroups
-    {
+    MMF_STAMP_PX(11);
+    {  // their reduction over the wave goes here, into the wait for the other workgroups
         float s32[32];
 #pragma unroll
         for (int k = 0; k < 29; ++k) s32[k] = L::hsum(isum[k]);
@@ -463,35 +670,8 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
         if ((lane & 1) == 0) lds.wave[wave][lane >> 1] = t;
     }
     __builtin_amdgcn_sched_barrier(0);
-
-    // ---- the count barrier: wave 0 polls the 16 shards until every workgroup of this model has arrived, then decides
-    //      sigma (RGBDOdometry.cpp:373-385) and lays out the pass's 256 weights ----
-    if (wave == 0) {
-        const unsigned long long* acc = st->gn_acc[a.it % 3];
-        unsigned c = 0, s2 = 0, ok = 0;
-        for (int poll = 0; poll < kGnMaxPolls; ++poll) {
-            const unsigned long long v = lane < kResShards ? __hip_atomic_load(acc + kResStride * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            unsigned arr = wave_sum_to_lane63((unsigned)(v >> kGnArriveShift));
-            c = wave_sum_to_lane63((unsigned)(v >> kResCountShift) & 0x3FFFFu);
-            s2 = wave_sum_to_lane63((unsigned)v);  // wraps at 2^32 like the reference's int
-            arr = (unsigned)__builtin_amdgcn_readlane((int)arr, 63);
-            if (arr == gridDim.x) {
-                ok = 1;
-                break;
-            }
-            for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
-        }
-        c = (unsigned)__builtin_amdgcn_readlane((int)c, 63), s2 = (unsigned)__builtin_amdgcn_readlane((int)s2, 63);
-        // sigmaVal of residual_decide without its double-precision square root and division: tmpError = sqrt(sum) / count is
-        // zero exactly when sum is (count <= 2^19: no underflow), and NaN -- not zero -- for 0 / 0
-        const float sigma_val = ((int)s2 == 0 && (int)c != 0) ? 1.0f : (float)(int)c;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lds.wtab[lane * 4 + q] = rgb_weight(sigma_val, (float)(lane * 4 + q));
-        if (lane == 63) lds.bar[2] = ok, lds.bar[3] = __builtin_bit_cast(unsigned, sigma_val);
-    }
-    __syncthreads();
-    MMF_STAMP(12);
-    if (!lds.bar[2] && blockIdx.x == 0 && tid == 0) st->gn_fault = 1;  // a workgroup of this launch never arrived
+    lds_barrier();  // C2: the solver wave starts polling
+    lds_barrier();  // D: sigma and the weight table are in LDS
     const float sigmaVal = __builtin_bit_cast(float, lds.bar[3]);
 
     // ---- photometric: rgbStep's rows (reduce.cu:504-535) ----
@@ -499,8 +679,6 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
 #pragma unroll
     for (int k = 0; k < 29; ++k) psum[k] = 0.f;
     rgb_rows<PX>(a.sobel_scale, a.fx, a.fy, sigmaVal, live, ph, psum, lds.wtab, true);
-
-    // ---- their sums over the wave; both sum sets over the workgroup -> one 256-byte record ----
     {
         float s32[32];
 #pragma unroll
@@ -509,30 +687,40 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
         const float t2 = wave_sum_transposed(s32);
         if ((lane & 1) == 0) lds.wave[wave][32 + (lane >> 1)] = t2;
     }
-    __syncthreads();
-    if (tid < 16) {
-        float4 s = *reinterpret_cast<const float4*>(&lds.wave[0][tid * 4]);
-        for (int wv = 1; wv < nwaves; ++wv) {  // fixed order: the launch geometry decides the sum, not the timing
-            const float4 t = *reinterpret_cast<const float4*>(&lds.wave[wv][tid * 4]);
-            s.x = s.x + t.x, s.y = s.y + t.y, s.z = s.z + t.z, s.w = s.w + t.w;
-        }
-        *reinterpret_cast<float4*>(a.rec_out + (size_t)blockIdx.x * kGnRec + tid * 4) = s;
-    }
-    MMF_STAMP(13);
+    lds_barrier();  // E: the solver wave adds the waves' sums up and stores the workgroup's record
 }
 
-// the chain's last solve + RGBDOdometry.cpp:464-467, 475-476: one workgroup per model
+// blockDim.x = 64 (solver wave) + the pixel waves (>= 4, a.lanes <= their lanes)
+template <int PX, bool ERR>
+__global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st, GnIterArgs a, BatchDelta bd) {
+    __shared__ GnLds lds;
+    if (gridDim.y > 1) gn_batch_shift(st, a, bd);
+    MMF_STAMP(5);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0)
+        gn_solver_wave(st, a, lds, blockIdx.x == 0, lane, (int)(blockDim.x >> 6) - 1);
+    else
+        gn_pixel_waves<PX, ERR>(st, a, lds, tid - 64, lane, wave);
+}
+
+// the chain's last solve + RGBDOdometry.cpp:464-467, 475-476: one workgroup (kBlock threads) per model, its first wave works
+__device__ __forceinline__ void gn_final_solve(OdomState* st, const GnIterArgs& a, GnLds& lds) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        GnSumLoads sl;
+        gn_sums_issue(st, a, sl, tid);
+        unsigned pc, ps;
+        gn_totals_to_lds(sl, lds, tid, pc, ps);
+        gn_solve_wave<true>(st, a, lds, true, tid, pc, ps);
+    }
+    __syncthreads();  // the state lane 0 stored is visible to the workgroup
+}
 __global__ __launch_bounds__(kBlock) void gn_final_kernel(OdomState* st, GnIterArgs a, BatchDelta bd) {
     __shared__ GnLds lds;
     if (gridDim.x > 1) {
-        const long long d = bd.d[blockIdx.x];
-        st = batch_shift(st, d);
-        a.rec_in = batch_shift(a.rec_in, d);
+        st = batch_shift(st, bd.d[blockIdx.x]);
     }
-    GnRecLoads rl;
-    gn_records_issue(st, a, rl);
-    gn_prologue_sums<true>(st, a, rl, lds, true);
-    gn_prologue_solve<true>(st, a, lds, true);
+    gn_final_solve(st, a, lds);
 }
 
 // the same, and the result goes to the host in the same launch (odom_publish_kernel's two waves behind the solve: the copy
@@ -541,14 +729,9 @@ __global__ __launch_bounds__(kBlock) void gn_final_publish_kernel(OdomState* st,
                                                                   unsigned seq) {
     __shared__ GnLds lds;
     if (gridDim.x > 1) {
-        const long long d = bd.d[blockIdx.x];
-        st = batch_shift(st, d);
-        a.rec_in = batch_shift(a.rec_in, d);
+        st = batch_shift(st, bd.d[blockIdx.x]);
     }
-    GnRecLoads rl;
-    gn_records_issue(st, a, rl);
-    gn_prologue_sums<true>(st, a, rl, lds, true);
-    gn_prologue_solve<true>(st, a, lds, true);  // ends with a workgroup barrier: the state lane 0 stored is visible to the workgroup
+    gn_final_solve(st, a, lds);
     if (threadIdx.x >= 64) {
         if (threadIdx.x == 64) odom_fusion_weight(st);
         return;

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <new>
@@ -90,6 +91,7 @@ struct mmf_ctx {
     void* slic_ws = nullptr;  // super-pixel resampling workspace (boxes, counts, sums), grown on demand
     size_t slic_ws_n = 0;
     char arch[64] = {0};
+    int cu_count = 0;  // compute units of the device (the one-launch Gauss-Newton chain needs its grid resident at once)
 };
 
 extern "C" int mmf_ctx_create(int device, void* stream, int private_stream, mmf_ctx** out) {
@@ -105,6 +107,7 @@ extern "C" int mmf_ctx_create(int device, void* stream, int private_stream, mmf_
     hipDeviceProp_t prop;
     MMF_HIP_TRY(hipGetDeviceProperties(&prop, device));
     std::snprintf(c->arch, sizeof(c->arch), "%s", prop.gcnArchName);
+    c->cu_count = prop.multiProcessorCount;
     if (std::strncmp(c->arch, "gfx950", 6) != 0) {
         std::string m = std::string("mmf_ctx_create: this library is built for gfx950 only, device is ") + c->arch;
         delete c;
@@ -770,7 +773,6 @@ struct mmf_odom {
     float* gn_partials_icp = nullptr;
     int2* gn_partials_res = nullptr;
     unsigned* gn_ticket = nullptr;
-    float* gn_rec[2] = {nullptr, nullptr};  // ping-pong partial records of the one-launch-per-iteration chain (gn_fused.hpp)
     float *icp_err = nullptr, *rgb_err = nullptr;  // Model::icpError / rgbError (R32F), written on the last level-0 iteration
     OdomState* state = nullptr;  // device
     OdomState* host_result = nullptr;  // pinned, device visible: odom_publish_kernel writes it, the host polls publish_seq
@@ -873,7 +875,6 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     const size_t o_pf = carve(sizeof(float) * kMaxGrid * kPartialStride), o_pi = carve(sizeof(float) * kMaxIcpGrid * kPartialStride),
                  o_pr = carve(sizeof(int2) * kMaxGrid), o_tk = carve(sizeof(unsigned) * kTicketWords), o_ei = carve(n0 * 4),
                  o_er = carve(n0 * 4);
-    const size_t o_rec0 = carve(sizeof(float) * kGnMaxGroups * kGnRec), o_rec1 = carve(sizeof(float) * kGnMaxGroups * kGnRec);
     o->slab_bytes = off;
     hipError_t e = hipMalloc(&o->slab, o->slab_bytes);
     if (e != hipSuccess) {
@@ -908,7 +909,6 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     o->gn_partials_f = (float*)(base + o_pf), o->gn_partials_icp = (float*)(base + o_pi);
     o->gn_partials_res = (int2*)(base + o_pr), o->gn_ticket = (unsigned*)(base + o_tk);
     o->icp_err = (float*)(base + o_ei), o->rgb_err = (float*)(base + o_er);
-    o->gn_rec[0] = (float*)(base + o_rec0), o->gn_rec[1] = (float*)(base + o_rec1);
     MMF_HIP_TRY(hipHostMalloc(&o->host_result, sizeof(OdomState), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(o->host_result, 0, sizeof(OdomState));
     MMF_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&o->host_result_dev), o->host_result, 0));
@@ -1416,43 +1416,53 @@ struct TrackBatch {
 };
 
 static bool odom_batchable(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom);
-// Launch geometry of gn_iter_kernel at a level of n pixels.  The launch is a chain of latencies -- prologue, two memory
-// round trips, the count barrier -- and every workgroup waits at that barrier for the slowest one, so (measured on MI355X,
-// tools/gn_ab.sh): at most one workgroup per CU (two on a CU reach the barrier 1.6 us after the others); four waves per
-// workgroup where that fits (a fifth wave doubles up on one SIMD and is the long pole of every arithmetic phase); as few
-// pixels per lane as those two allow (a lane's serial arithmetic is on the critical path: 320x240 takes 9.0 us with 2
-// pixels per lane in 150 workgroups, 10.6 with 4 in 75, 11.1 with 1 in 256 workgroups of five waves).
+// Launch geometry of gn_iter_kernel at a level of cols x rows pixels: a workgroup = the solver wave + the pixel waves.  The
+// launch is a chain of latencies -- records, solve, two memory round trips, the count barrier -- and every workgroup waits at
+// that barrier for the slowest one, so (measured on MI355X, tools/ab_libs.sh): at most one workgroup per CU (two on a CU
+// reach the barrier 1.6 us after the others); exactly four pixel waves, one per SIMD, where that fits (a fifth doubles up on
+// one SIMD and is the long pole of every arithmetic phase: what 640x480 suffered with four pixels per lane, 300 lanes in 256
+// workgroups); as few pixels per lane as those two allow (a lane's serial arithmetic is on the critical path).  Five pixels
+// per lane exist for 640x480: 240 workgroups x 256 lanes x 5.
 // MMF_GN_PX="p0,p1,p2" forces the pixels per lane of a level, MMF_GN_GROUPS the workgroup limit (tuning aids).
 struct GnGeometry {
     int px, lanes, threads, groups;
 };
-static bool gn_geometry(int level, int n, GnGeometry* out) {
+static bool gn_geometry(int level, int cols, int rows, GnGeometry* out) {
     static const std::array<int, 3> forced = []() {
         std::array<int, 3> f{{0, 0, 0}};
         if (const char* e = std::getenv("MMF_GN_PX")) std::sscanf(e, "%d,%d,%d", &f[0], &f[1], &f[2]);
         return f;
     }();
     static const int max_groups = []() { const char* e = std::getenv("MMF_GN_GROUPS"); return e ? std::atoi(e) : 256; }();
+    const int n = cols * rows;
     const int want = (level >= 0 && level < 3) ? forced[level] : 0;
-    auto allowed = [&](int px) { return !(want == 1 || want == 2 || want == 4) || px == want; };
-    for (int px = 1; px <= 4; px *= 2) {  // four waves per workgroup
-        const int groups = (n / px + kBlock - 1) / kBlock;
-        if (!allowed(px) || groups > max_groups || groups > kGnMaxGroups) continue;
-        *out = GnGeometry{px, kBlock, kBlock, groups};
-        return true;
-    }
-    for (int px = 4; px >= 1; px /= 2) {  // larger workgroups, as few of them as the limit asks for
+    // a lane's pixels lie in one row; the window words are 4-byte aligned columns
+    auto allowed = [&](int px) { return cols % px == 0 && cols % 4 == 0 && (!(want == 1 || want == 2 || want == 4 || want == 5) || px == want); };
+    static const int kPx[4] = {1, 2, 4, 5};
+    static const int lanes_env = []() { const char* e = std::getenv("MMF_GN_LANES"); return e ? std::atoi(e) : 0; }();
+    for (int pass = 0; pass < 2; ++pass)
+        for (int k = 0; k < 4; ++k) {  // four pixel waves per workgroup (MMF_GN_LANES: first try that many lanes)
+            const int px = kPx[k];
+            const int wl = pass == 0 ? lanes_env : kBlock;
+            if (wl < 64 || wl % 64) continue;
+            const int groups = (n / px + wl - 1) / wl;
+            if (!allowed(px) || groups > max_groups || groups > kGnMaxGroups) continue;
+            *out = GnGeometry{px, wl, wl + 64, groups};
+            return true;
+        }
+    for (int k = 3; k >= 0; --k) {  // larger workgroups, as few of them as the limit asks for
+        const int px = kPx[k];
         if (!allowed(px)) continue;
         const int total = n / px;
         const int lanes = std::max(kBlock, (total + max_groups - 1) / max_groups);
         const int groups = (total + lanes - 1) / lanes;
-        if (lanes > 64 * kGnMaxWaves || groups > kGnMaxGroups) continue;
-        *out = GnGeometry{px, lanes, (lanes + 63) / 64 * 64, groups};
+        if (lanes > 64 * (kGnMaxWaves - 1) || groups > kGnMaxGroups) continue;
+        *out = GnGeometry{px, lanes, (lanes + 63) / 64 * 64 + 64, groups};
         return true;
     }
     return false;
 }
-static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom);
+static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom, int models = 1);
 static unsigned fused_max_models();
 
 static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float rot[9], int rgb_only, float icp_weight,
@@ -1481,7 +1491,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     // both terms on and every level fits: ONE launch per iteration (gn_fused.hpp) instead of producer + step
     // (more than three models: the batched two-launch chain is as fast (four) or faster -- 8 models 1.40 ms against 1.60 --
     // because a model's workgroups hold their CUs at the count barrier while the next models' wait for a place)
-    const bool fused_chain = odom_fused_chain_ok(o, rgb_only, icp_weight, pyramid, fast_odom) &&
+    const bool fused_chain = odom_fused_chain_ok(o, rgb_only, icp_weight, pyramid, fast_odom, (int)ny) &&
                              (ny == 1 || (ny <= fused_max_models() && odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom)));
     int first_iter_level = MMF_NUM_PYRS - 1;  // the coarsest level that runs iterations
     while (first_iter_level > 0 && !iterations[first_iter_level]) --first_iter_level;
@@ -1522,12 +1532,12 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     std::memset(&final_args, 0, sizeof(final_args));
     if (fused_chain) {
         int it = 0;
-        unsigned prev_groups = 0;
         bool first = true;
         GnIterArgs a;
         std::memset(&a, 0, sizeof(a));
         static const int poll_sleep = []() { const char* e = std::getenv("MMF_GN_SLEEP"); return e ? std::atoi(e) : 1; }();
         a.poll_sleep = poll_sleep;
+        a.max_polls = kGnMaxPolls;
         for (int i = MMF_NUM_PYRS - 1; i >= 0; --i) {
             if (!iterations[i]) continue;
             const int cols = o->width >> i, rows = o->height >> i;
@@ -1542,7 +1552,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
             first = false;
             const float min_scale = (float)(std::pow((double)o->min_grad[i], 2.0) / std::pow((double)o->sobel_scale, 2.0));
             GnGeometry geo;
-            MMF_REQUIRE(gn_geometry(i, cols * rows, &geo), "odom_enqueue_tracking: no launch geometry for this level");
+            MMF_REQUIRE(gn_geometry(i, cols, rows, &geo), "odom_enqueue_tracking: no launch geometry for this level");
             const int px = geo.px, groups = geo.groups;
             a.lanes = geo.lanes;
             for (int j = 0; j < iterations[i]; ++j) {
@@ -1558,8 +1568,6 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 a.intr = in;
                 a.ifx = 1.0 / (double)in.fx, a.ify = 1.0 / (double)in.fy;
                 a.it = it;
-                a.prev_groups = prev_groups;
-                a.rec_in = o->gn_rec[(it + 1) & 1], a.rec_out = o->gn_rec[it & 1];
                 const bool err = last_l0 && (icp_err_dev || rgb_err_dev);
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (o->timing >= 2 && o->n_timed < kMaxTimedLaunches) {
@@ -1575,6 +1583,8 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
             q.launch((gn_iter_kernel<PXV, ERRV>), dim3(groups, ny), dim3(geo.threads), o->state, a, bd);                       \
     } while (0)
                 switch (px * 2 + (err ? 1 : 0)) {
+                    case 11: MMF_GN_LAUNCH(5, true); break;
+                    case 10: MMF_GN_LAUNCH(5, false); break;
                     case 9: MMF_GN_LAUNCH(4, true); break;
                     case 8: MMF_GN_LAUNCH(4, false); break;
                     case 5: MMF_GN_LAUNCH(2, true); break;
@@ -1585,13 +1595,10 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
 #undef MMF_GN_LAUNCH
                 MMF_HIP_TRY(hipGetLastError());
                 ++it;
-                prev_groups = (unsigned)groups;
             }
         }
         // the last solve + RGBDOdometry.cpp:464-467: one workgroup per model
         a.it = it;
-        a.prev_groups = prev_groups;
-        a.rec_in = o->gn_rec[(it + 1) & 1], a.rec_out = nullptr;
         a.intr = level_intr(o->fx, o->fy, o->cx, o->cy, 0);
         a.ifx = 1.0 / (double)a.intr.fx, a.ify = 1.0 / (double)a.intr.fy;
         final_args = a;
@@ -1801,7 +1808,31 @@ static unsigned fused_max_models() {  // MMF_GN_FUSED_MAX: up to how many models
     static const unsigned n = []() { const char* e = std::getenv("MMF_GN_FUSED_MAX"); return e ? (unsigned)std::max(1, std::atoi(e)) : 3u; }();
     return n;
 }
-static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom) {
+// How many workgroups of gn_iter_kernel<px, .> with `threads` threads the device holds at once: the occupancy the runtime
+// reports for the kernel (registers, LDS) x the compute units.  The launch spins on its own workgroups (count barrier), so a
+// grid beyond this could only time out; such sizes, partitioned or smaller devices take the two-launch chain.
+static long long gn_resident_groups(mmf_ctx* c, int px, int threads) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, int> per_cu;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(px, threads);
+    auto it = per_cu.find(key);
+    if (it == per_cu.end()) {
+        int nb = 0;
+        hipError_t e = hipErrorInvalidValue;
+        switch (px) {  // (the error-image variant uses no fewer registers: it bounds both)
+            case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gn_iter_kernel<5, true>, threads, 0); break;
+            case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gn_iter_kernel<4, true>, threads, 0); break;
+            case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gn_iter_kernel<2, true>, threads, 0); break;
+            case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gn_iter_kernel<1, true>, threads, 0); break;
+            default: break;
+        }
+        if (e != hipSuccess) nb = 0, (void)hipGetLastError();
+        it = per_cu.emplace(key, nb).first;
+    }
+    return (long long)it->second * c->cu_count;
+}
+static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom, int models) {
     static const bool env_enabled = []() {
         const char* v = std::getenv("MMF_GN_FUSED");
         return !(v && v[0] == '0');
@@ -1820,7 +1851,9 @@ static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int
         IcpArgs ia = odom_icp_args(o, i, o->icp_err);
         if (!residual_vec4_ok(ra) || icp_max_px(ia, 4) != 4 || !ia.prev_packed) return false;
         GnGeometry geo;
-        if (!gn_geometry(i, cols * rows, &geo)) return false;
+        if (!gn_geometry(i, cols, rows, &geo)) return false;
+        // the count barrier inside the launch needs every workgroup of it resident at once
+        if ((long long)geo.groups * models > gn_resident_groups(o->ctx, geo.px, geo.threads)) return false;
     }
     return true;
 }

@@ -77,7 +77,19 @@ struct OdomState {
     // the running transform: launch `it` reads gn_rt[it & 1] (it = 0: resultRt) and its workgroup 0 stores the updated
     // one to gn_rt[(it + 1) & 1], so no workgroup reads what another workgroup of the same launch writes
     double gn_rt[2][16];
+    // The 58 sums of a launch (29 ICP, 29 photometric: gn_fused.hpp) as 64-bit fixed-point integers: every workgroup adds its
+    // float partials, scaled by a power of two, with integer atomics -- exact and order independent, so the totals are the
+    // same bits however the launch is laid out, and the next launch reads 16 x 464 bytes instead of one 256-byte record per
+    // workgroup (61 KB at 640x480, fetched by EVERY workgroup: 0.8 us of a level-0 launch).  Atomics execute at the memory
+    // side on this chip whatever their scope (MI355X_MICROARCH.md, "Global float atomics"), so the sharding (by block index,
+    // kGnSumShards lines sets) is there against contention on a line only, never for correctness.  Rotation like gn_acc:
+    // launch `it` adds to gn_sum[it % 3], reads gn_sum[(it + 2) % 3] and zeroes gn_sum[(it + 1) % 3]; a kernel boundary lies
+    // between a buffer's writers and its readers.
+    alignas(128) long long gn_sum[3][16][64];
 };
+constexpr int kGnSumIcpExp = 30;  // ICP sums: value x 2^30 (per-workgroup partials < 2^23: 1280 pixels x |v|^2)
+constexpr int kGnSumRgbExp0 = 4;  // photometric sums: value x 2^(4 + 2 floor(log2 sigma)) -- the rows carry w = 1 / (sigma + |d|)
+constexpr int kGnSumShards = 16;
 constexpr int kResShards = 16;
 constexpr int kResStride = 16;  // 64-bit words between two shards (128 B)
 constexpr int kResCountShift = 40;
@@ -509,9 +521,11 @@ __device__ inline SolveIn load_solve_in(const OdomState* st) {
 
 #ifdef MMF_STAMPS  // diagnostic builds only (tools/rgb_step_probe.py): stamps inside the solve
 __device__ unsigned long long* g_mmf_dbg_solve = nullptr;
-#define MMF_SOLVE_STAMP(i)                                                                       \
-    do {                                                                                         \
-        if (g_mmf_dbg_solve) g_mmf_dbg_solve[blockIdx.x * 16 + (i)] = wall_clock64();             \
+#define MMF_SOLVE_STAMP(i)                                                                                         \
+    do {                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        if (g_mmf_dbg_solve && (threadIdx.x & 63) == 0) g_mmf_dbg_solve[blockIdx.x * 16 + (i)] = wall_clock64();    \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
     } while (0)
 #else
 #define MMF_SOLVE_STAMP(i) \
@@ -540,6 +554,26 @@ __device__ __forceinline__ double combine_element(OdomState* st, int l, double w
     else
         v = tot_icp ? (double)tot_icp[idx] : (double)tot_rgb[idx];
     if (st) {  // nullptr: no store (gn_iter_kernel: only the chain's last solve is visible to the host)
+        if (l < 36)
+            st->st.lastA[l] = v;
+        else
+            st->st.lastb[l - 36] = v;
+    }
+    return v;
+}
+
+// the same from totals held in double (the fixed-point sums of gn_fused.hpp): A = A_rgb + w^2 A_icp, b = b_rgb + w b_icp
+__device__ __forceinline__ double combine_element_d(OdomState* st, int l, double w, const double* tot_rgb, const double* tot_icp) {
+    int i, j;
+    if (l < 36) {
+        const int r = l / 6, c = l - r * 6;
+        i = r < c ? r : c, j = r < c ? c : r;
+    } else {
+        i = l - 36, j = 6;
+    }
+    const int idx = se3_packed_index(i, j);
+    const double v = l < 36 ? tot_rgb[idx] + w * w * tot_icp[idx] : tot_rgb[idx] + w * tot_icp[idx];
+    if (st) {
         if (l < 36)
             st->st.lastA[l] = v;
         else

@@ -838,6 +838,10 @@ __device__ __forceinline__ void so3_share(OdomState* dst, const OdomState* src) 
 
 // RGBDOdometry.cpp:221-228, 237, 252-255, 316-328.  Batched: block m = model m, poses from `poses`.
 __global__ void odom_begin_kernel(OdomState* st, BeginArgs a, BatchDelta bd, BeginPoses poses) {
+    if (threadIdx.x < 64) {  // the first gn_iter_kernel launch adds its sums here
+        OdomState* sm = gridDim.x > 1 ? batch_shift(st, bd.d[blockIdx.x]) : st;
+        for (int x = 0; x < kGnSumShards; ++x) sm->gn_sum[0][x][threadIdx.x] = 0ll;
+    }
     if (threadIdx.x != 0) return;
     const OdomState* leader = st;
     if (gridDim.x > 1) {

@@ -180,8 +180,11 @@ def test_batched_chain_equals_one_chain_per_model(gpu_ctx):
         for pf, pg in zip(f1[0][i], f2[0][i]):
             assert np.array_equal(pf, pg), i
         assert np.abs(f1[0][i][0] - a[0][i][0]).max() <= 1e-5, i  # the camera; object poses amplify one-ulp noise
+        # free-running object models over seven frames: the two chains add the same Jacobian rows up in different orders (exact
+        # fixed-point totals against a float tree), and an object's few thousand pixels turn such one-ulp differences into
+        # 1e-5 .. 1e-3 per frame in the ORACLE itself (test_oracle_fusion.py::test_object_tracking_is_sensitive_to_one_ulp_noise)
         for pf, pa in zip(f1[0][i][1:], a[0][i][1:]):
-            assert np.abs(pf - pa).max() <= 2e-3, i
+            assert np.abs(pf - pa).max() <= 1e-2, i
     assert all(s[2] == 19 for s in f1[2])
     for i in range(n_frames):
         for pa, pc in zip(a[0][i], c[0][i]):

@@ -26,12 +26,14 @@ from multimotionfusion_amd import synth  # noqa: E402
 from multimotionfusion_amd.cudafuncs import Context  # noqa: E402
 from multimotionfusion_amd.odometry import RGBDOdometry  # noqa: E402
 
-# slot order along a workgroup's timeline
-ORDER = [5, 0, 3, 4, 1, 2, 14, 15, 8, 9, 6, 10, 11, 12, 13]
-NAMES = ["index math + image loads issued", "records landed (barrier)", "record tree + combine", "(lane 0 starts)",
-         "6x6 LDLT", "rodrigues + resultRt", "pose compose + K R K^-1", "pose -> LDS -> SGPRs", "windows, warp, ICP projection",
-         "gathers landed + accept", "count: wave + block sum, arrive", "ICP rows", "count barrier (poll)",
-         "photometric rows + reduce + record"]
+# stamp slots (thread 0 = the solver wave, thread 64 = the first pixel wave) and what they mark
+SLOTS = [(5, "solver: start"), (0, "solver: state loaded"), (3, "solver: barrier A passed (records summed by the pixel waves)"),
+         (4, "solver: totals + combined system"), (1, "solver: lane 0 starts"), (2, "solver: 6x6 LDLT done"),
+         (14, "solver: rodrigues + resultRt done"), (15, "solver: pose compose + K R K^-1 done"),
+         (8, "solver: barrier B passed (pose in LDS)"), (9, "pixel: warp done, photometric gathers issued"),
+         (6, "pixel: ICP projection + gathers issued, accept done"), (7, "pixel: barrier C passed (counts in LDS)"),
+         (10, "solver: arrived at the count barrier"), (11, "pixel: ICP rows done"), (12, "solver: barrier D passed (sigma known)"),
+         (13, "solver: record stored")]
 
 
 def probe(W, H):
@@ -58,25 +60,16 @@ def probe(W, H):
     raw.mmf_debug_set_stamps(C.c_void_p(0))
     raw_s = stamps.cpu().numpy().reshape(-1, 16)
     nb = int(np.count_nonzero(raw_s[:, 13]))  # workgroups of the last launch (the host picks the geometry per level)
-    s = raw_s[1:nb][:, ORDER]
-    t0 = s[:, 0].min()
-    ph = np.diff(s, axis=1) * 0.01  # us
-    print(f"{W}x{H}: {nb} workgroups; first start .. last end {(s[:, -1].max() - t0) * 0.01:.2f} us, start spread "
-          f"{(s[:, 0].max() - t0) * 0.01:.2f} us, mean workgroup lifetime {((s[:, -1] - s[:, 0]).mean()) * 0.01:.2f} us")
-    for n, mean, mx in zip(NAMES, ph.mean(axis=0), ph.max(axis=0)):
-        print(f"    {n:42s} mean {mean:5.2f}  max {mx:5.2f} us")
-    print(f"    cumulative (mean, from the first start): " + ", ".join(f"{v:.2f}" for v in ((s - t0).mean(axis=0) * 0.01)))
-    arrive = (s[:, ORDER.index(10)] - t0) * 0.01
-    release = (s[:, ORDER.index(12)] - t0) * 0.01
-    q = lambda v: ", ".join(f"{np.percentile(v, p):.2f}" for p in (0, 50, 90, 99, 100))  # noqa: E731
-    print(f"    arrival at the count barrier (us after the first start; min, p50, p90, p99, max): {q(arrive)}; release: {q(release)}")
-    for k, name in ((ORDER.index(3), "records landed"), (ORDER.index(8), "pose known"), (ORDER.index(6), "gathers landed"), (ORDER.index(13), "end")):
-        print(f"    {name} (min, p50, p90, p99, max): {q((s[:, k] - t0) * 0.01)}")
-    if nb > 256:  # blocks b and b + 256 plausibly share a CU
-        idx = np.arange(1, nb)
-        shared = (idx < nb - 256) | (idx >= 256)
-        print(f"    arrival, workgroups that share a CU (by index) vs alone: {arrive[shared].mean():.2f} vs {arrive[~shared].mean():.2f} us; "
-              f"start: {((s[:, 0] - t0) * 0.01)[shared].mean():.2f} vs {((s[:, 0] - t0) * 0.01)[~shared].mean():.2f}")
+    s = raw_s[1:nb]
+    t0 = s[:, 5].min()
+    print(f"{W}x{H}: {nb} workgroups; first start .. last end {(s[:, 13].max() - t0) * 0.01:.2f} us, start spread "
+          f"{(s[:, 5].max() - t0) * 0.01:.2f} us")
+    q = lambda v: " ".join(f"{np.percentile(v, p):6.2f}" for p in (0, 50, 90, 100))  # noqa: E731
+    print("    us after the first workgroup's start:                               min    p50    p90    max")
+    for slot, name in sorted(SLOTS, key=lambda sn: np.median(s[:, sn[0]])):
+        if np.count_nonzero(s[:, slot]) == 0:
+            continue
+        print(f"    {name:66s} {q((s[:, slot] - t0) * 0.01)}")
     g.close()
     ctx.close()
 
