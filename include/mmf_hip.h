@@ -510,6 +510,10 @@ int mmf_debug_set_gn_fused(int on);
  * inside this library reads its images before the frame's second predict() (:821) overwrites them, 0 = leave it out (the
  * default), -1 = what the environment says (MMF_MID_PREDICT=1 turns it on).  Process wide. */
 int mmf_debug_set_mid_predict(int on);
+/* test / A-B hook: the bounded depth test of combinedPredict (splat_bound_kernel: every drawn surfel's centre fragment first,
+ * as a per-pixel bound that lets the splat skip occluded fragments and their atomics; same images).  1 = always, 0 = never,
+ * -1 = when the store holds two surfels per pixel or more (the default).  Process wide. */
+int mmf_debug_set_splat_bound(int mode);
 /* Model::computeFusionWeight (Model.cpp:876-891) for pose / lastPose (host 4x4), exported for tests */
 int mmf_compute_fusion_weight(const float pose[16], const float last_pose[16], float multiplier, float *out);
 

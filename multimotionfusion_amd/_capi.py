@@ -207,6 +207,7 @@ SIGNATURES = {
     "mmf_model_surfel_arrays": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint)]),
     "mmf_debug_set_gn_fused": (_i, [_i]),
     "mmf_debug_set_mid_predict": (_i, [_i]),
+    "mmf_debug_set_splat_bound": (_i, [_i]),
     "mmf_fusion_set_shard": (_i, [_vp, _i, _i]),
     "mmf_fusion_owns_model": (_i, [_vp, _i]),
     "mmf_fusion_set_model_pose": (_i, [_vp, _i, _fp]),

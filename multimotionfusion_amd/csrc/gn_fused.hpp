@@ -573,7 +573,6 @@ __device__ __forceinline__ void gn_pixel_waves(OdomState* st, const GnIterArgs& 
     struct f3pk {
         float x, y, z;
     };
-    float d0s[PX];
     uint8_t lis[PX];
     f3pk gv[PX], gn[PX];
     float4 cl[PX];
@@ -581,7 +580,6 @@ __device__ __forceinline__ void gn_pixel_waves(OdomState* st, const GnIterArgs& 
 #pragma unroll
     for (int p = 0; p < PX; ++p) {  // addresses clamped, masks applied afterwards
         const int gu = inb[p] ? u0s[p] : 0, gvv = inb[p] ? v0s[p] : 0;
-        d0s[p] = a.ra.last_depth[(size_t)gvv * a.ra.ld_stride + gu];
         lis[p] = a.ra.last_image[(size_t)gvv * a.ra.li_stride + gu];
         cl[p] = a.cloud4[(size_t)gvv * cols + gu];  // rgbStep's point (reduce.cu:522) and 1 / Z
     }
@@ -616,7 +614,10 @@ __device__ __forceinline__ void gn_pixel_waves(OdomState* st, const GnIterArgs& 
     float perr[PX];
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
-        const bool hit = inb[p] && d0s[p] > 0 && fabsf(td1s[p] - d0s[p]) <= a.ra.max_depth_delta && lis[p] != 0;
+        // lastDepth at the target (reduce.cu:813): the point's Z is that very float (projectPointsKernel, cudafuncs.cu:745:
+        // cloud.z = z), so the record's gather brings it along -- one gather per pixel less, in the phase the CU's address unit bounds
+        const float d0 = cl[p].z;
+        const bool hit = inb[p] && d0 > 0 && fabsf(td1s[p] - d0) <= a.ra.max_depth_delta && lis[p] != 0;
         const int idiff = own[p] - (int)lis[p];  // == (float)next - (float)last, exactly
         const int vy = hit ? idiff * idiff : 0;   // == (int)(diff * diff)
         perr[p] = hit ? 0.001f * vy : 0.0f;

@@ -2089,6 +2089,8 @@ struct mmf_model {
     unsigned* winner = nullptr;    // capacity
     float2* conf_time = nullptr;   // capacity + npix
     unsigned long long* keys = nullptr;  // npix
+    unsigned* zbound = nullptr;          // npix: splat_bound_kernel's per-pixel depth bound (0xFFFFFFFF between passes)
+    float4* rays = nullptr;              // npix: the pixels' normalised viewing rays (splat_ray_kernel), transposed
     // sparse index map (ModelProjection.cpp:28-41)
     unsigned* index = nullptr;
     float4 *vertConf = nullptr, *colorTime = nullptr, *normRad = nullptr;
@@ -2160,7 +2162,7 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     for (int k = 0; k < 3; ++k) o_cand[k] = carve(npix * 16);
     const size_t o_fa = carve((cap + npix) * 4), o_fb = carve(npix * 4), o_pa = carve((cap + npix) * 4),
                  o_pb = carve(npix * 4), o_bs = carve(((cap + npix) / 256 + 2) * 4), o_tot = carve(64),
-                 o_win = carve(cap * 4), o_ct = carve((cap + npix) * 8), o_keys = carve(npix * 8),
+                 o_win = carve(cap * 4), o_ct = carve((cap + npix) * 8), o_keys = carve(npix * 8), o_zb = carve(npix * 4), o_rays = carve(npix * 16),
                  o_idx = carve(npix * 4), o_vc = carve(npix * 16), o_ctm = carve(npix * 16), o_nr = carve(npix * 16),
                  o_img = carve(npix * 4), o_vxc = carve(npix * 16), o_nrr = carve(npix * 16), o_tt = carve(npix * 2), o_sd = carve(npix * 4), o_ex = carve(npix * 52),
                  o_fv = carve(npix * 16), o_fn = carve(npix * 16), o_fi = carve(npix * 4);
@@ -2181,6 +2183,8 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     m->block_sums = (unsigned*)(b + o_bs), m->totals = (unsigned*)(b + o_tot);
     m->winner = (unsigned*)(b + o_win), m->conf_time = (float2*)(b + o_ct);
     m->keys = (unsigned long long*)(b + o_keys);
+    m->zbound = (unsigned*)(b + o_zb);
+    m->rays = (float4*)(b + o_rays);
     m->index = (unsigned*)(b + o_idx);
     m->vertConf = (float4*)(b + o_vc), m->colorTime = (float4*)(b + o_ctm), m->normRad = (float4*)(b + o_nr);
     m->image = (uchar4*)(b + o_img), m->vertexConf = (float4*)(b + o_vxc), m->normalRadius = (float4*)(b + o_nrr);
@@ -2191,6 +2195,8 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     hipLaunchKernelGGL(fill_u32_kernel, grid1d(cap), dim3(256), 0, c->stream, m->winner, cap, kNoWinner);
     // the key image starts empty and every resolve kernel hands it back empty
     hipLaunchKernelGGL(fill_u64_kernel, grid1d(npix), dim3(256), 0, c->stream, m->keys, npix, kEmptyKey);
+    hipLaunchKernelGGL(fill_u32_kernel, grid1d(npix), dim3(256), 0, c->stream, m->zbound, npix, 0xFFFFFFFFu);
+    hipLaunchKernelGGL(splat_ray_kernel, grid1d(npix), dim3(256), 0, c->stream, make_cam(m, false), width, height, m->rays);
     MMF_HIP_TRY(hipGetLastError());
     MMF_HIP_TRY(hipHostMalloc(&m->host_totals, 64, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(m->host_totals, 0, 64);
@@ -2380,10 +2386,30 @@ extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cut
 // the two thumbnail counters of thumbnail_count_px (surfel_kernels.hpp): the count of the latest prediction is [tex_gen & 1]
 static unsigned* model_thumb_counts(mmf_model* m) { return &m->totals[4]; }
 // splat_kernel's launch: a fixed number of workgroups that deal the surfels out among their waves (surfel_kernels.hpp)
-static dim3 splat_grid(size_t bound) {
-    static const unsigned wgs = []() { const char* e = std::getenv("MMF_SPLAT_WGS"); return e ? (unsigned)std::max(1, std::atoi(e)) : 512u; }();
+// 512 workgroups = two waves per SIMD for a young map (most of its surfels are unstable and culled by the set-up); a DEEP
+// store (every surfel drawn, tens of fragments per pixel) needs the latency of its per-row LDS searches and bound look-ups
+// hidden: 2048 workgroups (124 -> 107 us on 740 k stable surfels at 640x480, tools/mature_splat_probe.py)
+static dim3 splat_grid(size_t bound, bool deep = false) {
+    static const unsigned wgs_env = []() { const char* e = std::getenv("MMF_SPLAT_WGS"); return e ? (unsigned)std::max(1, std::atoi(e)) : 0u; }();
+    const unsigned wgs = wgs_env ? wgs_env : (deep ? 2048u : 512u);
     const size_t one_per_thread = (bound + 255) / 256;
     return dim3((unsigned)std::max<size_t>(1, std::min<size_t>(one_per_thread, wgs)));
+}
+#ifdef MMF_SPLAT_COUNT
+extern "C" int mmf_debug_splat_counts(unsigned long long out[4], int reset) {
+    MMF_HIP_TRY(hipDeviceSynchronize());
+    MMF_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_splat_dbg), 32));
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        MMF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_splat_dbg), z, 32));
+    }
+    return MMF_OK;
+}
+#endif
+static std::atomic<int> g_splat_bound{-1};  // -1: by the surfel count; 0 / 1: mmf_debug_set_splat_bound (tests compare the two)
+extern "C" int mmf_debug_set_splat_bound(int mode) {
+    g_splat_bound.store(mode < 0 ? -1 : (mode ? 1 : 0));
+    return MMF_OK;
 }
 // ModelProjection::combinedPredict(ACTIVE) (ModelProjection.cpp:187-269); Model.h:210-214
 // fill_rgb / fill_depth != nullptr: Model::performFillIn in the same pass as the resolve (the orchestrator's predict)
@@ -2404,8 +2430,18 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     // right after clean() the exact count may still be in flight to the host: size the launch by the bound
     // and let the kernel read the count on the device instead of waiting for it
     const unsigned launch_count = m->count_pending ? m->count_bound : m->count;
+    // a DEEP store (two surfels per pixel and more: occluded layers) takes the bounded depth test (surfel_kernels.hpp,
+    // splat_bound_kernel): one more launch, a fraction of the fragments and of their atomics.  Same images either way.
+    const int bound_mode = g_splat_bound.load();
+    const bool deep_store = (size_t)launch_count >= 2 * (size_t)m->width * m->height;
+    const bool deep = bound_mode < 0 ? deep_store : bound_mode != 0;
+    a.zb = (deep && launch_count) ? m->zbound : nullptr;
+    a.rays = m->rays;
+    if (a.zb)
+        hipLaunchKernelGGL(splat_bound_kernel, grid1d(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
+                           m->count_pending ? m->totals : nullptr);
     if (launch_count)
-        hipLaunchKernelGGL(splat_kernel, splat_grid(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
+        hipLaunchKernelGGL(splat_kernel, splat_grid(launch_count, deep_store), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
                            m->keys, m->count_pending ? m->totals : nullptr);
     if (fill_rgb && fill_depth) {  // (a pending frame rider stays for the predictIndices that follows: frame_rider.hpp)
         hipLaunchKernelGGL(splat_resolve_fill_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0,
@@ -2438,6 +2474,7 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
     a.maxDepth = depth_cutoff;
     a.confThreshold = conf_threshold;
     a.time = time, a.maxTime = max_time, a.timeDelta = time_delta;
+    a.zb = nullptr, a.rays = m->rays;
     if (int rc0 = model_resolve_count(m)) return rc0;
     if (m->count)
         hipLaunchKernelGGL(splat_kernel, splat_grid(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,

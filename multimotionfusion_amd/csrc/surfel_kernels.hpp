@@ -505,6 +505,19 @@ __global__ __launch_bounds__(256) void untranspose_kernel(const T* __restrict__ 
     dst[i] = src[(size_t)x * rows + y];
 }
 
+constexpr int kSplatChunk = 8;  // pixels of a sprite row whose bounds and rays are fetched in one round trip (4 / 6: slower)
+#ifdef MMF_SPLAT_COUNT  // diagnostic builds (tools/mature_splat_probe.py): fragments considered / evaluated / drawn
+__device__ unsigned long long g_splat_dbg[4];
+#define MMF_SPLAT_TALLY(i, cond)                                                                                  \
+    do {                                                                                                          \
+        const unsigned long long b_ = __ballot(cond);                                                              \
+        if (b_ && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(b_)) atomicAdd(&g_splat_dbg[i], (unsigned long long)__popcll(b_)); \
+    } while (0)
+#else
+#define MMF_SPLAT_TALLY(i, cond) \
+    do {                         \
+    } while (0)
+#endif
 // ---- splat prediction ----------------------------------------------------------------------------
 struct SplatArgs {
     Mat4 t_inv;
@@ -513,16 +526,30 @@ struct SplatArgs {
     int cols, rows;
     float maxDepth, confThreshold;
     int time, maxTime, timeDelta;
+    // non-null: a per-pixel upper bound of the depth test's winner (transposed like the key image), filled by
+    // splat_bound_kernel before splat_kernel runs and handed back full (0xFFFFFFFF) by the resolve pass
+    unsigned* zb;
+    // the viewing ray of every pixel centre, normalised (combo_splat.frag:41-42), transposed like the key image: it depends on
+    // the camera alone, so the model keeps it as a table (splat_ray_kernel) instead of two divisions, a square root and a
+    // third division per fragment
+    const float4* rays;
 };
 
 struct SplatFrag {  // per-surfel quantities shared by the rasterising and the resolving pass
     v3 h, nrm;
     float rad;
     int x0, x1, y0, y1;
+    int cpx, cpy;    // the pixel the sprite's centre falls into (inside [x0, x1] x [y0, y1])
+    unsigned dmin;   // no fragment of this sprite has a smaller 24-bit depth
+    float hn;        // dot(h, nrm)
     bool ok;
 };
 
-__device__ __forceinline__ SplatFrag splat_setup(const float4 p, const float4 col, const float4 n, const SplatArgs& a) {
+// SIZE: also the sprite's bounding box (splat.vert:71-86: eight more divisions, two normalisations) -- what the rasterising
+// pass needs and the resolve pass and the bound's pre-pass do not; xw / yw: the window coordinates of the sprite's centre
+template <bool SIZE = true>
+__device__ __forceinline__ SplatFrag splat_setup(const float4 p, const float4 col, const float4 n, const SplatArgs& a, float* xw_out = nullptr,
+                                                 float* yw_out = nullptr) {
     SplatFrag f;
     f.ok = false;
     f.h = m4point(a.t_inv, V3(p.x, p.y, p.z));
@@ -538,6 +565,13 @@ __device__ __forceinline__ SplatFrag splat_setup(const float4 p, const float4 co
     f.nrm = v3normalize(m4dir(a.t_inv, V3(n.x, n.y, n.z)));
     f.rad = n.w;
     const v3 nrm = f.nrm;
+    if (!SIZE) {
+        f.hn = v3dot(h, nrm);
+        f.x0 = f.y0 = 0, f.x1 = a.cols - 1, f.y1 = a.rows - 1, f.cpx = f.cpy = 0, f.dmin = 0u;
+        if (xw_out) *xw_out = (xn + 1.0f) * (a.cols * 0.5f), *yw_out = (yn + 1.0f) * (a.rows * 0.5f);
+        f.ok = true;
+        return f;
+    }
     const v3 x1 = v3scale(v3scale(v3normalize(V3((nrm.y - nrm.z), -nrm.x, nrm.x)), f.rad), 1.41421356f);
     const v3 y1 = v3cross(nrm, x1);
     const v3 q1 = v3add(h, x1), q2 = v3add(h, y1), q3 = v3sub(h, y1), q4 = v3sub(h, x1);
@@ -554,21 +588,47 @@ __device__ __forceinline__ SplatFrag splat_setup(const float4 p, const float4 co
     int y0 = (int)ceilf(yw - hs - 0.5f), y1i = (int)ceilf(yw + hs - 0.5f) - 1;
     f.x0 = x0 < 0 ? 0 : x0, f.y0 = y0 < 0 ? 0 : y0;
     f.x1 = x1i > a.cols - 1 ? a.cols - 1 : x1i, f.y1 = y1i > a.rows - 1 ? a.rows - 1 : y1i;
+    f.cpx = min(max((int)floorf(xw), f.x0), f.x1), f.cpy = min(max((int)floorf(yw), f.y0), f.y1);
+    // a fragment that is not discarded lies within `rad` of h (combo_splat.frag:52), so its z is at least h.z - rad; the
+    // margin covers the rounding of that bound and of the fragment's own arithmetic, depth24 is monotonic
+    const float zlo = (h.z - f.rad) - (fabsf(h.z) + f.rad) * 4e-6f - 1e-7f;
+    f.dmin = depth24((zlo / (2 * a.maxDepth)) + 0.5f);
+    // ... unless its z is not a number: h.n / l.n with a NaN normal (a zero normal normalised) or 0 / 0 passes the radius test
+    // (a comparison with NaN is false) and depth24(NaN) = 0 wins every depth test, as in the plain pass
+    f.hn = v3dot(h, nrm);
+    if (!(fabsf(f.hn) > 0.f)) f.dmin = 0u;
     f.ok = true;
     return f;
 }
 
-// one fragment of combo_splat.frag: returns false when discarded; `z` = corrected_pos.z
+// one fragment of combo_splat.frag in three steps: the pixel's viewing ray (a property of the camera: SplatArgs::rays holds
+// it), the depth of the ray's intersection with the disc's plane, the disc test.  splat_fragment = all three: returns false
+// when discarded; `z` = corrected_pos.z
+__device__ __forceinline__ v3 splat_ray(const Cam& c, int px, int py) {
+    const float fcx = px + 0.5f, fcy = py + 0.5f;
+    return v3normalize(V3((fcx - c.cx) / c.fx, (fcy - c.cy) / c.fy, 1.0f));
+}
+__device__ __forceinline__ float splat_plane_q(const SplatFrag& f, v3 l) { return f.hn / v3dot(l, f.nrm); }  // corrected = l * q
+__device__ __forceinline__ unsigned splat_depth24(float z, float maxDepth) { return depth24((z / (2 * maxDepth)) + 0.5f); }
+__device__ __forceinline__ bool splat_in_disc(const SplatFrag& f, v3 l, float q) {
+    const v3 diff = v3sub(v3scale(l, q), f.h);
+    return !(v3dot(diff, diff) > f.rad * f.rad);
+}
 __device__ __forceinline__ bool splat_fragment(const SplatFrag& f, const SplatArgs& a, int px, int py, float& z,
                                                unsigned& d24) {
-    const float fcx = px + 0.5f, fcy = py + 0.5f;
-    const v3 l = v3normalize(V3((fcx - a.c.cx) / a.c.fx, (fcy - a.c.cy) / a.c.fy, 1.0f));
-    const v3 corrected = v3scale(l, v3dot(f.h, f.nrm) / v3dot(l, f.nrm));
-    const v3 diff = v3sub(corrected, f.h);
-    if (v3dot(diff, diff) > f.rad * f.rad) return false;
-    z = corrected.z;
-    d24 = depth24((corrected.z / (2 * a.maxDepth)) + 0.5f);
+    const v3 l = splat_ray(a.c, px, py);
+    const float q = splat_plane_q(f, l);
+    if (!splat_in_disc(f, l, q)) return false;
+    z = l.z * q;
+    d24 = splat_depth24(z, a.maxDepth);
     return true;
+}
+__global__ __launch_bounds__(256) void splat_ray_kernel(Cam c, int cols, int rows, float4* __restrict__ rays) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // transposed: i = px * rows + py
+    if (i >= cols * rows) return;
+    const int px = i / rows, py = i - px * rows;
+    const v3 l = splat_ray(c, px, py);
+    rays[i] = make_float4(l.x, l.y, l.z, 0.f);
 }
 
 // `count_dev` (optional): the exact surfel count where the previous clean pass left it on the device;
@@ -586,6 +646,34 @@ __device__ __forceinline__ bool splat_fragment(const SplatFrag& f, const SplatAr
 // is sized by -- after a fuse pass that is count + width x height: an object model of 4 000 surfels, seen from close up
 // (sprites of 40 x 40 pixels), ran as 1 215 workgroups of which 16 held all the fragments, 17-21 us at 640x480, longer
 // than the global model's 300 k surfels.  With every wave of the launch holding a few of those sprites' rows: 3-4 us.
+// Round 4: the depth test of a MATURE map.  atomicMin executes at the memory side on this chip (MI355X_MICROARCH.md,
+// "Global float atomics": ~1.3 TB/s of operands chip-wide, nothing cached), so a store that has seen a room from many sides --
+// four-fold overdraw, 18 M fragments of 8 bytes on 740 k stable surfels -- spends its 110 us there, whatever the fragment
+// arithmetic costs.  splat_bound_kernel runs first when a store is that deep (the host decides by the surfel count): every
+// drawn surfel's CENTRE fragment -- the very splat_fragment of its centre pixel -- goes into a 32-bit per-pixel bound by
+// atomicMin (one 4-byte atomic per surfel instead of one 8-byte atomic per fragment).  splat_kernel then reads the bound
+// (read-only during that launch: L2 resident) and skips a fragment BEFORE its arithmetic when even the nearest point of its
+// disc (h.z - rad) lies behind the bound, and skips the atomic when the fragment itself does.  Every skipped fragment
+// loses against a fragment that is drawn, so the key image -- and with it all four images -- keeps its bits.
+__global__ __launch_bounds__(256) void splat_bound_kernel(SurfelSoA s, int count, SplatArgs a_in, const unsigned* __restrict__ count_dev) {
+    MMF_MODEL_STREAM_PRIORITY();
+    const SplatArgs a = with_device_pose(a_in);
+    if (count_dev != nullptr) count = min((unsigned)count, *count_dev);
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= count) return;
+    const float4 p = s.pos[id], col = s.col[id];
+    if (p.w < a.confThreshold || (float)a.time - col.w > (float)a.timeDelta || col.w > (float)a.maxTime) return;  // (splat_setup's culls that need no arithmetic)
+    float xw, yw;
+    const SplatFrag f = splat_setup<false>(p, col, s.nrm[id], a, &xw, &yw);
+    if (!f.ok) return;
+    // the pixel the centre falls into (inside the sprite, whose side is at least one pixel; xn = 1 exactly lands one past the image)
+    const int cpx = min((int)floorf(xw), a.cols - 1), cpy = min((int)floorf(yw), a.rows - 1);
+    float z;
+    unsigned d24;
+    if (!splat_fragment(f, a, cpx, cpy, z, d24)) return;
+    atomicMin(&a.zb[(size_t)cpx * a.rows + cpy], d24);
+}
+
 __global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, SplatArgs a_in,
                                                     unsigned long long* __restrict__ keys,
                                                     const unsigned* __restrict__ count_dev) {
@@ -633,6 +721,34 @@ __global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, Spla
             const int row_first = lo ? row_end[wbase + lo - 1] : 0;
             const int py = g.y0 + (t - row_first);
             const unsigned sid = (unsigned)(base + lo);
+
+            if (a.zb != nullptr) {  // (uniform) the bounded depth test: eight pixels of the row at a time, their bounds in one round trip
+                for (int pb = g.x0; pb <= g.x1; pb += kSplatChunk) {
+                    unsigned zbv[kSplatChunk];
+                    float4 ray[kSplatChunk];
+#pragma unroll
+                    for (int e = 0; e < kSplatChunk; ++e) {
+                        const size_t at = (size_t)min(pb + e, g.x1) * a.rows + py;
+                        zbv[e] = a.zb[at];
+                        ray[e] = a.rays[at];
+                    }
+#pragma unroll
+                    for (int e = 0; e < kSplatChunk; ++e) {
+                        const int px = pb + e;
+                        MMF_SPLAT_TALLY(0, px <= g.x1);
+                        if (px > g.x1 || g.dmin > zbv[e]) continue;
+                        MMF_SPLAT_TALLY(1, true);
+                        // the depth first (a dot product and two divisions), the disc test only for fragments that can still win
+                        const v3 l = V3(ray[e].x, ray[e].y, ray[e].z);
+                        const float q = splat_plane_q(g, l);
+                        const unsigned d24 = splat_depth24(l.z * q, a.maxDepth);
+                        if (d24 > zbv[e] || !splat_in_disc(g, l, q)) continue;
+                        MMF_SPLAT_TALLY(2, true);
+                        atomicMin(&keys[(size_t)px * a.rows + py], ((unsigned long long)d24 << 32) | sid);
+                    }
+                }
+                continue;
+            }
             for (int px = g.x0; px <= g.x1; ++px) {
                 float z;
                 unsigned d24;
@@ -656,7 +772,7 @@ struct SplatTexel {
 // (x, y) -- threads run along x, the images are row-major -- gets its key.  Returns false outside the image.
 constexpr int kSplatTile = 16;
 __device__ __forceinline__ bool splat_tile_key(unsigned long long* __restrict__ keys, int cols, int rows, int& px, int& py,
-                                               unsigned long long& k, unsigned first_block = 0) {
+                                               unsigned long long& k, unsigned first_block = 0, unsigned* __restrict__ zb = nullptr) {
     __shared__ unsigned long long tile[kSplatTile][kSplatTile + 1];
     const int tiles_x = (cols + kSplatTile - 1) / kSplatTile;
     const int bid = (int)(blockIdx.x - first_block);
@@ -669,6 +785,7 @@ __device__ __forceinline__ bool splat_tile_key(unsigned long long* __restrict__ 
         if (x < cols && y < rows) {
             v = keys[(size_t)x * rows + y];
             if (v != kEmptyKey) keys[(size_t)x * rows + y] = kEmptyKey;
+            if (zb != nullptr) zb[(size_t)x * rows + y] = 0xFFFFFFFFu;  // (the bound of this pass: handed back full)
         }
         tile[cx][cy] = v;
     }
@@ -709,7 +826,7 @@ __device__ __forceinline__ SplatTexel splat_resolve_px(int i, unsigned long long
     const unsigned id = (unsigned)k;
     const int py = i / a.cols, px = i - py * a.cols;
     const float4 p = s.pos[id], col = s.col[id];
-    const SplatFrag f = splat_setup(p, col, s.nrm[id], a);
+    const SplatFrag f = splat_setup<false>(p, col, s.nrm[id], a);
     float z;
     unsigned d24;
     splat_fragment(f, a, px, py, z, d24);  // the winner's own fragment: same arithmetic as in splat_kernel
@@ -733,7 +850,7 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatAr
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
-    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k)) return;
+    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, 0, a.zb)) return;
     const int i = py * a.cols + px;
     const SplatTexel t = splat_resolve_px(i, k, s, a);
     image[i] = t.image;
@@ -749,12 +866,12 @@ __global__ __launch_bounds__(256) void splat_depth_resolve_kernel(SurfelSoA s, S
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
-    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k)) return;
+    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, 0, a.zb)) return;
     const int i = py * a.cols + px;
     float z = 0.f;
     if (k != kEmptyKey) {
         const unsigned id = (unsigned)k;
-        const SplatFrag f = splat_setup(s.pos[id], s.col[id], s.nrm[id], a);
+        const SplatFrag f = splat_setup<false>(s.pos[id], s.col[id], s.nrm[id], a);
         unsigned d24;
         splat_fragment(f, a, px, py, z, d24);
     }
@@ -1284,7 +1401,7 @@ __global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, Sp
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
-    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k)) return;
+    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, 0, a.zb)) return;
     const int i = py * a.cols + px;
     const SplatTexel t = splat_resolve_px(i, k, s, a);
     image[i] = t.image;

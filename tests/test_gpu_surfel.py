@@ -34,8 +34,17 @@ def test_filter_depth_bit_exact(gpu_ctx, orc, w, h):
     assert_bit_equal(out.cpu().numpy(), orc.bilateral_filter(f["depth"], CUTOFF), "bilateral filter")
 
 
+@pytest.fixture
+def splat_bound(gpu_ctx, request):
+    """combinedPredict's bounded depth test (splat_bound_kernel): -1 = by the surfel count, 1 = always"""
+    gpu_ctx.lib.mmf_debug_set_splat_bound(request.param)
+    yield request.param
+    gpu_ctx.lib.mmf_debug_set_splat_bound(-1)
+
+
+@pytest.mark.parametrize("splat_bound", [-1, 1], indirect=True)
 @pytest.mark.parametrize("w,h", [(640, 480), (160, 120)])
-def test_surfel_cycle_bit_exact(gpu_ctx, orc, w, h):
+def test_surfel_cycle_bit_exact(gpu_ctx, orc, w, h, splat_bound):
     """initialise -> (predictIndices, fuse, predictIndices, clean, combinedPredict, fill-in) x 3 frames."""
     from multimotionfusion_amd.model import filterDepth
     K, m = make_model(gpu_ctx, w, h)
@@ -100,6 +109,61 @@ def test_surfel_cycle_bit_exact(gpu_ctx, orc, w, h):
         assert_bit_equal(m.texture("fillNormal").cpu().numpy(), no, f"fill normal t={t}")
         assert_bit_equal(m.texture("fillImage").cpu().numpy(), io, f"fill image t={t}")
         assert m.requiresFillIn(0.75) == orc.requires_fill_in(image, 0.75)
+    m.close()
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (640, 480)])
+def test_bounded_splat_keeps_the_images_of_a_deep_store(gpu_ctx, orc, w, h):
+    """A store with occluded layers (what a room seen from many sides leaves: here the map of one frame plus three copies
+    pushed 2 / 4 / 6 cm behind the surfaces, all stable) is drawn with and without the bounded depth test: the four images
+    must keep their bits -- and equal the oracle's -- while most fragments are never evaluated."""
+    from multimotionfusion_amd.model import filterDepth
+    K, m = make_model(gpu_ctx, w, h)
+    poses = synth.trajectory(2, seed=9)
+    f0 = synth.render(poses[0], w, h, seed=0)
+    m.overridePose(poses[0])
+    m.initialise(dev(f0["rgb"]), dev(f0["depth"]), filterDepth(gpu_ctx, dev(f0["depth"]), CUTOFF), 1, MAXD)
+    base = m.downloadMap()
+    layers = []
+    cam = np.linalg.inv(poses[0]).astype(np.float64)
+    for step in (0.0, 0.02, 0.04, 0.06):
+        cp = base.copy()
+        pc = cp[:, :3].astype(np.float64) @ cam[:3, :3].T + cam[:3, 3]  # into the first camera's frame, along its rays, back
+        pc += step * pc / np.maximum(np.linalg.norm(pc, axis=1, keepdims=True), 1e-6)
+        cp[:, :3] = ((pc - cam[:3, 3]) @ cam[:3, :3]).astype(np.float32)
+        cp[:, 3] = 20.0
+        layers.append(cp)
+    rng = np.random.default_rng(4)
+    deep = np.concatenate(layers)
+    deep = deep[rng.permutation(deep.shape[0])][: 1024 * 1024 - 8]  # draw order unrelated to depth
+    # surfels with a zero normal (a first frame has them): their fragments' z is NaN, which wins every depth test -- in both passes
+    deep[rng.choice(deep.shape[0], 300, replace=False), 8:11] = 0.0
+    m.uploadMap(deep)
+    out = {}
+    for pose_i, pose in enumerate(poses):
+        m.overridePose(pose)
+        for mode in (0, 1):
+            gpu_ctx.lib.mmf_debug_set_splat_bound(mode)
+            try:
+                m.combinedPredict(MAXD, 2, 2, TIME_DELTA)
+            finally:
+                gpu_ctx.lib.mmf_debug_set_splat_bound(-1)
+            out[mode] = [m.texture(n).cpu().numpy().copy() for n in ("image", "vertexConf", "normalRadius", "time")]
+        for a, b, n in zip(out[0], out[1], ("image", "vertexConf", "normalRadius", "time")):
+            assert_bit_equal(a, b, f"{n}, pose {pose_i}: bounded against plain depth test")
+        if w <= 320:
+            image, vcp, nrp, tm = orc.combined_predict(deep, pose.astype(np.float32), K, w, h, MAXD, CONF, 2, 2, TIME_DELTA)
+            assert_bit_equal(out[1][0], image, "image against the oracle")
+            assert_bit_equal(out[1][1], vcp, "vertexConf against the oracle")
+        assert (out[1][1][..., 2] > 0).mean() > 0.2
+    # two passes in a row: the bound is handed back full by the resolve pass
+    gpu_ctx.lib.mmf_debug_set_splat_bound(1)
+    try:
+        m.combinedPredict(MAXD, 2, 2, TIME_DELTA)
+        again = m.texture("vertexConf").cpu().numpy()
+    finally:
+        gpu_ctx.lib.mmf_debug_set_splat_bound(-1)
+    assert_bit_equal(again, out[1][1], "second bounded pass")
     m.close()
 
 
