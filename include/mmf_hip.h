@@ -506,6 +506,15 @@ int mmf_debug_expf(mmf_ctx *ctx, const float *x_dev, int n, float *out_mmf_dev, 
 /* test / A-B hook: 1 = run the Gauss-Newton chain as one launch per iteration where it applies (the default), 0 = always as
  * producer + step launches, -1 = what the environment says (MMF_GN_FUSED=0 turns it off).  Process wide. */
 int mmf_debug_set_gn_fused(int on);
+/* The one-launch chain spins on its own workgroups (a count barrier inside every launch); the library checks the launch's
+ * occupancy before it uses that chain, but another process on the same GPU can still keep a launch from becoming resident as
+ * a whole.  A launch that gives up marks the chain's result void; the call that waits for it tracks the frame again on the
+ * two-launch chain from the pose it started with (RGBDOdometry.cpp:464-467: the call returns a pose, it never aborts) and the
+ * process stops using the one-launch chain.  recoveries: how often that happened; one_launch_chain_in_use: 0 afterwards.
+ * Either pointer may be NULL. */
+int mmf_gn_chain_status(int *recoveries, int *one_launch_chain_in_use);
+/* test hook: the next n one-launch chains of this process give up at their third launch */
+int mmf_debug_force_gn_fault(int n);
 /* test / A-B hook: 1 = enqueue the reference's first predict() of a frame (MultiMotionFusion.cpp:675) although nothing
  * inside this library reads its images before the frame's second predict() (:821) overwrites them, 0 = leave it out (the
  * default), -1 = what the environment says (MMF_MID_PREDICT=1 turns it on).  Process wide. */

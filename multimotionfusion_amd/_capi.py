@@ -207,6 +207,8 @@ SIGNATURES = {
     "mmf_model_surfel_arrays": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint)]),
     "mmf_debug_set_gn_fused": (_i, [_i]),
     "mmf_debug_set_mid_predict": (_i, [_i]),
+    "mmf_debug_force_gn_fault": (_i, [_i]),
+    "mmf_gn_chain_status": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "mmf_debug_set_splat_bound": (_i, [_i]),
     "mmf_fusion_set_shard": (_i, [_vp, _i, _i]),
     "mmf_fusion_owns_model": (_i, [_vp, _i]),

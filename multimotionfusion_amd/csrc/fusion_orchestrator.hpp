@@ -902,9 +902,13 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // of idle GPU per frame).
             // (With several models it is one model per process in the sharded configuration: the segmentation between
             // tracking and fusion touches masks, thresholds and the list, none of which a projection reads.)
+            mmf_model early_snapshot;  // the model's host bookkeeping before the passes enqueued ahead of the pose (see `retrack` below)
+            bool early_snapshot_valid = false;
             if (tracked.size() == 1 && !fr->bootstrap && !have_init && !g.rgb_only && f->tracking_ok) {
                 FusionModel* fm = tracked[0];
                 mmf_model* m = fm->model;
+                early_snapshot = *m, early_snapshot_valid = true;
+                m->abort_dev = &fm->odom->state->gn_fault;
                 // "nothing enqueued so far reads the odometries' sensor-side buffers or the other filtered-depth buffer" holds
                 // HERE, behind the one chain of this process; the passes enqueued next do not read them either.  No event
                 // says so any more (see below: the host knows when it has the pose; a marker behind the chain cost the
@@ -925,6 +929,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     fm->early_fused = rc == MMF_OK;
                 }
                 m->t_inv_dev = m->pose_dev = m->weight_dev = nullptr;
+                m->abort_dev = nullptr;
                 if (rc) return rc;
             }
             // the sensor-side image ring (this frame's / last frame's intensity pyramid, RGBDOdometry.cpp:469-473) lives in
@@ -964,6 +969,54 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 rc = fusion_prefetch_image(f, fr->next_rgb, f->tick + 1, true);
                 if (rc) return rc;
             }
+            // The one-launch chain can give up (its count barrier needs every workgroup of a launch resident: another process on
+            // the GPU can prevent that; OdomState::gn_fault).  Then nothing of the chain's result is valid and the passes enqueued
+            // ahead of the pose have done nothing (MMF_SPECULATION_GUARD): the model's host bookkeeping goes back to where it
+            // was, the process stops using that chain, and the frame's tracking is enqueued again -- the two-launch chain, from
+            // the poses the frame started with (fm->last_pose) -- before the results are picked up a second time.
+            auto retrack = [&]() -> int {
+                std::vector<mmf_odom*> odoms;
+                for (FusionModel* fm : tracked) odoms.push_back(fm->odom);
+                odom_retrack_prepare(odoms.data(), (int)odoms.size(), g.so3);
+                if (early_snapshot_valid) {
+                    *tracked[0]->model = early_snapshot;
+                    tracked[0]->early_done = tracked[0]->early_fused = false;
+                    early_snapshot_valid = false;
+                }
+                for (FusionModel* fm : tracked) fm->odom->defer_publish = false, fm->odom->rider = FrameRider();
+                if (batch_ok) {
+                    FusionModel* lead = tracked[0];
+                    TrackBatch tb;
+                    tb.n = (int)tracked.size();
+                    std::memset(&tb.bd, 0, sizeof(tb.bd));
+                    for (int k = 0; k < tb.n; ++k) {
+                        tb.o[k] = tracked[k]->odom;
+                        tb.bd.d[k] = (long long)(reinterpret_cast<char*>(tracked[k]->odom->slab) - reinterpret_cast<char*>(lead->odom->slab));
+                        for (int r = 0; r < 3; ++r) {
+                            for (int q = 0; q < 3; ++q) tb.poses.rot[k][r * 3 + q] = tracked[k]->last_pose[r * 4 + q];
+                            tb.poses.trans[k][r] = tracked[k]->last_pose[r * 4 + 3];
+                        }
+                    }
+                    int rc2 = odom_enqueue_tracking(lead->odom, tb.poses.trans[0], tb.poses.rot[0], g.rgb_only, g.icp_weight, g.pyramid,
+                                                    g.fast_odom, g.so3, lead->icp_error, lead->rgb_error, &tb);
+                    if (rc2) return rc2;
+                    for (size_t k = 1; k < tracked.size(); ++k) {
+                        MMF_HIP_TRY(hipEventRecord(tracked[k]->ev_done, lead->lane->stream));
+                        MMF_HIP_TRY(hipStreamWaitEvent(tracked[k]->lane->stream, tracked[k]->ev_done, 0));
+                    }
+                    return MMF_OK;
+                }
+                for (FusionModel* fm : tracked) {
+                    const float* p = fm->last_pose;
+                    const float trans[3] = {p[3], p[7], p[11]};
+                    const float rot[9] = {p[0], p[1], p[2], p[4], p[5], p[6], p[8], p[9], p[10]};
+                    int rc2 = odom_enqueue_tracking(fm->odom, trans, rot, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom, g.so3,
+                                                    fm->icp_error, fm->rgb_error);
+                    if (rc2) return rc2;
+                }
+                return MMF_OK;
+            };
+            bool retracked = false;
             for (size_t k = 0; k < n_models; ++k) {  // the results, model by model
                 FusionModel* fm = f->models[k];
                 float pose[16];
@@ -971,6 +1024,23 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 if (fm->tracking) {
                     float trans[3], rot[9];
                     rc = odom_finish_tracking(fm->odom, trans, rot);
+                    if (rc == kGnRetry && !retracked) {  // (at most once: the two-launch chain has no way to give up)
+                        // every chain of the frame is void with it (a batch is one chain; chains side by side are two-launch chains)
+                        for (FusionModel* t : tracked)
+                            if (t->tracking && t != fm && t->odom->result_of) {  // drain what the other lanes' chains still publish
+                                float tt[3], rr[9];
+                                (void)odom_finish_tracking(t->odom, tt, rr);
+                            }
+                        rc = retrack();
+                        if (rc) return rc;
+                        retracked = true;
+                        for (FusionModel* t : tracked) {  // poses already taken over from the void chain: back to the frame's start
+                            mmf_model_set_pose(t->model, t->last_pose);
+                            t->tracking = true;
+                        }
+                        k = (size_t)-1;  // pick the results up again, from the first model
+                        continue;
+                    }
                     if (rc) return rc;
                     for (int r = 0; r < 3; ++r) {
                         for (int q = 0; q < 3; ++q) pose[r * 4 + q] = rot[r * 3 + q];

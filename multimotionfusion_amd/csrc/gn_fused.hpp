@@ -375,6 +375,7 @@ __device__ __forceinline__ void gn_load_i16(const int16_t* __restrict__ p, int (
 
 // ---- the solver wave (wave 0 of every workgroup) ----
 __device__ __forceinline__ void gn_solver_wave(OdomState* st, const GnIterArgs& a, GnLds& lds, bool lead, int lane, int npw) {
+    const int fault = a.it > 0 ? __hip_atomic_load(&st->gn_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     GnSumLoads sl;
     if (a.it > 0) gn_sums_issue(st, a, sl, lane);
     if (lead) {  // what the launch after this one adds to starts from zero (nobody else touches those buffers during this launch)
@@ -383,6 +384,9 @@ __device__ __forceinline__ void gn_solver_wave(OdomState* st, const GnIterArgs& 
         for (int x = 0; x < kGnSumShards; ++x) st->gn_sum[(a.it + 1) % 3][x][lane] = 0ll;
     }
     MMF_STAMP(0);
+    // an earlier launch of this chain gave up (gn_fault): the chain's result is void, the host re-runs it on the two-launch
+    // chain; every wave of every workgroup reads the same word (a kernel boundary lies behind its writer) and leaves here
+    if (fault) return;
     if (a.it > 0) {
         unsigned pc, ps;
         gn_totals_to_lds(sl, lds, lane, pc, ps);
@@ -459,6 +463,7 @@ __device__ __forceinline__ void gn_solver_wave(OdomState* st, const GnIterArgs& 
 template <int PX, bool ERR>
 __device__ __forceinline__ void gn_pixel_waves(OdomState* st, const GnIterArgs& a, GnLds& lds, int ptid, int lane, int wave) {
     const OdomState* __restrict__ stc = st;  // what this launch only reads: scalar loads
+    const int fault = a.it > 0 ? __hip_atomic_load(&st->gn_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;  // (see gn_solver_wave)
     using T = typename std::conditional<PX % 2 == 0, v2f, float>::type;
     using L = lanevec<T>;
     constexpr int W = L::W, NV = PX / W;
@@ -535,6 +540,7 @@ __device__ __forceinline__ void gn_pixel_waves(OdomState* st, const GnIterArgs& 
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (fault) return;
     lds_barrier();  // B: the pose is in LDS
     float K[9], kt[3];
 #pragma unroll
@@ -707,6 +713,7 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st
 // the chain's last solve + RGBDOdometry.cpp:464-467, 475-476: one workgroup (kBlock threads) per model, its first wave works
 __device__ __forceinline__ void gn_final_solve(OdomState* st, const GnIterArgs& a, GnLds& lds) {
     const int tid = threadIdx.x;
+    if (st->gn_fault) return;  // (uniform) the chain's result is void: the state goes to the host as it is, the fault word with it
     if (tid < 64) {
         GnSumLoads sl;
         gn_sums_issue(st, a, sl, tid);

@@ -802,6 +802,8 @@ struct mmf_odom {
     // such launches from different streams can each hold part of the GPU and wait for the rest forever, so an owner that
     // keeps several chains in flight at once (the orchestrator without batching) clears this and gets the two-launch chain.
     bool exclusive_chain = true;
+    bool retry_so3_prefetched = false;  // what the last odom_enqueue_tracking consumed (a chain that gives up is enqueued again)
+    const OdomState* retry_so3_stage = nullptr;
     bool pending_icp = false, pending_so3 = false;  // mode of the tracking call that is in flight (enqueue -> finish)
     hipStream_t track_stream = nullptr;             // the stream that call's chain runs on (the batch leader's)
     mmf_odom* result_of = nullptr;                  // the odometry (batch leader) whose chain publishes this one's result
@@ -1464,6 +1466,10 @@ static bool gn_geometry(int level, int cols, int rows, GnGeometry* out) {
 }
 static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom, int models = 1);
 static unsigned fused_max_models();
+static std::atomic<bool> g_gn_latched_off{false};
+static std::atomic<int> g_gn_force_fault{0};
+static std::atomic<int> g_gn_recoveries{0};
+constexpr int kGnRetry = 1;  // odom_finish_tracking: the one-launch chain gave up; track again (odom_retrack_prepare)
 
 static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float rot[9], int rgb_only, float icp_weight,
                                  int pyramid, int fast_odom, int so3, float* icp_err_dev, float* rgb_err_dev,
@@ -1519,6 +1525,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     Enqueuer q(c->stream, (graphs_enabled() && !o->timing && odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom)) ? &o->gn_graphs : nullptr);
     q.launch(odom_begin_kernel, dim3(ny), dim3(64), o->state, b, bd, poses);
 
+    o->retry_so3_prefetched = o->so3_prefetched, o->retry_so3_stage = o->so3_stage;  // (odom_retrack_prepare)
     const bool so3_ran_here = so3 && !o->so3_prefetched;  // in the leader's state: shared with the others at the first level begin
     if (so3 && !o->so3_prefetched) {  // :239-310
         int rc = odom_enqueue_so3(o, q);
@@ -1538,6 +1545,8 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         static const int poll_sleep = []() { const char* e = std::getenv("MMF_GN_SLEEP"); return e ? std::atoi(e) : 1; }();
         a.poll_sleep = poll_sleep;
         a.max_polls = kGnMaxPolls;
+        bool force_fault = false;
+        for (int n = g_gn_force_fault.load(); n > 0 && !force_fault;) force_fault = g_gn_force_fault.compare_exchange_weak(n, n - 1);
         for (int i = MMF_NUM_PYRS - 1; i >= 0; --i) {
             if (!iterations[i]) continue;
             const int cols = o->width >> i, rows = o->height >> i;
@@ -1568,6 +1577,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 a.intr = in;
                 a.ifx = 1.0 / (double)in.fx, a.ify = 1.0 / (double)in.fy;
                 a.it = it;
+                a.max_polls = (it == 2 && force_fault) ? 0 : kGnMaxPolls;
                 const bool err = last_l0 && (icp_err_dev || rgb_err_dev);
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (o->timing >= 2 && o->n_timed < kMaxTimedLaunches) {
@@ -1802,6 +1812,21 @@ static bool odom_batchable(mmf_odom* o, int rgb_only, float icp_weight, int pyra
 static std::atomic<int> g_gn_fused{-1};  // -1: MMF_GN_FUSED decides (default on); 0 / 1: mmf_debug_set_gn_fused
 extern "C" int mmf_debug_set_gn_fused(int on) {
     g_gn_fused.store(on < 0 ? -1 : (on ? 1 : 0));
+    if (on) g_gn_latched_off.store(false);  // (a test that asks for the one-launch chain again gets it)
+    return MMF_OK;
+}
+// test hook: the next n one-launch chains of this process give up at their third launch (the count barrier of that launch
+// polls zero times), as if a workgroup had never arrived: exercises the recovery below without another process on the GPU
+extern "C" int mmf_debug_force_gn_fault(int n) {
+    g_gn_force_fault.store(n < 0 ? 0 : n);
+    return MMF_OK;
+}
+// how often a one-launch chain gave up and its frame was tracked again on the two-launch chain, and whether the one-launch
+// chain is still in use (it is latched off by the first such event: whatever kept its workgroups from being resident
+// together -- another process on this GPU -- is likely still there)
+extern "C" int mmf_gn_chain_status(int* recoveries, int* one_launch_chain_in_use) {
+    if (recoveries) *recoveries = g_gn_recoveries.load();
+    if (one_launch_chain_in_use) *one_launch_chain_in_use = g_gn_latched_off.load() ? 0 : 1;
     return MMF_OK;
 }
 static unsigned fused_max_models() {  // MMF_GN_FUSED_MAX: up to how many models one one-launch chain carries
@@ -1838,7 +1863,7 @@ static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int
         return !(v && v[0] == '0');
     }();
     const int forced = g_gn_fused.load();
-    const bool enabled = (forced < 0 ? env_enabled : forced != 0) && o->exclusive_chain;
+    const bool enabled = (forced < 0 ? env_enabled : forced != 0) && o->exclusive_chain && !g_gn_latched_off.load();
     const bool icp = !rgb_only && icp_weight > 0, rgb = rgb_only || icp_weight < 100;
     if (!enabled || !icp || !rgb || rgb_only) return false;
     const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};
@@ -1901,7 +1926,7 @@ static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
     }
 
     const OdomState* r = o->host_result;
-    MMF_REQUIRE(!r->gn_fault, "odometry: a Gauss-Newton launch gave up waiting for its own workgroups (count barrier)");
+    if (r->gn_fault) return kGnRetry;  // the one-launch chain gave up: nothing of its result is valid
     std::memcpy(trans, r->trans_out, sizeof(float) * 3);
     std::memcpy(rot, r->rot_out, sizeof(float) * 9);
     // members the reference leaves untouched in a given mode keep their previous values
@@ -1924,11 +1949,35 @@ static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
     return MMF_OK;
 }
 
+// A one-launch chain gave up (odom_finish_tracking returned kGnRetry for a model it tracked): the process stops using that
+// chain, and every odometry the chain drove is put back to where odom_enqueue_tracking found it -- the image ring (:469-473)
+// and the prefetched SO3 pre-alignment it consumed -- so that the same call can be enqueued again and take the two-launch
+// chain from the pose the frame started with.  RGBDOdometry.cpp:464-467: the call returns a pose or reverts, it never aborts.
+static void odom_retrack_prepare(mmf_odom* const* odoms, int n, int so3) {
+    g_gn_latched_off.store(true);
+    g_gn_recoveries.fetch_add(1);
+    for (int k = 0; k < n; ++k) {
+        mmf_odom* o = odoms[k];
+        if (so3)
+            for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(o->last_next_image[i], o->next_image[i]);
+        o->so3_prefetched = odoms[0]->retry_so3_prefetched, o->so3_stage = odoms[0]->retry_so3_stage;
+        o->track_stream = nullptr, o->result_of = nullptr;
+    }
+}
+
 extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[3], float rot[9], int rgb_only,
                                                        float icp_weight, int pyramid, int fast_odom, int so3,
                                                        float* icp_err_dev, float* rgb_err_dev) {
     MMF_REQUIRE(o && trans && rot, "mmf_odom_get_incremental_transformation: null argument");
+    const float trans0[3] = {trans[0], trans[1], trans[2]};
+    float rot0[9];
+    std::memcpy(rot0, rot, sizeof(rot0));
     int rc = odom_enqueue_tracking(o, trans, rot, rgb_only, icp_weight, pyramid, fast_odom, so3, icp_err_dev, rgb_err_dev);
+    if (rc) return rc;
+    rc = odom_finish_tracking(o, trans, rot);
+    if (rc != kGnRetry) return rc;
+    odom_retrack_prepare(&o, 1, so3);
+    rc = odom_enqueue_tracking(o, trans0, rot0, rgb_only, icp_weight, pyramid, fast_odom, so3, icp_err_dev, rgb_err_dev);
     if (rc) return rc;
     return odom_finish_tracking(o, trans, rot);
 }
@@ -2064,6 +2113,7 @@ struct mmf_model {
     unsigned long long tex_gen = 0;    // bumped by every pass that rewrites the prediction / fill-in images
     const float* pose_dev = nullptr;    // likewise the pose itself and computeFusionWeight(1) (OdomState::pose_out,
     const float* weight_dev = nullptr;  // fusion_weight) for a fuse pass; `weighting` is then the multiplier
+    const int* abort_dev = nullptr;    // ... and the word that tells such a pass that the result it would read is void (MMF_SPECULATION_GUARD)
     const float* t_inv_dev = nullptr;  // set by the orchestrator around projections it enqueues before the tracked pose has
                                        // reached the host: the device copy of inverse(pose) (OdomState::pose_inv)
     FrameRider rider;  // set by the orchestrator for the predict() right behind a chain: carried by its resolve launch
@@ -2349,6 +2399,7 @@ static IndexArgs model_index_args(mmf_model* m, int time, float depth_cutoff, in
     IndexArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
     a.t_inv_dev = m->t_inv_dev;
+    a.abort_dev = m->abort_dev;
     a.c = make_cam(m, false);
     a.cols = m->width, a.rows = m->height;
     a.maxDepth = depth_cutoff;
@@ -2422,6 +2473,7 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     SplatArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
     a.t_inv_dev = m->t_inv_dev;
+    a.abort_dev = m->abort_dev;
     a.c = make_cam(m, false);
     a.cols = m->width, a.rows = m->height;
     a.maxDepth = depth_cutoff;
@@ -2469,6 +2521,7 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
     SplatArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
     a.t_inv_dev = m->t_inv_dev;
+    a.abort_dev = m->abort_dev;
     a.c = make_cam(m, false);
     a.cols = m->width, a.rows = m->height;
     a.maxDepth = depth_cutoff;
@@ -2501,6 +2554,7 @@ static int model_fuse(mmf_model* m, int time, const uint8_t* rgb, const uint8_t*
     a.time = time;
     a.weighting = weighting;
     a.pose_dev = m->pose_dev, a.weight_dev = m->weight_dev, a.weight_mult = weighting;
+    a.abort_dev = m->abort_dev;
     a.maskID = m->id;
     a.maxDepth = depth_cutoff < m->max_depth ? depth_cutoff : m->max_depth;  // std::min(depthCutoff, maxDepth) (Model.cpp:928)
     a.count = (int)m->count;
@@ -2532,6 +2586,7 @@ extern "C" int mmf_model_clean(mmf_model* m, int time, int time_delta, float dep
     CleanArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
     a.t_inv_dev = m->t_inv_dev;
+    a.abort_dev = m->abort_dev;
     a.c = make_cam(m, false);
     a.cols = m->width, a.rows = m->height;
     a.time = time, a.timeDelta = time_delta;
@@ -2545,7 +2600,7 @@ extern "C" int mmf_model_clean(mmf_model* m, int time, int time_delta, float dep
                        m->index, m->vertConf, m->colorTime, depth_filtered, mask, m->flags_a, m->conf_time, m->block_sums);
     hipLaunchKernelGGL(clean_scatter_kernel, grid1d(n), dim3(256), 0, c->stream, m->set[m->cur], m->meas, (int)m->count,
                        npix, m->flags_a, m->block_sums, m->conf_time, m->set[1 - m->cur], m->capacity, &m->totals[0],
-                       m->host_totals_dev + kCountWord, ++m->count_seq);
+                       m->host_totals_dev + kCountWord, ++m->count_seq, m->abort_dev);
     MMF_HIP_TRY(hipGetLastError());
     // glGetQueryObjectuiv(countQuery) in the reference (Model.cpp:1166) stalls for the count; here the scatter's last
     // workgroup stores it into the host's pinned words, where the next call that needs it on the host picks it up

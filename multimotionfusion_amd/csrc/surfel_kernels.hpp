@@ -420,9 +420,19 @@ __device__ __forceinline__ Args with_device_pose(const Args& in) {
     return a;
 }
 
+// A pass enqueued before the tracked pose has reached the host also carries `abort_dev`: a word of the odometry's device state
+// that is non-zero when the tracking result it would read is not valid (OdomState::gn_fault: the one-launch chain gave up and
+// the host re-runs the frame's tracking on the two-launch chain).  Such a pass then does NOTHING -- the host, which learns the
+// same word with the pose, takes its own bookkeeping back and enqueues the pass again behind the new result.
+#define MMF_SPECULATION_GUARD(args)                              \
+    do {                                                         \
+        if ((args).abort_dev != nullptr && *(args).abort_dev != 0) return; \
+    } while (0)
+
 struct IndexArgs {
     Mat4 t_inv;
     const float* t_inv_dev;  // non-null: the 16 floats to use instead of t_inv (see with_device_pose)
+    const int* abort_dev;
     Cam c;
     int cols, rows;
     float maxDepth;
@@ -457,6 +467,7 @@ __global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, 
         frame_rider_run<1u>(rider);
         return;
     }
+    MMF_SPECULATION_GUARD(a_in);
     const IndexArgs a = with_device_pose(a_in);
     const int id = (int)(blockIdx.x - (rider.st ? 1u : 0u)) * 256 + threadIdx.x;
     if (id >= count) return;
@@ -476,6 +487,7 @@ __global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexAr
         frame_rider_run<2u>(rider);
         return;
     }
+    MMF_SPECULATION_GUARD(a_in);
     const IndexArgs a = with_device_pose(a_in);
     const int i = (int)(blockIdx.x - (rider.st ? 1u : 0u)) * 256 + threadIdx.x;
     if (i >= a.cols * a.rows) return;
@@ -522,6 +534,7 @@ __device__ unsigned long long g_splat_dbg[4];
 struct SplatArgs {
     Mat4 t_inv;
     const float* t_inv_dev;  // non-null: the 16 floats to use instead of t_inv (see with_device_pose)
+    const int* abort_dev;
     Cam c;
     int cols, rows;
     float maxDepth, confThreshold;
@@ -657,6 +670,7 @@ __global__ __launch_bounds__(256) void splat_ray_kernel(Cam c, int cols, int row
 // loses against a fragment that is drawn, so the key image -- and with it all four images -- keeps its bits.
 __global__ __launch_bounds__(256) void splat_bound_kernel(SurfelSoA s, int count, SplatArgs a_in, const unsigned* __restrict__ count_dev) {
     MMF_MODEL_STREAM_PRIORITY();
+    MMF_SPECULATION_GUARD(a_in);
     const SplatArgs a = with_device_pose(a_in);
     if (count_dev != nullptr) count = min((unsigned)count, *count_dev);
     const int id = blockIdx.x * 256 + threadIdx.x;
@@ -678,6 +692,7 @@ __global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, Spla
                                                     unsigned long long* __restrict__ keys,
                                                     const unsigned* __restrict__ count_dev) {
     MMF_MODEL_STREAM_PRIORITY();
+    MMF_SPECULATION_GUARD(a_in);
     const SplatArgs a = with_device_pose(a_in);
     __shared__ SplatFrag frag_lds[256];
     __shared__ int row_end[256];  // inclusive scan of the sprite heights inside each wave
@@ -847,6 +862,7 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatAr
                                                             unsigned short* __restrict__ time_out, unsigned* __restrict__ thumb,
                                                             int gen) {
     MMF_MODEL_STREAM_PRIORITY();
+    MMF_SPECULATION_GUARD(a_in);
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
@@ -884,6 +900,7 @@ struct FuseArgs {
     const float* pose_dev;    // non-null: the model pose (16 floats) to use instead of `pose`, and
     const float* weight_dev;  // computeFusionWeight(1) to use instead of `weighting` / weight_mult -- for a fuse pass that
     float weight_mult;        // is enqueued before the tracked pose has reached the host (with_device_pose)
+    const int* abort_dev;
     Cam c;  // ifx, ify = (float)(1.0 / fx) computed in double on the host (Model.cpp:920-921)
     int cols, rows;
     int time;
@@ -904,6 +921,7 @@ __global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restric
                                                         const float4* __restrict__ normRad, FuseArgs a_in, SurfelSoA meas,
                                                         unsigned* __restrict__ new_flags, unsigned* __restrict__ winner) {
     MMF_MODEL_STREAM_PRIORITY();
+    MMF_SPECULATION_GUARD(a_in);
     FuseArgs a = a_in;
     if (a_in.pose_dev) {
 #pragma unroll
@@ -1085,6 +1103,7 @@ __global__ __launch_bounds__(256) void fuse_update_index_kernel(SurfelSoA s, int
                                                                 unsigned* __restrict__ winner, IndexArgs a_in,
                                                                 unsigned long long* __restrict__ keys) {
     MMF_MODEL_STREAM_PRIORITY();
+    MMF_SPECULATION_GUARD(a_in);
     const IndexArgs a = with_device_pose(a_in);
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
@@ -1104,6 +1123,7 @@ __global__ __launch_bounds__(256) void fuse_update_index_kernel(SurfelSoA s, int
 struct CleanArgs {
     Mat4 t_inv;
     const float* t_inv_dev;  // non-null: the 16 floats to use instead of t_inv (with_device_pose)
+    const int* abort_dev;
     Cam c;
     int cols, rows;
     int time, timeDelta;
@@ -1264,6 +1284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MMF_CLEAN_W
                                                          unsigned* __restrict__ keep, float2* __restrict__ conf_time,
                                                          unsigned* __restrict__ block_sums) {
     MMF_MODEL_STREAM_PRIORITY();
+    MMF_SPECULATION_GUARD(a_in);
     const CleanArgs a = with_device_pose(a_in);
     const int e = blockIdx.x * 256 + threadIdx.x;
     unsigned k = 0u;
@@ -1284,8 +1305,10 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
                                                             const unsigned* __restrict__ block_sums,
                                                             const float2* __restrict__ conf_time, SurfelSoA dst,
                                                             int capacity, unsigned* __restrict__ total_out,
-                                                            unsigned* __restrict__ total_host, unsigned seq) {
+                                                            unsigned* __restrict__ total_host, unsigned seq,
+                                                            const int* __restrict__ abort_dev) {
     MMF_MODEL_STREAM_PRIORITY();
+    if (abort_dev != nullptr && *abort_dev != 0) return;  // (MMF_SPECULATION_GUARD: neither surfels nor the count are published)
     __shared__ unsigned wave_part[4], wave_kept[4];
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1398,6 +1421,7 @@ __global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, Sp
                                                                  float4* __restrict__ normal_out, uchar4* __restrict__ image_out,
                                                                  unsigned* __restrict__ thumb, int gen) {
     MMF_MODEL_STREAM_PRIORITY();
+    MMF_SPECULATION_GUARD(a_in);
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;

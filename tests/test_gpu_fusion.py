@@ -615,3 +615,56 @@ def test_the_first_prediction_of_a_frame_is_never_read(gpu_ctx):
             for k, a, b in zip(names, ref[i][1], got[i][1]):
                 assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (i, k)
         assert np.array_equal(ref_map.view(np.uint32), got_map.view(np.uint32))
+
+
+@pytest.mark.parametrize("hint", [False, True])
+def test_a_chain_that_gives_up_is_tracked_again(gpu_ctx, hint):
+    """The one-launch Gauss-Newton chain spins on its own workgroups; when a launch gives up (forced here: its count barrier
+    polls zero times, as if another process held part of the GPU) the frame must come out as if the two-launch chain had
+    tracked it -- same pose, same map, although the projections, the fuse and the clean pass had been enqueued ahead of the
+    pose -- and the process stops using the one-launch chain.  Reference: RGBDOdometry.cpp:464-467 (the call returns a pose)."""
+    import ctypes as C
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    lib = gpu_ctx.lib
+    w, h, n, fault_at = 320, 240, 7, 3
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=23)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+    rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+
+    def status():
+        rec, use = C.c_int(0), C.c_int(0)
+        assert lib.mmf_gn_chain_status(C.byref(rec), C.byref(use)) == 0
+        return rec.value, use.value
+
+    def run(forced):
+        lib.mmf_debug_set_gn_fused(-1)  # (also clears the latch an earlier run left)
+        rec0, use0 = status()
+        assert use0 == 1
+        g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+        out = []
+        for i in range(n):
+            if i == fault_at:
+                if forced:
+                    lib.mmf_debug_force_gn_fault(1)
+                else:
+                    lib.mmf_debug_set_gn_fused(0)  # the frames a recovery leaves to the two-launch chain
+            nxt = (rgb[i + 1], depth[i + 1]) if hint and i + 1 < n else None
+            g.processFrame(rgb[i], depth[i], timestamp=i, next=nxt)
+            out.append(np.asarray(g.getCurrPose()).copy())
+            if forced and i == fault_at:
+                assert status() == (rec0 + 1, 0), "the chain's give-up was not noticed"
+        smap = g.getBackgroundModel().downloadMap()
+        it = g.getFrameOdometry().iterations_run
+        g.close()
+        lib.mmf_debug_force_gn_fault(0)
+        lib.mmf_debug_set_gn_fused(-1)
+        return out, smap, it
+
+    pa, ma, ita = run(True)
+    pb, mb, itb = run(False)
+    assert ita == itb == 19
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert np.array_equal(a, b), (i, np.abs(a - b).max())
+    assert ma.shape == mb.shape and np.array_equal(ma.view(np.uint32), mb.view(np.uint32))
+    assert status()[1] == 1

@@ -199,3 +199,47 @@ def test_batched_chain_equals_one_chain_per_model(gpu_ctx):
         assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32))
     assert a[2] == b[2] and all(s[2] == 19 for s in a[2])
     assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)) and (a[3] > 0).sum() > 100  # every model's own error image
+
+
+def test_a_batched_chain_that_gives_up_is_tracked_again(gpu_ctx):
+    """Two models in ONE one-launch chain (gridDim.y = 2): a launch that gives up (forced) voids the chain for both; the frame's
+    tracking is enqueued again as the batched two-launch chain from both start poses.  Poses and maps equal, bit for bit, a run
+    that switches to the two-launch chain at that frame by itself."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    lib = gpu_ctx.lib
+    w, h, n_frames, n_obj, fault_at = 320, 240, 6, 1, 4
+    K, poses, traj, frames, objs = scene(w, h, n_frames, n_obj, seed=33)
+    rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+
+    def run(forced):
+        lib.mmf_debug_set_gn_fused(1)
+        g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1, preallocated_models=n_obj)
+        known, out, keep = [0], [], []
+        try:
+            for i, f in enumerate(frames):
+                spawn = 1 <= i <= n_obj
+                if spawn:
+                    known.append(i)
+                keep.append(dev(gt_mask(f["ids"], known)))
+                if i == fault_at:
+                    if forced:
+                        lib.mmf_debug_force_gn_fault(1)
+                    else:
+                        lib.mmf_debug_set_gn_fused(0)
+                g.processFrame(rgb[i], depth[i], timestamp=i, mask=keep[-1], hasNewLabel=spawn)
+                out.append([m.getPose() for m in g.getModels()])
+            maps = [m.downloadMap() for m in g.getModels()]
+        finally:
+            g.close()
+            lib.mmf_debug_force_gn_fault(0)
+            lib.mmf_debug_set_gn_fused(-1)
+        return out, maps
+
+    pa, ma = run(True)
+    pb, mb = run(False)
+    assert len(pa[-1]) == 2
+    for i in range(n_frames):
+        for k, (a, b) in enumerate(zip(pa[i], pb[i])):
+            assert np.array_equal(a, b), (i, k, np.abs(a - b).max())
+    for a, b in zip(ma, mb):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))

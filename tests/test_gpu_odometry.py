@@ -259,3 +259,47 @@ def test_far_off_start_pose_and_divergence_guard(gpu_ctx, orc):
         assert np.array_equal(Rg, Ro)
     else:
         assert np.allclose(tg, to, atol=1e-4) or (np.isnan(tg).any() and np.isnan(to).any())
+
+
+def test_get_incremental_transformation_survives_a_chain_that_gives_up(gpu_ctx):
+    """mmf_odom_get_incremental_transformation: a one-launch chain that gives up (forced) is followed by the two-launch chain in
+    the same call; the result is the two-launch chain's, bit for bit, and the image ring / SO3 state are where a single call
+    leaves them (a second call gives the same answer as after an undisturbed first one)."""
+    import ctypes as C
+    from multimotionfusion_amd.odometry import RGBDOdometry
+    lib = gpu_ctx.lib
+    w, h = 320, 240
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(3, seed=3)
+    frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
+
+    def run(forced):
+        lib.mmf_debug_set_gn_fused(-1 if forced else 0)
+        g = RGBDOdometry(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+        pose = poses[0].astype(np.float32)
+        res = []
+        g.initFirstRGB(dev(frames[0]["rgb"]))
+        for k in (1, 2):
+            g.initICPModel(dev(frames[k - 1]["vertex"]), dev(frames[k - 1]["normal"]), 15.0, pose)
+            g.initRGBModel(dev(frames[k - 1]["rgb"]))
+            g.buildDepthPyramid(dev(frames[k]["depth"]))
+            g.initICP(depthCutoff=15.0)
+            g.initRGB(dev(frames[k]["rgb"]))
+            if forced and k == 1:
+                lib.mmf_debug_force_gn_fault(1)
+            t, R = g.getIncrementalTransformation(pose[:3, 3], pose[:3, :3], False, 10.0, True, False, True)
+            res.append((t.copy(), R.copy(), g.iterations_run, g.lastICPCount, g.lastRGBCount))
+            pose = pose.copy()
+            pose[:3, 3], pose[:3, :3] = t, R
+        g.close()
+        lib.mmf_debug_force_gn_fault(0)
+        lib.mmf_debug_set_gn_fused(-1)
+        return res
+
+    a, b = run(True), run(False)
+    rec, use = C.c_int(0), C.c_int(0)
+    lib.mmf_gn_chain_status(C.byref(rec), C.byref(use))
+    assert rec.value >= 1 and use.value == 1
+    for (ta, Ra, ia, ca, ra), (tb, Rb, ib, cb, rb) in zip(a, b):
+        assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb)
+        assert ia == ib == 19 and ca == cb and ra == rb
