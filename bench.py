@@ -34,7 +34,7 @@ if REPO not in sys.path:
 ICP_WEIGHT = 10.0  # GUI default (GUI/MainController.cpp:333-345)
 DEPTH_CUTOFF = 15.0
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md
-N_FRAMES = 30  # frames of the static sequence; the map is reset when the sequence wraps
+N_FRAMES = 30  # frames of the static sequence (played forwards and backwards: no reset)
 N_FRAMES_OBJECTS = 10  # frames of the moving-object sequences (played forwards and backwards: no reset)
 SCHEDULE = (10, 5, 4)  # Gauss-Newton iterations at pyramid levels 0, 1, 2 (RGBDOdometry.cpp:312-314)
 
@@ -57,12 +57,21 @@ def gn_iter_bytes(n_px):
     return 110 * n_px + 116
 
 
-def gn_iter_bytes_moved(n_px, correspondences):
+def gn_px(w, h):
+    """pixels per lane of the level-0 gn_iter_kernel launch (csrc/mmf_hip.hip, gn_geometry: the fewest of 1, 2, 4, 5 that
+    divide the width and give at most 256 workgroups of 256 pixel lanes)"""
+    for px in (1, 2, 4, 5):
+        if w % px == 0 and -(-(w * h // px) // 256) <= 256:
+            return px
+    return 4
+
+
+def gn_iter_bytes_moved(n_px, correspondences, groups):
     """What the launch has to move at the least, its design counted: the ICP reduction's 48 B/px, the correspondence search's
-    14 B/px (2 x i16 gradients, f32 depth, u8 intensity, gathered f32 depth + u8 intensity), rgbStep's 12-byte point of every
-    correspondence (the DataTerm records of the reference -- 16 B/px written, 16 read -- stay in registers), one 256-byte
-    partial record per 1024 pixels."""
-    return 62 * n_px + 12 * correspondences + n_px // 4
+    9 B/px (2 x i16 gradients, f32 depth, u8 intensity), per correspondence the gathered u8 intensity and the 16-byte point
+    record {X, Y, Z, 1/Z} (its Z is the gathered depth the reference reads separately; the DataTerm records of the
+    reference -- 16 B/px written, 16 read -- stay in registers), 58 64-bit atomics per workgroup for the sums."""
+    return 57 * n_px + 17 * correspondences + 464 * groups
 
 
 def gn_chain_bytes(w, h):
@@ -123,7 +132,7 @@ def cpu_baseline(frames, K, W, H):
         per_level.append(float(np.median(ts)))
     schedule_s = sum(it * t for it, t in zip(SCHEDULE, per_level))
     return {
-        "value": 1.0 / frame_s, "unit": "frames/s", "cores": 1, "kind": "port",
+        "value": 1.0 / frame_s, "unit": "frames/s", "cores": 1, "kind": "port", "first_predict_elided": False,
         "sample": (f"oracle/fusion.py processFrame (the whole step the GPU value measures: filter, tracking, splat, index map, fuse, "
                    f"clean) on frames 1..{n_timed} of the same {W}x{H} sequence, one host thread, {frame_s * n_timed:.1f} s of CPU work"),
         "icp_reduce_openmp": {"frames_per_s_schedule_only": 1.0 / schedule_s, "cores": orc.omp_threads(libpath),
@@ -133,18 +142,34 @@ def cpu_baseline(frames, K, W, H):
     }
 
 
+def source_stamp():
+    """sha256 over the kernels' sources (csrc/ + include/): profiles/ figures carry it, and bench.py quotes a committed figure
+    only while it was measured on the code that is running"""
+    import hashlib
+    hsh = hashlib.sha256()
+    for root in (os.path.join(REPO, "multimotionfusion_amd", "csrc"), os.path.join(REPO, "include")):
+        for name in sorted(os.listdir(root)):
+            with open(os.path.join(root, name), "rb") as fp:
+                hsh.update(name.encode() + b"\0" + fp.read())
+    return hsh.hexdigest()[:16]
+
+
 def rocprof_launch_us(kernel_substr):
     """Average / minimum duration of the roofline kernel in the committed rocprofv3 kernel trace OF THIS COMMAND
     (profiles/r03_bench_under_rocprofv3.txt, written by tools/collect_profiles.sh; tools/kstats.py's line format); None
     without it.  It stands beside the live event figure: the judge can reproduce `frac` from profiles/ alone."""
-    path = os.path.join(REPO, "profiles", "r03_bench_under_rocprofv3.txt")
+    path = os.path.join(REPO, "profiles", "r04_bench_under_rocprofv3.txt")
     try:
         with open(path) as fp:
-            for line in fp:
-                if line.startswith(kernel_substr) and "avg=" in line and "min=" in line:
-                    avg = float(line.split("avg=")[1].split("us")[0])
-                    mn = float(line.split("min=")[1].split()[0])
-                    return avg, mn, "profiles/r03_bench_under_rocprofv3.txt"
+            lines = fp.read().splitlines()
+        stamp = [ln.split()[-1] for ln in lines if ln.startswith("source_stamp")]
+        if not stamp or stamp[0] != source_stamp():  # measured on other kernels than the ones running: say nothing
+            return None, None, None
+        for line in lines:
+            if line.startswith(kernel_substr) and "avg=" in line and "min=" in line:
+                avg = float(line.split("avg=")[1].split("us")[0])
+                mn = float(line.split("min=")[1].split()[0])
+                return avg, mn, "profiles/r04_bench_under_rocprofv3.txt (source_stamp %s)" % stamp[0]
     except (OSError, ValueError, IndexError):
         pass
     return None, None, None
@@ -154,12 +179,15 @@ def pmc_traffic(kernel_substr, W, H):
     """HBM traffic per launch of the roofline kernel from the committed rocprofv3 --pmc summary (separate FETCH_SIZE /
     WRITE_SIZE passes, gfx950 corrections applied by tools/pmc_summary.py); None when there is no summary for this
     kernel and frame size."""
-    path = os.path.join(REPO, "profiles", "r03_pmc_summary.json")
+    path = os.path.join(REPO, "profiles", "r04_pmc_summary.json")
     try:
         with open(path) as fp:
-            for rec in json.load(fp)["kernels"]:
+            doc = json.load(fp)
+            if doc.get("source_stamp") != source_stamp():
+                return None, None
+            for rec in doc["kernels"]:
                 if kernel_substr in rec["kernel"] and rec["width"] == W and rec["height"] == H and rec["level"] == 0:
-                    return float(rec["traffic_bytes_per_launch"]), "profiles/r03_pmc_summary.json"
+                    return float(rec["traffic_bytes_per_launch"]), "profiles/r04_pmc_summary.json"
     except (OSError, KeyError, ValueError):
         pass
     return None, None
@@ -253,14 +281,14 @@ def main():
         state = {"frame": 0}
 
         def step(i):
-            k = state["frame"] % len(frames)
-            if state["frame"] and k == 0:  # sequence wrapped: start a fresh map (the trajectory jumps back)
-                mmf.reset()
+            # the sequence is played forwards and backwards (0 .. 29, 28 .. 1, 0 ..): no frame of the run is an initialise-only
+            # frame behind a reset, and the map grows to the size the sequence gives it instead of starting over every 30 frames
+            k = pingpong(state["frame"], len(frames))
             state["frame"] += 1
-            kn = state["frame"] % len(frames)
+            kn = pingpong(state["frame"], len(frames))
             # the next frame's buffers ride along (mmf_frame::next_*): its filter, pyramids and SO3 pre-alignment are
             # enqueued while this call waits for its pose and overlap this frame's fusion on two side streams
-            nxt = (d_rgb[kn], d_depth[kn]) if PREFETCH and kn != 0 else None
+            nxt = (d_rgb[kn], d_depth[kn]) if PREFETCH else None
             if os.environ.get("MMF_BENCH_SEPARATE_PREFETCH"):
                 mmf.processFrame(d_rgb[k], d_depth[k], timestamp=i)
                 if nxt:
@@ -275,8 +303,12 @@ def main():
         models_per_gpu = 1
         workload = (f"{W}x{H} synthetic RGB-D sequence through MultiMotionFusion::processFrame, static scene (no segmentation): "
                     "bilateral filter, dense ICP+RGB odometry (SO3 + 4/5/10 Gauss-Newton iterations, icpWeight 10) against the "
-                    "surfel splat, index map, fuse, clean, splat + fill-in; one rigid-body model; the next frame's depth filter, "
-                    "input pyramids and SO3 pre-alignment run on two side streams during the current frame's fusion")
+                    "surfel splat, index map, fuse, clean, splat + fill-in; one rigid-body model; the 30-frame sequence is played forwards "
+                    "and backwards (no reset: the map grows to its steady size); every call is handed the NEXT frame's device buffers as "
+                    "well (mmf_frame::next_*, an argument the reference's processFrame does not have -- a log reader can give it, a live "
+                    "camera cannot): its depth filter, input pyramids and SO3 pre-alignment run on two side streams during the current "
+                    "frame; the frame's FIRST predict() (MultiMotionFusion.cpp:675) is elided -- with loop closure off nothing reads its "
+                    "images before the second predict() (:821) overwrites them (test_the_first_prediction_of_a_frame_is_never_read)")
 
     def make_shard_workload(W, H):
         """The per-rigid-body shard: moving rigid objects, mask = ground-truth ids, one rigid-body model per rank (rank 0 the
@@ -317,9 +349,13 @@ def main():
         # then costs a process time slice -- 44 ms instead of 1.7 ms per step at two ranks -- so it is off there by default)
         PREFETCH_SHARD = os.environ.get("MMF_BENCH_PREFETCH", "1" if backend == "nccl" or world == 1 else "0") != "0"
 
+        acc = state.setdefault("acc", {"wait_frame_s": 0.0, "gather_poses_end_s": 0.0, "process_frame_s": 0.0, "post_frame_s": 0.0,
+                                         "steps": 0, "tracked_in_first_timed_step": None})
+
         def step(i):
             n = state["frame"]
             state["frame"] += 1
+            t_a = time.perf_counter()
 
             def post(m):  # start the broadcast of step m's frame into buffer m % NB (once)
                 if m in posted:
@@ -340,12 +376,16 @@ def main():
 
             post(n)
             post(n + 1)
+            t_b = time.perf_counter()
             for m in (n, n + 1):  # the compute stream waits for the collectives of this frame and of the one it prefetches;
                 for w_ in pending.pop(m, []):  # the host does not
                     w_.wait()
+            t_c = time.perf_counter()
             post(n + 2)
             posted.discard(n - 1)
+            t_d = time.perf_counter()
             take_poses(n - 2)  # the all-gather of two steps ago: long complete, the host does not wait for the GPU here
+            t_e = time.perf_counter()
             spawn = 1 <= n < world  # object id n appears in the mask of step n: a new label (one per frame)
             if world == 1:
                 kk, kn = pingpong(n, N_FRAMES_OBJECTS), pingpong(n + 1, N_FRAMES_OBJECTS)
@@ -355,12 +395,23 @@ def main():
                 b, bn = n % NB, (n + 1) % NB
                 mmf.processFrame(rgb_in[b], depth_in[b], timestamp=i, mask=mask_in[b], hasNewLabel=spawn,
                                  next=(rgb_in[bn], depth_in[bn]) if PREFETCH_SHARD else None)
+            t_f = time.perf_counter()
             if state.get("own") is None and ctx.lib.mmf_fusion_num_models(mmf.handle) > rank:
                 state["own"] = mmf.getModels()[rank]  # this rank's model has joined the list
             pose = state["own"].getPose() if state.get("own") is not None else np.eye(4, dtype=np.float32)
             give_pose(n, pose)
+            if state.get("timed"):  # where a rank's step goes (host wall clock; the first 8-GPU run must say what bounds it)
+                acc["post_frame_s"] += (t_b - t_a) + (t_d - t_c)
+                acc["wait_frame_s"] += t_c - t_b
+                acc["gather_poses_end_s"] += t_e - t_d
+                acc["process_frame_s"] += t_f - t_e
+                acc["steps"] += 1
+                if acc["tracked_in_first_timed_step"] is None:
+                    own = state.get("own")
+                    acc["tracked_in_first_timed_step"] = bool(own is not None and mmf.getModelOdometry(rank).iterations_run > 0)
             return pose
 
+        step.state = state
         # Every rank learns every model's pose (18 floats per rank) without a host round trip in the step: the record goes
         # up from pinned memory behind the frame's work, the all-gather follows it on RCCL's stream, a side stream brings
         # the result down into pinned memory and records an event; the step that starts two frames later reads it.
@@ -464,6 +515,9 @@ def main():
         # steps) showed up as one 41 ms step = 7 % of a 600-step run (MMF_BENCH_FRAME_TIMES=1 prints the per-step times)
         gc.collect()
         gc.disable()
+        st_ = getattr(step, "state", None)  # (the sharded step accounts for where its time goes inside the timed region only)
+        if st_ is not None:
+            st_["timed"] = True
         t0 = time.perf_counter()
         pose = None
         stamps = [] if os.environ.get("MMF_BENCH_FRAME_TIMES") else None  # diagnostic: per-step host times to stderr
@@ -475,6 +529,8 @@ def main():
                 lt.append(mmf.lastTimings())
         fence()
         dt = time.perf_counter() - t0
+        if st_ is not None:
+            st_["timed"] = False
         gc.enable()
         if stamps:
             d = np.diff(np.array([t0] + stamps)) * 1e6
@@ -494,6 +550,19 @@ def main():
         models_per_gpu = 1
 
     elapsed, last_pose = timed_run(step, fence, args.warmup, args.steps)
+    per_rank = None
+    if world > 1:  # where every rank's step went (host wall clock inside the timed region), gathered before anything else runs
+        acc = dict(step.state["acc"])
+        n_acc = max(1, acc.pop("steps"))
+        tracked0 = acc.pop("tracked_in_first_timed_step")
+        mine = {"rank": rank, "tracked_a_model_in_the_first_timed_step": bool(tracked0), **{k[:-2] + "_ms_per_step": v / n_acc * 1e3 for k, v in acc.items()}}
+        mine["step_ms"] = sum(v for k, v in mine.items() if k.endswith("_ms_per_step"))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
+        assert ranks_seen == world, f"{ranks_seen} ranks answered, {world} expected"
+        assert all(g_["tracked_a_model_in_the_first_timed_step"] for g_ in gathered), \
+            f"a rank had no model to track at the start of the timed region: {gathered}"
 
     # ---- roofline of the dominant kernel of the frame: the level-0 producer launch of the Gauss-Newton loop
     # (track_producer_kernel: ICP J^T J reduction + photometric correspondence pass), timed INSIDE processFrame by
@@ -523,7 +592,7 @@ def main():
         n_surfels = model.lastCount()
         t_err = None
         if not config5:  # accuracy sanity of the last tracked frame against the known trajectory (relative to frame 0)
-            k = (state["frame"] - 1) % len(frames)
+            k = pingpong(state["frame"] - 1, len(frames))
             gt = np.linalg.inv(poses[0]) @ poses[k]
             t_err = float(np.linalg.norm(last_pose[:3, 3] - gt[:3, 3]))
 
@@ -531,7 +600,8 @@ def main():
         fused = tm["rgb_step_l0"]["launches"] == 0  # the chain ran as one launch per iteration (csrc/gn_fused.hpp)
         if fused:
             n_corr = int(mmf.getFrameOdometry().lastRGBCount)
-            b_launch, kernel, formula = gn_iter_bytes(n0), "gn_iter_kernel<4> level 0", "SURVEY 8(d): icpStep 48 N + 116, computeRgbResidual 30 N, rgbStep 32 N"
+            px0 = gn_px(W, H)
+            b_launch, kernel, formula = gn_iter_bytes(n0), f"gn_iter_kernel<{px0}> level 0", "SURVEY 8(d): icpStep 48 N + 116, computeRgbResidual 30 N, rgbStep 32 N"
             kname = "gn_iter_kernel"
         else:
             b_launch, kernel, formula = producer_bytes(n0), "track_producer_kernel<2,true> level 0", "48 N (ICP) + 14 N read + 8 N written (correspondence pass)"
@@ -540,24 +610,25 @@ def main():
         traffic, traffic_src = pmc_traffic(kname, W, H)
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                     "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": f"{kernel} ({W}x{H}): " + ("one whole Gauss-Newton iteration: record sum + 6x6 solve + pose update, ICP JtJ "
+                    "kernel": f"{kernel} ({W}x{H}): " + ("one whole Gauss-Newton iteration: previous sums + 6x6 solve + pose update, ICP JtJ "
                                                          "reduction, photometric correspondence search + Jacobian reduction" if fused else
                                                          "ICP JtJ reduction + photometric correspondence pass"),
                     "us_per_launch": us, "us_per_launch_min": tm["producer_l0"]["min_us"], "launches_timed": tm["producer_l0"]["launches"],
                     "bytes_per_launch": b_launch, "bytes_formula": formula,
                     "timing": "hipExtLaunchKernelGGL start/stop events per launch inside processFrame"}
-        r_avg, r_min, r_src = rocprof_launch_us("gn_iter_kernel<4, false>" if fused else "track_producer_kernel") if (W, H) == (640, 480) else (None, None, None)
+        r_avg, r_min, r_src = rocprof_launch_us(f"gn_iter_kernel<{gn_px(W, H)}, false>" if fused else "track_producer_kernel") if (W, H) == (640, 480) else (None, None, None)
         if r_avg:  # the committed kernel trace of this command, beside the live events
             roofline["us_per_launch_rocprofv3"] = r_avg
             roofline["us_per_launch_rocprofv3_min"] = r_min
             roofline["frac_by_rocprofv3"] = b_launch / (r_avg * 1e-6) / 1e9 / HBM_PEAK_GBPS
             roofline["rocprofv3_source"] = r_src
         if fused:
-            moved = gn_iter_bytes_moved(n0, n_corr)
+            moved = gn_iter_bytes_moved(n0, n_corr, -(-(n0 // gn_px(W, H)) // 256))
             roofline["bytes_moved_by_design"] = moved
             roofline["frac_of_bytes_moved"] = moved / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS
-            roofline["note"] = ("the launch is a chain of dependent latencies (records -> solve -> search -> count barrier -> rows), not a stream: "
-                                "DESIGN.md section 4c has the phase times")
+            roofline["note"] = ("achieved / frac credit the launch with the bytes of the three reference functions it replaces (the contract's "
+                                "algorithmic bytes); it moves about half of them (frac_of_bytes_moved). The launch is a chain of dependent "
+                                "latencies (sums -> solve -> search -> count barrier -> rows), not a stream: DESIGN.md section 4c has the phase times")
         per_level = {f"l{l}": {"producer_us": tm[f"producer_l{l}"]["mean_us"], "rgb_step_us": tm[f"rgb_step_l{l}"]["mean_us"],
                                "producer_min_us": tm[f"producer_l{l}"]["min_us"], "rgb_step_min_us": tm[f"rgb_step_l{l}"]["min_us"],
                                "producer_GBps": (gn_iter_bytes if fused else producer_bytes)(n0 >> (2 * l)) / max(tm[f"producer_l{l}"]["mean_us"], 1e-9) / 1e3}
@@ -617,6 +688,10 @@ def main():
                        "parallelism": f"model-shard x{world}"},
             "roofline": roofline,
             "gn_chain": gn_chain,
+            **({"per_rank": per_rank, "slowest_rank": max(per_rank, key=lambda r_: r_["step_ms"])["rank"],
+                "per_rank_what": "host wall clock per step inside the timed region: post_frame = starting the broadcasts, wait_frame = "
+                                 "mmf_shard_wait_frame (or the torch work handles), gather_poses_end = picking up the all-gather of two steps "
+                                 "ago, process_frame = the call itself (it ends when the rank's pose is on the host)"} if per_rank else {}),
             "icp_kernel_standalone": icp_standalone,
             "surfel_passes": surfel_passes,
             "device": ctx.device_name(),
@@ -774,11 +849,8 @@ def main():
                 if i == 10:
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                k = i % len(frames)
-                if i and k == 0:
-                    g.reset()
-                kn = (i + 1) % len(frames)
-                nxt = host_frames[kn] if announce and kn != 0 else None
+                k, kn = pingpong(i, len(frames)), pingpong(i + 1, len(frames))  # (as the headline loop: no reset)
+                nxt = host_frames[kn] if announce else None
                 g.processFrameHost(host_frames[k], timestamp=i, next=nxt)
             torch.cuda.synchronize()
             fps = n_steps / (time.perf_counter() - t1)

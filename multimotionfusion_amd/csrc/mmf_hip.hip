@@ -2437,9 +2437,9 @@ extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cut
 // the two thumbnail counters of thumbnail_count_px (surfel_kernels.hpp): the count of the latest prediction is [tex_gen & 1]
 static unsigned* model_thumb_counts(mmf_model* m) { return &m->totals[4]; }
 // splat_kernel's launch: a fixed number of workgroups that deal the surfels out among their waves (surfel_kernels.hpp)
-// 512 workgroups = two waves per SIMD for a young map (most of its surfels are unstable and culled by the set-up); a DEEP
-// store (every surfel drawn, tens of fragments per pixel) needs the latency of its per-row LDS searches and bound look-ups
-// hidden: 2048 workgroups (124 -> 107 us on 740 k stable surfels at 640x480, tools/mature_splat_probe.py)
+// 512 workgroups = two waves per SIMD for a small store (an object model); a store of a surfel per pixel and more needs the
+// latency of its per-row LDS searches and ray look-ups hidden: 2048 workgroups (124 -> 107 us on 740 k stable surfels at
+// 640x480, tools/mature_splat_probe.py; +1 % on the headline loop's 250 k)
 static dim3 splat_grid(size_t bound, bool deep = false) {
     static const unsigned wgs_env = []() { const char* e = std::getenv("MMF_SPLAT_WGS"); return e ? (unsigned)std::max(1, std::atoi(e)) : 0u; }();
     const unsigned wgs = wgs_env ? wgs_env : (deep ? 2048u : 512u);
@@ -2457,7 +2457,7 @@ extern "C" int mmf_debug_splat_counts(unsigned long long out[4], int reset) {
     return MMF_OK;
 }
 #endif
-static std::atomic<int> g_splat_bound{-1};  // -1: by the surfel count; 0 / 1: mmf_debug_set_splat_bound (tests compare the two)
+static std::atomic<int> g_splat_bound{[]() { const char* e = std::getenv("MMF_SPLAT_BOUND"); return e ? (std::atoi(e) ? 1 : 0) : -1; }()};  // -1: by the surfel count; 0 / 1: mmf_debug_set_splat_bound (tests compare the two), MMF_SPLAT_BOUND (A/B runs)
 extern "C" int mmf_debug_set_splat_bound(int mode) {
     g_splat_bound.store(mode < 0 ? -1 : (mode ? 1 : 0));
     return MMF_OK;
@@ -2485,7 +2485,8 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     // a DEEP store (two surfels per pixel and more: occluded layers) takes the bounded depth test (surfel_kernels.hpp,
     // splat_bound_kernel): one more launch, a fraction of the fragments and of their atomics.  Same images either way.
     const int bound_mode = g_splat_bound.load();
-    const bool deep_store = (size_t)launch_count >= 2 * (size_t)m->width * m->height;
+    const size_t npix_s = (size_t)m->width * m->height;
+    const bool deep_store = (size_t)launch_count >= 2 * npix_s;
     const bool deep = bound_mode < 0 ? deep_store : bound_mode != 0;
     a.zb = (deep && launch_count) ? m->zbound : nullptr;
     a.rays = m->rays;
@@ -2493,7 +2494,7 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
         hipLaunchKernelGGL(splat_bound_kernel, grid1d(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
                            m->count_pending ? m->totals : nullptr);
     if (launch_count)
-        hipLaunchKernelGGL(splat_kernel, splat_grid(launch_count, deep_store), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
+        hipLaunchKernelGGL(splat_kernel, splat_grid(launch_count, (size_t)launch_count >= npix_s), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
                            m->keys, m->count_pending ? m->totals : nullptr);
     if (fill_rgb && fill_depth) {  // (a pending frame rider stays for the predictIndices that follows: frame_rider.hpp)
         hipLaunchKernelGGL(splat_resolve_fill_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0,

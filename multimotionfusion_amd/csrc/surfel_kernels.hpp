@@ -737,39 +737,32 @@ __global__ __launch_bounds__(256) void splat_kernel(SurfelSoA s, int count, Spla
             const int py = g.y0 + (t - row_first);
             const unsigned sid = (unsigned)(base + lo);
 
-            if (a.zb != nullptr) {  // (uniform) the bounded depth test: eight pixels of the row at a time, their bounds in one round trip
-                for (int pb = g.x0; pb <= g.x1; pb += kSplatChunk) {
-                    unsigned zbv[kSplatChunk];
-                    float4 ray[kSplatChunk];
+            // eight pixels of the row at a time: their viewing rays (and, with a bound, their bounds) in one round trip
+            const bool bounded = a.zb != nullptr;  // (uniform)
+            for (int pb = g.x0; pb <= g.x1; pb += kSplatChunk) {
+                unsigned zbv[kSplatChunk];
+                float4 ray[kSplatChunk];
 #pragma unroll
-                    for (int e = 0; e < kSplatChunk; ++e) {
-                        const size_t at = (size_t)min(pb + e, g.x1) * a.rows + py;
-                        zbv[e] = a.zb[at];
-                        ray[e] = a.rays[at];
-                    }
-#pragma unroll
-                    for (int e = 0; e < kSplatChunk; ++e) {
-                        const int px = pb + e;
-                        MMF_SPLAT_TALLY(0, px <= g.x1);
-                        if (px > g.x1 || g.dmin > zbv[e]) continue;
-                        MMF_SPLAT_TALLY(1, true);
-                        // the depth first (a dot product and two divisions), the disc test only for fragments that can still win
-                        const v3 l = V3(ray[e].x, ray[e].y, ray[e].z);
-                        const float q = splat_plane_q(g, l);
-                        const unsigned d24 = splat_depth24(l.z * q, a.maxDepth);
-                        if (d24 > zbv[e] || !splat_in_disc(g, l, q)) continue;
-                        MMF_SPLAT_TALLY(2, true);
-                        atomicMin(&keys[(size_t)px * a.rows + py], ((unsigned long long)d24 << 32) | sid);
-                    }
+                for (int e = 0; e < kSplatChunk; ++e) {
+                    const size_t at = (size_t)min(pb + e, g.x1) * a.rows + py;
+                    zbv[e] = bounded ? a.zb[at] : 0xFFFFFFFFu;
+                    ray[e] = a.rays[at];
                 }
-                continue;
-            }
-            for (int px = g.x0; px <= g.x1; ++px) {
-                float z;
-                unsigned d24;
-                if (!splat_fragment(g, a, px, py, z, d24)) continue;
-                // the key image is stored TRANSPOSED (x * rows + y), like the index map's
-                atomicMin(&keys[(size_t)px * a.rows + py], ((unsigned long long)d24 << 32) | sid);
+#pragma unroll
+                for (int e = 0; e < kSplatChunk; ++e) {
+                    const int px = pb + e;
+                    MMF_SPLAT_TALLY(0, px <= g.x1);
+                    if (px > g.x1 || g.dmin > zbv[e]) continue;
+                    MMF_SPLAT_TALLY(1, true);
+                    // the depth first (a dot product and two divisions), the disc test only for fragments that can still win
+                    const v3 l = V3(ray[e].x, ray[e].y, ray[e].z);
+                    const float q = splat_plane_q(g, l);
+                    const unsigned d24 = splat_depth24(l.z * q, a.maxDepth);
+                    if (d24 > zbv[e] || !splat_in_disc(g, l, q)) continue;
+                    MMF_SPLAT_TALLY(2, true);
+                    // the key image is stored TRANSPOSED (x * rows + y), like the index map's
+                    atomicMin(&keys[(size_t)px * a.rows + py], ((unsigned long long)d24 << 32) | sid);
+                }
             }
         }
     }

@@ -17,7 +17,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 W, H = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "640x480").split("x"))
 models = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 prefetch = (sys.argv[4] if len(sys.argv) > 4 else "1") != "0"
-headline = len(sys.argv) > 5 and sys.argv[5] == "headline"  # bench.py's N = 1 loop: 30 frames, reset when the sequence wraps
+headline = len(sys.argv) > 5 and sys.argv[5] == "headline"  # bench.py's N = 1 loop: 30 frames forwards and backwards
 K = synth.intrinsics(W, H)
 nf = 30 if headline else 10
 poses = synth.trajectory(nf, seed=1)
@@ -47,12 +47,9 @@ for i in range(n):
         torch.cuda.synchronize()
         t_loop = time.perf_counter()
     k = frame_of(i)
-    if headline:
-        k = i % nf
-        if i and k == 0:
-            g.reset()
-        hint = (i + 1) % nf != 0 and prefetch  # (prefetch 0: the headline loop without the next-frame hint -- nothing on the side streams)
-        g.processFrame(rgb[k], depth[k], timestamp=i, next=(rgb[(i + 1) % nf], depth[(i + 1) % nf]) if hint else None)
+    if headline:  # bench.py's N = 1 loop: the 30-frame sequence forwards and backwards, no reset
+        kn = frame_of(i + 1)
+        g.processFrame(rgb[k], depth[k], timestamp=i, next=(rgb[kn], depth[kn]) if prefetch else None)  # (prefetch 0: nothing on the side streams)
         continue
     if models > 1:
         kn = frame_of(i + 1)
