@@ -1422,7 +1422,11 @@ extern "C" int mmf_fusion_process_frame_host_next(mmf_fusion* f, const uint8_t* 
         if (int rc = fusion_stage_host_begin(f, after_begin)) return rc;  // staged and sent up beside this call's own work
     }
     int rc = fusion_process_frame_impl(f, &fr);
-    if (rc) return rc;
+    if (rc) {  // the staging thread may still be reading the caller's next_* buffers: not past this call's return
+        const std::string why = mmf_last_error();
+        (void)fusion_stage_host_next(f);
+        return fail(rc, why);
+    }
     return fusion_stage_host_next(f);  // (paths that enqueue no prefetch never reached the staging point)
 }
 

@@ -18,7 +18,13 @@ class HostFrame:
     __slots__ = ("rgb", "depth", "rgb_ptr", "depth_ptr")
 
     def __init__(self, rgb, depth):
-        assert rgb.dtype == np.uint8 and depth.dtype == np.float32 and rgb.flags.c_contiguous and depth.flags.c_contiguous
+        # raw addresses reach a C memcpy / DMA: the wrong dtype or stride would be an out-of-bounds host read (and an
+        # `assert` disappears under python -O), so convertible inputs are converted and anything else is refused
+        rgb, depth = np.ascontiguousarray(rgb), np.ascontiguousarray(depth)
+        if rgb.dtype != np.uint8 or depth.dtype != np.float32:
+            raise TypeError(f"HostFrame: rgb must be uint8 and depth float32 (metres), got {rgb.dtype} / {depth.dtype}")
+        if rgb.ndim != 3 or rgb.shape[2] != 3 or depth.shape != rgb.shape[:2]:
+            raise TypeError(f"HostFrame: rgb (H, W, 3) and depth (H, W) expected, got {rgb.shape} / {depth.shape}")
         self.rgb, self.depth = rgb, depth  # (kept alive with the addresses)
         self.rgb_ptr, self.depth_ptr = rgb.ctypes.data, depth.ctypes.data
 

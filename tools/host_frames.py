@@ -1,5 +1,9 @@
-"""Frames/s of processFrame with HOST frames announced one call ahead (mmf_fusion_process_frame_host_next), and with device
-frames + next-frame hint for comparison, in one process.   python tools/host_frames.py [frames]"""
+"""GPU box: frames/s of the drop-in call with HOST frames (mmf_fusion_process_frame_host[_next]) against device frames, one
+process, same sequence (forwards and backwards, as bench.py): announced / unannounced, caller buffers page-locked by the
+library on first sight (default) or staged through pinned copies (MMF_HOST_REGISTER=0).
+
+    python tools/host_frames.py [steps]
+"""
 import os
 import sys
 import time
@@ -7,38 +11,50 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
 from multimotionfusion_amd import synth  # noqa: E402
 from multimotionfusion_amd.cudafuncs import Context  # noqa: E402
 from multimotionfusion_amd.fusion import HostFrame, MultiMotionFusion  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-W, H, nf = 640, 480, 30
+W, H, N = 640, 480, 30
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 K = synth.intrinsics(W, H)
-poses = synth.trajectory(nf, seed=1)
+poses = synth.trajectory(N, seed=1)
 frames = [synth.render(p, W, H, seed=i) for i, p in enumerate(poses)]
-ctx = Context(0)
-dev = [(torch.from_numpy(f["rgb"]).cuda(), torch.from_numpy(f["depth"]).cuda()) for f in frames]
 host = [HostFrame(f["rgb"], f["depth"]) for f in frames]
-import gc  # noqa: E402
-gc.collect()
-gc.disable()
-for mode in ("device", "host", "device", "host"):
-    g = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"])
-    t0 = None
-    for i in range(n + 40):
-        if i == 40:
+d_rgb = [torch.from_numpy(f["rgb"]).cuda() for f in frames]
+d_depth = [torch.from_numpy(f["depth"]).cuda() for f in frames]
+ctx = Context(0)
+
+
+def pp(i):
+    p = i % (2 * N - 2)
+    return p if p < N else 2 * N - 2 - p
+
+
+def run(kind):
+    g = MultiMotionFusion(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], icp_weight=10.0)
+    t1 = 0.0
+    for i in range(20 + steps):
+        if i == 20:
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        k = i % nf
-        if i and k == 0:
-            g.reset()
-        last = (i + 1) % nf == 0
-        if mode == "host":
-            g.processFrameHost(host[k], timestamp=i, next=None if last else host[k + 1])
+            t1 = time.perf_counter()
+        k, kn = pp(i), pp(i + 1)
+        if kind == "device":
+            g.processFrame(d_rgb[k], d_depth[k], timestamp=i, next=(d_rgb[kn], d_depth[kn]))
+        elif kind == "device, no hint":
+            g.processFrame(d_rgb[k], d_depth[k], timestamp=i)
+        elif kind == "host, announced":
+            g.processFrameHost(host[k], timestamp=i, next=host[kn])
         else:
-            nxt = None if last else dev[k + 1]
-            g.processFrame(dev[k][0], dev[k][1], timestamp=i, next=nxt)
+            g.processFrameHost(host[k], timestamp=i)
     torch.cuda.synchronize()
-    print("%-6s frames: %.0f frames/s" % (mode, n / (time.perf_counter() - t0)))
+    fps = steps / (time.perf_counter() - t1)
     g.close()
+    return fps
+
+
+for rep in range(2):
+    print("  ".join(f"{kind}: {run(kind):.0f}" for kind in ("device", "host, announced", "device, no hint", "host, unannounced")), flush=True)
+ctx.close()
