@@ -517,7 +517,7 @@ int mmf_gn_chain_status(int *recoveries, int *one_launch_chain_in_use);
 int mmf_debug_force_gn_fault(int n);
 /* test / A-B hook: 1 = enqueue the reference's first predict() of a frame (MultiMotionFusion.cpp:675) although nothing
  * inside this library reads its images before the frame's second predict() (:821) overwrites them, 0 = leave it out (the
- * default), -1 = what the environment says (MMF_MID_PREDICT=1 turns it on).  Process wide. */
+ * default; -1 = the default).  Process wide. */
 int mmf_debug_set_mid_predict(int on);
 /* test / A-B hook: the bounded depth test of combinedPredict (splat_bound_kernel: every drawn surfel's centre fragment first,
  * as a per-pixel bound that lets the splat skip occluded fragments and their atomics; same images).  1 = always, 0 = never,

@@ -87,7 +87,6 @@ struct mmf_fusion {
     OdomState* so3_stage[2] = {nullptr, nullptr};
     int so3_stage_ready = -1;               // which of the two holds the pre-alignment of the upcoming frame; -1: none
     const uint8_t* image_pre_rgb = nullptr;  // the image side of this frame (intensity pyramid, gradients, SO3) is enqueued already
-    GraphCache depth_chain_graphs, image_chain_graphs;  // the two launch chains of a prefetch (launch_graph.hpp)
     hipStream_t side = nullptr;   // depth chain: filter, depth pyramid, vertex / normal maps
     hipStream_t side2 = nullptr;  // image chain: intensity pyramid, gradients, SO3 pre-alignment
     float* side_partials = nullptr;   // reduction scratch of the SO3 launches on side2 (never the context's: the
@@ -574,9 +573,7 @@ extern "C" int mmf_debug_set_mid_predict(int on) {
     return MMF_OK;
 }
 static bool fusion_mid_predict() {
-    static const bool env_on = std::getenv("MMF_MID_PREDICT") != nullptr;
-    const int forced = g_mid_predict.load();
-    return forced < 0 ? env_on : forced != 0;
+    return g_mid_predict.load() > 0;
 }
 
 // predictIndices -> fuse -> predictIndices -> clean of one model (:791-816 per model; models never read each
@@ -587,7 +584,7 @@ static int fusion_fuse_clean_model(mmf_fusion* f, FusionModel* fm, float weighti
     int rc = indices_done ? MMF_OK : mmf_model_predict_indices(fm->model, f->tick, g.max_depth_processed, g.time_delta);
     if (rc) return rc;
     // (the fuse's update pass projects the surfels for the predictIndices behind it: MMF_FUSE_INDEX=0 keeps the two apart)
-    static const bool merged = []() { const char* e = std::getenv("MMF_FUSE_INDEX"); return !e || e[0] != '0'; }();
+    const bool merged = tunables().fuse_index;
     const IndexArgs ia = model_index_args(fm->model, f->tick, g.max_depth_processed, g.time_delta);
     rc = model_fuse(fm->model, f->tick, f->frame_rgb, f->mask, f->frame_depth, f->depth_filtered, g.max_depth_processed, weighting,
                     merged ? &ia : nullptr);
@@ -648,7 +645,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     MMF_HIP_TRY(hipSetDevice(c->device));
     const auto t_begin = std::chrono::steady_clock::now();
     // MMF_HOST_TRACE=1: where the calling thread is, in us after the call began, at six points of the call (averages over 100 calls)
-    static const bool host_trace = std::getenv("MMF_HOST_TRACE") != nullptr;
+    const bool host_trace = tunables().host_trace;
     auto stamp = [&](int i) {
         if (host_trace) f->trace_us[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
     };
@@ -745,10 +742,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             //   =off: at the end of the call with the depth side.
             // so3_stage: this frame's own pre-alignment ran ahead as well -- inside the chain it reads the LAST frame's level-2
             // image, the half of the image ring the next frame's pyramid is written to.
-            static const int early_image = []() {
-                const char* e = std::getenv("MMF_EARLY_IMAGE");
-                return !e ? 2 : (std::strcmp(e, "off") == 0 ? 0 : (std::strcmp(e, "chain") == 0 ? 1 : 2));
-            }();
+            const int early_image = tunables().early_image;
             const bool next_from_host = f->host_next.slot >= 0 && f->up_dev[0] != nullptr;  // (a frame still being uploaded)
             const bool image_early_any = fr->next_rgb && fr->next_depth && f->side2 && g.so3 && so3_stage != nullptr;
             const bool image_early_ok = image_early_any && !next_from_host;
@@ -835,7 +829,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     }
                     collect_prep(stages, tracked[k], (k == 0 && tracked[k] == global && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE);
                 }
-                rc = stages.launch(st, graphs_enabled() ? &lead->odom->prep_graphs : nullptr);
+                rc = stages.launch(st);
                 if (rc) return rc;
                 // (a PREP_ALL collect above prepared this frame's image side as well; NOT when the pending gradients are the
                 // next frame's, from the image side enqueued ahead a few lines up)
@@ -873,7 +867,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     PrepStages stages;
                 stages.set_critical(true);  // the model's stream
                     collect_prep(stages, fm, (fm == global && one_pass && !prefetched) ? PREP_ALL : PREP_MODEL_SIDE);
-                    rc = stages.launch(fm->lane->stream, graphs_enabled() ? &fm->odom->prep_graphs : nullptr);
+                    rc = stages.launch(fm->lane->stream);
                     if (rc) return rc;
                     if (fm == global && one_pass && !prefetched) odom_adopt_gradients(global->odom);  // (PREP_ALL: this frame's image side as well)
                 } else if (k > 0) {  // prepared on the leader's stream
@@ -887,14 +881,12 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 fm->odom->exclusive_chain = tracked.size() == 1;  // several chains side by side: no in-launch barriers
                 // The frame's first projection, enqueued right behind this chain (below), carries the hand-over to the host and
                 // the fusion weight on one extra workgroup (frame_rider.hpp): the chain's last launch is the solve alone (13 ->
-                // 5.7 us on the stream a frame waits for).  MMF_RIDER=0: both at the end of the chain's last launch.
-                static const bool rider = []() { const char* e = std::getenv("MMF_RIDER"); return !e || e[0] != '0'; }();
-                fm->odom->defer_publish = rider && tracked.size() == 1 && !fr->bootstrap && !have_init && !g.rgb_only && f->tracking_ok;
+                // 5.7 us on the stream a frame waits for).
+                fm->odom->defer_publish = tracked.size() == 1 && !fr->bootstrap && !have_init && !g.rgb_only && f->tracking_ok;
                 rc = odom_enqueue_tracking(fm->odom, trans, rot, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom, g.so3,
                                            fm->icp_error, fm->rgb_error);
                 if (rc) return rc;
             }
-            bool inputs_free_early = false;
             // One model on the context's stream, nothing between its tracking and its fusion that the host decides: the
             // frame's first projections -- predict() (:675) and the first predictIndices (:792) -- are enqueued right here,
             // behind the chain and the copy of its result, with the inverse pose read from the odometry's device state.
@@ -939,23 +931,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             const bool global_tracks_somewhere = !(have_init && !fr->icp_refine);
             if (g.so3 && global_tracks_somewhere && !global_tracked)
                 for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(global->odom->last_next_image[i], global->odom->next_image[i]);
-            // EXPERIMENT (MMF_PREFETCH_EARLY=1, off; profiles/r02_ab_graphs_prefetch.txt): mmf_frame::next_* enqueued
-            // here, while the chains run and the host would only wait, instead of at the end of the call.  Correct (an
-            // event behind the chain orders it) but 20 % SLOWER: the side streams then sit on a barrier packet for the
-            // whole chain, and a dependent chain on another queue runs slower next to parked queues (308 -> 370-450 us).
             if (early_image == 1 && image_early_ok && !tracked.empty()) {  // (see above)
                 rc = fusion_prefetch_image(f, fr->next_rgb, f->tick + 1, true);
                 if (rc) return rc;
-            }
-            static const bool early = std::getenv("MMF_PREFETCH_EARLY") != nullptr;
-            if (early && fr->next_rgb && fr->next_depth && !tracked.empty() && tracked[0]->lane->stream == c->stream &&
-                (tracked.size() == 1 || batch_ok)) {
-                MMF_HIP_TRY(hipEventRecord(f->ev_inputs_free, c->stream));
-                f->inputs_free_recorded = true;
-                inputs_free_early = true;
-                rc = fusion_prefetch_impl(f, fr->next_rgb, fr->next_depth, f->tick + 1);
-                if (rc) return rc;
-                next_prefetched = true;
             }
             stamp(0);
             // a host frame announced for the next call: staged and sent up now, while the GPU tracks and the host would only wait
@@ -1065,7 +1043,6 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // buffer, and the HOST knows it: every chain's result has been received, so every chain -- and whatever its
             // stream held before it, e.g. this frame's own image-side preparation -- has run.  The next frame's side-stream
             // work, enqueued from here on, needs no event to wait for (inputs_free_recorded stays false).
-            (void)inputs_free_early;
             if (one_pass && lanes_wait) MMF_HIP_TRY(hipEventRecord(f->ev_frame_ready, c->stream));
 
             if (g.enable_multiple_models) {  // :407-622
@@ -1223,7 +1200,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                                  only->fill_in ? fusion_thumb_count(m) : nullptr, (const float*)m->fill_vertex,
                                  (const float*)m->fill_normal, (const uint8_t*)m->fill_image, PREP_MODEL_SIDE,
                                  (m->width / 20) * (m->height / 20), 0.75f);
-            rc = stages.launch(st, graphs_enabled() ? &only->odom->prep_graphs : nullptr);
+            rc = stages.launch(st);
             if (rc) return rc;
             only->spec_tex_gen = m->tex_gen;
             only->spec_f2f = g.frame_to_frame_rgb;
@@ -1385,7 +1362,7 @@ extern "C" int mmf_fusion_process_frame_host_next(mmf_fusion* f, const uint8_t* 
     if (int rc = fusion_stage_host_next(f)) return rc;  // (nothing of an earlier announcement is still being staged)
     // what a refilled slot's upload has to wait for: the work enqueued before this call -- nothing, when the last call
     // ended with the host holding a pose from the fusion's stream (every lane joins that stream at the end of a frame)
-    static const bool host_knows = std::getenv("MMF_HOST_UP_EVENTS") == nullptr;
+    const bool host_knows = !tunables().host_up_events;
     const bool after_begin = !(host_knows && f->host_caught_up);
     if (after_begin) MMF_HIP_TRY(hipEventRecord(f->ev_up_begin, c->stream));
     int slot;
@@ -1487,7 +1464,7 @@ static int fusion_prefetch_image(mmf_fusion* f, const uint8_t* rgb, int tick_at_
     identity16(identity);
     hipStream_t img_stream = f->side2;
     if (!ahead && f->inputs_free_recorded) MMF_HIP_TRY(hipStreamWaitEvent(img_stream, f->ev_inputs_free, 0));
-    Enqueuer qi(img_stream, graphs_enabled() ? &f->image_chain_graphs : nullptr);
+    Enqueuer qi(img_stream);
     int rc = odom_prepare_batched(odom, nullptr, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity, nullptr,
                                   nullptr, nullptr, nullptr, PREP_INPUT_IMAGE, img_stream, &qi);
     if (rc) return rc;
@@ -1527,7 +1504,7 @@ static int fusion_prefetch_impl(mmf_fusion* f, const uint8_t* rgb, const float* 
     // hence behind ev_inputs_free.  Enqueued before the image chain when that is still to come: it is five launches that
     // start with the 40 us filter, the image chain fifteen short ones.
     float* target = f->filtered[1 - f->cur];
-    Enqueuer qd(f->side, graphs_enabled() ? &f->depth_chain_graphs : nullptr);
+    Enqueuer qd(f->side);
     int rc = filter_depth_on(c, qd, depth, f->width, f->height, g.depth_cutoff, target);
     if (rc) return rc;
     rc = odom_prepare_batched(odom, target, g.max_depth_processed, rgb, 3, nullptr, nullptr, nullptr, 4, identity, nullptr,

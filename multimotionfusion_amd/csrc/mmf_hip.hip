@@ -29,6 +29,7 @@
 #include "prep_batch.hpp"
 #include "pose_algebra.hpp"
 #include "track_kernels.hpp"
+#include "tunables.hpp"
 #include "gn_fused.hpp"
 
 using namespace mmf;
@@ -101,6 +102,7 @@ extern "C" int mmf_ctx_create(int device, void* stream, int private_stream, mmf_
         return fail(MMF_ERR_NO_DEVICE, "mmf_ctx_create: no HIP device visible");
     MMF_REQUIRE(device >= 0 && device < count, "mmf_ctx_create: device index out of range");
     MMF_HIP_TRY(hipSetDevice(device));
+    (void)tunables();  // the environment switches are read here, once
     mmf_ctx* c = new (std::nothrow) mmf_ctx();
     MMF_REQUIRE(c != nullptr, "mmf_ctx_create: out of host memory");
     c->device = device;
@@ -199,11 +201,8 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // icp_kernel2 lands within 0.2 us at 640x480 (the launch is bound by its two memory round trips
 // and the dispatch floor, no longer by instruction issue), so one default serves all levels.
 static int icp_default_variant(int /*npix*/) {
-    static const int forced = [] {  // tuning aid: MMF_ICP_VARIANT=<GEN*1000000 + PX*10000 + BLOCK>
-        const char* e = std::getenv("MMF_ICP_VARIANT");
-        return e ? std::atoi(e) : 0;
-    }();
-    return forced ? forced : 2020256;
+    const int forced = tunables().icp_variant;  // tuning aid: MMF_ICP_VARIANT=<GEN*1000000 + PX*10000 + BLOCK>
+    return forced > 0 ? forced : 2020256;
 }
 
 template <int W, int NV, int BLOCK, bool PACKED, int MODE>
@@ -730,22 +729,8 @@ extern "C" int mmf_compute_derivative_images(mmf_ctx* c, const uint8_t* src, siz
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxTimedLaunches = 48;  // 19 iterations x (producer + step)
 
-// MMF_GRAPHS=1 sends the launch chains (preparation, Gauss-Newton chain, the two prefetch chains) as hipGraph replays
-// (launch_graph.hpp).  Off by default: measured on MI355X the host enqueues a chain in 44-127 us instead of 135-177 us,
-// but the GPU is what a frame waits for, and each graph launch starts ~10 us later than the first kernel of a
-// launch-by-launch chain does: first kernel .. chain end 362-366 us vs 341-343 us, frame 0.550-0.575 vs 0.517-0.525 ms.
-static bool graphs_enabled() {
-    static const bool on = []() {
-        const char* v = std::getenv("MMF_GRAPHS");
-        return v && v[0] && v[0] != '0';
-    }();
-    return on;
-}
-
 struct mmf_odom {
     mmf_ctx* ctx = nullptr;
-    GraphCache gn_graphs;    // the Gauss-Newton chain of odom_enqueue_tracking (launch_graph.hpp)
-    GraphCache prep_graphs;  // the model-side preparation launches in front of it (fusion_orchestrator.hpp)
     int width = 0, height = 0;
     float cx = 0, cy = 0, fx = 0, fy = 0;
     float dist_thres = 0, angle_thres = 0;
@@ -1099,8 +1084,8 @@ extern "C" int mmf_odom_init_first_rgb(mmf_odom* o, const uint8_t* rgb, size_t s
 
 // ---- the whole per-frame preparation in four launches (prep_batch.hpp) -------------------------
 static size_t prep_big_job() {  // pixels from which a job's workgroups take four tiles each; MMF_PREP_BIG=0: never
-    static const size_t n = []() { const char* e = std::getenv("MMF_PREP_BIG"); return e ? (std::atol(e) > 0 ? (size_t)std::atol(e) : ~(size_t)0) : (size_t)200000; }();
-    return n;
+    const long n = tunables().prep_big;
+    return n < 0 ? (size_t)200000 : (n > 0 ? (size_t)n : ~(size_t)0);
 }
 struct PrepBuilder {  // the jobs of one stage (possibly of several models); launched kMaxPrepJobs at a time
     std::vector<PrepJob> jobs;
@@ -1144,8 +1129,8 @@ struct PrepStages {  // the four dependent launches of a frame's preparation
             if (int rc = pb.launch(q)) return rc;
         return MMF_OK;
     }
-    int launch(hipStream_t stream, GraphCache* cache = nullptr) {
-        Enqueuer q(stream, cache);
+    int launch(hipStream_t stream) {
+        Enqueuer q(stream);
         if (int rc = launch(q)) return rc;
         MMF_HIP_TRY(q.flush());
         return MMF_OK;
@@ -1179,17 +1164,17 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     // The coarsest level's model-side products (transformed + packed maps, point cloud) are computed in the SAME stage as
     // its pyramid step, from the level above (PREP_RESIZE_TP, PREP_PYR_PROJECT): the model side is three dependent launches
     // instead of four.  MMF_PREP_MERGE=0: the four-stage form (A/B aid).
-    static const bool merge_last = []() { const char* e = std::getenv("MMF_PREP_MERGE"); return !e || std::atoi(e) != 0; }();
+    const bool merge_last = tunables().prep_merge != 0;
     // ... and level 0 and the first pyramid step are computed straight from the prediction's images (PREP_TEX_*): two
     // dependent launches.  MMF_PREP_MERGE=1: only the last stage merged (A/B aid).
-    static const bool merge_first = []() { const char* e = std::getenv("MMF_PREP_MERGE"); return !e || std::atoi(e) >= 2; }();
+    const bool merge_first = tunables().prep_merge >= 2;
     // The model maps in the global frame go out as the packed records (and {X, Y, Z, 1/Z} point records) the chains gather
     // from; the planar copies and the AoS cloud of the first-generation kernels (25 -> 14 MB written per frame at level 0)
     // only for the first-generation ICP kernel (MMF_ICP_VARIANT 1xxxxxx) or on request: MMF_PREP_PLANAR=1.
-    static const bool planar = []() { const char* e = std::getenv("MMF_PREP_PLANAR"); return (e && e[0] != '0') || icp_default_variant(0) / 1000000 == 1; }();
+    const bool planar = tunables().prep_planar || icp_default_variant(0) / 1000000 == 1;
     // The sensor frame's normal map of a level is computed in the same job as its vertex map, from the depth image
     // (PREP_VMAP_NMAP): the depth side is three dependent launches instead of four.  MMF_PREP_VN=0: apart (A/B aid).
-    static const bool merge_vn = []() { const char* e = std::getenv("MMF_PREP_VN"); return !e || e[0] != '0'; }();
+    const bool merge_vn = tunables().prep_vn;
     auto intr_f = [&](PrepJob& j, int lvl, bool cutoff_too, float cutoff) {
         const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, lvl);
         j.f[0] = 1.f / in.fx, j.f[1] = 1.f / in.fy, j.f[2] = in.cx, j.f[3] = in.cy;
@@ -1314,7 +1299,7 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
         // The model side's level-0 products come straight from the prediction's images (merge_first) and nothing of the
         // preparation reads them: they go into the LAST of its two launches, beside the small jobs of levels 1 and 2, and the
         // first launch is the three quarter-size pyramid jobs alone (MMF_PREP_L0_LATE=0: in the first, as before).
-        static const bool l0_late = []() { const char* e = std::getenv("MMF_PREP_L0_LATE"); return !e || e[0] != '0'; }();
+        const bool l0_late = tunables().prep_l0_late;
         level_jobs(model_side && merge_first && merge_last && l0_late && !in_img && !in_depth ? stages.stage[2] : pb, 0);
         down_jobs(pb, 1, nullptr);
     }
@@ -1430,28 +1415,20 @@ struct GnGeometry {
     int px, lanes, threads, groups;
 };
 static bool gn_geometry(int level, int cols, int rows, GnGeometry* out) {
-    static const std::array<int, 3> forced = []() {
-        std::array<int, 3> f{{0, 0, 0}};
-        if (const char* e = std::getenv("MMF_GN_PX")) std::sscanf(e, "%d,%d,%d", &f[0], &f[1], &f[2]);
-        return f;
-    }();
-    static const int max_groups = []() { const char* e = std::getenv("MMF_GN_GROUPS"); return e ? std::atoi(e) : 256; }();
+    const int* forced = tunables().gn_px;
+    const int max_groups = tunables().gn_groups;
     const int n = cols * rows;
     const int want = (level >= 0 && level < 3) ? forced[level] : 0;
     // a lane's pixels lie in one row; the window words are 4-byte aligned columns
     auto allowed = [&](int px) { return cols % px == 0 && cols % 4 == 0 && (!(want == 1 || want == 2 || want == 4 || want == 5) || px == want); };
     static const int kPx[4] = {1, 2, 4, 5};
-    static const int lanes_env = []() { const char* e = std::getenv("MMF_GN_LANES"); return e ? std::atoi(e) : 0; }();
-    for (int pass = 0; pass < 2; ++pass)
-        for (int k = 0; k < 4; ++k) {  // four pixel waves per workgroup (MMF_GN_LANES: first try that many lanes)
-            const int px = kPx[k];
-            const int wl = pass == 0 ? lanes_env : kBlock;
-            if (wl < 64 || wl % 64) continue;
-            const int groups = (n / px + wl - 1) / wl;
-            if (!allowed(px) || groups > max_groups || groups > kGnMaxGroups) continue;
-            *out = GnGeometry{px, wl, wl + 64, groups};
-            return true;
-        }
+    for (int k = 0; k < 4; ++k) {  // four pixel waves per workgroup (three, 192 lanes: no different, tools/ab_env.sh)
+        const int px = kPx[k];
+        const int groups = (n / px + kBlock - 1) / kBlock;
+        if (!allowed(px) || groups > max_groups || groups > kGnMaxGroups) continue;
+        *out = GnGeometry{px, kBlock, kBlock + 64, groups};
+        return true;
+    }
     for (int k = 3; k >= 0; --k) {  // larger workgroups, as few of them as the limit asks for
         const int px = kPx[k];
         if (!allowed(px)) continue;
@@ -1522,7 +1499,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[0], c->stream));
     // from here to the last step: kernels only, all on the fused-producer path when `odom_batchable` -- recorded and
     // sent as one graph launch (launch_graph.hpp).  The measurement modes and the other paths launch one by one.
-    Enqueuer q(c->stream, (graphs_enabled() && !o->timing && odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom)) ? &o->gn_graphs : nullptr);
+    Enqueuer q(c->stream);
     q.launch(odom_begin_kernel, dim3(ny), dim3(64), o->state, b, bd, poses);
 
     o->retry_so3_prefetched = o->so3_prefetched, o->retry_so3_stage = o->so3_stage;  // (odom_retrack_prepare)
@@ -1542,8 +1519,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
         bool first = true;
         GnIterArgs a;
         std::memset(&a, 0, sizeof(a));
-        static const int poll_sleep = []() { const char* e = std::getenv("MMF_GN_SLEEP"); return e ? std::atoi(e) : 1; }();
-        a.poll_sleep = poll_sleep;
+        a.poll_sleep = tunables().gn_sleep;
         a.max_polls = kGnMaxPolls;
         bool force_fault = false;
         for (int n = g_gn_force_fault.load(); n > 0 && !force_fault;) force_fault = g_gn_force_fault.compare_exchange_weak(n, n - 1);
@@ -1830,8 +1806,7 @@ extern "C" int mmf_gn_chain_status(int* recoveries, int* one_launch_chain_in_use
     return MMF_OK;
 }
 static unsigned fused_max_models() {  // MMF_GN_FUSED_MAX: up to how many models one one-launch chain carries
-    static const unsigned n = []() { const char* e = std::getenv("MMF_GN_FUSED_MAX"); return e ? (unsigned)std::max(1, std::atoi(e)) : 3u; }();
-    return n;
+    return (unsigned)tunables().gn_fused_max;
 }
 // How many workgroups of gn_iter_kernel<px, .> with `threads` threads the device holds at once: the occupancy the runtime
 // reports for the kernel (registers, LDS) x the compute units.  The launch spins on its own workgroups (count barrier), so a
@@ -1858,10 +1833,7 @@ static long long gn_resident_groups(mmf_ctx* c, int px, int threads) {
     return (long long)it->second * c->cu_count;
 }
 static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom, int models) {
-    static const bool env_enabled = []() {
-        const char* v = std::getenv("MMF_GN_FUSED");
-        return !(v && v[0] == '0');
-    }();
+    const bool env_enabled = tunables().gn_fused;
     const int forced = g_gn_fused.load();
     const bool enabled = (forced < 0 ? env_enabled : forced != 0) && o->exclusive_chain && !g_gn_latched_off.load();
     const bool icp = !rgb_only && icp_weight > 0, rgb = rgb_only || icp_weight < 100;
@@ -2349,7 +2321,7 @@ static int filter_depth_on(mmf_ctx* c, Enqueuer& q, const float* depth, int cols
 }
 static int filter_depth_on(mmf_ctx* c, hipStream_t stream, const float* depth, int cols, int rows, float max_depth,
                            float* out) {
-    Enqueuer q(stream, nullptr);
+    Enqueuer q(stream);
     if (int rc = filter_depth_on(c, q, depth, cols, rows, max_depth, out)) return rc;
     MMF_HIP_TRY(q.flush());
     return MMF_OK;
@@ -2441,8 +2413,7 @@ static unsigned* model_thumb_counts(mmf_model* m) { return &m->totals[4]; }
 // latency of its per-row LDS searches and ray look-ups hidden: 2048 workgroups (124 -> 107 us on 740 k stable surfels at
 // 640x480, tools/mature_splat_probe.py; +1 % on the headline loop's 250 k)
 static dim3 splat_grid(size_t bound, bool deep = false) {
-    static const unsigned wgs_env = []() { const char* e = std::getenv("MMF_SPLAT_WGS"); return e ? (unsigned)std::max(1, std::atoi(e)) : 0u; }();
-    const unsigned wgs = wgs_env ? wgs_env : (deep ? 2048u : 512u);
+    const unsigned wgs = tunables().splat_wgs > 0 ? (unsigned)tunables().splat_wgs : (deep ? 2048u : 512u);
     const size_t one_per_thread = (bound + 255) / 256;
     return dim3((unsigned)std::max<size_t>(1, std::min<size_t>(one_per_thread, wgs)));
 }
@@ -2457,7 +2428,7 @@ extern "C" int mmf_debug_splat_counts(unsigned long long out[4], int reset) {
     return MMF_OK;
 }
 #endif
-static std::atomic<int> g_splat_bound{[]() { const char* e = std::getenv("MMF_SPLAT_BOUND"); return e ? (std::atoi(e) ? 1 : 0) : -1; }()};  // -1: by the surfel count; 0 / 1: mmf_debug_set_splat_bound (tests compare the two), MMF_SPLAT_BOUND (A/B runs)
+static std::atomic<int> g_splat_bound{-2};  // -2: what the environment says (MMF_SPLAT_BOUND), else by the surfel count; -1 / 0 / 1: mmf_debug_set_splat_bound
 extern "C" int mmf_debug_set_splat_bound(int mode) {
     g_splat_bound.store(mode < 0 ? -1 : (mode ? 1 : 0));
     return MMF_OK;
@@ -2484,7 +2455,7 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     const unsigned launch_count = m->count_pending ? m->count_bound : m->count;
     // a DEEP store (two surfels per pixel and more: occluded layers) takes the bounded depth test (surfel_kernels.hpp,
     // splat_bound_kernel): one more launch, a fraction of the fragments and of their atomics.  Same images either way.
-    const int bound_mode = g_splat_bound.load();
+    const int bound_mode = g_splat_bound.load() == -2 ? tunables().splat_bound : g_splat_bound.load();
     const size_t npix_s = (size_t)m->width * m->height;
     const bool deep_store = (size_t)launch_count >= 2 * npix_s;
     const bool deep = bound_mode < 0 ? deep_store : bound_mode != 0;

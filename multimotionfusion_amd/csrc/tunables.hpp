@@ -1,0 +1,69 @@
+// tunables.hpp -- every environment switch of the library, read ONCE (the first mmf_ctx_create) into one struct.
+// None changes a result: they select between bit-identical ways of scheduling the same work (A/B aids, measured in
+// LABNOTES.md) or size a launch.  Defaults are the shipped configuration.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace mmf {
+
+struct Tunables {
+    // ---- Gauss-Newton chain (gn_fused.hpp, mmf_hip.hip: gn_geometry, odom_fused_chain_ok) ----
+    bool gn_fused = true;     // MMF_GN_FUSED=0: always the two-launch chain (producer + step)
+    int gn_fused_max = 3;     // MMF_GN_FUSED_MAX: models one one-launch chain carries (gridDim.y)
+    int gn_px[3] = {0, 0, 0}; // MMF_GN_PX="p0,p1,p2": pixels per lane of a level (0 = by geometry)
+    int gn_groups = 256;      // MMF_GN_GROUPS: workgroups per model per launch at most
+    int gn_sleep = 1;         // MMF_GN_SLEEP: s_sleep(1) repetitions between two polls of the count barrier
+    int icp_variant = -1;     // MMF_ICP_VARIANT: shape of the stand-alone ICP kernel (-1 = by size)
+    // ---- preparation jobs (prep_batch.hpp) ----
+    int prep_merge = 2;       // MMF_PREP_MERGE=0|1|2: four / three / two model-side preparation stages
+    bool prep_vn = true;      // MMF_PREP_VN=0: a level's vertex and normal maps as two jobs
+    bool prep_l0_late = true; // MMF_PREP_L0_LATE=0: the model side's level-0 jobs in its first launch
+    long prep_big = -1;       // MMF_PREP_BIG=<pixels>|0: from how many pixels a job's workgroups take four tiles each
+    bool prep_planar = false; // MMF_PREP_PLANAR=1: also write the planar model maps and the AoS point cloud
+    // ---- orchestrator (fusion_orchestrator.hpp) ----
+    int early_image = 2;      // MMF_EARLY_IMAGE=start|chain|off: where the next frame's image side is enqueued
+    bool fuse_index = true;   // MMF_FUSE_INDEX=0: fuse's update pass and the index map's projection as two launches
+    bool host_up_events = false;  // MMF_HOST_UP_EVENTS=1: host frames: always order a ring slot's upload by events
+    bool host_trace = false;  // MMF_HOST_TRACE=1: the calling thread's timeline (stderr, every 100 calls)
+    // ---- surfel passes ----
+    int splat_wgs = 0;        // MMF_SPLAT_WGS: workgroups of a splat launch (0 = by the store's size)
+    int splat_bound = -1;     // MMF_SPLAT_BOUND=0|1: the bounded depth test never / always (-1 = by the store's size)
+};
+
+inline const Tunables& tunables() {
+    static const Tunables t = []() {
+        Tunables v;
+        auto flag = [](const char* name, bool dflt) {
+            const char* e = std::getenv(name);
+            return e ? (e[0] != '0' && e[0] != '\0') : dflt;
+        };
+        auto num = [](const char* name, long dflt) {
+            const char* e = std::getenv(name);
+            return e ? std::atol(e) : dflt;
+        };
+        v.gn_fused = flag("MMF_GN_FUSED", true);
+        v.gn_fused_max = (int)num("MMF_GN_FUSED_MAX", 3);
+        if (v.gn_fused_max < 1) v.gn_fused_max = 1;
+        if (const char* e = std::getenv("MMF_GN_PX")) std::sscanf(e, "%d,%d,%d", &v.gn_px[0], &v.gn_px[1], &v.gn_px[2]);
+        v.gn_groups = (int)num("MMF_GN_GROUPS", 256);
+        v.gn_sleep = (int)num("MMF_GN_SLEEP", 1);
+        v.icp_variant = (int)num("MMF_ICP_VARIANT", -1);
+        v.prep_merge = (int)num("MMF_PREP_MERGE", 2);
+        v.prep_vn = flag("MMF_PREP_VN", true);
+        v.prep_l0_late = flag("MMF_PREP_L0_LATE", true);
+        v.prep_big = num("MMF_PREP_BIG", -1);
+        v.prep_planar = flag("MMF_PREP_PLANAR", false);
+        if (const char* e = std::getenv("MMF_EARLY_IMAGE")) v.early_image = std::strcmp(e, "off") == 0 ? 0 : (std::strcmp(e, "chain") == 0 ? 1 : 2);
+        v.fuse_index = flag("MMF_FUSE_INDEX", true);
+        v.host_up_events = flag("MMF_HOST_UP_EVENTS", false);
+        v.host_trace = flag("MMF_HOST_TRACE", false);
+        v.splat_wgs = (int)num("MMF_SPLAT_WGS", 0);
+        if (std::getenv("MMF_SPLAT_BOUND")) v.splat_bound = num("MMF_SPLAT_BOUND", 0) ? 1 : 0;
+        return v;
+    }();
+    return t;
+}
+
+}  // namespace mmf

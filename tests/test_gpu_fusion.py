@@ -387,45 +387,6 @@ def test_cpp_function_level_shim_on_the_device(tmp_path):
 
 
 @pytest.mark.gpu
-def test_graph_replay_gives_the_same_bits():
-    """MMF_GRAPHS=1 (csrc/launch_graph.hpp): the preparation, Gauss-Newton and prefetch launch chains go out as hipGraph
-    replays with per-frame argument updates -- same kernels, same arguments, so poses and surfels must not change.
-    (The switch is read once per process: two child processes.)"""
-    import hashlib  # noqa: F401
-    import os
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = (
-        "import sys, hashlib, numpy as np, torch\n"
-        f"sys.path.insert(0, {repo!r})\n"
-        "from multimotionfusion_amd import synth\n"
-        "from multimotionfusion_amd.cudafuncs import Context\n"
-        "from multimotionfusion_amd.fusion import MultiMotionFusion\n"
-        "w, h, n = 320, 240, 8\n"
-        "K = synth.intrinsics(w, h)\n"
-        "poses = synth.trajectory(n, seed=21)\n"
-        "fr = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]\n"
-        "up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
-        "rgb, depth = [up(f['rgb']) for f in fr], [up(f['depth']) for f in fr]\n"
-        "ctx = Context(0)\n"
-        "g = MultiMotionFusion(ctx, w, h, K['cx'], K['cy'], K['fx'], K['fy'])\n"
-        "hh = hashlib.sha256()\n"
-        "for i in range(n):\n"
-        "    g.processFrame(rgb[i], depth[i], timestamp=i, next=(rgb[i + 1], depth[i + 1]) if i + 1 < n else None)\n"
-        "    hh.update(np.ascontiguousarray(g.getCurrPose()).tobytes())\n"
-        "hh.update(np.ascontiguousarray(g.getBackgroundModel().downloadMap()).tobytes())\n"
-        "print('digest', hh.hexdigest())\n")
-    out = []
-    for graphs in ("0", "1"):
-        env = dict(os.environ, MMF_GRAPHS=graphs)
-        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=env)
-        assert r.returncode == 0, r.stderr[-2000:]
-        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0])
-    assert out[0] == out[1]
-
-
-@pytest.mark.gpu
 def test_end_of_frame_model_preparation_is_dropped_when_its_inputs_change(gpu_ctx, orc):
     """processFrame prepares the model side of the next frame's tracking at its end (from the final prediction and the
     tracked pose).  That work must only be used if nothing changed in between: a pose set by the caller (checked against
