@@ -476,6 +476,13 @@ int mmf_fusion_set_model_pose(mmf_fusion *f, int index, const float pose[16]);
  *   mmf_shard_gather_poses_begin / _end   the same exchange without stalling a frame: _begin enqueues it (pinned
  *                        buffers, an event, no synchronisation), _end waits for the OLDEST one in flight and applies it
  *                        (call it one or two frames later; up to three may be in flight)
+ *                        STALENESS CONTRACT: a rank's copy of a model it does not own carries the pose of the newest
+ *                        exchange that rank has applied -- the current frame's under the blocking form, one to three frames
+ *                        old under _begin / _end.  Nothing on the data path reads those copies (a rank tracks and fuses its
+ *                        own models only).  The pose log (mmf_fusion_pose_log / export_poses) is written by a model's OWNER
+ *                        only; an object model's entry is global_pose * inverse(pose) (MultiMotionFusion.cpp:829-846) with
+ *                        the global pose as that rank holds it, so on ranks other than the global model's it is exact only
+ *                        under the blocking form.
  *   mmf_shard_gather_maps      what the segmentation reads of every model (Segmentation.cpp:214-223): the ICP-error image
  *                        and the confidence channel of the splat's vertex image, averaged per super-pixel
  *                        (mmf_slic_downsample) where the model lives and all-gathered: out_dev[n_models][2][nspix] on every

@@ -549,7 +549,7 @@ static void odom_alias_sensor_side(mmf_odom* o, const mmf_odom* primary) {
 
 // the covered thumbnail samples of a model's latest prediction (thumbnail_count_px)
 static const int* fusion_thumb_count(const mmf_model* m) {
-    return reinterpret_cast<const int*>(&m->totals[4 + (m->tex_gen & 1)]);
+    return reinterpret_cast<const int*>(&m->totals[4 + (m->thumb_gen & 1)]);
 }
 
 // Model::combinedPredict(ACTIVE) + Model::performFillIn of one model (the body of predict(), :863-875)
@@ -1153,6 +1153,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     for (size_t k = 0; k < f->models.size(); ++k) {
         FusionModel* fm = f->models[k];
         if (fm->pose_log.capacity() == 0) continue;  // isLoggingPoses()
+        // sharded: a model is logged by the rank that runs it -- the copies other ranks keep as bookkeeping hold poses that
+        // arrive with the exchange, one to three frames late under mmf_shard_gather_poses_begin / _end (mmf_hip.h)
+        if (f->shard_world > 1 && !fusion_owns(f, k)) continue;
         float T[16];
         if (k == 0) {
             std::memcpy(T, global_pose, sizeof(T));

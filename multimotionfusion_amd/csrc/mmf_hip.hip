@@ -2083,6 +2083,9 @@ struct mmf_model {
     float max_depth = FLT_MAX;  // Model::maxDepth (Model.h:129, set per object from the segmentation: MultiMotionFusion.cpp:486,586)
     int capacity = 0;
     unsigned long long tex_gen = 0;    // bumped by every pass that rewrites the prediction / fill-in images
+    // generation of the thumbnail counters (thumbnail_count_px): bumped only by the resolve passes that count into them, so that
+    // a stand-alone performFillIn (which rewrites images but counts nothing) cannot flip the slot a reader looks at
+    unsigned long long thumb_gen = 0;
     const float* pose_dev = nullptr;    // likewise the pose itself and computeFusionWeight(1) (OdomState::pose_out,
     const float* weight_dev = nullptr;  // fusion_weight) for a fuse pass; `weighting` is then the multiplier
     const int* abort_dev = nullptr;    // ... and the word that tells such a pass that the result it would read is void (MMF_SPECULATION_GUARD)
@@ -2406,7 +2409,7 @@ extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cut
     return model_predict_indices(m, time, depth_cutoff, time_delta, false);
 }
 
-// the two thumbnail counters of thumbnail_count_px (surfel_kernels.hpp): the count of the latest prediction is [tex_gen & 1]
+// the two thumbnail counters of thumbnail_count_px (surfel_kernels.hpp): the count of the latest prediction is [thumb_gen & 1]
 static unsigned* model_thumb_counts(mmf_model* m) { return &m->totals[4]; }
 // splat_kernel's launch: a fixed number of workgroups that deal the surfels out among their waves (surfel_kernels.hpp)
 // 512 workgroups = two waves per SIMD for a small store (an object model); a store of a surfel per pixel and more needs the
@@ -2441,6 +2444,7 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     mmf_ctx* c = m->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
     ++m->tex_gen;
+    ++m->thumb_gen;
     SplatArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
     a.t_inv_dev = m->t_inv_dev;
@@ -2471,10 +2475,10 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
         hipLaunchKernelGGL(splat_resolve_fill_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0,
                            c->stream, m->set[m->cur], a, m->keys, m->image, m->vertexConf, m->normalRadius, m->time_tex, fill_depth,
                            fill_rgb, lost ? 1 : 0, (lost || frame_to_frame_rgb) ? 1 : 0, m->fill_vertex, m->fill_normal,
-                           m->fill_image, model_thumb_counts(m), (int)(m->tex_gen & 1));
+                           m->fill_image, model_thumb_counts(m), (int)(m->thumb_gen & 1));
     } else
         hipLaunchKernelGGL(splat_resolve_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys, m->image,
-                           m->vertexConf, m->normalRadius, m->time_tex, model_thumb_counts(m), (int)(m->tex_gen & 1));
+                           m->vertexConf, m->normalRadius, m->time_tex, model_thumb_counts(m), (int)(m->thumb_gen & 1));
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }

@@ -234,3 +234,29 @@ def test_a_rank_holds_no_store_for_models_it_does_not_own(gpu_ctx):
     frame_bytes = 4 * w * h * 8  # the frames uploaded after the first one, in both runs
     assert full > 3 * 100e6  # three object models with stores, odometry slabs, streams
     assert lean < frame_bytes + 16e6, (full, lean)
+
+
+def test_a_model_is_logged_by_the_rank_that_runs_it(gpu_ctx):
+    """Round-3 advisor finding: every rank wrote pose-log entries for every model, from bookkeeping copies that the asynchronous
+    exchange fills one to three frames late.  A rank logs the models it runs and nothing else (mmf_hip.h, staleness contract)."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    w, h, n = 320, 240, 5
+    K = synth.intrinsics(w, h)
+    poses = synth.trajectory(n, seed=1)
+    objs = synth.make_objects(1, seed=2)
+    traj = synth.object_trajectories(objs, n, seed=2)
+    frames = [synth.render(poses[i], w, h, seed=i, objects=objs, object_poses=[t[i] for t in traj]) for i in range(n)]
+    logs = {}
+    for rank in (0, 1):
+        g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1, pose_logging=1)
+        g.setShard(rank, 2)
+        keep = []
+        for i in range(n):
+            ids = frames[i]["ids"]
+            keep.append((dev(frames[i]["rgb"]), dev(frames[i]["depth"]), dev(np.where(ids <= min(i, 1), ids, 0).astype(np.uint8))))
+            g.processFrame(keep[-1][0], keep[-1][1], timestamp=i, mask=keep[-1][2], hasNewLabel=i == 1)
+        assert len(g.getModels()) == 2
+        logs[rank] = [len(g.getPoseLog(k)[0]) for k in range(2)]
+        g.close()
+    assert logs[0][0] == n and logs[0][1] == 0, logs  # rank 0 runs the static scene
+    assert logs[1][0] == 0 and logs[1][1] > 0, logs   # rank 1 runs the object
