@@ -36,7 +36,7 @@
 #include "track_kernels.hpp"
 
 #ifndef MMF_ABL
-#define MMF_ABL 0  // diagnostic builds only (tools/gn_floor_probe.sh): 64 = the dependent phases alone, no pixel work
+#define MMF_ABL 0  // diagnostic builds only (tools/gn_floor_probe.sh): 64 = the dependent phases alone, no pixel work; + 4096 = no solve either
 #endif
 
 namespace mmf {
@@ -172,13 +172,15 @@ __device__ __forceinline__ void gn_first_pose(OdomState* st, GnLds& lds, bool le
 __device__ __forceinline__ void gn_solve_rows(const double* A_lds, const double* rt_old, const float* sf, const LevelIntr& in,
                                               double ifx, double ify, int lane, double* xch, float* pose, double (&nr)[4]) {
 #pragma clang fp contract(fast)
+    if (MMF_ABL & 4096) {
+        if (lane < 24) pose[lane] = (lane % 4 == 0 ? 1.f : 0.f) + (float)A_lds[lane] * 1e-30f;
+        for (int c = 0; c < 4; ++c) nr[c] = rt_old[c];
+        return;
+    }
     double A[36], b[6], result[6];
     for (int k = 0; k < 36; ++k) A[k] = A_lds[k];
     for (int k = 0; k < 6; ++k) b[k] = A_lds[36 + k];
     MMF_SOLVE_STAMP(1);
-    if (MMF_ABL & 256) {
-        for (int k = 0; k < 6; ++k) result[k] = b[k] * 1e-12 + A[k * 7] * 1e-14;
-    } else
     ldlt_solve_recip<6>(A, b, result);
     MMF_SOLVE_STAMP(2);
     const int r = lane < 3 ? lane : 0;
@@ -193,7 +195,7 @@ __device__ __forceinline__ void gn_solve_rows(const double* A_lds, const double*
             vx *= itheta, vy *= itheta, vz *= itheta;
             cc = cos(theta), ca = sin(theta), cb = 1. - cc;
         }
-    } else if (!(MMF_ABL & 512) && y >= DBL_EPSILON * DBL_EPSILON) {
+    } else if (y >= DBL_EPSILON * DBL_EPSILON) {
         ca = 1.0 + y * (-1.0 / 6 + y * (1.0 / 120 + y * (-1.0 / 5040 + y * (1.0 / 362880 + y * (-1.0 / 39916800 + y * (1.0 / 6227020800.0))))));
         cb = 0.5 + y * (-1.0 / 24 + y * (1.0 / 720 + y * (-1.0 / 40320 + y * (1.0 / 3628800 + y * (-1.0 / 479001600 + y * (1.0 / 87178291200.0))))));
         cc = 1.0 - cb * y;
@@ -248,7 +250,7 @@ __device__ __forceinline__ void gn_solve_rows(const double* A_lds, const double*
         const double b0 = xch[0 * 4 + cb2], b1 = xch[1 * 4 + cb2], b2 = xch[2 * 4 + cb2];
         const double c00 = N[5] * N[10] - N[6] * N[9], c01 = N[6] * N[8] - N[4] * N[10], c02 = N[4] * N[9] - N[5] * N[8];
         const double det = N[0] * c00 + N[1] * c01 + N[2] * c02;
-        const double id = (MMF_ABL & 1024) ? 1.0 + det * 1e-12 : tail_rcp(det);
+        const double id = tail_rcp(det);
         // inverse[r][j] = (m[(j+1)%3][(r+1)%3] m[(j+2)%3][(r+2)%3] - m[(j+1)%3][(r+2)%3] m[(j+2)%3][(r+1)%3]) / det
         const double i0 = (a1 * b2 - b1 * a2) * id, i1 = (a2 * b0 - b2 * a0) * id, i2 = (a0 * b1 - b0 * a1) * id;
         const double t3 = -(i0 * N[3] + i1 * N[7] + i2 * N[11]);

@@ -1,8 +1,8 @@
-"""profiles/r03_pmc_summary.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not fit one pass) of
+"""profiles/r04_pmc_summary.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not fit one pass) of
 tools/profile_frames.py: HBM-side traffic per launch of the Gauss-Newton kernel (per pyramid level = per grid size) and of the
 surfel / preparation kernels of a frame.
 
-    python tools/pmc_to_json.py <fetch dir> <write dir> <width> <height> [out.json]
+    python tools/pmc_to_json.py <fetch dir> <write dir> <width> <height> [out.json] [source stamp]
 
 Corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE
 tallies 128-byte read requests at 64 bytes, so it is doubled (calibrated there for 16-B-per-lane streams; round 1 found the
@@ -30,7 +30,8 @@ def load(d):
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
 W, H = int(sys.argv[3]), int(sys.argv[4])
-out = sys.argv[5] if len(sys.argv) > 5 else "profiles/r03_pmc_summary.json"
+out = sys.argv[5] if len(sys.argv) > 5 else "profiles/r04_pmc_summary.json"
+STAMP = sys.argv[6] if len(sys.argv) > 6 else None  # bench.source_stamp() of the kernels that were measured
 CORR = "2 x FETCH_SIZE (gfx950: 128-byte requests tallied at 64 bytes) + WRITE_SIZE, KiB -> bytes"
 recs = []
 
@@ -53,8 +54,8 @@ for kern in PER_KERNEL:
     f = fetch[fetch["Kernel_Name"].str.startswith(kern) & (fetch["Counter_Name"] == "FETCH_SIZE")]["Counter_Value"]
     w = write[write["Kernel_Name"].str.startswith(kern) & (write["Counter_Name"] == "WRITE_SIZE")]["Counter_Value"]
     rec(kern, f, w, level=None)
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/profile_frames.py 30 "
-                     f"{W}x{H} 1 0", "kernels": recs}, open(out, "w"), indent=1)
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/profile_frames.py 60 "
+                     f"{W}x{H} 1 0 headline", "source_stamp": STAMP, "kernels": recs}, open(out, "w"), indent=1)
 for r in recs:
     print(f"{r['kernel']:28s} level {r['level']} launches {r['launches']:4d} fetch {r['FETCH_SIZE_KiB_mean']:9.1f} KiB write "
           f"{r['WRITE_SIZE_KiB_mean']:9.1f} KiB -> {r['traffic_bytes_per_launch'] / 1e6:7.2f} MB per launch")
