@@ -2412,9 +2412,9 @@ extern "C" int mmf_model_predict_indices(mmf_model* m, int time, float depth_cut
 // the two thumbnail counters of thumbnail_count_px (surfel_kernels.hpp): the count of the latest prediction is [thumb_gen & 1]
 static unsigned* model_thumb_counts(mmf_model* m) { return &m->totals[4]; }
 // splat_kernel's launch: a fixed number of workgroups that deal the surfels out among their waves (surfel_kernels.hpp)
-// 512 workgroups = two waves per SIMD for a small store (an object model); a store of a surfel per pixel and more needs the
-// latency of its per-row LDS searches and ray look-ups hidden: 2048 workgroups (124 -> 107 us on 740 k stable surfels at
-// 640x480, tools/mature_splat_probe.py; +1 % on the headline loop's 250 k)
+// 512 workgroups = two waves per SIMD for a small store (an object model); a store of half a surfel per pixel and more
+// needs the latency of its LDS searches and ray look-ups hidden: 2048 workgroups (combinedPredict 55 -> 52 us on the
+// headline loop's 246 k surfels, 124 -> 107 us on 740 k; 1024 / 1280 / 4096: within 1 us of 2048)
 static dim3 splat_grid(size_t bound, bool deep = false) {
     const unsigned wgs = tunables().splat_wgs > 0 ? (unsigned)tunables().splat_wgs : (deep ? 2048u : 512u);
     const size_t one_per_thread = (bound + 255) / 256;
@@ -2469,8 +2469,8 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
         hipLaunchKernelGGL(splat_bound_kernel, grid1d(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
                            m->count_pending ? m->totals : nullptr);
     if (launch_count)
-        hipLaunchKernelGGL(splat_kernel, splat_grid(launch_count, (size_t)launch_count >= npix_s), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
-                           m->keys, m->count_pending ? m->totals : nullptr);
+        hipLaunchKernelGGL(a.zb ? splat_kernel<true> : splat_kernel<false>, splat_grid(launch_count, (size_t)launch_count >= npix_s / 2), dim3(256), 0, c->stream,
+                           m->set[m->cur], (int)launch_count, a, m->keys, m->count_pending ? m->totals : nullptr);
     if (fill_rgb && fill_depth) {  // (a pending frame rider stays for the predictIndices that follows: frame_rider.hpp)
         hipLaunchKernelGGL(splat_resolve_fill_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0,
                            c->stream, m->set[m->cur], a, m->keys, m->image, m->vertexConf, m->normalRadius, m->time_tex, fill_depth,
@@ -2506,7 +2506,7 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
     a.zb = nullptr, a.rays = m->rays;
     if (int rc0 = model_resolve_count(m)) return rc0;
     if (m->count)
-        hipLaunchKernelGGL(splat_kernel, splat_grid(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
+        hipLaunchKernelGGL(splat_kernel<false>, splat_grid(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,
                            m->keys, nullptr);
     hipLaunchKernelGGL(splat_depth_resolve_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys,
                        m->synth_depth);

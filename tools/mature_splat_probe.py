@@ -32,7 +32,8 @@ tick = g.getTick()
 g.close()
 m = Model(ctx, W, H, K["cx"], K["cy"], K["fx"], K["fy"], 0, CONF)
 layers = []
-for step in (0.0, 0.02, 0.04, 0.06):
+NL = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+for step in (0.0, 0.02, 0.04, 0.06)[:NL]:
     cp = base.copy()
     cp[:, :3] += step * cp[:, :3] / np.maximum(np.linalg.norm(cp[:, :3], axis=1, keepdims=True), 1e-6)
     cp[:, 3] = np.maximum(cp[:, 3], 20.0)
