@@ -29,6 +29,9 @@ cd $R
 bash tools/gn_floor_probe.sh > $O/r04_gn_floor_probe.txt 2>&1
 python3 tools/mature_splat_probe.py > $O/r04_mature_splat_probe.txt 2>&1
 python3 tools/host_frames.py > $O/r04_host_frames.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -o /tmp/pipeline_probe tools/pipeline_probe.hip && timeout -k 5 120 /tmp/pipeline_probe > $O/r04_pipeline_probe.txt 2>&1
+bash tools/pmc_kernel.sh splat_kernel "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" > $O/r04_splat_counters.txt 2>&1
+rm -rf $R/gpurun_out/pmck*
 echo "probes done"
 MMF_BENCH_WORKLOAD=config5 python bench.py --no-cpu-baseline --no-extras > $O/r04_bench_config5_n1.json 2>> $O/bench.err
 MMF_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/r04_bench_gloo_n2.json 2>> $O/bench.err
