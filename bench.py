@@ -628,7 +628,7 @@ def main():
             roofline["frac_of_bytes_moved"] = moved / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS
             roofline["note"] = ("achieved / frac credit the launch with the bytes of the three reference functions it replaces (the contract's "
                                 "algorithmic bytes); it moves about half of them (frac_of_bytes_moved). The launch is a chain of dependent "
-                                "latencies (sums -> solve -> search -> count barrier -> rows), not a stream: DESIGN.md section 4c has the phase times")
+                                "latencies (sums -> solve -> search -> count barrier -> rows), not a stream: DESIGN.md section 4.1 has the phase times")
         per_level = {f"l{l}": {"producer_us": tm[f"producer_l{l}"]["mean_us"], "rgb_step_us": tm[f"rgb_step_l{l}"]["mean_us"],
                                "producer_min_us": tm[f"producer_l{l}"]["min_us"], "rgb_step_min_us": tm[f"rgb_step_l{l}"]["min_us"],
                                "producer_GBps": (gn_iter_bytes if fused else producer_bytes)(n0 >> (2 * l)) / max(tm[f"producer_l{l}"]["mean_us"], 1e-9) / 1e3}
