@@ -2431,6 +2431,13 @@ extern "C" int mmf_debug_splat_counts(unsigned long long out[4], int reset) {
     return MMF_OK;
 }
 #endif
+extern "C" int mmf_debug_depth_keys(mmf_ctx* c, const float* z_dev, int n, float max_depth, unsigned* fast_dev, unsigned* divided_dev) {
+    MMF_REQUIRE(c && z_dev && fast_dev && divided_dev && n > 0, "mmf_debug_depth_keys: bad argument");
+    MMF_HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(depth_key_probe_kernel, grid1d((size_t)n), dim3(256), 0, c->stream, z_dev, n, max_depth, fast_dev, divided_dev);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
 static std::atomic<int> g_splat_bound{-2};  // -2: what the environment says (MMF_SPLAT_BOUND), else by the surfel count; -1 / 0 / 1: mmf_debug_set_splat_bound
 extern "C" int mmf_debug_set_splat_bound(int mode) {
     g_splat_bound.store(mode < 0 ? -1 : (mode ? 1 : 0));

@@ -675,17 +675,27 @@ __global__ __launch_bounds__(256) void splat_bound_kernel(SurfelSoA s, int count
 // RN(q + r y) IS the correctly rounded quotient (Markstein's theorem; the division the compiler emits ends in these very
 // steps, after refining a reciprocal that here is a constant of the launch).  Where the theorem does not reach -- quotients
 // in the denormal range -- the + 0.5 of depth24's argument absorbs the difference (checked over all 2^32 inputs for
-// b = 1.4, 6, 9, 10, 24.6, 40: no key differs); an infinite z stays itself.
+// b = 1.4, 6, 9, 10, 24.6, 40 on the CPU: no key differs; on the device for 39 cut-offs between 1e-3 and 1e6:
+// tests/test_gpu_surfel.py); an infinite or overflowing quotient stays what the first product made of it.
 struct SplatDepthScale {
     float b, y;
 };
 __device__ __forceinline__ SplatDepthScale splat_depth_scale(float maxDepth) { return SplatDepthScale{2 * maxDepth, 1.0f / (2 * maxDepth)}; }
 __device__ __forceinline__ unsigned splat_depth24_fast(float z, const SplatDepthScale& d) {
-    float q = z * d.y;
-    const float r = __builtin_fmaf(-d.b, q, z);
-    q = __builtin_fmaf(r, d.y, q);
-    if (!(fabsf(z) <= 3.4028234e38f)) q = z;
+    const float q0 = z * d.y;
+    const float r = __builtin_fmaf(-d.b, q0, z);
+    float q = __builtin_fmaf(r, d.y, q0);
+    if (!(fabsf(q0) <= 3.4028234e38f)) q = q0;  // z infinite or not a number, or a quotient that overflows: inf - inf above
     return depth24(q + 0.5f);
+}
+
+// test hook (mmf_debug_depth_keys): both forms of the depth key for n depths
+__global__ __launch_bounds__(256) void depth_key_probe_kernel(const float* __restrict__ z, int n, float maxDepth, unsigned* __restrict__ fast,
+                                                              unsigned* __restrict__ divided) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    fast[i] = splat_depth24_fast(z[i], splat_depth_scale(maxDepth));
+    divided[i] = splat_depth24(z[i], maxDepth);
 }
 
 // The rasterising pass.  `count_dev` (optional): the exact surfel count where the previous clean pass left it on the device;

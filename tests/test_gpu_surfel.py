@@ -340,3 +340,34 @@ def test_object_model_cycle_bit_exact(gpu_ctx, orc, w, h, obj_id):
         assert_bit_equal(m.texture("normalRadius").cpu().numpy(), nrp, f"splat normalRadius t={t}")
         assert (vcp[..., 2] > 0).sum() > 100
     m.close()
+
+
+@pytest.mark.gpu
+def test_depth_key_without_the_division_is_the_depth_key(gpu_ctx):
+    """combo_splat.frag's depth is (z / (2 maxDepth)) + 0.5; the rasterising pass computes the quotient from a reciprocal of the
+    launch's constant with one correction step (splat_depth24_fast).  Same 24-bit key for every float a depth can be -- random
+    bit patterns (denormals, infinities, NaNs, negatives), the plausible range densely, values around key boundaries -- and for
+    every cut-off, not only the ones a test scene uses."""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    bits = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    dense = rng.uniform(-1.0, 30.0, n).astype(np.float32)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.1754944e-38, 3.4028235e38, -3.4028235e38], np.float32)
+    cutoffs = [0.7, 3.0, 4.5, 5.0, 12.3, 20.0, 100.0] + list(rng.uniform(0.05, 200.0, 24).astype(np.float32)) + \
+              list(np.exp(rng.uniform(np.log(1e-3), np.log(1e6), 8)).astype(np.float32))
+    fast = torch.empty(n, dtype=torch.int32, device="cuda")
+    div = torch.empty(n, dtype=torch.int32, device="cuda")
+    for md in cutoffs:
+        md = float(np.float32(md))
+        # depths whose quotient sits next to a key boundary: (k + 0.5) / 16777215 - 0.5, times 2 maxDepth, +- a few ulps
+        k = rng.integers(0, 1 << 24, n // 4)
+        edge = (((k + 0.5) / 16777215.0 - 0.5) * (2.0 * md)).astype(np.float32)
+        edge = np.concatenate([edge, np.nextafter(edge, np.float32(np.inf)), np.nextafter(edge, np.float32(-np.inf)), edge[: n // 4 - special.size], special])
+        for z in (bits, dense, edge):
+            zd = torch.from_numpy(np.ascontiguousarray(z)).cuda()
+            assert gpu_ctx.lib.mmf_debug_depth_keys(gpu_ctx.handle, zd.data_ptr(), int(zd.numel()), md, fast.data_ptr(), div.data_ptr()) == 0
+            torch.cuda.synchronize()
+            a, b = fast[: zd.numel()].cpu().numpy(), div[: zd.numel()].cpu().numpy()
+            bad = np.nonzero(a != b)[0]
+            assert bad.size == 0, (md, z[bad[:4]], a[bad[:4]], b[bad[:4]])
