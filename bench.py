@@ -335,9 +335,30 @@ def main():
         # backend is RCCL; MMF_BENCH_SHARD=torch keeps them in torch.distributed (the gloo rehearsal's only choice).
         sh = None
         if world > 1 and os.environ.get("MMF_BENCH_SHARD", "rccl" if backend == "nccl" else "torch") == "rccl":
-            uid = [shard.Shard.unique_id(ctx.lib) if rank == 0 else None]
+            # (never run on more than one GPU before the driver's scaling run: if the library's RCCL binding cannot come up
+            # on some rank -- librccl missing, a communicator that does not initialise -- every rank falls back to the
+            # torch.distributed twin of the same two exchanges, and the workload text of the line says which one ran)
+            ok = 1
+            try:
+                uid = [shard.Shard.unique_id(ctx.lib) if rank == 0 else None]
+            except Exception as e:  # noqa: BLE001
+                uid, ok = [None], 0
+                print(f"[bench] rank {rank}: mmf_shard unique id failed: {e}", file=sys.stderr)
             dist.broadcast_object_list(uid, src=0)
-            sh = shard.Shard(ctx, rank, world, uid[0])
+            if uid[0] is not None and ok:
+                try:
+                    sh = shard.Shard(ctx, rank, world, uid[0])
+                except Exception as e:  # noqa: BLE001
+                    ok = 0
+                    print(f"[bench] rank {rank}: mmf_shard over RCCL did not come up: {e}", file=sys.stderr)
+            else:
+                ok = 0
+            flag = torch.tensor([ok], device=dev if backend == "nccl" else "cpu", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if sh is not None:
+                    sh.close()
+                sh = None
 
         class _SlotWait:  # the work-handle shape of the torch path
             def __init__(self, s_, slot):
