@@ -530,6 +530,10 @@ int mmf_debug_set_mid_predict(int on);
  * as a per-pixel bound that lets the splat skip occluded fragments and their atomics; same images).  1 = always, 0 = never,
  * -1 = when the store holds two surfels per pixel or more (the default).  Process wide. */
 int mmf_debug_set_splat_bound(int mode);
+/* test / A-B hook: object models in the producer + step chain (csrc/extent.hpp, ChainGeom: their passes skip the blocks outside
+ * the model's own depth and walk the images with a quarter of the workgroups).  1 = on, 0 = every model is tracked like the
+ * camera model, -1 = the default (MMF_TRACK_CULL, on).  Process wide. */
+int mmf_debug_set_track_cull(int mode);
 /* test hook: the 24-bit depth key of combo_splat.frag's gl_FragDepth for n depths, as the rasterising pass computes it (the
  * division by 2 max_depth as three multiply-adds, csrc/surfel_kernels.hpp: splat_depth24_fast) and with the division */
 int mmf_debug_depth_keys(mmf_ctx *ctx, const float *z_dev, int n, float max_depth, unsigned *fast_dev, unsigned *divided_dev);

@@ -210,6 +210,7 @@ SIGNATURES = {
     "mmf_debug_force_gn_fault": (_i, [_i]),
     "mmf_gn_chain_status": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "mmf_debug_set_splat_bound": (_i, [_i]),
+    "mmf_debug_set_track_cull": (_i, [_i]),
     "mmf_debug_depth_keys": (_i, [_vp, _vp, _i, _f, _vp, _vp]),
     "mmf_fusion_set_shard": (_i, [_vp, _i, _i]),
     "mmf_fusion_owns_model": (_i, [_vp, _i]),

@@ -70,6 +70,7 @@ struct mmf_fusion {
     uint8_t* mask = nullptr;          // textures[MASK]: all zeros unless enableMultipleModels
     bool mask_is_zero = false;
     int tick = 1;                     // MultiMotionFusion.cpp:36
+    unsigned extent_seq = 0;          // number of the frame whose model-side preparation notes extents (extent.hpp): only ever grows
     int tracking_ok = 1;
     const uint8_t* frame_rgb = nullptr;  // this frame's inputs (device), kept for predict()
     const float* frame_depth = nullptr;
@@ -801,6 +802,8 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // producer path and no model went through a pose-initialisation round on its own stream; else one chain
             // per model on the model's stream.  Either way nothing waits here.
             const bool batched = tracked.size() > 1 && tracked.size() <= (size_t)kMaxBatch && !have_init && g.batch_tracking;
+            const unsigned ext_gen = ++f->extent_seq;
+            for (FusionModel* fm : tracked) fm->odom->sparse = fm != global && !fm->fill_in;  // an object model: extent.hpp, ChainGeom
             auto collect_prep = [&](PrepStages& stages, FusionModel* fm, int side) {
                 const mmf_model* m = fm->model;
                 const uint8_t* pi = (const uint8_t*)((g.frame_to_frame_rgb && fm->fill_in) ? m->fill_image : m->image);
@@ -810,7 +813,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                                      (const float*)m->normalRadius, pi, 4, pose,
                                      fm->fill_in ? fusion_thumb_count(m) : nullptr, (const float*)m->fill_vertex,
                                      (const float*)m->fill_normal, (const uint8_t*)m->fill_image, side, (m->width / 20) * (m->height / 20),
-                                     0.75f);
+                                     0.75f, fm->odom->sparse ? ext_gen : 0u);
             };
             bool batch_ok = batched;
             if (batched) {

@@ -355,9 +355,11 @@ __device__ __forceinline__ void sum_int2_records(const int2* __restrict__ rec, u
 // then sums the records); grid_reduce = grid_arrive + the plain record sum.
 template <int NV, int BLOCK, typename T>
 __device__ __forceinline__ bool grid_arrive(T (&v)[NV], T* __restrict__ partials,
-                                            unsigned* __restrict__ tickets, GridReduceLds<T, BLOCK>& lds) {
+                                            unsigned* __restrict__ tickets, GridReduceLds<T, BLOCK>& lds, unsigned nblocks = 0u) {
+    // nblocks (optional): the workgroups [0, nblocks) of the launch take part (the others have left: a model of a batched launch
+    // that walks its image with fewer workgroups than the launch has per model)
     const int tid = threadIdx.x;
-    const unsigned nblocks = gridDim.x;
+    if (nblocks == 0u) nblocks = gridDim.x;
     block_reduce_store<NV, BLOCK, true>(v, partials, lds, blockIdx.x, nblocks);
     if (tid < 64) {
         // the storing wave drains its write-through stores before the signal

@@ -336,6 +336,7 @@ extern "C" int mmf_icp_step(mmf_ctx* c, const float Rcurr[9], const float tcurr[
     a.cols = cols;
     a.rows = rows;
     a.prev_packed = nullptr;
+    a.extent = nullptr, a.extent_gen = 0u;
     a.err_map = err_map_dev;
     a.err_stride = stride_elems(err_map_step, cols, 4);
     int records = 0;
@@ -380,6 +381,7 @@ static RgbResidualArgs make_residual_args(float min_scale, const int16_t* dIdx, 
     a.err_map = err_map;
     a.err_stride = stride_elems(err_step, cols, 4);
     a.intr = LevelIntr{0, 0, 0, 0};
+    a.extent = nullptr, a.extent_gen = 0u;
     return a;
 }
 
@@ -449,6 +451,7 @@ extern "C" int mmf_rgb_step(mmf_ctx* c, const mmf_dataterm* corres_dev, float si
     RgbStepArgs a;
     a.next_level = 0;
     a.final_step = 0;
+    a.extent = nullptr, a.extent_gen = 0u;
     a.cols_magic = 0;
     a.residual_partials = nullptr;
     a.residual_records = 0;
@@ -468,11 +471,11 @@ extern "C" int mmf_rgb_step(mmf_ctx* c, const mmf_dataterm* corres_dev, float si
     if ((cols * rows) % 4 == 0) {
         const int grid = reduce_grid(cols * rows, kBlock * 4);
         hipLaunchKernelGGL((rgb_step_kernel<FINISH_RAW, 4>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state,
-                           a, c->partials_f, c->ticket, BatchDelta{});
+                           a, c->partials_f, c->ticket, BatchDelta{}, ChainGeom{});
     } else {
         const int grid = reduce_grid(cols * rows, kBlock);
         hipLaunchKernelGGL((rgb_step_kernel<FINISH_RAW, 1>), dim3(grid), dim3(kBlock), 0, c->stream, c->scratch_state,
-                           a, c->partials_f, c->ticket, BatchDelta{});
+                           a, c->partials_f, c->ticket, BatchDelta{}, ChainGeom{});
     }
     MMF_HIP_TRY(hipGetLastError());
     float tot[32];
@@ -759,6 +762,13 @@ struct mmf_odom {
     int2* gn_partials_res = nullptr;
     unsigned* gn_ticket = nullptr;
     float *icp_err = nullptr, *rgb_err = nullptr;  // Model::icpError / rgbError (R32F), written on the last level-0 iteration
+    // extent.hpp: four words per level, noted by the model-side preparation jobs when the owner asks for it (extent_gen != 0:
+    // the number of the frame they were noted for), read by the two-launch chain's passes
+    unsigned long long* extent = nullptr;
+    unsigned extent_gen = 0;
+    // an OBJECT model (set by the orchestrator): the two-launch chain walks its images with a quarter of the workgroups
+    // (track_kernels.hpp: ChainGeom), batched or alone
+    bool sparse = false;
     OdomState* state = nullptr;  // device
     OdomState* host_result = nullptr;  // pinned, device visible: odom_publish_kernel writes it, the host polls publish_seq
     OdomState* host_result_dev = nullptr;
@@ -861,7 +871,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     size_t o_state = carve(sizeof(OdomState));
     const size_t o_pf = carve(sizeof(float) * kMaxGrid * kPartialStride), o_pi = carve(sizeof(float) * kMaxIcpGrid * kPartialStride),
                  o_pr = carve(sizeof(int2) * kMaxGrid), o_tk = carve(sizeof(unsigned) * kTicketWords), o_ei = carve(n0 * 4),
-                 o_er = carve(n0 * 4);
+                 o_er = carve(n0 * 4), o_ex = carve(MMF_NUM_PYRS * 4 * sizeof(unsigned long long));
     o->slab_bytes = off;
     hipError_t e = hipMalloc(&o->slab, o->slab_bytes);
     if (e != hipSuccess) {
@@ -896,6 +906,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     o->gn_partials_f = (float*)(base + o_pf), o->gn_partials_icp = (float*)(base + o_pi);
     o->gn_partials_res = (int2*)(base + o_pr), o->gn_ticket = (unsigned*)(base + o_tk);
     o->icp_err = (float*)(base + o_ei), o->rgb_err = (float*)(base + o_er);
+    o->extent = (unsigned long long*)(base + o_ex);
     MMF_HIP_TRY(hipHostMalloc(&o->host_result, sizeof(OdomState), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(o->host_result, 0, sizeof(OdomState));
     MMF_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&o->host_result_dev), o->host_result, 0));
@@ -1152,7 +1163,7 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
                                  const uint8_t* pred_image, int pred_channels, const float pose[16],
                                  const int* sel = nullptr, const float* alt_vertex = nullptr,
                                  const float* alt_normal = nullptr, const uint8_t* alt_image = nullptr,
-                                 int side = PREP_ALL, int sel_total = 0, float sel_ratio = 0.f) {
+                                 int side = PREP_ALL, int sel_total = 0, float sel_ratio = 0.f, unsigned ext_gen = 0) {
     const bool in_img = (side & PREP_INPUT_IMAGE) != 0, in_depth = (side & PREP_INPUT_DEPTH) != 0;
     const bool model_side = (side & PREP_MODEL_SIDE) != 0;
     const int W = o->width, H = o->height;
@@ -1175,6 +1186,12 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     // The sensor frame's normal map of a level is computed in the same job as its vertex map, from the depth image
     // (PREP_VMAP_NMAP): the depth side is three dependent launches instead of four.  MMF_PREP_VN=0: apart (A/B aid).
     const bool merge_vn = tunables().prep_vn;
+    // ext_gen != 0: the jobs that write the model's depth and vertex pyramids note the extent of what is valid (extent.hpp)
+    const bool note_extent = model_side && merge_first && merge_last && ext_gen != 0;
+    auto noted = [&](PrepJob& j, int lvl) {
+        if (note_extent) j.ext = o->extent + 4 * lvl, j.ext_gen = ext_gen;
+    };
+    if (model_side) o->extent_gen = note_extent ? ext_gen : 0u;
     auto intr_f = [&](PrepJob& j, int lvl, bool cutoff_too, float cutoff) {
         const LevelIntr in = level_intr(o->fx, o->fy, o->cx, o->cy, lvl);
         j.f[0] = 1.f / in.fx, j.f[1] = 1.f / in.fy, j.f[2] = in.cx, j.f[3] = in.cy;
@@ -1194,11 +1211,13 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             t.dst0 = planar ? o->vmaps_g_prev[0] : nullptr, t.dst1 = planar ? o->nmaps_g_prev[0] : nullptr, t.dst2 = o->prev_packed[0];
             for (int k = 0; k < 9; ++k) t.f[k] = R[k];
             t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
+            noted(t, 0);
             PrepJob& p = pb.add(PREP_TEX_PROJECT, cols, rows);
             p.src0 = pred_vertex, p.sel = sel, p.alt0 = alt_vertex;
             p.dst0 = planar ? o->cloud[0] : nullptr, p.dst1 = o->cloud4[0], p.dst2 = o->last_depth[0];
             intr_f(p, 0, false, 0.f);
             p.f[4] = o->max_depth_rgb;
+            noted(p, 0);
             PrepJob& il = pb.add(PREP_INTENSITY, W, H);
             il.src0 = pred_image, il.dst0 = o->last_image[0], il.scols = W * pred_channels, il.channels = pred_channels;
             il.sel = sel, il.alt0 = alt_image;
@@ -1209,6 +1228,7 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
             for (int k = 0; k < 9; ++k) t.f[k] = R[k];
             t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
+            noted(t, lvl);
             PrepJob& p = pb.add(PREP_PROJECT, cols, rows);
             p.src0 = o->last_depth[lvl], p.dst0 = planar ? o->cloud[lvl] : nullptr, p.dst1 = o->cloud4[lvl];
             intr_f(p, lvl, false, 0.f);
@@ -1234,6 +1254,7 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             PrepJob& d = pb.add(PREP_TEX_PYR_F, cols, rows);
             d.src0 = pred_vertex, d.sel = sel, d.alt0 = alt_vertex, d.scols = W, d.srows = H;
             d.dst0 = o->last_depth[1], d.f[0] = o->max_depth_rgb;
+            noted(d, 1);
             PrepJob& u = pb.add(PREP_TEX_PYR_U8, cols, rows);
             u.src0 = pred_image, u.sel = sel, u.alt0 = alt_image, u.scols = W, u.srows = H, u.channels = pred_channels;
             u.dst0 = o->last_image[1];
@@ -1249,10 +1270,12 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
             for (int k = 0; k < 9; ++k) t.f[k] = R[k];
             t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
+            noted(t, lvl);
             PrepJob& p = pb.add(PREP_PYR_PROJECT, cols, rows);
             p.src0 = o->last_depth[lvl - 1], p.scols = W >> (lvl - 1), p.srows = H >> (lvl - 1);
             p.dst0 = planar ? o->cloud[lvl] : nullptr, p.dst1 = o->cloud4[lvl], p.dst2 = o->last_depth[lvl];
             intr_f(p, lvl, false, 0.f);
+            noted(p, lvl);
         } else if (model_side) {
             pyr(pb, PREP_PYRDOWN_F, o->last_depth[lvl - 1], o->last_depth[lvl], lvl);
             pyr(pb, PREP_PYRDOWN_U8, o->last_image[lvl - 1], o->last_image[lvl], lvl);
@@ -1355,6 +1378,7 @@ static IcpArgs odom_icp_args(mmf_odom* o, int level, float* err_map) {
     a.prev_packed = o->prev_packed[level];
     a.err_map = err_map;
     a.err_stride = cols;
+    a.extent = nullptr, a.extent_gen = 0u;
     icp_args_derive(a);
     return a;
 }
@@ -1444,6 +1468,11 @@ static bool gn_geometry(int level, int cols, int rows, GnGeometry* out) {
 static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom, int models = 1);
 static unsigned fused_max_models();
 static std::atomic<bool> g_gn_latched_off{false};
+static std::atomic<int> g_track_cull{-1};  // -1: tunables().track_cull; 0 / 1: mmf_debug_set_track_cull
+extern "C" int mmf_debug_set_track_cull(int mode) {
+    g_track_cull.store(mode < 0 ? -1 : (mode ? 1 : 0));
+    return MMF_OK;
+}
 static std::atomic<int> g_gn_force_fault{0};
 static std::atomic<int> g_gn_recoveries{0};
 constexpr int kGnRetry = 1;  // odom_finish_tracking: the one-launch chain gave up; track again (odom_retrack_prepare)
@@ -1476,6 +1505,21 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     // because a model's workgroups hold their CUs at the count barrier while the next models' wait for a place)
     const bool fused_chain = odom_fused_chain_ok(o, rgb_only, icp_weight, pyramid, fast_odom, (int)ny) &&
                              (ny == 1 || (ny <= fused_max_models() && odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom)));
+    // Object models in the two-launch chain (extent.hpp, track_kernels.hpp: ChainGeom): their passes skip what lies outside
+    // the model's own depth when the preparation noted its extents for this frame, and they walk their images with a
+    // quarter of the workgroups.  MMF_TRACK_CULL=0 / mmf_debug_set_track_cull(0): every model like the first.
+    const bool sparse_on = (g_track_cull.load() < 0 ? tunables().track_cull : g_track_cull.load()) != 0;
+    const bool lead_sparse = sparse_on && o->sparse;
+    bool foll_sparse = sparse_on && batch && ny > 1;
+    unsigned foll_gen = foll_sparse ? batch->o[1]->extent_gen : 0u;
+    for (unsigned m = 1; m < ny && foll_sparse; ++m) {
+        foll_sparse = batch->o[m]->sparse;
+        if (batch->o[m]->extent_gen != foll_gen) foll_gen = 0u;
+    }
+    if (!foll_sparse) foll_gen = 0u;
+    // (the kernels drop the first model's extent in a batch; a sparse model tracked alone keeps its own)
+    const unsigned cull_gen = ny > 1 ? foll_gen : (lead_sparse ? o->extent_gen : 0u);
+    auto quarter = [](int full) { return std::max(std::min(full, 32), (full + 3) / 4); };
     int first_iter_level = MMF_NUM_PYRS - 1;  // the coarsest level that runs iterations
     while (first_iter_level > 0 && !iterations[first_iter_level]) --first_iter_level;
 
@@ -1625,19 +1669,27 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                                         o->last_image[i], 0, o->next_image[i], 0, o->corres[i], o->max_depth_delta_rgb,
                                         cols, rows, last_l0 ? rgb_err_dev : nullptr, 0);
                 ra.intr = in;
+                ra.extent = cull_gen ? o->extent + 4 * i : nullptr, ra.extent_gen = cull_gen;
                 res_vec4 = residual_vec4_ok(ra);
                 res_records = reduce_grid(cols * rows, res_vec4 ? kBlock * 4 : kBlock);
             }
+            ChainGeom geom;
+            std::memset(&geom, 0, sizeof(geom));
             IcpArgs ia;
             int ipx = 1;
             if (icp) {
                 ia = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
+                ia.extent = cull_gen ? o->extent + 4 * i : nullptr, ia.extent_gen = cull_gen;
                 ipx = std::min(2, icp_max_px(ia, 2));
             }
             const bool fuse_producers = rgb && icp && res_vec4 && icp2_fits(ia, kBlock, ipx) &&
                                         icp_default_variant(cols * rows) / 1000000 != 1;
             if (fuse_producers) {  // ICP reduction + correspondence pass side by side in one launch
                 icp_records = (cols * rows + kBlock * ipx - 1) / (kBlock * ipx);
+                if (lead_sparse)  // (every model of this launch, then)
+                    res_records = quarter(res_records);
+                else if (foll_sparse)
+                    geom.res_f = (unsigned)quarter(res_records);
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (o->timing >= 2 && o->n_timed < kMaxTimedLaunches) {
                     e0 = o->ev_kernel[2 * o->n_timed], e1 = o->ev_kernel[2 * o->n_timed + 1];
@@ -1645,18 +1697,18 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 }
                 if (!e0 && ipx == 2)
                     q.launch((track_producer_kernel<2, true>), dim3(icp_records + res_records, ny), dim3(kBlock), o->state, ia,
-                             (unsigned)icp_records, ra, o->gn_partials_icp, o->gn_partials_res, bd);
+                             (unsigned)icp_records, ra, o->gn_partials_icp, o->gn_partials_res, bd, geom);
                 else if (!e0)
                     q.launch((track_producer_kernel<1, true>), dim3(icp_records + res_records, ny), dim3(kBlock), o->state, ia,
-                             (unsigned)icp_records, ra, o->gn_partials_icp, o->gn_partials_res, bd);
+                             (unsigned)icp_records, ra, o->gn_partials_icp, o->gn_partials_res, bd, geom);
                 else if (ipx == 2)
                     hipExtLaunchKernelGGL((track_producer_kernel<2, true>), dim3(icp_records + res_records, ny), dim3(kBlock), 0,
                                           c->stream, e0, e1, 0, o->state, ia, (unsigned)icp_records, ra, o->gn_partials_icp,
-                                          o->gn_partials_res, bd);
+                                          o->gn_partials_res, bd, geom);
                 else
                     hipExtLaunchKernelGGL((track_producer_kernel<1, true>), dim3(icp_records + res_records, ny), dim3(kBlock), 0,
                                           c->stream, e0, e1, 0, o->state, ia, (unsigned)icp_records, ra, o->gn_partials_icp,
-                                          o->gn_partials_res, bd);
+                                          o->gn_partials_res, bd, geom);
                 MMF_HIP_TRY(hipGetLastError());
             } else {
                 MMF_REQUIRE(ny == 1, "odom_enqueue_tracking: this level cannot be batched");
@@ -1697,6 +1749,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 a.rows = rows;
                 a.cols_magic = ra.cols_magic;
                 a.intr = in;
+                a.extent = ra.extent, a.extent_gen = ra.extent_gen;
                 // the last step of a level also does the next level's gn_level_begin (one launch less per
                 // level).  Not with rgbOnly: its divergence `break` skips the finishing lane.
                 a.next_level = 0;
@@ -1707,7 +1760,11 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                     a.intr = level_intr(o->fx, o->fy, o->cx, o->cy, i - 1);  // only read by the finishing lane's rgb_prepare
                     begin_folded = true;
                 }
-                const int grid = reduce_grid(cols * rows, kBlock * 4);  // width, height are multiples of 4
+                int grid = reduce_grid(cols * rows, kBlock * 4);  // width, height are multiples of 4
+                if (fuse_producers && lead_sparse)
+                    grid = quarter(grid);
+                else if (fuse_producers && foll_sparse)
+                    geom.step_f = (unsigned)quarter(grid);
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (o->timing >= 2 && o->n_timed < kMaxTimedLaunches) {
                     e0 = o->ev_kernel[2 * o->n_timed], e1 = o->ev_kernel[2 * o->n_timed + 1];
@@ -1715,16 +1772,16 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 }
                 if (!e0 && res_vec4)  // the 4-pixel correspondence pass wrote compact records
                     q.launch((rgb_step_kernel<FINISH_GN, 4, true>), dim3(grid, ny), dim3(kBlock), o->state, a, o->gn_partials_f,
-                             o->gn_ticket, bd);
+                             o->gn_ticket, bd, geom);
                 else if (!e0)
                     q.launch((rgb_step_kernel<FINISH_GN, 4, false>), dim3(grid, ny), dim3(kBlock), o->state, a, o->gn_partials_f,
-                             o->gn_ticket, bd);
+                             o->gn_ticket, bd, geom);
                 else if (res_vec4)
                     hipExtLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, true>), dim3(grid, ny), dim3(kBlock), 0, c->stream, e0, e1,
-                                          0, o->state, a, o->gn_partials_f, o->gn_ticket, bd);
+                                          0, o->state, a, o->gn_partials_f, o->gn_ticket, bd, geom);
                 else
                     hipExtLaunchKernelGGL((rgb_step_kernel<FINISH_GN, 4, false>), dim3(grid, ny), dim3(kBlock), 0, c->stream, e0,
-                                          e1, 0, o->state, a, o->gn_partials_f, o->gn_ticket, bd);
+                                          e1, 0, o->state, a, o->gn_partials_f, o->gn_ticket, bd, geom);
                 MMF_HIP_TRY(hipGetLastError());
             }
         }

@@ -13,6 +13,7 @@
 // PREP_PYR_PROJECT), the depth side of the sensor frame THREE (PREP_VMAP_NMAP), its image side four; a launch on the
 // model's stream costs ~4.5 us before it does anything, which is most of what a small stage takes.
 #pragma once
+#include "extent.hpp"
 #include "icp_kernels.hpp"
 #include "map_kernels.hpp"
 
@@ -66,6 +67,10 @@ struct PrepJob {
     int sel_total;
     float sel_ratio;
     float f[12];
+    // non-null: the job notes the bounding box of the valid pixels it writes (extent.hpp) -- the model-side depth and
+    // vertex jobs of an object model, whose chain skips what lies outside
+    unsigned long long* ext;
+    unsigned ext_gen;
 };
 
 constexpr int kMaxPrepJobs = 24;  // 24 x 144 B of kernel arguments; longer job lists go out as several launches
@@ -103,10 +108,10 @@ __device__ __forceinline__ void transform_pack_store(int x, int y, int rows, int
     o[1] = make_float2(vd.z, nd.x);
     o[2] = make_float2(nd.y, nd.z);
 }
-__device__ __forceinline__ void transform_pack_px(int x, int y, int rows, int cols, const float* __restrict__ vsrc,
+__device__ __forceinline__ bool transform_pack_px(int x, int y, int rows, int cols, const float* __restrict__ vsrc,
                                                   const float* __restrict__ nsrc, m33 R, f3 t, float* __restrict__ vdst,
                                                   float* __restrict__ ndst, float* __restrict__ packed) {
-    if (x >= cols || y >= rows) return;
+    if (x >= cols || y >= rows) return false;
     f3 vs = make_f3(0.f, 0.f, 0.f), ns = vs;
     vs.x = vsrc[(size_t)y * cols + x];
     const bool v_ok = !(vs.x != vs.x);
@@ -121,6 +126,7 @@ __device__ __forceinline__ void transform_pack_px(int x, int y, int rows, int co
         ns.z = nsrc[(size_t)(y + 2 * rows) * cols + x];
     }
     transform_pack_store(x, y, rows, cols, v_ok, vs, n_ok, ns, R, t, vdst, ndst, packed);
+    return v_ok;  // (the vertex is valid)
 }
 
 // pixel (x, y) of job J
@@ -140,8 +146,9 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             m33 R;
 #pragma unroll
             for (int k = 0; k < 9; ++k) R.m[k] = J.f[k];
-            transform_pack_px(x, y, rows, cols, (const float*)src0, (const float*)src1, R, make_f3(J.f[9], J.f[10], J.f[11]),
-                              (float*)J.dst0, (float*)J.dst1, (float*)J.dst2);
+            const bool v_ok = transform_pack_px(x, y, rows, cols, (const float*)src0, (const float*)src1, R, make_f3(J.f[9], J.f[10], J.f[11]),
+                                                (float*)J.dst0, (float*)J.dst1, (float*)J.dst2);
+            extent_note(J.ext, J.ext_gen, x, y, v_ok);
             break;
         }
         case PREP_COPY_MAPS:
@@ -175,6 +182,7 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             const bool n_ok = resize_map_value<true>(x, y, J.srows, (const float*)src1, J.scols, ns);
             transform_pack_store(x, y, rows, cols, v_ok, vs, n_ok, ns, R, make_f3(J.f[9], J.f[10], J.f[11]), (float*)J.dst0,
                                  (float*)J.dst1, (float*)J.dst2);
+            extent_note(J.ext, J.ext_gen, x, y, v_ok);
             break;
         }
         case PREP_TEX_TP: {
@@ -188,6 +196,7 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             const f3 ns = ok ? make_f3(n.x, n.y, n.z) : make_f3(qnan(), qnan(), qnan());
             transform_pack_store(x, y, rows, cols, !(vs.x != vs.x), vs, !(ns.x != ns.x), ns, R, make_f3(J.f[9], J.f[10], J.f[11]),
                                  (float*)J.dst0, (float*)J.dst1, (float*)J.dst2);
+            extent_note(J.ext, J.ext_gen, x, y, !(vs.x != vs.x));
             break;
         }
         case PREP_TEX_PROJECT: {
@@ -195,6 +204,7 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             const float z = vertex_depth_value(((const float4*)src0)[(size_t)y * cols + x].z, J.f[4]);
             ((float*)J.dst2)[(size_t)y * cols + x] = z;
             project_points_store(x, y, z, cols, (float*)J.dst0, J.f[0], J.f[1], J.f[2], J.f[3], (float4*)J.dst1);
+            extent_note(J.ext, J.ext_gen, x, y, !(z != z));
             break;
         }
         case PREP_TEX_PYR_F: {
@@ -202,8 +212,10 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             const float4* tex = (const float4*)src0;
             const int scols = J.scols;
             const float cutoff = J.f[0];
-            ((float*)J.dst0)[(size_t)y * cols + x] = pyrdown_gauss_f_taps(
+            const float z = pyrdown_gauss_f_taps(
                 x, y, scols, J.srows, [&](int yy, int xx) { return vertex_depth_value(tex[(size_t)yy * scols + xx].z, cutoff); });
+            ((float*)J.dst0)[(size_t)y * cols + x] = z;
+            extent_note(J.ext, J.ext_gen, x, y, !(z != z));
             break;
         }
         case PREP_TEX_PYR_U8: {
@@ -269,6 +281,7 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             const float z = pyrdown_gauss_f_value(x, y, (const float*)src0, J.scols, J.scols, J.srows);
             ((float*)J.dst2)[(size_t)y * cols + x] = z;
             project_points_store(x, y, z, cols, (float*)J.dst0, J.f[0], J.f[1], J.f[2], J.f[3], (float4*)J.dst1);
+            extent_note(J.ext, J.ext_gen, x, y, !(z != z));
             break;
         }
         default: break;

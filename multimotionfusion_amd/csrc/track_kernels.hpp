@@ -10,6 +10,7 @@
 // one launch per reduction (grid_reduce.hpp) and no host synchronisation between iterations.
 #pragma once
 #include "device_math.hpp"
+#include "extent.hpp"
 #include "grid_reduce.hpp"
 #include "icp_kernels.hpp"
 #include "odom_state.hpp"
@@ -99,6 +100,10 @@ struct RgbResidualArgs {
     float* err_map;
     int err_stride;
     LevelIntr intr;
+    // non-null (object models): the level's extent of the model's own depth (extent.hpp) -- the 256-pixel blocks outside it
+    // hold no pixel that can take part, and neither this pass nor rgb_step_kernel touches them
+    const unsigned long long* extent;
+    unsigned extent_gen;
 };
 
 // Like the ICP kernel this one only produces partial records {count, sum diff^2}; they are summed
@@ -154,6 +159,9 @@ __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st
     const float* K = st->krkinv;
     const float ktx = st->kt[0], kty = st->kt[1], ktz = st->kt[2];
     const int level_break = GN ? st->level_break : 0;  // consumed after the image loads are in flight
+    const bool cull = GN && ALIGNED && a.extent != nullptr;  // (uniform)
+    ExtentBox box{0, 0, 0, 0};
+    if (cull) box = extent_load(a.extent, a.extent_gen);
 
     for (int g = bid * kBlock + threadIdx.x; g < N4; g += nblocks * kBlock) {
         int i, j0;
@@ -163,6 +171,11 @@ __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st
             i = g / gpr, j0 = (g - i * gpr) * 4;
         }
         const int k0 = i * cols + j0;  // index of the group's first record
+        // the wave's 256 pixels all outside the model's own depth: every one of them fails `!(d1 != d1)` below
+        if (cull && extent_misses(box, (unsigned)(g - (int)(threadIdx.x & 63u)) * 4u, 256u, cols, a.cols_magic)) {
+            if (a.err_map) *reinterpret_cast<float4*>(a.err_map + (size_t)i * a.err_stride + j0) = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
         // twelve unconditional word loads from clamped addresses (conditions applied afterwards), so
         // they and the four loads below are one round trip
         unsigned ww[4][3];
@@ -352,6 +365,16 @@ __device__ __forceinline__ T* batch_shift(T* p, long long d) {
     return p ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + d) : p;
 }
 
+// An OBJECT model's images are empty outside a box of a hundred pixels (extent.hpp), and what a workgroup of these launches
+// costs is mostly fixed -- state, reduction, hand-over -- so such a model walks its image with a quarter of the workgroups
+// in the two photometric passes (grid-stride passes, most of them skipped) whether it is tracked in a batch or alone: its launch geometry, and with it the
+// order of its float sums, is a property of the model.  In a batched launch (gridDim.y = model, one gridDim.x for all) the
+// surplus workgroups of such a model leave at once.
+struct ChainGeom {
+    unsigned res_f;   // track_producer_kernel: correspondence workgroups of the models behind the first (0: the launch's own)
+    unsigned step_f;  // rgb_step_kernel: likewise
+};
+
 // Both producers of one Gauss-Newton iteration in ONE launch: workgroups [0, icp_blocks) run the
 // ICP reduction, the rest the photometric correspondence pass.  The two passes are independent
 // (RGBDOdometry.cpp:363-410), so running them side by side removes a launch boundary and lets
@@ -360,8 +383,16 @@ template <int W, bool PACKED>
 __global__ __launch_bounds__(kBlock) void track_producer_kernel(const OdomState* __restrict__ st, IcpArgs ia,
                                                                 unsigned icp_blocks, RgbResidualArgs ra,
                                                                 float* __restrict__ icp_partials,
-                                                                int2* __restrict__ res_partials, BatchDelta bd) {
+                                                                int2* __restrict__ res_partials, BatchDelta bd, ChainGeom geom) {
     __shared__ GridReduceLds<float, kBlock> lds;
+    // (the ICP workgroups keep the launch's count for every model: a grid-stride ICP pass keeps its 58 running sums live
+    // across its loads and takes the whole kernel from 80 to 151 registers)
+    const unsigned my_icp = icp_blocks;
+    unsigned my_res = gridDim.x - icp_blocks;
+    if (blockIdx.y > 0 && geom.res_f) {
+        my_res = geom.res_f;
+        if (blockIdx.x >= my_res + my_icp) return;
+    }
     if (gridDim.y > 1) {  // model blockIdx.y: its state, model-side maps, records and error images (wave uniform)
         const long long d = bd.d[blockIdx.y];
         st = batch_shift(st, d);
@@ -370,21 +401,22 @@ __global__ __launch_bounds__(kBlock) void track_producer_kernel(const OdomState*
         ra.last_depth = batch_shift(ra.last_depth, d), ra.next_depth = batch_shift(ra.next_depth, d);
         ra.last_image = batch_shift(ra.last_image, d), ra.corres = batch_shift(ra.corres, d);
         ra.err_map = batch_shift(ra.err_map, d);
+        ra.extent = blockIdx.y ? batch_shift(ra.extent, d) : nullptr;  // (the batch's first model is the dense one)
+        ia.extent = blockIdx.y ? batch_shift(ia.extent, d) : nullptr;
         icp_partials = batch_shift(icp_partials, d), res_partials = batch_shift(res_partials, d);
     }
     // st->level_break is checked inside the blocks, after their state-independent loads are in flight
     using T = typename std::conditional<W == 2, v2f, float>::type;
     // the correspondence workgroups are the long pole of the launch (phase stamps): they take the
     // FIRST block indices so that they are dispatched first
-    const unsigned res_blocks = gridDim.x - icp_blocks;
-    if (blockIdx.x >= res_blocks) {
-        const unsigned bid = blockIdx.x - res_blocks;
+    if (blockIdx.x >= my_res) {
+        const unsigned bid = blockIdx.x - my_res;
         if (ia.err_map)
-            icp_block2<T, 1, kBlock, PACKED, true, true>(st, ia, icp_partials, lds, bid, icp_blocks);
+            icp_block2<T, 1, kBlock, PACKED, true, true>(st, ia, icp_partials, lds, bid, my_icp);
         else
-            icp_block2<T, 1, kBlock, PACKED, false, true>(st, ia, icp_partials, lds, bid, icp_blocks);
+            icp_block2<T, 1, kBlock, PACKED, false, true>(st, ia, icp_partials, lds, bid, my_icp);
     } else {
-        residual_block4<true>(st, ra, res_partials, reinterpret_cast<GridReduceLds<int, kBlock>&>(lds), blockIdx.x, res_blocks);
+        residual_block4<true>(st, ra, res_partials, reinterpret_cast<GridReduceLds<int, kBlock>&>(lds), blockIdx.x, my_res);
     }
 }
 
@@ -432,6 +464,8 @@ struct RgbStepArgs {
     LevelIntr intr;       // intrinsics the finishing lane prepares the NEXT correspondence pass with
     int next_level;       // 1: that pass belongs to the next pyramid level (gn_level_begin_kernel folded in)
     int final_step;       // 1: the very last step of the frame: the finishing lane also does odom_end
+    const unsigned long long* extent;  // as RgbResidualArgs::extent: the blocks the correspondence pass skipped hold no record
+    unsigned extent_gen;
 };
 
 // RGBDOdometry.cpp:464-467, 475-476
@@ -540,26 +574,38 @@ __device__ __forceinline__ void rgb_rows(float sobel_scale, float fx, float fy, 
 template <int MODE, int PX, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict__ st, RgbStepArgs a,
                                                           float* __restrict__ partials,
-                                                          unsigned* __restrict__ ticket, BatchDelta bd) {
+                                                          unsigned* __restrict__ ticket, BatchDelta bd, ChainGeom geom) {
     __shared__ GridReduceLds<float, kBlock> lds;
+    unsigned nblocks = gridDim.x;
+    const unsigned icp_records = a.icp_records;
+    if (blockIdx.y > 0 && geom.step_f) {  // (ChainGeom)
+        nblocks = geom.step_f;
+        if (blockIdx.x >= nblocks) return;
+    }
     if (gridDim.y > 1) {  // model blockIdx.y (see BatchDelta)
         const long long d = bd.d[blockIdx.y];
         st = batch_shift(st, d);
         a.corres = batch_shift(a.corres, d), a.cloud = batch_shift(a.cloud, d), a.cloud4 = batch_shift(a.cloud4, d);
         a.icp_partials = batch_shift(a.icp_partials, d), a.residual_partials = batch_shift(a.residual_partials, d);
         partials = batch_shift(partials, d), ticket = batch_shift(ticket, d);
+        a.extent = blockIdx.y ? batch_shift(a.extent, d) : nullptr;
     }
     MMF_STAMP(0);
     const int N = a.cols * a.rows;
     int i0 = (blockIdx.x * kBlock + threadIdx.x) * PX;
     const bool live = i0 < N;
+    const bool cull = COMPACT && a.extent != nullptr;  // (uniform)
+    ExtentBox box{0, 0, 0, 0};
+    if (cull) box = extent_load(a.extent, a.extent_gen);
+    // this wave's records were never written (residual_block4 skipped the block): nothing to add
+    const bool skip = cull && extent_misses(box, (unsigned)(i0 - (int)(threadIdx.x & 63u) * PX), 64u * PX, a.cols, a.cols_magic);
     static_assert(!COMPACT || PX % 2 == 0, "compact records are loaded in pairs");
     constexpr int NQ = COMPACT ? PX / 2 : PX;          // 16-byte loads per lane
     constexpr int REC = COMPACT ? (int)sizeof(CorresPk) : (int)sizeof(mmf_dataterm);
     const char* recs = reinterpret_cast<const char*>(a.corres);
     int4 raws[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) raws[q] = reinterpret_cast<const int4*>(recs + (size_t)(live ? i0 : 0) * REC)[q];
+    for (int q = 0; q < NQ; ++q) raws[q] = skip ? make_int4(0, 0, 0, 0) : reinterpret_cast<const int4*>(recs + (size_t)(live ? i0 : 0) * REC)[q];
     __builtin_amdgcn_sched_barrier(0);
     // state reads (wave-uniform scalar loads), not consumed before the gathers are in flight
     float sigma = st->sigmaVal;
@@ -576,7 +622,7 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     }
     __builtin_amdgcn_sched_barrier(0);
     RgbLane<PX> lane;
-    rgb_gather<PX, COMPACT>(a, raws, live ? i0 : 0, lane);
+    if (!skip) rgb_gather<PX, COMPACT>(a, raws, live ? i0 : 0, lane);
     __builtin_amdgcn_sched_barrier(0);
 
     int res_count = 0, res_sigma = 0;
@@ -601,9 +647,10 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     if (sigma == 1234.5f && lane.X[0] == 1234.5f && lane.gx[0] == 77 && lane.gy[PX - 1] == 78) sum[0] = lane.Z[PX - 1];
     MMF_STAMP(3);
 #endif
-    rgb_rows<PX>(a.sobel_scale, a.fx, a.fy, sigma, live, lane, sum);
+    if (!skip) rgb_rows<PX>(a.sobel_scale, a.fx, a.fy, sigma, live, lane, sum);
     // images beyond the grid's single pass
-    for (i0 += gridDim.x * kBlock * PX; i0 < N; i0 += gridDim.x * kBlock * PX) {
+    for (i0 += nblocks * kBlock * PX; i0 < N; i0 += nblocks * kBlock * PX) {
+        if (cull && extent_misses(box, (unsigned)(i0 - (int)(threadIdx.x & 63u) * PX), 64u * PX, a.cols, a.cols_magic)) continue;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) raws[q] = reinterpret_cast<const int4*>(recs + (size_t)i0 * REC)[q];
         rgb_gather<PX, COMPACT>(a, raws, i0, lane);
@@ -614,11 +661,11 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     if (sum[5] == 1234.5f) sum[0] += 1.f;
     MMF_STAMP(4);
 #endif
-    const bool is_last_wg = grid_arrive<29, kBlock>(sum, partials, ticket, lds);
+    const bool is_last_wg = grid_arrive<29, kBlock>(sum, partials, ticket, lds, nblocks);
     MMF_STAMP(5);
     if (!is_last_wg) return;
     if (MODE == FINISH_RAW) {
-        sum_partial_records<kBlock, true>(partials, gridDim.x, lds);
+        sum_partial_records<kBlock, true>(partials, nblocks, lds);
         if (threadIdx.x == 0)
             for (int k = 0; k < 29; ++k) st->out_f[k] = lds.total[k];
     }
@@ -626,7 +673,7 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
         const bool icp = st->icp != 0;  // wave-uniform
         // the photometric records of this launch and the ICP records of the preceding one (kernel
         // boundary => plain loads), all loads in flight together
-        sum_partial_records2<kBlock>(partials, gridDim.x, a.icp_partials, icp ? a.icp_records : 0u, lds);
+        sum_partial_records2<kBlock>(partials, nblocks, a.icp_partials, icp ? icp_records : 0u, lds);
         MMF_STAMP(6);
         // the 36 + 6 elements of the combined system by 42 lanes (and their lastA / lastb stores), so that the
         // solving lane starts from the finished matrix

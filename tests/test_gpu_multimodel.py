@@ -174,8 +174,23 @@ def test_batched_chain_equals_one_chain_per_model(gpu_ctx):
     try:
         a, b = run(1), run(0)
         c = run(1, hint=True)  # and with the next frame's sensor side (and SO3 pre-alignment) prepared on the side streams
+        # Object models walk their images with a quarter of the workgroups and skip the blocks outside the model's own depth
+        # (csrc/extent.hpp, ChainGeom), batched or alone -- a, b, c above.  Told not to, every model is tracked like the camera
+        # model: again the same bits batched and alone, and the same poses up to the order of the float sums.
+        gpu_ctx.lib.mmf_debug_set_track_cull(0)
+        d, e = run(1), run(0)
     finally:
         gpu_ctx.lib.mmf_debug_set_gn_fused(-1)
+        gpu_ctx.lib.mmf_debug_set_track_cull(-1)
+    for i in range(n_frames):
+        for k, (pd, pe) in enumerate(zip(d[0][i], e[0][i])):
+            assert np.array_equal(pd, pe), (i, k)
+        assert np.abs(a[0][i][0] - d[0][i][0]).max() <= 1e-5, i  # the camera
+        for pa, pd in zip(a[0][i][1:], d[0][i][1:]):  # free-running object models: see the bound below
+            assert np.abs(pa - pd).max() <= 1e-2, i
+    for sd, se in zip(d[1], e[1]):
+        assert np.array_equal(sd.view(np.uint32), se.view(np.uint32))
+    assert d[2] == e[2]
     for i in range(n_frames):
         for pf, pg in zip(f1[0][i], f2[0][i]):
             assert np.array_equal(pf, pg), i
