@@ -1,14 +1,16 @@
 // extent.hpp -- the image extent of a model's prediction at one pyramid level.
 //
-// An object model predicts a few thousand surfels: its depth / vertex pyramids (Model.cpp:359-407, RGBDOdometry.cpp:108-179)
-// are NaN outside a box of a hundred pixels, yet every pass of its Gauss-Newton chain walks the whole image
-// (MultiMotionFusion.cpp:312-387 does too -- the reference's cost, not a design).  The preparation jobs that WRITE those
-// pyramids note the bounding box of what they write that is valid (one ballot per 64-pixel row segment, four atomics per
-// segment with a valid pixel), and the photometric passes of a batched chain skip the 256-pixel blocks outside it: a pixel
+// An object model predicts a few thousand surfels: its depth pyramid (Model.cpp:359-407, RGBDOdometry.cpp:108-179) is NaN
+// outside a box of a hundred pixels, yet every pass of its Gauss-Newton chain walks the whole image
+// (MultiMotionFusion.cpp:312-387 does too -- the reference's cost, not a design).  The preparation job that WRITES the
+// COARSEST level of that pyramid notes the bounding box of what it writes that is valid (one ballot per 64-pixel row
+// segment, four atomics per segment with a valid pixel: a few dozen segments at 160x120 -- noting it at every level, three
+// thousand same-address atomics per model, doubled the preparation launches of eight models), the finer levels scale the box
+// up, and the photometric passes of the two-launch chain skip the 256-pixel blocks outside it: a pixel
 // takes part in computeRgbResidual / rgbStep only if ITS OWN model depth is a number (reduce.cu:600: `!isnan(d1)`; next_depth
 // is the prediction's depth, RGBDOdometry.cpp:179), so a skipped block contributes exactly the zeros it would have added.
 //
-// Four 64-bit words per level, all raised by atomicMax: {gen << 32 | 0xFFFF - x0, gen << 32 | x1, gen << 32 | 0xFFFF - y0,
+// Four 64-bit words per box (three boxes per model: extent_of_level), all raised by atomicMax: {gen << 32 | 0xFFFF - x0, gen << 32 | x1, gen << 32 | 0xFFFF - y0,
 // gen << 32 | y1}.  `gen` is the frame's number: a newer frame's first note supersedes whatever an older frame left, nothing
 // is ever reset, and a word whose upper half is not this frame's says "no valid pixel".
 #pragma once
@@ -39,13 +41,30 @@ __device__ __forceinline__ void extent_note(unsigned long long* words, unsigned 
 struct ExtentBox {
     int x0, y0, x1, y1;  // inclusive; empty: x1 < x0
 };
-// (uniform address: four scalar loads)
-__device__ __forceinline__ ExtentBox extent_load(const unsigned long long* words, unsigned gen) {
+// (uniform address: four scalar loads).  `shift`: the box was noted `shift` pyramid levels above the one that asks
+__device__ __forceinline__ ExtentBox extent_load(const unsigned long long* words, unsigned gen, int shift = 0) {
     ExtentBox e{1, 1, 0, 0};
     const unsigned long long w0 = words[0], w1 = words[1], w2 = words[2], w3 = words[3];
     if ((unsigned)(w0 >> 32) != gen || (unsigned)(w1 >> 32) != gen || (unsigned)(w2 >> 32) != gen || (unsigned)(w3 >> 32) != gen) return e;
     e.x0 = 0xFFFF - (int)(unsigned)(w0 & 0xFFFFFFFFull), e.x1 = (int)(unsigned)(w1 & 0xFFFFFFFFull);
     e.y0 = 0xFFFF - (int)(unsigned)(w2 & 0xFFFFFFFFull), e.y1 = (int)(unsigned)(w3 & 0xFFFFFFFFull);
+    e.x0 <<= shift, e.y0 <<= shift;
+    e.x1 = ((e.x1 + 1) << shift) - 1, e.y1 = ((e.y1 + 1) << shift) - 1;
+    return e;
+}
+__device__ __forceinline__ ExtentBox extent_hull(ExtentBox a, ExtentBox b) {
+    if (a.x1 < a.x0) return b;
+    if (b.x1 < b.x0) return a;
+    return ExtentBox{min(a.x0, b.x0), min(a.y0, b.y0), max(a.x1, b.x1), max(a.y1, b.y1)};
+}
+// The box of a three-level depth pyramid's level `level` (0 = finest) from the model's 12 words: [8..11] = the valid pixels of
+// level 2, [4..7] / [0..3] = the valid pixels in the LAST column or row of level 1 / level 0.  A depth that is a number makes
+// its parent a number -- the parent's 5x5 window holds it (cudafuncs.cu:333-364) -- except in the last column and row of the
+// finer image, which that window leaves out (its quirk: [max(0, 2x - 2), min(2x + 3, cols - 1))): hence the two extra boxes.
+__device__ __forceinline__ ExtentBox extent_of_level(const unsigned long long* words, unsigned gen, int level) {
+    ExtentBox e = extent_load(words + 8, gen, 2 - level);
+    if (level <= 1) e = extent_hull(e, extent_load(words + 4, gen, 1 - level));
+    if (level == 0) e = extent_hull(e, extent_load(words, gen, 0));
     return e;
 }
 // do the `count` pixels from linear index `first` on (row major, `cols` per row, cols_magic = floor(2^32 / cols) + 1) all

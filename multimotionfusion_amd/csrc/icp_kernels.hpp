@@ -23,7 +23,6 @@
 // differs (fixed by the launch geometry, hence run-to-run deterministic).
 #pragma once
 #include "device_math.hpp"
-#include "extent.hpp"
 #include "grid_reduce.hpp"
 #include "odom_state.hpp"
 
@@ -95,11 +94,6 @@ struct IcpArgs {
     int cols, rows;
     float* err_map;  // optional
     int err_stride;
-    // non-null (object models of a batched or sparse chain): the level's extent of the model's valid vertices (extent.hpp).
-    // A pixel that projects outside it would gather a NaN vertex and fail every test of reduce.cu:300-318; it is treated
-    // like one that projects outside the image instead (same sums, same error value 0) and gathers nothing
-    const unsigned long long* extent;
-    unsigned extent_gen;
 };
 
 // PX consecutive floats of one plane row as ONE load instruction (4, 8 or 16 bytes per lane)
@@ -149,8 +143,7 @@ struct IcpProj {
 };
 
 template <typename T>
-__device__ __forceinline__ IcpProj<T> icp_project_v(const IcpPose& P, const IcpArgs& a, f3t<T> vcurr, bool boxed = false,
-                                                    ExtentBox box = ExtentBox{0, 0, 0, 0}) {
+__device__ __forceinline__ IcpProj<T> icp_project_v(const IcpPose& P, const IcpArgs& a, f3t<T> vcurr) {
     using L = lanevec<T>;
     IcpProj<T> p;
     const f3t<T> rv = mul(P.Rcurr, vcurr);
@@ -162,8 +155,7 @@ __device__ __forceinline__ IcpProj<T> icp_project_v(const IcpPose& P, const IcpA
 #pragma unroll
     for (int e = 0; e < L::W; ++e) {
         const int ux = float2int_rn(L::get(px, e)), uy = float2int_rn(L::get(py, e));
-        bool in = !(ux < 0 || uy < 0 || ux >= a.cols || uy >= a.rows || L::get(p.vcurr_cp.z, e) < 0);
-        if (boxed) in = in && ux >= box.x0 && ux <= box.x1 && uy >= box.y0 && uy <= box.y1;  // (uniform condition)
+        const bool in = !(ux < 0 || uy < 0 || ux >= a.cols || uy >= a.rows || L::get(p.vcurr_cp.z, e) < 0);
         p.inside[e] = in;
         p.ux[e] = in ? ux : 0;  // outside: read element 0 (a valid address), masked afterwards
         p.uy[e] = in ? uy : 0;
@@ -236,9 +228,6 @@ __device__ __forceinline__ void icp_block2(const OdomState* __restrict__ st, con
     constexpr int W = L::W, PX = W * NV;
     const IcpPose P = load_icp_pose(st);
     const int level_break = CHECK_BREAK ? st->level_break : 0;
-    ExtentBox box{0, 0, 0, 0};
-    const bool boxed = a.extent != nullptr;  // (uniform)
-    if (boxed) box = extent_load(a.extent, a.extent_gen);
 
     T sum[29];
     if (MULTI) {
@@ -284,7 +273,7 @@ __device__ __forceinline__ void icp_block2(const OdomState* __restrict__ st, con
                 L::set(v.y, e, cur[1][g * W + e]);
                 L::set(v.z, e, cur[2][g * W + e]);
             }
-            pr[g] = icp_project_v<T>(P, a, v, boxed, box);
+            pr[g] = icp_project_v<T>(P, a, v);
         }
 
         // ---- round trip 2: every gather of the lane issued before any is consumed ----------

@@ -336,7 +336,6 @@ extern "C" int mmf_icp_step(mmf_ctx* c, const float Rcurr[9], const float tcurr[
     a.cols = cols;
     a.rows = rows;
     a.prev_packed = nullptr;
-    a.extent = nullptr, a.extent_gen = 0u;
     a.err_map = err_map_dev;
     a.err_stride = stride_elems(err_map_step, cols, 4);
     int records = 0;
@@ -381,7 +380,7 @@ static RgbResidualArgs make_residual_args(float min_scale, const int16_t* dIdx, 
     a.err_map = err_map;
     a.err_stride = stride_elems(err_step, cols, 4);
     a.intr = LevelIntr{0, 0, 0, 0};
-    a.extent = nullptr, a.extent_gen = 0u;
+    a.extent = nullptr, a.extent_gen = 0u, a.extent_level = 0;
     return a;
 }
 
@@ -451,7 +450,7 @@ extern "C" int mmf_rgb_step(mmf_ctx* c, const mmf_dataterm* corres_dev, float si
     RgbStepArgs a;
     a.next_level = 0;
     a.final_step = 0;
-    a.extent = nullptr, a.extent_gen = 0u;
+    a.extent = nullptr, a.extent_gen = 0u, a.extent_level = 0;
     a.cols_magic = 0;
     a.residual_partials = nullptr;
     a.residual_records = 0;
@@ -762,7 +761,7 @@ struct mmf_odom {
     int2* gn_partials_res = nullptr;
     unsigned* gn_ticket = nullptr;
     float *icp_err = nullptr, *rgb_err = nullptr;  // Model::icpError / rgbError (R32F), written on the last level-0 iteration
-    // extent.hpp: four words per level, noted by the model-side preparation jobs when the owner asks for it (extent_gen != 0:
+    // extent.hpp: three boxes of four words (extent_of_level), noted by the model-side preparation's depth jobs when the owner asks for it (extent_gen != 0:
     // the number of the frame they were noted for), read by the two-launch chain's passes
     unsigned long long* extent = nullptr;
     unsigned extent_gen = 0;
@@ -1188,7 +1187,7 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
     const bool merge_vn = tunables().prep_vn;
     // ext_gen != 0: the jobs that write the model's depth and vertex pyramids note the extent of what is valid (extent.hpp)
     const bool note_extent = model_side && merge_first && merge_last && ext_gen != 0;
-    auto noted = [&](PrepJob& j, int lvl) {
+    auto noted = [&](PrepJob& j, int lvl) {  // (the depth jobs: extent.hpp, extent_of_level)
         if (note_extent) j.ext = o->extent + 4 * lvl, j.ext_gen = ext_gen;
     };
     if (model_side) o->extent_gen = note_extent ? ext_gen : 0u;
@@ -1211,7 +1210,6 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             t.dst0 = planar ? o->vmaps_g_prev[0] : nullptr, t.dst1 = planar ? o->nmaps_g_prev[0] : nullptr, t.dst2 = o->prev_packed[0];
             for (int k = 0; k < 9; ++k) t.f[k] = R[k];
             t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
-            noted(t, 0);
             PrepJob& p = pb.add(PREP_TEX_PROJECT, cols, rows);
             p.src0 = pred_vertex, p.sel = sel, p.alt0 = alt_vertex;
             p.dst0 = planar ? o->cloud[0] : nullptr, p.dst1 = o->cloud4[0], p.dst2 = o->last_depth[0];
@@ -1228,7 +1226,6 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
             for (int k = 0; k < 9; ++k) t.f[k] = R[k];
             t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
-            noted(t, lvl);
             PrepJob& p = pb.add(PREP_PROJECT, cols, rows);
             p.src0 = o->last_depth[lvl], p.dst0 = planar ? o->cloud[lvl] : nullptr, p.dst1 = o->cloud4[lvl];
             intr_f(p, lvl, false, 0.f);
@@ -1270,7 +1267,6 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             const float R[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
             for (int k = 0; k < 9; ++k) t.f[k] = R[k];
             t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
-            noted(t, lvl);
             PrepJob& p = pb.add(PREP_PYR_PROJECT, cols, rows);
             p.src0 = o->last_depth[lvl - 1], p.scols = W >> (lvl - 1), p.srows = H >> (lvl - 1);
             p.dst0 = planar ? o->cloud[lvl] : nullptr, p.dst1 = o->cloud4[lvl], p.dst2 = o->last_depth[lvl];
@@ -1378,7 +1374,6 @@ static IcpArgs odom_icp_args(mmf_odom* o, int level, float* err_map) {
     a.prev_packed = o->prev_packed[level];
     a.err_map = err_map;
     a.err_stride = cols;
-    a.extent = nullptr, a.extent_gen = 0u;
     icp_args_derive(a);
     return a;
 }
@@ -1669,7 +1664,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                                         o->last_image[i], 0, o->next_image[i], 0, o->corres[i], o->max_depth_delta_rgb,
                                         cols, rows, last_l0 ? rgb_err_dev : nullptr, 0);
                 ra.intr = in;
-                ra.extent = cull_gen ? o->extent + 4 * i : nullptr, ra.extent_gen = cull_gen;
+                ra.extent = cull_gen ? o->extent : nullptr, ra.extent_gen = cull_gen, ra.extent_level = i;
                 res_vec4 = residual_vec4_ok(ra);
                 res_records = reduce_grid(cols * rows, res_vec4 ? kBlock * 4 : kBlock);
             }
@@ -1679,7 +1674,6 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
             int ipx = 1;
             if (icp) {
                 ia = odom_icp_args(o, i, last_l0 ? icp_err_dev : nullptr);
-                ia.extent = cull_gen ? o->extent + 4 * i : nullptr, ia.extent_gen = cull_gen;
                 ipx = std::min(2, icp_max_px(ia, 2));
             }
             const bool fuse_producers = rgb && icp && res_vec4 && icp2_fits(ia, kBlock, ipx) &&
@@ -1749,7 +1743,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 a.rows = rows;
                 a.cols_magic = ra.cols_magic;
                 a.intr = in;
-                a.extent = ra.extent, a.extent_gen = ra.extent_gen;
+                a.extent = ra.extent, a.extent_gen = ra.extent_gen, a.extent_level = ra.extent_level;
                 // the last step of a level also does the next level's gn_level_begin (one launch less per
                 // level).  Not with rgbOnly: its divergence `break` skips the finishing lane.
                 a.next_level = 0;

@@ -67,8 +67,8 @@ struct PrepJob {
     int sel_total;
     float sel_ratio;
     float f[12];
-    // non-null: the job notes the bounding box of the valid pixels it writes (extent.hpp) -- the model-side depth and
-    // vertex jobs of an object model, whose chain skips what lies outside
+    // non-null: the job notes a bounding box of the valid depths it writes (extent.hpp: extent_of_level) -- all of them at the
+    // coarsest level of an object model's depth pyramid, those in the last column / row at the two finer ones
     unsigned long long* ext;
     unsigned ext_gen;
 };
@@ -146,9 +146,8 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             m33 R;
 #pragma unroll
             for (int k = 0; k < 9; ++k) R.m[k] = J.f[k];
-            const bool v_ok = transform_pack_px(x, y, rows, cols, (const float*)src0, (const float*)src1, R, make_f3(J.f[9], J.f[10], J.f[11]),
-                                                (float*)J.dst0, (float*)J.dst1, (float*)J.dst2);
-            extent_note(J.ext, J.ext_gen, x, y, v_ok);
+            transform_pack_px(x, y, rows, cols, (const float*)src0, (const float*)src1, R, make_f3(J.f[9], J.f[10], J.f[11]),
+                              (float*)J.dst0, (float*)J.dst1, (float*)J.dst2);
             break;
         }
         case PREP_COPY_MAPS:
@@ -182,7 +181,6 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             const bool n_ok = resize_map_value<true>(x, y, J.srows, (const float*)src1, J.scols, ns);
             transform_pack_store(x, y, rows, cols, v_ok, vs, n_ok, ns, R, make_f3(J.f[9], J.f[10], J.f[11]), (float*)J.dst0,
                                  (float*)J.dst1, (float*)J.dst2);
-            extent_note(J.ext, J.ext_gen, x, y, v_ok);
             break;
         }
         case PREP_TEX_TP: {
@@ -196,7 +194,6 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             const f3 ns = ok ? make_f3(n.x, n.y, n.z) : make_f3(qnan(), qnan(), qnan());
             transform_pack_store(x, y, rows, cols, !(vs.x != vs.x), vs, !(ns.x != ns.x), ns, R, make_f3(J.f[9], J.f[10], J.f[11]),
                                  (float*)J.dst0, (float*)J.dst1, (float*)J.dst2);
-            extent_note(J.ext, J.ext_gen, x, y, !(vs.x != vs.x));
             break;
         }
         case PREP_TEX_PROJECT: {
@@ -204,7 +201,7 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             const float z = vertex_depth_value(((const float4*)src0)[(size_t)y * cols + x].z, J.f[4]);
             ((float*)J.dst2)[(size_t)y * cols + x] = z;
             project_points_store(x, y, z, cols, (float*)J.dst0, J.f[0], J.f[1], J.f[2], J.f[3], (float4*)J.dst1);
-            extent_note(J.ext, J.ext_gen, x, y, !(z != z));
+            extent_note(J.ext, J.ext_gen, x, y, !(z != z) && (x == cols - 1 || y == rows - 1));  // (extent_of_level: level 0's last column / row)
             break;
         }
         case PREP_TEX_PYR_F: {
@@ -215,7 +212,7 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             const float z = pyrdown_gauss_f_taps(
                 x, y, scols, J.srows, [&](int yy, int xx) { return vertex_depth_value(tex[(size_t)yy * scols + xx].z, cutoff); });
             ((float*)J.dst0)[(size_t)y * cols + x] = z;
-            extent_note(J.ext, J.ext_gen, x, y, !(z != z));
+            extent_note(J.ext, J.ext_gen, x, y, !(z != z) && (x == cols - 1 || y == rows - 1));  // (level 1's last column / row)
             break;
         }
         case PREP_TEX_PYR_U8: {

@@ -100,10 +100,11 @@ struct RgbResidualArgs {
     float* err_map;
     int err_stride;
     LevelIntr intr;
-    // non-null (object models): the level's extent of the model's own depth (extent.hpp) -- the 256-pixel blocks outside it
+    // non-null (object models): the extent of the model's own depth (extent.hpp) -- the 256-pixel blocks outside it
     // hold no pixel that can take part, and neither this pass nor rgb_step_kernel touches them
     const unsigned long long* extent;
     unsigned extent_gen;
+    int extent_level;  // this pass's pyramid level (extent_of_level)
 };
 
 // Like the ICP kernel this one only produces partial records {count, sum diff^2}; they are summed
@@ -161,7 +162,7 @@ __device__ __forceinline__ void residual_block4(const OdomState* __restrict__ st
     const int level_break = GN ? st->level_break : 0;  // consumed after the image loads are in flight
     const bool cull = GN && ALIGNED && a.extent != nullptr;  // (uniform)
     ExtentBox box{0, 0, 0, 0};
-    if (cull) box = extent_load(a.extent, a.extent_gen);
+    if (cull) box = extent_of_level(a.extent, a.extent_gen, a.extent_level);
 
     for (int g = bid * kBlock + threadIdx.x; g < N4; g += nblocks * kBlock) {
         int i, j0;
@@ -402,7 +403,6 @@ __global__ __launch_bounds__(kBlock) void track_producer_kernel(const OdomState*
         ra.last_image = batch_shift(ra.last_image, d), ra.corres = batch_shift(ra.corres, d);
         ra.err_map = batch_shift(ra.err_map, d);
         ra.extent = blockIdx.y ? batch_shift(ra.extent, d) : nullptr;  // (the batch's first model is the dense one)
-        ia.extent = blockIdx.y ? batch_shift(ia.extent, d) : nullptr;
         icp_partials = batch_shift(icp_partials, d), res_partials = batch_shift(res_partials, d);
     }
     // st->level_break is checked inside the blocks, after their state-independent loads are in flight
@@ -466,6 +466,7 @@ struct RgbStepArgs {
     int final_step;       // 1: the very last step of the frame: the finishing lane also does odom_end
     const unsigned long long* extent;  // as RgbResidualArgs::extent: the blocks the correspondence pass skipped hold no record
     unsigned extent_gen;
+    int extent_level;
 };
 
 // RGBDOdometry.cpp:464-467, 475-476
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void rgb_step_kernel(OdomState* __restrict_
     const bool live = i0 < N;
     const bool cull = COMPACT && a.extent != nullptr;  // (uniform)
     ExtentBox box{0, 0, 0, 0};
-    if (cull) box = extent_load(a.extent, a.extent_gen);
+    if (cull) box = extent_of_level(a.extent, a.extent_gen, a.extent_level);
     // this wave's records were never written (residual_block4 skipped the block): nothing to add
     const bool skip = cull && extent_misses(box, (unsigned)(i0 - (int)(threadIdx.x & 63u) * PX), 64u * PX, a.cols, a.cols_magic);
     static_assert(!COMPACT || PX % 2 == 0, "compact records are loaded in pairs");
