@@ -1211,6 +1211,34 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             only->spec_tex_gen = m->tex_gen;
             only->spec_f2f = g.frame_to_frame_rgb;
             only->spec_valid = true;
+        } else if (owned > (int)fused_max_models() && f->shard_world <= 1 && g.batch_tracking && owned <= kMaxBatch && tunables().spec_prep_all) {
+            // Several models on this GPU: the same for all of them, in the launches they will share (the batched chain's
+            // preparation: one set of stages, every model's jobs).  At the start of the next call these ~50 jobs were what the
+            // calling thread enqueued first -- 130 us of it and as much of the GPU's -- while the GPU had nothing else to do; here
+            // they queue up behind the frame's last passes.  A model whose pose or prediction changes before it is tracked
+            // (a pose initialisation, a caller's predict()) is prepared again then (spec_hit).  From four models on: with two or
+            // three (the one-launch chain) the call's start is short and the early preparation measured 6 % slower.
+            PrepStages stages;
+            stages.set_critical(true);
+            const unsigned ext_gen = ++f->extent_seq;
+            for (size_t k = 0; k < f->models.size(); ++k) {
+                if (!fusion_owns(f, k)) continue;
+                FusionModel* fm = f->models[k];
+                const mmf_model* m = fm->model;
+                const uint8_t* pi = (const uint8_t*)((g.frame_to_frame_rgb && fm->fill_in) ? m->fill_image : m->image);
+                fm->odom->sparse = fm != global && !fm->fill_in;
+                mmf_model_get_pose(fm->model, fm->spec_pose);
+                odom_prepare_collect(stages, fm->odom, f->depth_filtered, g.max_depth_processed, rgb, 3, (const float*)m->vertexConf,
+                                     (const float*)m->normalRadius, pi, 4, fm->spec_pose,
+                                     fm->fill_in ? fusion_thumb_count(m) : nullptr, (const float*)m->fill_vertex,
+                                     (const float*)m->fill_normal, (const uint8_t*)m->fill_image, PREP_MODEL_SIDE,
+                                     (m->width / 20) * (m->height / 20), 0.75f, fm->odom->sparse ? ext_gen : 0u);
+                fm->spec_tex_gen = m->tex_gen;
+                fm->spec_f2f = g.frame_to_frame_rgb;
+                fm->spec_valid = true;
+            }
+            rc = stages.launch(c->stream);  // (every lane has joined this stream just above)
+            if (rc) return rc;
         }
     }
     stamp(5);

@@ -29,6 +29,7 @@ struct Tunables {
     bool host_trace = false;  // MMF_HOST_TRACE=1: the calling thread's timeline (stderr, every 100 calls)
     // ---- surfel passes ----
     int track_cull = 1;       // MMF_TRACK_CULL=0: object models are tracked like the camera model (whole image, full grids)
+    int spec_prep_all = 1;    // MMF_SPEC_PREP_ALL=0: with several models per GPU the model-side preparation waits for the next call
     int splat_wgs = 0;        // MMF_SPLAT_WGS: workgroups of a splat launch (0 = by the store's size)
     int splat_bound = -1;     // MMF_SPLAT_BOUND=0|1: the bounded depth test never / always (-1 = by the store's size)
 };
@@ -61,6 +62,7 @@ inline const Tunables& tunables() {
         v.host_up_events = flag("MMF_HOST_UP_EVENTS", false);
         v.host_trace = flag("MMF_HOST_TRACE", false);
         v.track_cull = (int)num("MMF_TRACK_CULL", 1);
+        v.spec_prep_all = (int)num("MMF_SPEC_PREP_ALL", 1);
         v.splat_wgs = (int)num("MMF_SPLAT_WGS", 0);
         if (std::getenv("MMF_SPLAT_BOUND")) v.splat_bound = num("MMF_SPLAT_BOUND", 0) ? 1 : 0;
         return v;
