@@ -526,9 +526,9 @@ int mmf_debug_force_gn_fault(int n);
  * inside this library reads its images before the frame's second predict() (:821) overwrites them, 0 = leave it out (the
  * default; -1 = the default).  Process wide. */
 int mmf_debug_set_mid_predict(int on);
-/* test / A-B hook: the bounded depth test of combinedPredict (splat_bound_kernel: every drawn surfel's centre fragment first,
- * as a per-pixel bound that lets the splat skip occluded fragments and their atomics; same images).  1 = always, 0 = never,
- * -1 = when the store holds two surfels per pixel or more (the default).  Process wide. */
+/* test / A-B hook: the early depth test of combinedPredict (splat_kernel<true>: the rasterising pass reads a pixel's key before it
+ * evaluates a fragment there and skips what cannot win; same images).  1 = always, 0 = never, -1 = when the store holds two
+ * surfels per pixel or more (the default).  Process wide. */
 int mmf_debug_set_splat_bound(int mode);
 /* test / A-B hook: object models in the producer + step chain (csrc/extent.hpp, ChainGeom: their passes skip the blocks outside
  * the model's own depth and walk the images with a quarter of the workgroups).  1 = on, 0 = every model is tracked like the

@@ -2165,7 +2165,6 @@ struct mmf_model {
     unsigned* winner = nullptr;    // capacity
     float2* conf_time = nullptr;   // capacity + npix
     unsigned long long* keys = nullptr;  // npix
-    unsigned* zbound = nullptr;          // npix: splat_bound_kernel's per-pixel depth bound (0xFFFFFFFF between passes)
     float4* rays = nullptr;              // npix: the pixels' normalised viewing rays (splat_ray_kernel), transposed
     // sparse index map (ModelProjection.cpp:28-41)
     unsigned* index = nullptr;
@@ -2238,7 +2237,7 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     for (int k = 0; k < 3; ++k) o_cand[k] = carve(npix * 16);
     const size_t o_fa = carve((cap + npix) * 4), o_fb = carve(npix * 4), o_pa = carve((cap + npix) * 4),
                  o_pb = carve(npix * 4), o_bs = carve(((cap + npix) / 256 + 2) * 4), o_tot = carve(64),
-                 o_win = carve(cap * 4), o_ct = carve((cap + npix) * 8), o_keys = carve(npix * 8), o_zb = carve(npix * 4), o_rays = carve(npix * 16),
+                 o_win = carve(cap * 4), o_ct = carve((cap + npix) * 8), o_keys = carve(npix * 8), o_rays = carve(npix * 16),
                  o_idx = carve(npix * 4), o_vc = carve(npix * 16), o_ctm = carve(npix * 16), o_nr = carve(npix * 16),
                  o_img = carve(npix * 4), o_vxc = carve(npix * 16), o_nrr = carve(npix * 16), o_tt = carve(npix * 2), o_sd = carve(npix * 4), o_ex = carve(npix * 52),
                  o_fv = carve(npix * 16), o_fn = carve(npix * 16), o_fi = carve(npix * 4);
@@ -2259,7 +2258,6 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     m->block_sums = (unsigned*)(b + o_bs), m->totals = (unsigned*)(b + o_tot);
     m->winner = (unsigned*)(b + o_win), m->conf_time = (float2*)(b + o_ct);
     m->keys = (unsigned long long*)(b + o_keys);
-    m->zbound = (unsigned*)(b + o_zb);
     m->rays = (float4*)(b + o_rays);
     m->index = (unsigned*)(b + o_idx);
     m->vertConf = (float4*)(b + o_vc), m->colorTime = (float4*)(b + o_ctm), m->normRad = (float4*)(b + o_nr);
@@ -2271,7 +2269,6 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
     hipLaunchKernelGGL(fill_u32_kernel, grid1d(cap), dim3(256), 0, c->stream, m->winner, cap, kNoWinner);
     // the key image starts empty and every resolve kernel hands it back empty
     hipLaunchKernelGGL(fill_u64_kernel, grid1d(npix), dim3(256), 0, c->stream, m->keys, npix, kEmptyKey);
-    hipLaunchKernelGGL(fill_u32_kernel, grid1d(npix), dim3(256), 0, c->stream, m->zbound, npix, 0xFFFFFFFFu);
     hipLaunchKernelGGL(splat_ray_kernel, grid1d(npix), dim3(256), 0, c->stream, make_cam(m, false), width, height, m->rays);
     MMF_HIP_TRY(hipGetLastError());
     MMF_HIP_TRY(hipHostMalloc(&m->host_totals, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -2489,7 +2486,7 @@ extern "C" int mmf_debug_depth_keys(mmf_ctx* c, const float* z_dev, int n, float
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }
-static std::atomic<int> g_splat_bound{-2};  // -2: what the environment says (MMF_SPLAT_BOUND), else by the surfel count; -1 / 0 / 1: mmf_debug_set_splat_bound
+static std::atomic<int> g_splat_bound{-2};  // the early depth test of a deep store; -2: what the environment says (MMF_SPLAT_BOUND), else by the surfel count; -1 / 0 / 1: mmf_debug_set_splat_bound
 extern "C" int mmf_debug_set_splat_bound(int mode) {
     g_splat_bound.store(mode < 0 ? -1 : (mode ? 1 : 0));
     return MMF_OK;
@@ -2515,19 +2512,16 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     // right after clean() the exact count may still be in flight to the host: size the launch by the bound
     // and let the kernel read the count on the device instead of waiting for it
     const unsigned launch_count = m->count_pending ? m->count_bound : m->count;
-    // a DEEP store (two surfels per pixel and more: occluded layers) takes the bounded depth test (surfel_kernels.hpp,
-    // splat_bound_kernel): one more launch, a fraction of the fragments and of their atomics.  Same images either way.
+    // a DEEP store (two surfels per pixel and more: occluded layers) looks at the key image before it evaluates a fragment
+    // (surfel_kernels.hpp, splat_kernel<true>): a fraction of the fragments and of their atomics.  Same images either way.
     const int bound_mode = g_splat_bound.load() == -2 ? tunables().splat_bound : g_splat_bound.load();
     const size_t npix_s = (size_t)m->width * m->height;
     const bool deep_store = (size_t)launch_count >= 2 * npix_s;
     const bool deep = bound_mode < 0 ? deep_store : bound_mode != 0;
-    a.zb = (deep && launch_count) ? m->zbound : nullptr;
+    a.early_z = deep ? 1 : 0;
     a.rays = m->rays;
-    if (a.zb)
-        hipLaunchKernelGGL(splat_bound_kernel, grid1d(launch_count), dim3(256), 0, c->stream, m->set[m->cur], (int)launch_count, a,
-                           m->count_pending ? m->totals : nullptr);
     if (launch_count)
-        hipLaunchKernelGGL(a.zb ? splat_kernel<true> : splat_kernel<false>, splat_grid(launch_count, (size_t)launch_count >= npix_s / 2), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(deep ? splat_kernel<true> : splat_kernel<false>, splat_grid(launch_count, (size_t)launch_count >= npix_s / 2), dim3(256), 0, c->stream,
                            m->set[m->cur], (int)launch_count, a, m->keys, m->count_pending ? m->totals : nullptr);
     if (fill_rgb && fill_depth) {  // (a pending frame rider stays for the predictIndices that follows: frame_rider.hpp)
         hipLaunchKernelGGL(splat_resolve_fill_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0,
@@ -2561,7 +2555,7 @@ extern "C" int mmf_model_synthesize_depth(mmf_model* m, float depth_cutoff, floa
     a.maxDepth = depth_cutoff;
     a.confThreshold = conf_threshold;
     a.time = time, a.maxTime = max_time, a.timeDelta = time_delta;
-    a.zb = nullptr, a.rays = m->rays;
+    a.early_z = 0, a.rays = m->rays;
     if (int rc0 = model_resolve_count(m)) return rc0;
     if (m->count)
         hipLaunchKernelGGL(splat_kernel<false>, splat_grid(m->count), dim3(256), 0, c->stream, m->set[m->cur], (int)m->count, a,

@@ -538,9 +538,9 @@ struct SplatArgs {
     int cols, rows;
     float maxDepth, confThreshold;
     int time, maxTime, timeDelta;
-    // non-null: a per-pixel upper bound of the depth test's winner (transposed like the key image), filled by
-    // splat_bound_kernel before splat_kernel runs and handed back full (0xFFFFFFFF) by the resolve pass
-    unsigned* zb;
+    // != 0: a DEEP store (two surfels per pixel and more): the rasterising pass looks at the key image before it evaluates a
+    // fragment (splat_kernel<true>)
+    int early_z;
     // the viewing ray of every pixel centre, normalised (combo_splat.frag:41-42), transposed like the key image: it depends on
     // the camera alone, so the model keeps it as a table (splat_ray_kernel) instead of two divisions, a square root and a
     // third division per fragment
@@ -643,34 +643,14 @@ __global__ __launch_bounds__(256) void splat_ray_kernel(Cam c, int cols, int row
     rays[i] = make_float4(l.x, l.y, l.z, 0.f);
 }
 
-// The depth test of a DEEP store (a room seen from many sides: two surfels per pixel and more, four-fold overdraw).
-// splat_bound_kernel runs first when the host finds the store that deep (by the surfel count): every drawn surfel's CENTRE
-// fragment -- the very splat_fragment of its centre pixel -- goes into a 32-bit per-pixel bound by atomicMin.  splat_kernel
-// then reads the bound (read-only during that launch: L2 resident) and skips a fragment when even the nearest point of its
-// disc (h.z - rad) lies behind the bound, and skips the atomic when the fragment itself does.  Every skipped fragment loses
-// against a fragment that is drawn, so the key image -- and with it all four images -- keeps its bits.  740 k stable
-// surfels at 640x480 (18 M fragments): 105 -> 87 us for the whole combinedPredict; a store of one surfel per pixel gains
-// nothing (the pre-pass costs what it saves), so the host's threshold is two.
-__global__ __launch_bounds__(256) void splat_bound_kernel(SurfelSoA s, int count, SplatArgs a_in, const unsigned* __restrict__ count_dev) {
-    MMF_MODEL_STREAM_PRIORITY();
-    MMF_SPECULATION_GUARD(a_in);
-    const SplatArgs a = with_device_pose(a_in);
-    if (count_dev != nullptr) count = min((unsigned)count, *count_dev);
-    const int id = blockIdx.x * 256 + threadIdx.x;
-    if (id >= count) return;
-    const float4 p = s.pos[id], col = s.col[id];
-    if (p.w < a.confThreshold || (float)a.time - col.w > (float)a.timeDelta || col.w > (float)a.maxTime) return;  // (splat_setup's culls that need no arithmetic)
-    float xw, yw;
-    const SplatFrag f = splat_setup<false>(p, col, s.nrm[id], a, &xw, &yw);
-    if (!f.ok) return;
-    // the pixel the centre falls into (inside the sprite, whose side is at least one pixel; xn = 1 exactly lands one past the image)
-    const int cpx = min((int)floorf(xw), a.cols - 1), cpy = min((int)floorf(yw), a.rows - 1);
-    float z;
-    unsigned d24;
-    if (!splat_fragment(f, a, cpx, cpy, z, d24)) return;
-    atomicMin(&a.zb[(size_t)cpx * a.rows + cpy], d24);
-}
-
+// The depth test of a DEEP store (a room seen from many sides: two surfels per pixel and more, four-fold overdraw): most
+// fragments lose it.  splat_kernel<true> reads the pixel's key as its cache sees it, in the round trip of the rays, skips a
+// fragment when even the nearest point of its disc (h.z - rad) lies behind that key's depth, and skips the atomic when the
+// fragment itself does.  A stale look is a LARGER key (keys only ever fall during the pass), i.e. a fragment drawn that an
+// up-to-date look would have skipped: the key image -- and with it all four images -- keeps its bits.  740 k stable surfels
+// at 640x480 (18 M fragments): combinedPredict 105 -> 81 us (a pre-pass that wrote every surfel's centre fragment into a
+// per-pixel bound first, this round's first form: 87 us); the headline loop's 246 k surfels would LOSE 2.5 us to the extra
+// load per pixel slot, so the host asks for it from two surfels per pixel on.
 // z / (2 maxDepth) for the depth key, without the division: with y = RN(1 / b), q = RN(z y), r = z - b q (one fma, exact),
 // RN(q + r y) IS the correctly rounded quotient (Markstein's theorem; the division the compiler emits ends in these very
 // steps, after refining a reciprocal that here is a constant of the launch).  Where the theorem does not reach -- quotients
@@ -724,7 +704,7 @@ struct SplatRowLds {  // per surfel of the wave's pass, structure of arrays: lan
     unsigned dmin[256];
     int seg_end[256];     // inclusive scan of rows x segments per row inside each wave
 };
-template <bool BOUNDED>
+template <bool EARLYZ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void splat_kernel(SurfelSoA s, int count, SplatArgs a_in,
                                                     unsigned long long* __restrict__ keys,
                                                     const unsigned* __restrict__ count_dev) {
@@ -770,7 +750,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void s
             L.x01[t] = (unsigned)f.x0 | ((unsigned)f.x1 << 16);
             L.y0n[t] = (unsigned)f.y0 | ((unsigned)nseg << 16);
             L.magic[t] = nseg > 1 ? 0xFFFFFFFFu / (unsigned)nseg + 1u : 0u;
-            if (BOUNDED) L.dmin[t] = f.dmin;
+            if (EARLYZ) L.dmin[t] = f.dmin;
             L.seg_end[t] = scan;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -795,15 +775,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void s
             SplatFrag g;
             g.nrm = V3(L.nx[e], L.ny[e], L.nz[e]), g.hn = L.hn[e];
             g.h = V3(L.hx[e], L.hy[e], L.hz[e]), g.rad = L.rad[e];
-            const unsigned dmin = BOUNDED ? L.dmin[e] : 0u;
+            const unsigned dmin = EARLYZ ? L.dmin[e] : 0u;
 
-            // the segment's viewing rays (and, with a bound, its bounds) in one round trip
+            // the segment's viewing rays (and, for a deep store, its pixels' keys) in one round trip
             unsigned zbv[kSplatSeg];
             float4 ray[kSplatSeg];
 #pragma unroll
             for (int k = 0; k < kSplatSeg; ++k) {
                 const size_t at = (size_t)min(pb + k, x1) * a.rows + py;
-                zbv[k] = BOUNDED ? a.zb[at] : 0xFFFFFFFFu;
+                zbv[k] = EARLYZ ? (unsigned)(keys[at] >> 32) : 0xFFFFFFFFu;
                 ray[k] = a.rays[at];
             }
             // all four fragments first, then their atomics: a wait for a ray that follows an atomic in program order would
@@ -816,7 +796,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void s
                 const v3 l = V3(ray[k].x, ray[k].y, ray[k].z);
                 const float q = splat_plane_q(g, l);
                 d24v[k] = splat_depth24_fast(l.z * q, ds);
-                draw[k] = pb + k <= x1 && !(BOUNDED && (dmin > zbv[k] || d24v[k] > zbv[k])) && splat_in_disc(g, l, q);
+                draw[k] = pb + k <= x1 && !(EARLYZ && (dmin > zbv[k] || d24v[k] > zbv[k])) && splat_in_disc(g, l, q);
                 MMF_SPLAT_TALLY(0, pb + k <= x1);
                 MMF_SPLAT_TALLY(2, draw[k]);
             }
@@ -839,7 +819,7 @@ struct SplatTexel {
 // (x, y) -- threads run along x, the images are row-major -- gets its key.  Returns false outside the image.
 constexpr int kSplatTile = 16;
 __device__ __forceinline__ bool splat_tile_key(unsigned long long* __restrict__ keys, int cols, int rows, int& px, int& py,
-                                               unsigned long long& k, unsigned first_block = 0, unsigned* __restrict__ zb = nullptr) {
+                                               unsigned long long& k, unsigned first_block = 0) {
     __shared__ unsigned long long tile[kSplatTile][kSplatTile + 1];
     const int tiles_x = (cols + kSplatTile - 1) / kSplatTile;
     const int bid = (int)(blockIdx.x - first_block);
@@ -852,7 +832,6 @@ __device__ __forceinline__ bool splat_tile_key(unsigned long long* __restrict__ 
         if (x < cols && y < rows) {
             v = keys[(size_t)x * rows + y];
             if (v != kEmptyKey) keys[(size_t)x * rows + y] = kEmptyKey;
-            if (zb != nullptr) zb[(size_t)x * rows + y] = 0xFFFFFFFFu;  // (the bound of this pass: handed back full)
         }
         tile[cx][cy] = v;
     }
@@ -918,7 +897,7 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatAr
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
-    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, 0, a.zb)) return;
+    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, 0)) return;
     const int i = py * a.cols + px;
     const SplatTexel t = splat_resolve_px(i, k, s, a);
     image[i] = t.image;
@@ -934,7 +913,7 @@ __global__ __launch_bounds__(256) void splat_depth_resolve_kernel(SurfelSoA s, S
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
-    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, 0, a.zb)) return;
+    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, 0)) return;
     const int i = py * a.cols + px;
     float z = 0.f;
     if (k != kEmptyKey) {
@@ -1477,7 +1456,7 @@ __global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, Sp
     const SplatArgs a = with_device_pose(a_in);
     int px, py;
     unsigned long long k;
-    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, 0, a.zb)) return;
+    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, 0)) return;
     const int i = py * a.cols + px;
     const SplatTexel t = splat_resolve_px(i, k, s, a);
     image[i] = t.image;

@@ -36,7 +36,7 @@ def test_filter_depth_bit_exact(gpu_ctx, orc, w, h):
 
 @pytest.fixture
 def splat_bound(gpu_ctx, request):
-    """combinedPredict's bounded depth test (splat_bound_kernel): -1 = by the surfel count, 1 = always"""
+    """combinedPredict's early depth test (splat_kernel<true>: the key image is read before a fragment is evaluated): -1 = by the surfel count, 1 = always"""
     gpu_ctx.lib.mmf_debug_set_splat_bound(request.param)
     yield request.param
     gpu_ctx.lib.mmf_debug_set_splat_bound(-1)
@@ -115,7 +115,7 @@ def test_surfel_cycle_bit_exact(gpu_ctx, orc, w, h, splat_bound):
 @pytest.mark.parametrize("w,h", [(320, 240), (640, 480)])
 def test_bounded_splat_keeps_the_images_of_a_deep_store(gpu_ctx, orc, w, h):
     """A store with occluded layers (what a room seen from many sides leaves: here the map of one frame plus three copies
-    pushed 2 / 4 / 6 cm behind the surfaces, all stable) is drawn with and without the bounded depth test: the four images
+    pushed 2 / 4 / 6 cm behind the surfaces, all stable) is drawn with and without the early depth test (splat_kernel<true>): the four images
     must keep their bits -- and equal the oracle's -- while most fragments are never evaluated."""
     from multimotionfusion_amd.model import filterDepth
     K, m = make_model(gpu_ctx, w, h)

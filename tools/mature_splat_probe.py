@@ -1,5 +1,5 @@
 """GPU box: combinedPredict on a DEEP store (one frame's map + three occluded copies, ~740 k stable surfels at 640x480) with the
-plain and with the bounded depth test (mmf_debug_set_splat_bound), HIP events around the pass, median of 15.
+plain and with the early depth test (splat_kernel<true>: mmf_debug_set_splat_bound), HIP events around the pass, median of 15.
 
     python tools/mature_splat_probe.py [WxH]
 """
@@ -43,7 +43,7 @@ deep = np.concatenate(layers)[: 1024 * 1024 - 310000]
 m.uploadMap(deep)
 m.overridePose(pose_now)
 ref = None
-for mode, name in ((0, "plain"), (1, "bounded"), (0, "plain"), (1, "bounded")):
+for mode, name in ((0, "plain"), (1, "early-z"), (0, "plain"), (1, "early-z")):
     ctx.lib.mmf_debug_set_splat_bound(mode)
     ts = []
     for rep in range(18):
@@ -67,7 +67,7 @@ if os.environ.get("MMF_HIP_LIB") and "count" in os.environ["MMF_HIP_LIB"]:  # a 
     ctx.lib.mmf_debug_set_splat_bound(1)
     m.combinedPredict(MAXD, tick, tick, TIME_DELTA)
     raw.mmf_debug_splat_counts(out, 1)
-    print("bounded pass: fragments in sprites %.2f M, past the disc-depth bound %.2f M, drawn (atomics) %.2f M" % (out[0] / 1e6, out[1] / 1e6, out[2] / 1e6))
+    print("early-z pass: fragments in sprites %.2f M, past the disc-depth bound %.2f M, drawn (atomics) %.2f M" % (out[0] / 1e6, out[1] / 1e6, out[2] / 1e6))
 ctx.lib.mmf_debug_set_splat_bound(-1)
 m.close()
 ctx.close()
