@@ -897,6 +897,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // of idle GPU per frame).
             // (With several models it is one model per process in the sharded configuration: the segmentation between
             // tracking and fusion touches masks, thresholds and the list, none of which a projection reads.)
+            static_assert(std::is_trivially_copyable<mmf_model>::value, "the speculation rollback below copies mmf_model by value");
             mmf_model early_snapshot;  // the model's host bookkeeping before the passes enqueued ahead of the pose (see `retrack` below)
             bool early_snapshot_valid = false;
             if (tracked.size() == 1 && !fr->bootstrap && !have_init && !g.rgb_only && f->tracking_ok) {
@@ -1022,6 +1023,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                         k = (size_t)-1;  // pick the results up again, from the first model
                         continue;
                     }
+                    if (rc == kGnRetry) return gn_retry_twice();
                     if (rc) return rc;
                     for (int r = 0; r < 3; ++r) {
                         for (int q = 0; q < 3; ++q) pose[r * 4 + q] = rot[r * 3 + q];

@@ -142,7 +142,7 @@ __device__ __forceinline__ bool gn_sum_add(OdomState* st, int it, int lane, floa
     const bool ok = __builtin_fabs(d) < 9007199254740992.0;  // 2^53 per workgroup: 512 of them fit 2^62 (a NaN fails too)
     const long long q = ok ? (long long)__builtin_rint(d) : 0ll;
     if (lane < 58)
-        (void)__hip_atomic_fetch_add(&st->gn_sum[it % 3][blockIdx.x % kGnSumShards][lane], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        (void)__hip_atomic_fetch_add(&st->gn_sum[it % 3][blockIdx.x % kGnSumShards][lane], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (same global_atomic_add_x2 as workgroup scope on gfx950; agent is what the memory model asks for)
     return ok || lane >= 58;
 }
 

@@ -24,7 +24,6 @@
 #include <type_traits>
 #include <vector>
 
-#include "launch_graph.hpp"
 #include "map_kernels.hpp"
 #include "prep_batch.hpp"
 #include "pose_algebra.hpp"
@@ -33,6 +32,24 @@
 #include "gn_fused.hpp"
 
 using namespace mmf;
+
+// The enqueue side of a chain of dependent kernel launches: launches go out in call order on one stream, the first error
+// is kept (`flush`).  (Rounds 2-3 could replay such a chain as a hipGraph; a graph launch reaches the GPU ~10 us later than
+// the first kernel of a launch-by-launch chain and the replay is gone: LABNOTES.md.)
+struct Enqueuer {
+    hipStream_t stream = nullptr;
+    hipError_t err = hipSuccess;
+
+    explicit Enqueuer(hipStream_t s) : stream(s) {}
+
+    template <typename... KArgs, typename... Args>
+    void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, Args&&... args) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, static_cast<KArgs>(args)...);
+        const hipError_t e = hipGetLastError();
+        if (err == hipSuccess) err = e;
+    }
+    hipError_t flush() const { return err; }  // everything launched so far is on the stream; the first error, if any
+};
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -1470,7 +1487,10 @@ extern "C" int mmf_debug_set_track_cull(int mode) {
 }
 static std::atomic<int> g_gn_force_fault{0};
 static std::atomic<int> g_gn_recoveries{0};
-constexpr int kGnRetry = 1;  // odom_finish_tracking: the one-launch chain gave up; track again (odom_retrack_prepare)
+// odom_finish_tracking: the one-launch chain gave up; track again (odom_retrack_prepare).  A private sentinel, outside the
+// public mmf_status range (include/mmf_hip.h: 0 and small negatives): it never leaves the library (gn_retry_twice).
+constexpr int kGnRetry = 0x6e726574;
+static int gn_retry_twice() { return fail(MMF_ERR_STATE, "odometry: tracking gave up twice (the two-launch chain reported a fault)"); }
 
 static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float rot[9], int rgb_only, float icp_weight,
                                  int pyramid, int fast_odom, int so3, float* icp_err_dev, float* rgb_err_dev,
@@ -1536,8 +1556,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     b.first_intr = level_intr(o->fx, o->fy, o->cx, o->cy, fused_chain ? first_iter_level : MMF_NUM_PYRS - 1);
     o->n_timed = 0;
     if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[0], c->stream));
-    // from here to the last step: kernels only, all on the fused-producer path when `odom_batchable` -- recorded and
-    // sent as one graph launch (launch_graph.hpp).  The measurement modes and the other paths launch one by one.
+    // from here to the last step: kernels only, enqueued one by one in call order (Enqueuer keeps the first error)
     Enqueuer q(c->stream);
     q.launch(odom_begin_kernel, dim3(ny), dim3(64), o->state, b, bd, poses);
 
@@ -2002,7 +2021,8 @@ extern "C" int mmf_odom_get_incremental_transformation(mmf_odom* o, float trans[
     odom_retrack_prepare(&o, 1, so3);
     rc = odom_enqueue_tracking(o, trans0, rot0, rgb_only, icp_weight, pyramid, fast_odom, so3, icp_err_dev, rgb_err_dev);
     if (rc) return rc;
-    return odom_finish_tracking(o, trans, rot);
+    rc = odom_finish_tracking(o, trans, rot);
+    return rc == kGnRetry ? gn_retry_twice() : rc;
 }
 
 // measurement mode: per-launch durations of the Gauss-Newton kernels from the dispatches' own timestamps

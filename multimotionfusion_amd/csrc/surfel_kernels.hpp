@@ -783,7 +783,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void s
 #pragma unroll
             for (int k = 0; k < kSplatSeg; ++k) {
                 const size_t at = (size_t)min(pb + k, x1) * a.rows + py;
-                zbv[k] = EARLYZ ? (unsigned)(keys[at] >> 32) : 0xFFFFFFFFu;
+                // (an atomic relaxed load: the compiler may neither hoist nor merge it across the atomicMin's of the same image)
+                zbv[k] = EARLYZ ? (unsigned)(__hip_atomic_load(&keys[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) : 0xFFFFFFFFu;
                 ray[k] = a.rays[at];
             }
             // all four fragments first, then their atomics: a wait for a ray that follows an atomic in program order would

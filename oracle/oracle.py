@@ -13,9 +13,10 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_DIR, "liboracle.so")
 
 
-def build(force=False, march=None, out=None, extra=None):
+def build(force=False, march=None, out=None, extra=None, contract=None):
     """make the oracle library (gcc).  `march`/`out` let bench.py build a -march=native copy; `extra` adds compiler
-    flags (-DORC_LIBM_EXP: the C library's expf instead of the shared mmf_expf)."""
+    flags (-DORC_LIBM_EXP: the C library's expf instead of the shared mmf_expf); `contract` = "fast" with an FMA `march`
+    builds the contracting variant that tests/test_oracle_contraction.py compares the checker with."""
     target = out or "liboracle.so"
     path = os.path.join(_DIR, target)
     src_m = max(os.path.getmtime(os.path.join(_DIR, f))
@@ -28,8 +29,28 @@ def build(force=False, march=None, out=None, extra=None):
         cmd.append(f"MARCH={march}")
     if extra:
         cmd.append(f"EXTRA={extra}")
+    if contract:
+        cmd.append(f"CONTRACT={contract}")
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
     return path
+
+
+class use_lib:
+    """`with use_lib(path):` -- every wrapper below that takes the default library takes `path` instead (tests that run the
+    same steps through two builds of the oracle)."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global LIB
+        self.saved, LIB = LIB, self.path
+        return lib(self.path)
+
+    def __exit__(self, *exc):
+        global LIB
+        LIB = self.saved
+        return False
 
 
 class _Dataterm(C.Structure):
