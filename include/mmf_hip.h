@@ -522,6 +522,19 @@ int mmf_debug_set_gn_fused(int on);
 int mmf_gn_chain_status(int *recoveries, int *one_launch_chain_in_use);
 /* test hook: the next n one-launch chains of this process give up at their third launch */
 int mmf_debug_force_gn_fault(int n);
+/* test hooks of the object models' walk in the one-launch chain (csrc/gn_fused.hpp: an object model's ICP term covers only the
+ * rectangle of sensor pixels its prediction can reach under the iteration's pose).  Checking mode (process wide): such models
+ * walk the WHOLE image and count the correspondences icpStep accepts outside that rectangle.  mmf_debug_odom_sparse_outside:
+ * that count over the last chain of an odometry (0 or the rectangle is wrong), whether the chain walked it by its extents, and
+ * rect = the level-0 rectangle of the chain's last launch {x0, y0, width, rows}, the most passes a level-0 rectangle took, and
+ * whether the rectangles were derived (1) or the whole image (0), then the lanes the box of the model's own depth needed at
+ * levels 0 / 1 / 2 (what its next chain is sized by).  Any pointer may be NULL. */
+int mmf_debug_set_sparse_check(int on);
+/* test hook: object models get n workgroups per launch of the one-launch chain at every level (0: the default, 32 / 24 / 16);
+ * with n = 1 no object's extent fits, the chain reports it, the frame is tracked again on the two-launch chain and the model's
+ * next chain is sized by what its box needed -- the one-launch chain stays in use (mmf_gn_chain_status) */
+int mmf_debug_set_sparse_groups(int n);
+int mmf_debug_odom_sparse_outside(mmf_odom *o, unsigned *outside, int *walked_by_extent, int rect[9]);
 /* test / A-B hook: 1 = enqueue the reference's first predict() of a frame (MultiMotionFusion.cpp:675) although nothing
  * inside this library reads its images before the frame's second predict() (:821) overwrites them, 0 = leave it out (the
  * default; -1 = the default).  Process wide. */

@@ -208,6 +208,9 @@ SIGNATURES = {
     "mmf_debug_set_gn_fused": (_i, [_i]),
     "mmf_debug_set_mid_predict": (_i, [_i]),
     "mmf_debug_force_gn_fault": (_i, [_i]),
+    "mmf_debug_set_sparse_check": (_i, [_i]),
+    "mmf_debug_set_sparse_groups": (_i, [_i]),
+    "mmf_debug_odom_sparse_outside": (_i, [_vp, C.POINTER(C.c_uint), C.POINTER(_i), C.POINTER(_i)]),
     "mmf_gn_chain_status": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "mmf_debug_set_splat_bound": (_i, [_i]),
     "mmf_debug_set_track_cull": (_i, [_i]),

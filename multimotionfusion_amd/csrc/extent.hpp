@@ -77,4 +77,42 @@ __device__ __forceinline__ bool extent_misses(const ExtentBox& e, unsigned first
     return e.x1 < e.x0 || xb < e.x0 || xa > e.x1 || yb < e.y0 || ya > e.y1;
 }
 
+
+// ---- the model's predicted VERTICES: their pixel box and depth range at level 0 ----
+// Six more words behind the twelve above ([12..14] the minima, [15..17] the maxima of pixel x, pixel y and camera-frame z of the
+// prediction's valid vertices), noted by the preparation job that writes the level-0 global-frame records (prep_batch.hpp:
+// PREP_TEX_TP), one set of atomics per WORKGROUP with a valid vertex.  A vertex is valid where the prediction drew something
+// (copy_maps_px: z != 0) -- NOT the same set as the valid depths above (verticesToDepth drops z > 6 m, cudafuncs.cu:602-613).
+// The coarser levels' vertices are averages of four valid finer ones (cudafuncs.cu:366-417): their pixels are the level-0 box
+// shifted right, their depths lie in the same range.  What it is for: gn_fused.hpp, gn_sparse_icp_box.
+constexpr int kExtentWords = 18;
+__device__ __forceinline__ unsigned aabb_key(float f) {  // monotonic in f (no NaN: only valid vertices are noted)
+    const unsigned b = __builtin_bit_cast(unsigned, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float aabb_unkey(unsigned k) {
+    return __builtin_bit_cast(float, (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+// one thread: lo / hi of {x, y, z} over the valid vertices its workgroup wrote (called only when there is one)
+__device__ __forceinline__ void aabb_note(unsigned long long* words, unsigned gen, const float (&lo)[3], const float (&hi)[3]) {
+    const unsigned long long g = (unsigned long long)gen << 32;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        atomicMax(&words[12 + k], g | (unsigned long long)(0xFFFFFFFFu - aabb_key(lo[k])));
+        atomicMax(&words[15 + k], g | (unsigned long long)aabb_key(hi[k]));
+    }
+}
+// (uniform address: six scalar loads)  false: this frame noted no valid vertex
+__device__ __forceinline__ bool aabb_load(const unsigned long long* words, unsigned gen, float (&lo)[3], float (&hi)[3]) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const unsigned long long a = words[12 + k], b = words[15 + k];
+        ok = ok && (unsigned)(a >> 32) == gen && (unsigned)(b >> 32) == gen;
+        lo[k] = aabb_unkey(0xFFFFFFFFu - (unsigned)(a & 0xFFFFFFFFull));
+        hi[k] = aabb_unkey((unsigned)(b & 0xFFFFFFFFull));
+    }
+    return ok;
+}
+
 }  // namespace mmf

@@ -1213,7 +1213,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             only->spec_tex_gen = m->tex_gen;
             only->spec_f2f = g.frame_to_frame_rgb;
             only->spec_valid = true;
-        } else if (owned > (int)fused_max_models() && f->shard_world <= 1 && g.batch_tracking && owned <= kMaxBatch && tunables().spec_prep_all) {
+        } else if (owned > 3 && f->shard_world <= 1 && g.batch_tracking && owned <= kMaxBatch && tunables().spec_prep_all) {
             // Several models on this GPU: the same for all of them, in the launches they will share (the batched chain's
             // preparation: one set of stages, every model's jobs).  At the start of the next call these ~50 jobs were what the
             // calling thread enqueued first -- 130 us of it and as much of the GPU's -- while the GPU had nothing else to do; here

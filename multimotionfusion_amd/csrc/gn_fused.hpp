@@ -58,6 +58,8 @@ struct GnIterArgs {
     int poll_sleep;  // s_sleep(1) repetitions between two polls of the count barrier
     int lanes;       // pixel lanes of a workgroup (<= blockDim.x - 64; the rest only help with the reductions)
     int max_polls;   // kGnMaxPolls (a test forces a time-out with 0: mmf_debug_force_gn_fault)
+    int check_sparse;  // test mode (mmf_debug_set_sparse_check): object models walk the WHOLE image and count what icpStep
+                       // accepts outside the rectangle they would have walked (OdomState::gn_dbg_outside)
 };
 
 struct GnLds {
@@ -71,6 +73,7 @@ struct GnLds {
     int wsum[kGnMaxWaves][2];
     unsigned bar[4];
     float wtab[256];  // rgbStep's weight by |diff| for this pass's sigma
+    int sbox[10];     // an object model's ICP walk of this launch (gn_sparse_icp_box): x0, y0, lanes per row, rows, passes
 };
 
 // A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the
@@ -137,12 +140,12 @@ __device__ __forceinline__ void gn_totals_to_lds(const GnSumLoads& sl, GnLds& ld
     else if (lane < 29) lds.sf[lane - 16] = sl.sf;
 }
 // lane k < 58 adds sum k of this workgroup (float) to the launch's sums; false: the value does not fit the fixed-point range
-__device__ __forceinline__ bool gn_sum_add(OdomState* st, int it, int lane, float v, int rgb_exp) {
+__device__ __forceinline__ bool gn_sum_add(OdomState* st, int it, int lane, float v, int rgb_exp, unsigned bid) {
     const double d = __builtin_ldexp((double)v, lane < 29 ? kGnSumIcpExp : rgb_exp);  // exact
     const bool ok = __builtin_fabs(d) < 9007199254740992.0;  // 2^53 per workgroup: 512 of them fit 2^62 (a NaN fails too)
     const long long q = ok ? (long long)__builtin_rint(d) : 0ll;
     if (lane < 58)
-        (void)__hip_atomic_fetch_add(&st->gn_sum[it % 3][blockIdx.x % kGnSumShards][lane], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (same global_atomic_add_x2 as workgroup scope on gfx950; agent is what the memory model asks for)
+        (void)__hip_atomic_fetch_add(&st->gn_sum[it % 3][bid % kGnSumShards][lane], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (same global_atomic_add_x2 as workgroup scope on gfx950; agent is what the memory model asks for)
     return ok || lane >= 58;
 }
 
@@ -326,8 +329,8 @@ __device__ __forceinline__ void gn_solve_wave(OdomState* st, const GnIterArgs& a
 }
 
 // model blockIdx.y of a batched launch: everything model-side moves by the distance between the slabs
-__device__ __forceinline__ void gn_batch_shift(OdomState*& st, GnIterArgs& a, const BatchDelta& bd) {
-    const long long d = bd.d[blockIdx.y];
+__device__ __forceinline__ void gn_batch_shift(OdomState*& st, GnIterArgs& a, const BatchDelta& bd, unsigned model) {
+    const long long d = bd.d[model];
     st = batch_shift(st, d);
     a.ia.vmap_g_prev.base = batch_shift(a.ia.vmap_g_prev.base, d), a.ia.nmap_g_prev.base = batch_shift(a.ia.nmap_g_prev.base, d);
     a.ia.prev_packed = batch_shift(a.ia.prev_packed, d), a.ia.err_map = batch_shift(a.ia.err_map, d);
@@ -375,8 +378,90 @@ __device__ __forceinline__ void gn_load_i16(const int16_t* __restrict__ p, int (
     }
 }
 
-// ---- the solver wave (wave 0 of every workgroup) ----
-__device__ __forceinline__ void gn_solver_wave(OdomState* st, const GnIterArgs& a, GnLds& lds, bool lead, int lane, int npw) {
+// ---- an OBJECT model in the one-launch chain: which sensor pixels can take part in its ICP term at all ----
+// icpStep (reduce.cu:257-299) moves a sensor pixel's point into the model's camera, q = Rprev^-1 (Rcurr v + tcurr - tprev),
+// projects it to a pixel of the model's maps and accepts the correspondence only if the vertex stored there is a number and
+// lies within distThresh of the point (RGBDOdometry.h:35).  Hence for every accepted correspondence: q projects into the pixel
+// box B of the model's valid vertices (extent.hpp: noted at level 0, shifted for the coarser levels), and q.z lies within
+// distThresh of a model depth, i.e. in [zlo - d, zhi + d].  That set -- a slab of the cone over B -- is convex with eight
+// corners; v = Rcurr^T (Rprev q + tprev - tcurr) maps it into the sensor camera, where a vertex lies on the viewing ray of
+// its own pixel (createVMap, cudafuncs.cu:109-130): that pixel is inside the bounding rectangle of the eight projected
+// corners (all in front of the camera: projection keeps convex hulls).  Every other sensor pixel adds exact zeros to the 29
+// sums; the model's workgroups walk the rectangle only (gn_pixel_waves_sparse), in as many passes as it takes.
+// Margins: B grows by one pixel (the projection is rounded to the nearest), d by 1 % + 1 mm, the rectangle by two pixels.
+// A corner that is not in front of the camera, a pose that is not a number, or a launch that writes the error image (its
+// texels record distances WITHOUT the threshold, reduce.cu:275): the whole image.
+struct GnSparseCtx {
+    bool box_ok, full;  // the preparation noted vertices for this frame; walk the whole image (the error-image launch)
+    float lo[3], hi[3];  // pixel x, pixel y (level 0), camera-frame z of the model's valid vertices
+    float Rprev[9], tprev[3];
+    int px, level;       // pixels per lane of this launch, its pyramid level
+};
+// one wave; lds.pose complete (written by lanes of this very wave)
+__device__ __forceinline__ void gn_sparse_icp_box(OdomState* st, const GnIterArgs& a, GnLds& lds, const GnSparseCtx& sp, int lane, int groups,
+                                                  bool lead) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int cols = a.ia.cols, rows = a.ia.rows;
+    int x0 = 0, y0 = 0, x1 = cols - 1, y1 = rows - 1;
+    bool derived = false;
+    if (!sp.box_ok) {
+        x1 = -1;  // the model predicted nothing: no pass
+    } else {
+        const float d = a.ia.dist_thres * 1.01f + 1e-3f;
+        const float za = sp.lo[2] - d, zb = sp.hi[2] + d;
+        const int c = lane & 7;
+        // corner c of B at this level (grown by a pixel), on the near or the far plane of the slab
+        const float bu = (c & 1) ? (float)((int)sp.hi[0] >> sp.level) + 1.f : (float)((int)sp.lo[0] >> sp.level) - 1.f;
+        const float bv = (c & 2) ? (float)((int)sp.hi[1] >> sp.level) + 1.f : (float)((int)sp.lo[1] >> sp.level) - 1.f;
+        const float z = (c & 4) ? zb : za;
+        const float qx = (bu - a.ia.intr.cx) / a.ia.intr.fx * z, qy = (bv - a.ia.intr.cy) / a.ia.intr.fy * z, qz = z;
+        // g = Rprev q + tprev - tcurr, v = Rcurr^T g
+        const float gx = sp.Rprev[0] * qx + sp.Rprev[1] * qy + sp.Rprev[2] * qz + sp.tprev[0] - lds.pose[9];
+        const float gy = sp.Rprev[3] * qx + sp.Rprev[4] * qy + sp.Rprev[5] * qz + sp.tprev[1] - lds.pose[10];
+        const float gz = sp.Rprev[6] * qx + sp.Rprev[7] * qy + sp.Rprev[8] * qz + sp.tprev[2] - lds.pose[11];
+        const float vx = lds.pose[0] * gx + lds.pose[3] * gy + lds.pose[6] * gz;
+        const float vy = lds.pose[1] * gx + lds.pose[4] * gy + lds.pose[7] * gz;
+        const float vz = lds.pose[2] * gx + lds.pose[5] * gy + lds.pose[8] * gz;
+        const bool ok = za > 0.05f && vz > 0.05f && vz < 1e6f && fabsf(vx) < 1e6f && fabsf(vy) < 1e6f;  // (a NaN fails)
+        const float u = ok ? vx * a.ia.intr.fx / vz + a.ia.intr.cx : 0.f, v = ok ? vy * a.ia.intr.fy / vz + a.ia.intr.cy : 0.f;
+        float umin = fminf(fmaxf(u, -1e6f), 1e6f), vmin = fminf(fmaxf(v, -1e6f), 1e6f), umax = umin, vmax = vmin;
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+            umin = fminf(umin, __shfl_xor(umin, m)), umax = fmaxf(umax, __shfl_xor(umax, m));
+            vmin = fminf(vmin, __shfl_xor(vmin, m)), vmax = fmaxf(vmax, __shfl_xor(vmax, m));
+        }
+        if ((__builtin_amdgcn_ballot_w64(ok) & 0xFFull) == 0xFFull) {
+            x0 = max(0, (int)floorf(umin) - 2), x1 = min(cols - 1, (int)ceilf(umax) + 2);
+            y0 = max(0, (int)floorf(vmin) - 2), y1 = min(rows - 1, (int)ceilf(vmax) + 2);
+            derived = true;
+        }
+    }
+    const bool none = x1 < x0 || y1 < y0;
+    const int x0a = x0 - x0 % sp.px;  // a lane's run of px pixels starts on a multiple of px (cols is one: the run stays in its row)
+    int lpr = none ? 0 : (x1 - x0a + sp.px) / sp.px, nr = none ? 0 : y1 - y0 + 1;
+    const int per_pass = groups * a.lanes;
+    if (lane == 0) {
+        lds.sbox[6] = x0a, lds.sbox[7] = y0, lds.sbox[8] = lpr, lds.sbox[9] = nr;  // (read in checking mode only)
+        const bool whole = a.check_sparse != 0 || sp.full;
+        const int rect_passes = (lpr * nr + per_pass - 1) / per_pass;
+        if (whole) lpr = cols / sp.px, nr = rows;
+        lds.sbox[0] = whole ? 0 : x0a, lds.sbox[1] = whole ? 0 : y0, lds.sbox[2] = lpr, lds.sbox[3] = nr;
+        lds.sbox[4] = (lpr * nr + per_pass - 1) / per_pass;
+        lds.sbox[5] = groups;
+        if (lead && sp.level == 0) {  // what a test or a tool looks at (mmf_debug_odom_sparse_outside)
+            st->gn_dbg_rect[0] = x0a, st->gn_dbg_rect[1] = y0, st->gn_dbg_rect[2] = lpr * sp.px, st->gn_dbg_rect[3] = nr;
+            st->gn_dbg_rect[4] = max(st->gn_dbg_rect[4], rect_passes), st->gn_dbg_rect[5] = derived ? 1 : 0;
+        }
+    }
+}
+
+// ---- the solver wave (wave 0 of every workgroup).  bid / groups: this workgroup's index among its model's and their number
+//      (the launch's blockIdx.x / gridDim.x unless several models share a one-dimensional grid: gn_iter_mixed_kernel);
+//      sp: non-null for an object model walked by its extents ----
+__device__ __forceinline__ void gn_solver_wave(OdomState* st, const GnIterArgs& a, GnLds& lds, unsigned bid, unsigned groups, int lane, int npw,
+                                               const GnSparseCtx* sp = nullptr) {
+    const bool lead = bid == 0;
     const int fault = a.it > 0 ? __hip_atomic_load(&st->gn_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     GnSumLoads sl;
     if (a.it > 0) gn_sums_issue(st, a, sl, lane);
@@ -397,6 +482,7 @@ __device__ __forceinline__ void gn_solver_wave(OdomState* st, const GnIterArgs& 
     } else {
         gn_first_pose(st, lds, lead, lane);
     }
+    if (sp != nullptr) gn_sparse_icp_box(st, a, lds, *sp, lane, (int)groups, lead);
     lds_barrier();  // B: the pose is in LDS
     MMF_STAMP(8);
     lds_barrier();  // C: every pixel wave's {count, sum diff^2} is in LDS
@@ -408,7 +494,7 @@ __device__ __forceinline__ void gn_solver_wave(OdomState* st, const GnIterArgs& 
         c = wave_sum_to_lane63(c), s2 = wave_sum_to_lane63(s2);
         if (lane == 63) {
             const unsigned long long word = (1ull << kGnArriveShift) | ((unsigned long long)c << kResCountShift) | (unsigned long long)s2;
-            (void)__hip_atomic_fetch_add(&st->gn_acc[a.it % 3][kResStride * (blockIdx.x % kResShards)], word, __ATOMIC_RELAXED,
+            (void)__hip_atomic_fetch_add(&st->gn_acc[a.it % 3][kResStride * (bid % kResShards)], word, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -430,7 +516,7 @@ __device__ __forceinline__ void gn_solver_wave(OdomState* st, const GnIterArgs& 
             c = wave_sum_to_lane63((unsigned)(v >> kResCountShift) & 0x3FFFFu);
             s2 = wave_sum_to_lane63((unsigned)v);  // wraps at 2^32 like the reference's int
             arr = (unsigned)__builtin_amdgcn_readlane((int)arr, 63);
-            if (arr == gridDim.x) {
+            if (arr == groups) {
                 ok = 1;
                 break;
             }
@@ -449,7 +535,7 @@ __device__ __forceinline__ void gn_solver_wave(OdomState* st, const GnIterArgs& 
         const int col = lane < 29 ? lane : (lane < 58 ? 32 + (lane - 29) : 63);
         float v = lds.wave[1][col];
         for (int wv = 2; wv <= npw; ++wv) v = v + lds.wave[wv][col];  // fixed order: the launch geometry decides the sum, not the timing
-        const bool fits = gn_sum_add(st, a.it, lane, v, gn_rgb_exp(sigma_val));
+        const bool fits = gn_sum_add(st, a.it, lane, v, gn_rgb_exp(sigma_val), bid);
         // 1: a workgroup of this launch never arrived (ANY workgroup that gives up says so: the one that arrives last sees a
         // full count although the early ones built their rows from a partial sigma); 2: a sum left the fixed-point range.
         // Either way the host re-runs the frame's tracking on the two-launch chain (odom_finish_tracking).
@@ -463,14 +549,14 @@ __device__ __forceinline__ void gn_solver_wave(OdomState* st, const GnIterArgs& 
 //      (PX = 4, 2), the packed model maps.  ERR: the launch also writes the two error images (the last level-0 iteration,
 //      RGBDOdometry.cpp:367,408). ----
 template <int PX, bool ERR>
-__device__ __forceinline__ void gn_pixel_waves(OdomState* st, const GnIterArgs& a, GnLds& lds, int ptid, int lane, int wave) {
+__device__ __forceinline__ void gn_pixel_waves(OdomState* st, const GnIterArgs& a, GnLds& lds, int ptid, int lane, int wave, unsigned bid) {
     const OdomState* __restrict__ stc = st;  // what this launch only reads: scalar loads
     const int fault = a.it > 0 ? __hip_atomic_load(&st->gn_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;  // (see gn_solver_wave)
     using T = typename std::conditional<PX % 2 == 0, v2f, float>::type;
     using L = lanevec<T>;
     constexpr int W = L::W, NV = PX / W;
     const int cols = a.ra.cols, rows = a.ra.rows, N = cols * rows;
-    int k0 = (blockIdx.x * a.lanes + ptid) * PX;
+    int k0 = ((int)bid * a.lanes + ptid) * PX;
     const bool live = ptid < a.lanes && k0 < N;  // the other lanes stay active for the reductions: pixel 0, masked
     k0 = live ? k0 : 0;
     const int i = (int)__umulhi((unsigned)k0, a.ra.cols_magic), j0 = k0 - i * cols;
@@ -699,17 +785,335 @@ __device__ __forceinline__ void gn_pixel_waves(OdomState* st, const GnIterArgs& 
     lds_barrier();  // E: the solver wave adds the waves' sums up and stores the workgroup's record
 }
 
+// ---- the pixel waves of an OBJECT model (gn_iter_mixed_kernel).  The same per-pixel code as gn_pixel_waves on two pixel sets of
+//      the model's own: the photometric term over the box of its own depth (x0a, y0, lpr lanes per row, nr rows: one pass,
+//      the kernel has checked that it fits), the ICP term over the rectangle lds.sbox describes (gn_sparse_icp_box: known
+//      with the pose), in sbox[4] passes.  A pixel outside the first box has no depth of its own (reduce.cu:600), one
+//      outside the second cannot pass icpStep's distance test: both add exact zeros in the dense walk. ----
+template <int PX, bool ERR>
+__device__ __forceinline__ void gn_pixel_waves_sparse(OdomState* st, const GnIterArgs& a, GnLds& lds, int ptid, int lane, int wave, unsigned bid,
+                                                      int x0a, int y0, int lpr, int nr) {
+    const OdomState* __restrict__ stc = st;
+    const int fault = a.it > 0 ? __hip_atomic_load(&st->gn_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    using T = typename std::conditional<PX % 2 == 0, v2f, float>::type;
+    using L = lanevec<T>;
+    constexpr int W = L::W, NV = PX / W;
+    const int cols = a.ra.cols, rows = a.ra.rows;
+    const unsigned q = bid * (unsigned)a.lanes + (unsigned)ptid;
+    const unsigned prow = lpr ? q / (unsigned)lpr : 0u;
+    const bool live = ptid < a.lanes && lpr != 0 && prow < (unsigned)nr;  // the other lanes stay active for the reductions: pixel 0, masked
+    const int i = live ? y0 + (int)prow : 0, j0 = live ? x0a + (int)(q - prow * (unsigned)lpr) * PX : 0;
+    const int jb = (j0 - 2) & ~3, sb = j0 - 2 - jb;
+
+    // ---- loads that do not depend on the pose: the photometric pass's images ----
+    unsigned ww[4][3];
+    bool win[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) win[k] = jb + 4 * k >= 0 && jb + 4 * k < cols;
+#pragma unroll
+    for (int dr = -2; dr <= 1; ++dr) {
+        const int u = min(max(i + dr, 0), rows - 1);
+        const uint8_t* rowp = a.ra.next_image + (size_t)u * a.ra.ni_stride;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ww[dr + 2][k] = *reinterpret_cast<const unsigned*>(rowp + (win[k] ? jb + 4 * k : (j0 & ~3)));
+    }
+    int valxs[PX], valys[PX];
+    float d1s[PX];
+    gn_load_i16<PX>(a.ra.dIdx + (size_t)i * a.ra.d_stride + j0, valxs);
+    gn_load_i16<PX>(a.ra.dIdy + (size_t)i * a.ra.d_stride + j0, valys);
+    gn_load_f32<PX>(a.ra.next_depth + (size_t)i * a.ra.nd_stride + j0, d1s);
+    IcpPose P;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P.Rprev_inv[k] = stc->Rprev_inv[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P.tprev[k] = stc->tprev[k];
+    __builtin_amdgcn_sched_barrier(0);
+    bool cand[PX];
+    int own[PX];
+    {
+        unsigned nz[3] = {0x80808080u, 0x80808080u, 0x80808080u};
+#pragma unroll
+        for (int dr = -2; dr <= 1; ++dr) {
+            const bool rowin = (i + dr) >= 0 && (i + dr) < rows;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) nz[k] &= rowin ? nonzero_bytes(ww[dr + 2][k]) : 0x80808080u;
+        }
+        const unsigned okw = (win[0] ? byte_flags_to_bits(nz[0]) : 0xFu) | ((win[1] ? byte_flags_to_bits(nz[1]) : 0xFu) << 4) |
+                             ((win[2] ? byte_flags_to_bits(nz[2]) : 0xFu) << 8);
+        const unsigned long long lo = (unsigned long long)ww[2][0] | ((unsigned long long)ww[2][1] << 32);
+        const unsigned long long hi = (unsigned long long)ww[2][1] | ((unsigned long long)ww[2][2] << 32);
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const int x = j0 + p;
+            const bool valid = live && x < cols - 5 && i < rows - 1 && ((okw >> (sb + p)) & 0xFu) == 0xFu;
+            const float mTwo = (float)((valxs[p] * valxs[p]) + (valys[p] * valys[p]));
+            cand[p] = valid && mTwo >= a.ra.min_scale && !(d1s[p] != d1s[p]);
+            const int b = sb + 2 + p;
+            own[p] = (int)(((b < 8 ? lo : hi) >> (8 * (b < 8 ? b : b - 4))) & 0xFFull);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (fault) return;
+    lds_barrier();  // B: the pose and the ICP rectangle are in LDS
+    float K[9], kt[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P.Rcurr[k] = uniform_f(lds.pose[k]), K[k] = uniform_f(lds.pose[12 + k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P.tcurr[k] = uniform_f(lds.pose[9 + k]), kt[k] = uniform_f(lds.pose[21 + k]);
+    const int sx0 = __builtin_amdgcn_readfirstlane(lds.sbox[0]), sy0 = __builtin_amdgcn_readfirstlane(lds.sbox[1]);
+    const unsigned slpr = (unsigned)__builtin_amdgcn_readfirstlane(lds.sbox[2]), snr = (unsigned)__builtin_amdgcn_readfirstlane(lds.sbox[3]);
+    const int npass = __builtin_amdgcn_readfirstlane(lds.sbox[4]);
+    const unsigned sgroups = (unsigned)__builtin_amdgcn_readfirstlane(lds.sbox[5]);
+
+    // ---- photometric correspondence search: warp (reduce.cu:799-812), then its gathers at once ----
+    bool inb[PX];
+    int u0s[PX], v0s[PX];
+    float td1s[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        const int x = j0 + p, y = i;
+        const float d1 = d1s[p];
+        inb[p] = false;
+        u0s[p] = v0s[p] = 0;
+        td1s[p] = 0.f;
+        if (cand[p]) {
+            td1s[p] = (float)(d1 * (K[6] * x + K[7] * y + K[8]) + kt[2]);
+            u0s[p] = float2int_rn((d1 * (K[0] * x + K[1] * y + K[2]) + kt[0]) / td1s[p]);
+            v0s[p] = float2int_rn((d1 * (K[3] * x + K[4] * y + K[5]) + kt[1]) / td1s[p]);
+            inb[p] = u0s[p] >= 0 && v0s[p] >= 0 && u0s[p] < cols && v0s[p] < rows;
+        }
+    }
+    struct f3pk {
+        float x, y, z;
+    };
+    uint8_t lis[PX];
+    float4 cl[PX];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        const int gu = inb[p] ? u0s[p] : 0, gvv = inb[p] ? v0s[p] : 0;
+        lis[p] = a.ra.last_image[(size_t)gvv * a.ra.li_stride + gu];
+        cl[p] = a.cloud4[(size_t)gvv * cols + gu];
+    }
+    // ---- ICP: the sensor's vertices and normals of this lane's run in a pass ----
+    float cur[6][PX];
+    int si = 0, sj = 0;
+    bool slive = false;
+    auto icp_pass_load = [&](int pass) {
+        const unsigned sq = ((unsigned)pass * sgroups + bid) * (unsigned)a.lanes + (unsigned)ptid;
+        const unsigned srow = slpr ? sq / slpr : 0u;
+        slive = ptid < a.lanes && slpr != 0 && srow < snr;
+        si = slive ? sy0 + (int)srow : 0, sj = slive ? sx0 + (int)(sq - srow * slpr) * PX : 0;
+        const float* pv = a.ia.vmap_curr.base + (size_t)si * a.ia.vmap_curr.stride + sj;
+        const float* pn = a.ia.nmap_curr.base + (size_t)si * a.ia.nmap_curr.stride + sj;
+        const size_t sv = (size_t)rows * a.ia.vmap_curr.stride, sn = (size_t)rows * a.ia.nmap_curr.stride;
+        gn_load_f32<PX>(pv, cur[0]);
+        gn_load_f32<PX>(pv + sv, cur[1]);
+        gn_load_f32<PX>(pv + 2 * sv, cur[2]);
+        gn_load_f32<PX>(pn, cur[3]);
+        gn_load_f32<PX>(pn + sn, cur[4]);
+        gn_load_f32<PX>(pn + 2 * sn, cur[5]);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- photometric: accept / reject (reduce.cu:813-836), the wave's {count, sum diff^2} ----
+    // The correspondences wait in LDS while the ICP passes run (six words per pixel: with them in registers across the pass
+    // loop the kernel needs 246 registers -- one workgroup per CU instead of two, and the launch's workgroups must all be resident)
+    __shared__ unsigned stash[6 * PX][64 * (kGnMaxWaves - 1)];
+    int cnt = 0, sq2 = 0;
+    float perr[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        const float d0 = cl[p].z;
+        const bool hit = inb[p] && d0 > 0 && fabsf(td1s[p] - d0) <= a.ra.max_depth_delta && lis[p] != 0;
+        const int idiff = own[p] - (int)lis[p];
+        const int vy = hit ? idiff * idiff : 0;
+        perr[p] = hit ? 0.001f * vy : 0.0f;
+        cnt += hit ? 1 : 0;
+        sq2 += vy;
+        stash[6 * p + 0][ptid] = __builtin_bit_cast(unsigned, cl[p].x), stash[6 * p + 1][ptid] = __builtin_bit_cast(unsigned, cl[p].y);
+        stash[6 * p + 2][ptid] = __builtin_bit_cast(unsigned, cl[p].z), stash[6 * p + 3][ptid] = __builtin_bit_cast(unsigned, cl[p].w);
+        stash[6 * p + 4][ptid] = ((unsigned)valxs[p] & 0xFFFFu) | ((unsigned)valys[p] << 16);  // (Sobel sums of bytes: 16 bits each)
+        stash[6 * p + 5][ptid] = hit ? (unsigned)(idiff + 256) : 0u;                          // 0: no correspondence
+    }
+    if (ERR && a.ra.err_map && live) gn_store_f32<PX>(a.ra.err_map + (size_t)i * a.ra.err_stride + j0, perr);
+    cnt = wave_sum_to_lane63(cnt);
+    sq2 = wave_sum_to_lane63(sq2);
+    if (lane == 63) lds.wsum[wave][0] = cnt, lds.wsum[wave][1] = sq2;
+    lds_barrier();  // C: the solver wave adds the workgroup's counts to the launch's and waits for the others
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- ICP: projection, gathers, Jacobian rows (reduce.cu:257-368), pass by pass ----
+    T isum[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) isum[k] = L::splat(0.f);
+    for (int pass = 0; pass < npass; ++pass) {  // (uniform)
+        icp_pass_load(pass);
+        __builtin_amdgcn_sched_barrier(0);
+        IcpProj<T> pr[NV];
+#pragma unroll
+        for (int h = 0; h < NV; ++h) {
+            f3t<T> v;
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                L::set(v.x, e, cur[0][h * W + e]);
+                L::set(v.y, e, cur[1][h * W + e]);
+                L::set(v.z, e, cur[2][h * W + e]);
+            }
+            pr[h] = icp_project_v<T>(P, a.ia, v);
+        }
+        f3pk gv[PX], gn[PX];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qq = 0; qq < PX; ++qq) {
+            const f3pk* src = reinterpret_cast<const f3pk*>(a.ia.prev_packed) + 2 * ((size_t)pr[qq / W].uy[qq % W] * cols + pr[qq / W].ux[qq % W]);
+            gv[qq] = src[0];
+            gn[qq] = src[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float ierr[PX];
+        const float inl0 = L::hsum(isum[28]);
+#pragma unroll
+        for (int h = 0; h < NV; ++h) {
+            f3t<T> n, vp, np;
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                L::set(n.x, e, cur[3][h * W + e]), L::set(n.y, e, cur[4][h * W + e]), L::set(n.z, e, cur[5][h * W + e]);
+                L::set(vp.x, e, gv[h * W + e].x), L::set(vp.y, e, gv[h * W + e].y), L::set(vp.z, e, gv[h * W + e].z);
+                L::set(np.x, e, gn[h * W + e].x), L::set(np.y, e, gn[h * W + e].y), L::set(np.z, e, gn[h * W + e].z);
+            }
+            float er[W];
+            icp_rows_v<ERR, false, T>(P, a.ia, pr[h], slive, n, vp, np, isum, er);
+            if (ERR) {
+#pragma unroll
+                for (int e = 0; e < W; ++e) ierr[h * W + e] = er[e];
+            }
+        }
+        if (a.check_sparse && !ERR) {  // (uniform) what this run added although the rectangle does not hold it
+            const int rx = lds.sbox[6], ry = lds.sbox[7], rl = lds.sbox[8], rn = lds.sbox[9];
+            const bool in_rect = rl != 0 && si >= ry && si < ry + rn && sj >= rx && sj < rx + rl * PX;
+            const float added = L::hsum(isum[28]) - inl0;
+            if (slive && !in_rect && added > 0.f) atomicAdd(&st->gn_dbg_outside, (unsigned)added);
+        }
+        if (ERR && slive) {  // (the error-image launch walks the whole image: every texel of both images is written)
+            if (a.ia.err_map) gn_store_f32<PX>(a.ia.err_map + (size_t)si * a.ia.err_stride + sj, ierr);
+            // the photometric image outside the box the photometric lanes cover: what the dense walk writes there
+            const bool covered = lpr != 0 && si >= y0 && si < y0 + nr && sj >= x0a && sj < x0a + lpr * PX;
+            if (a.ra.err_map && !covered) {
+                float zeros[PX];
+#pragma unroll
+                for (int p = 0; p < PX; ++p) zeros[p] = 0.f;
+                gn_store_f32<PX>(a.ra.err_map + (size_t)si * a.ra.err_stride + sj, zeros);
+            }
+        }
+    }
+    {
+        float s32[32];
+#pragma unroll
+        for (int k = 0; k < 29; ++k) s32[k] = L::hsum(isum[k]);
+        s32[29] = s32[30] = s32[31] = 0.f;
+        const float t = wave_sum_transposed(s32);
+        if ((lane & 1) == 0) lds.wave[wave][lane >> 1] = t;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();  // C2: the solver wave starts polling
+    lds_barrier();  // D: sigma and the weight table are in LDS
+    const float sigmaVal = __builtin_bit_cast(float, lds.bar[3]);
+
+    // ---- photometric: rgbStep's rows (reduce.cu:504-535) ----
+    RgbLane<PX> ph;
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        ph.X[p] = __builtin_bit_cast(float, stash[6 * p + 0][ptid]), ph.Y[p] = __builtin_bit_cast(float, stash[6 * p + 1][ptid]);
+        ph.Z[p] = __builtin_bit_cast(float, stash[6 * p + 2][ptid]), ph.invz[p] = __builtin_bit_cast(float, stash[6 * p + 3][ptid]);
+        const unsigned gxy = stash[6 * p + 4][ptid], dv = stash[6 * p + 5][ptid];
+        ph.gx[p] = (int)(short)(gxy & 0xFFFFu), ph.gy[p] = (int)(short)(gxy >> 16);
+        ph.c[p].diff = dv ? (float)((int)dv - 256) : 0.f;
+        ph.c[p].valid = dv ? 1 : 0;
+    }
+    float psum[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) psum[k] = 0.f;
+    rgb_rows<PX>(a.sobel_scale, a.fx, a.fy, sigmaVal, live, ph, psum, lds.wtab, true);
+    {
+        float s32[32];
+#pragma unroll
+        for (int k = 0; k < 29; ++k) s32[k] = psum[k];
+        s32[29] = s32[30] = s32[31] = 0.f;
+        const float t2 = wave_sum_transposed(s32);
+        if ((lane & 1) == 0) lds.wave[wave][32 + (lane >> 1)] = t2;
+    }
+    lds_barrier();  // E: the solver wave adds the waves' sums up
+}
+
 // blockDim.x = 64 (solver wave) + the pixel waves (>= 4, a.lanes <= their lanes)
 template <int PX, bool ERR>
 __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_kernel(OdomState* st, GnIterArgs a, BatchDelta bd) {
     __shared__ GnLds lds;
-    if (gridDim.y > 1) gn_batch_shift(st, a, bd);
+    if (gridDim.y > 1) gn_batch_shift(st, a, bd, blockIdx.y);
     MMF_STAMP(5);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave == 0)
-        gn_solver_wave(st, a, lds, blockIdx.x == 0, lane, (int)(blockDim.x >> 6) - 1);
+        gn_solver_wave(st, a, lds, blockIdx.x, gridDim.x, lane, (int)(blockDim.x >> 6) - 1);
     else
-        gn_pixel_waves<PX, ERR>(st, a, lds, tid - 64, lane, wave);
+        gn_pixel_waves<PX, ERR>(st, a, lds, tid - 64, lane, wave, blockIdx.x);
+}
+
+// Several models in ONE launch with a geometry PER MODEL (MultiMotionFusion.cpp:312-387: the models' trackings are independent):
+// a one-dimensional grid, workgroups [start[m], start[m + 1]) belong to model m.  The camera model (and any model without
+// extents) is walked as in gn_iter_kernel; an OBJECT model -- a few thousand pixels of prediction in an otherwise empty image
+// -- by a fraction of the workgroups (gn_pixel_waves_sparse): its photometric term over the box of its own depth, its ICP
+// term over the rectangle its prediction can reach under this iteration's pose.  The count barrier stays per model, and
+// ALL workgroups of the launch must be resident together (the host budgets start[n] against the occupancy).
+struct GnBatchGeom {
+    int start[kMaxBatch + 1];
+    unsigned sparse_mask;  // bit m: model m is an object model with extents noted for this frame
+    unsigned ext_gen;      // ... the frame number they carry
+    int level;             // this launch's pyramid level (extent_of_level)
+    const unsigned long long* extent;  // the first model's extent words (in its slab: the others' by BatchDelta)
+};
+constexpr int kGnFaultExtent = 3;  // OdomState::gn_fault: an object model's extent does not fit its workgroups (the host walks it densely from then on)
+
+template <int PX, bool ERR>
+__global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_mixed_kernel(OdomState* st, GnIterArgs a, BatchDelta bd, GnBatchGeom g) {
+    __shared__ GnLds lds;
+    unsigned model = 0;
+#pragma unroll
+    for (int m = 1; m < kMaxBatch; ++m) model = ((int)blockIdx.x >= g.start[m] && g.start[m] < g.start[m + 1]) ? (unsigned)m : model;  // (uniform)
+    const unsigned bid = blockIdx.x - (unsigned)g.start[model], groups = (unsigned)(g.start[model + 1] - g.start[model]);
+    gn_batch_shift(st, a, bd, model);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!((g.sparse_mask >> model) & 1u)) {
+        if (wave == 0)
+            gn_solver_wave(st, a, lds, bid, groups, lane, (int)(blockDim.x >> 6) - 1);
+        else
+            gn_pixel_waves<PX, ERR>(st, a, lds, tid - 64, lane, wave, bid);
+        return;
+    }
+    const unsigned long long* ext = batch_shift(g.extent, bd.d[model]);
+    // the box of the model's own depth at this level (pose independent: the photometric term's pixels), PX-aligned runs
+    const ExtentBox pb = extent_of_level(ext, g.ext_gen, g.level);
+    const bool none = pb.x1 < pb.x0 || pb.y1 < pb.y0;
+    const int x0a = none ? 0 : pb.x0 - pb.x0 % PX, lpr = none ? 0 : (pb.x1 - x0a + PX) / PX, nr = none ? 0 : pb.y1 - pb.y0 + 1;
+    if (bid == 0 && tid == 0) st->gn_need[g.level] = lpr * nr;
+    if ((long long)lpr * nr > (long long)groups * a.lanes) {  // (uniform over the model's workgroups: all leave, none waits)
+        if (bid == 0 && tid == 0 && (a.it == 0 || !__hip_atomic_load(&st->gn_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+            __hip_atomic_store(&st->gn_fault, kGnFaultExtent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (wave == 0) {
+        GnSparseCtx sp;
+        sp.box_ok = aabb_load(ext, g.ext_gen, sp.lo, sp.hi);
+        sp.full = ERR;
+        sp.px = PX, sp.level = g.level;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sp.Rprev[k] = st->Rprev[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sp.tprev[k] = st->tprev[k];
+        gn_solver_wave(st, a, lds, bid, groups, lane, (int)(blockDim.x >> 6) - 1, &sp);
+    } else {
+        gn_pixel_waves_sparse<PX, ERR>(st, a, lds, tid - 64, lane, wave, bid, x0a, pb.y0, lpr, nr);
+    }
 }
 
 // the chain's last solve + RGBDOdometry.cpp:464-467, 475-476: one workgroup (kBlock threads) per model, its first wave works

@@ -785,6 +785,12 @@ struct mmf_odom {
     // an OBJECT model (set by the orchestrator): the two-launch chain walks its images with a quarter of the workgroups
     // (track_kernels.hpp: ChainGeom), batched or alone
     bool sparse = false;
+    // ... and the one-launch chain by its extents with a fraction of the workgroups (gn_fused.hpp: gn_iter_mixed_kernel), as
+    // many as the box of its own depth needed in its LAST chain plus a quarter (OdomState::gn_need; 0: no chain yet)
+    int gn_need[MMF_NUM_PYRS] = {0, 0, 0};
+    int last_gn_fault = 0;          // OdomState::gn_fault of the last result picked up (odom_finish_tracking)
+    bool walked_by_extent = false;  // the last chain enqueued walked this model by its extents (gn_iter_mixed_kernel)
+    bool two_launch_once = false;  // the next chain this odometry leads is the two-launch chain (a frame tracked again)
     OdomState* state = nullptr;  // device
     OdomState* host_result = nullptr;  // pinned, device visible: odom_publish_kernel writes it, the host polls publish_seq
     OdomState* host_result_dev = nullptr;
@@ -887,7 +893,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     size_t o_state = carve(sizeof(OdomState));
     const size_t o_pf = carve(sizeof(float) * kMaxGrid * kPartialStride), o_pi = carve(sizeof(float) * kMaxIcpGrid * kPartialStride),
                  o_pr = carve(sizeof(int2) * kMaxGrid), o_tk = carve(sizeof(unsigned) * kTicketWords), o_ei = carve(n0 * 4),
-                 o_er = carve(n0 * 4), o_ex = carve(MMF_NUM_PYRS * 4 * sizeof(unsigned long long));
+                 o_er = carve(n0 * 4), o_ex = carve(kExtentWords * sizeof(unsigned long long));
     o->slab_bytes = off;
     hipError_t e = hipMalloc(&o->slab, o->slab_bytes);
     if (e != hipSuccess) {
@@ -1227,6 +1233,7 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
             t.dst0 = planar ? o->vmaps_g_prev[0] : nullptr, t.dst1 = planar ? o->nmaps_g_prev[0] : nullptr, t.dst2 = o->prev_packed[0];
             for (int k = 0; k < 9; ++k) t.f[k] = R[k];
             t.f[9] = pose[3], t.f[10] = pose[7], t.f[11] = pose[11];
+            if (note_extent) t.aabb = o->extent, t.ext_gen = ext_gen;  // (extent.hpp: the pixel box and depth range of the valid vertices)
             PrepJob& p = pb.add(PREP_TEX_PROJECT, cols, rows);
             p.src0 = pred_vertex, p.sel = sel, p.alt0 = alt_vertex;
             p.dst0 = planar ? o->cloud[0] : nullptr, p.dst1 = o->cloud4[0], p.dst2 = o->last_depth[0];
@@ -1477,8 +1484,31 @@ static bool gn_geometry(int level, int cols, int rows, GnGeometry* out) {
     }
     return false;
 }
-static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom, int models = 1);
+struct GnChainPlan {  // how the one-launch chain walks the models of a batch (gn_fused.hpp: GnBatchGeom)
+    unsigned sparse_mask = 0, ext_gen = 0;
+    int groups[MMF_NUM_PYRS][kMaxBatch];  // workgroups of model m at level l
+};
+static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom, const TrackBatch* batch = nullptr,
+                                bool sparse_on = false, GnChainPlan* plan = nullptr);
 static unsigned fused_max_models();
+// workgroups of an OBJECT model per launch of the one-launch chain at pyramid level l (a property of the model, batched or
+// alone: its float sums keep their order): its photometric box must fit them in ONE pass (32 x 1280 pixels at 640x480 level 0,
+// a box of 200 x 200), its ICP rectangle takes as many passes as it needs
+static std::atomic<int> g_sparse_groups{0};  // test hook (mmf_debug_set_sparse_groups): that many at every level instead
+// need: the lanes the model's box took in its last chain (0: unknown -- 32 / 24 / 16 workgroups, a box of 200 x 200 at 640x480);
+// lanes: pixel lanes of a workgroup.  Returns dense_groups when the model is better walked like the camera model.
+static int gn_sparse_groups(int level, int dense_groups, int need, int lanes) {
+    static const int k[MMF_NUM_PYRS] = {32, 24, 16};
+    const int forced = g_sparse_groups.load();
+    if (forced > 0) return std::min(dense_groups, forced);
+    int want = k[level < MMF_NUM_PYRS ? level : MMF_NUM_PYRS - 1];
+    if (need > 0) want = std::max(8, (need + need / 4 + lanes - 1) / lanes + 1);
+    return want * 4 >= dense_groups * 3 ? dense_groups : want;
+}
+extern "C" int mmf_debug_set_sparse_groups(int n) {
+    g_sparse_groups.store(n > 0 ? n : 0);
+    return MMF_OK;
+}
 static std::atomic<bool> g_gn_latched_off{false};
 static std::atomic<int> g_track_cull{-1};  // -1: tunables().track_cull; 0 / 1: mmf_debug_set_track_cull
 extern "C" int mmf_debug_set_track_cull(int mode) {
@@ -1486,6 +1516,23 @@ extern "C" int mmf_debug_set_track_cull(int mode) {
     return MMF_OK;
 }
 static std::atomic<int> g_gn_force_fault{0};
+static std::atomic<int> g_sparse_check{0};
+// test hooks of the object models' walk in the one-launch chain (gn_fused.hpp: gn_sparse_icp_box): checking mode on / off, and the
+// number of correspondences the last chain of an odometry accepted outside the rectangle it would have walked (must be 0)
+extern "C" int mmf_debug_set_sparse_check(int on) {
+    g_sparse_check.store(on ? 1 : 0);
+    return MMF_OK;
+}
+extern "C" int mmf_debug_odom_sparse_outside(mmf_odom* o, unsigned* outside, int* walked_by_extent, int rect[9]) {
+    if (!o || !o->host_result) return fail(MMF_ERR_INVALID, "mmf_debug_odom_sparse_outside: null argument");
+    if (outside) *outside = o->host_result->gn_dbg_outside;
+    if (walked_by_extent) *walked_by_extent = o->walked_by_extent ? 1 : 0;
+    if (rect) {
+        std::memcpy(rect, o->host_result->gn_dbg_rect, sizeof(int) * 6);
+        std::memcpy(rect + 6, o->gn_need, sizeof(int) * 3);
+    }
+    return MMF_OK;
+}
 static std::atomic<int> g_gn_recoveries{0};
 // odom_finish_tracking: the one-launch chain gave up; track again (odom_retrack_prepare).  A private sentinel, outside the
 // public mmf_status range (include/mmf_hip.h: 0 and small negatives): it never leaves the library (gn_retry_twice).
@@ -1518,12 +1565,22 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     // both terms on and every level fits: ONE launch per iteration (gn_fused.hpp) instead of producer + step
     // (more than three models: the batched two-launch chain is as fast (four) or faster -- 8 models 1.40 ms against 1.60 --
     // because a model's workgroups hold their CUs at the count barrier while the next models' wait for a place)
-    const bool fused_chain = odom_fused_chain_ok(o, rgb_only, icp_weight, pyramid, fast_odom, (int)ny) &&
-                             (ny == 1 || (ny <= fused_max_models() && odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom)));
-    // Object models in the two-launch chain (extent.hpp, track_kernels.hpp: ChainGeom): their passes skip what lies outside
+    // Object models (extent.hpp): in the two-launch chain (track_kernels.hpp: ChainGeom) their passes skip what lies outside
     // the model's own depth when the preparation noted its extents for this frame, and they walk their images with a
-    // quarter of the workgroups.  MMF_TRACK_CULL=0 / mmf_debug_set_track_cull(0): every model like the first.
+    // quarter of the workgroups; in the one-launch chain (gn_fused.hpp: gn_iter_mixed_kernel) they walk their extents with a
+    // fraction of the workgroups, which is what lets ALL models of a frame be resident in one launch.
+    // MMF_TRACK_CULL=0 / mmf_debug_set_track_cull(0): every model like the first.
     const bool sparse_on = (g_track_cull.load() < 0 ? tunables().track_cull : g_track_cull.load()) != 0;
+    bool two_launch_once = false;  // (odom_retrack_prepare: this frame is being tracked again)
+    for (unsigned m = 0; m < ny; ++m) {
+        mmf_odom* om = batch ? batch->o[m] : o;
+        two_launch_once = two_launch_once || om->two_launch_once;
+        om->two_launch_once = false;
+    }
+    GnChainPlan plan;
+    for (unsigned m = 0; m < ny; ++m) (batch ? batch->o[m] : o)->walked_by_extent = false;
+    const bool fused_chain = !two_launch_once && odom_fused_chain_ok(o, rgb_only, icp_weight, pyramid, fast_odom, batch, sparse_on, &plan) &&
+                             (ny == 1 || (ny <= fused_max_models() && odom_batchable(o, rgb_only, icp_weight, pyramid, fast_odom)));
     const bool lead_sparse = sparse_on && o->sparse;
     bool foll_sparse = sparse_on && batch && ny > 1;
     unsigned foll_gen = foll_sparse ? batch->o[1]->extent_gen : 0u;
@@ -1573,12 +1630,14 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     bool final_pending = false;
     std::memset(&final_args, 0, sizeof(final_args));
     if (fused_chain) {
+        for (unsigned m = 0; m < ny; ++m) (batch ? batch->o[m] : o)->walked_by_extent = ((plan.sparse_mask >> m) & 1u) != 0;
         int it = 0;
         bool first = true;
         GnIterArgs a;
         std::memset(&a, 0, sizeof(a));
         a.poll_sleep = tunables().gn_sleep;
         a.max_polls = kGnMaxPolls;
+        a.check_sparse = g_sparse_check.load();
         bool force_fault = false;
         for (int n = g_gn_force_fault.load(); n > 0 && !force_fault;) force_fault = g_gn_force_fault.compare_exchange_weak(n, n - 1);
         for (int i = MMF_NUM_PYRS - 1; i >= 0; --i) {
@@ -1598,6 +1657,14 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
             MMF_REQUIRE(gn_geometry(i, cols, rows, &geo), "odom_enqueue_tracking: no launch geometry for this level");
             const int px = geo.px, groups = geo.groups;
             a.lanes = geo.lanes;
+            // object models walked by their extents: one one-dimensional grid, a geometry per model (GnBatchGeom)
+            GnBatchGeom gg;
+            std::memset(&gg, 0, sizeof(gg));
+            const bool mixed = plan.sparse_mask != 0;
+            if (mixed) {
+                for (unsigned m = 0; m < (unsigned)kMaxBatch; ++m) gg.start[m + 1] = gg.start[m] + (m < ny ? plan.groups[i][m] : 0);
+                gg.sparse_mask = plan.sparse_mask, gg.ext_gen = plan.ext_gen, gg.level = i, gg.extent = o->extent;
+            }
             for (int j = 0; j < iterations[i]; ++j) {
                 const bool last_l0 = (i == 0 && j == iterations[i] - 1);
                 a.ra = make_residual_args(min_scale, o->dIdx[i], 0, o->dIdy[i], 0, o->last_depth[i], 0,
@@ -1620,7 +1687,12 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 }
 #define MMF_GN_LAUNCH(PXV, ERRV)                                                                                              \
     do {                                                                                                                      \
-        if (e0)                                                                                                               \
+        if (mixed && e0)                                                                                                      \
+            hipExtLaunchKernelGGL((gn_iter_mixed_kernel<PXV, ERRV>), dim3(gg.start[kMaxBatch]), dim3(geo.threads), 0, c->stream, \
+                                  e0, e1, 0, o->state, a, bd, gg);                                                            \
+        else if (mixed)                                                                                                       \
+            q.launch((gn_iter_mixed_kernel<PXV, ERRV>), dim3(gg.start[kMaxBatch]), dim3(geo.threads), o->state, a, bd, gg);     \
+        else if (e0)                                                                                                          \
             hipExtLaunchKernelGGL((gn_iter_kernel<PXV, ERRV>), dim3(groups, ny), dim3(geo.threads), 0, c->stream, e0, e1, 0,      \
                                   o->state, a, bd);                                                                           \
         else                                                                                                                  \
@@ -1881,28 +1953,49 @@ static unsigned fused_max_models() {  // MMF_GN_FUSED_MAX: up to how many models
 // How many workgroups of gn_iter_kernel<px, .> with `threads` threads the device holds at once: the occupancy the runtime
 // reports for the kernel (registers, LDS) x the compute units.  The launch spins on its own workgroups (count barrier), so a
 // grid beyond this could only time out; such sizes, partitioned or smaller devices take the two-launch chain.
-static long long gn_resident_groups(mmf_ctx* c, int px, int threads) {
+static long long gn_resident_groups(mmf_ctx* c, int px, int threads, bool mixed = false) {
     static std::mutex mu;
     static std::map<std::pair<int, int>, int> per_cu;
     std::lock_guard<std::mutex> lock(mu);
-    const auto key = std::make_pair(px, threads);
+    const auto key = std::make_pair(px + (mixed ? 100 : 0), threads);
     auto it = per_cu.find(key);
     if (it == per_cu.end()) {
-        int nb = 0;
-        hipError_t e = hipErrorInvalidValue;
-        switch (px) {  // (the error-image variant uses no fewer registers: it bounds both)
-            case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gn_iter_kernel<5, true>, threads, 0); break;
-            case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gn_iter_kernel<4, true>, threads, 0); break;
-            case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gn_iter_kernel<2, true>, threads, 0); break;
-            case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gn_iter_kernel<1, true>, threads, 0); break;
+        int nb = 0, nb2 = 0;
+        hipError_t e = hipErrorInvalidValue, e2 = hipSuccess;
+        switch (px + (mixed ? 100 : 0)) {  // (both variants of a launch shape: the smaller occupancy bounds the chain)
+#define MMF_OCC(PXV, KERNEL)                                                                                  \
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERNEL<PXV, true>, threads, 0);                  \
+    e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, KERNEL<PXV, false>, threads, 0);               \
+    break
+            case 5: MMF_OCC(5, gn_iter_kernel);
+            case 4: MMF_OCC(4, gn_iter_kernel);
+            case 2: MMF_OCC(2, gn_iter_kernel);
+            case 1: MMF_OCC(1, gn_iter_kernel);
+            case 105: MMF_OCC(5, gn_iter_mixed_kernel);
+            case 104: MMF_OCC(4, gn_iter_mixed_kernel);
+            case 102: MMF_OCC(2, gn_iter_mixed_kernel);
+            case 101: MMF_OCC(1, gn_iter_mixed_kernel);
+#undef MMF_OCC
             default: break;
         }
+        if (e2 != hipSuccess) e = e2;
+        nb = std::min(nb, nb2);
         if (e != hipSuccess) nb = 0, (void)hipGetLastError();
         it = per_cu.emplace(key, nb).first;
     }
     return (long long)it->second * c->cu_count;
 }
-static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom, int models) {
+static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int pyramid, int fast_odom, const TrackBatch* batch,
+                                bool sparse_on, GnChainPlan* plan) {
+    const int models = batch ? batch->n : 1;
+    // the models walked by their extents: object models whose preparation noted extents for THIS frame (one number for all)
+    GnChainPlan pl;
+    for (int m = 0; m < models && sparse_on; ++m) {
+        const mmf_odom* om = batch ? batch->o[m] : o;
+        if (!om->sparse || om->extent_gen == 0) continue;
+        if (pl.ext_gen == 0) pl.ext_gen = om->extent_gen;
+        if (om->extent_gen == pl.ext_gen) pl.sparse_mask |= 1u << m;
+    }
     const bool env_enabled = tunables().gn_fused;
     const int forced = g_gn_fused.load();
     const bool enabled = (forced < 0 ? env_enabled : forced != 0) && o->exclusive_chain && !g_gn_latched_off.load();
@@ -1920,8 +2013,15 @@ static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int
         GnGeometry geo;
         if (!gn_geometry(i, cols, rows, &geo)) return false;
         // the count barrier inside the launch needs every workgroup of it resident at once
-        if ((long long)geo.groups * models > gn_resident_groups(o->ctx, geo.px, geo.threads)) return false;
+        long long total = 0;
+        for (int m = 0; m < models; ++m) {
+            const mmf_odom* om = batch ? batch->o[m] : o;
+            pl.groups[i][m] = ((pl.sparse_mask >> m) & 1u) ? gn_sparse_groups(i, geo.groups, om->gn_need[i], geo.lanes) : geo.groups;
+            total += pl.groups[i][m];
+        }
+        if (total > gn_resident_groups(o->ctx, geo.px, geo.threads, pl.sparse_mask != 0)) return false;
     }
+    if (plan) *plan = pl;
     return true;
 }
 
@@ -1968,7 +2068,12 @@ static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
     }
 
     const OdomState* r = o->host_result;
-    if (r->gn_fault) return kGnRetry;  // the one-launch chain gave up: nothing of its result is valid
+    if (o->walked_by_extent) std::memcpy(o->gn_need, r->gn_need, sizeof(o->gn_need));  // (valid also when the chain gave up)
+    if (r->gn_fault) {  // the one-launch chain gave up: nothing of its result is valid
+        o->last_gn_fault = r->gn_fault;
+        return kGnRetry;
+    }
+    o->last_gn_fault = 0;
     std::memcpy(trans, r->trans_out, sizeof(float) * 3);
     std::memcpy(rot, r->rot_out, sizeof(float) * 9);
     // members the reference leaves untouched in a given mode keep their previous values
@@ -1996,10 +2101,19 @@ static int odom_finish_tracking(mmf_odom* o, float trans[3], float rot[9]) {
 // and the prefetched SO3 pre-alignment it consumed -- so that the same call can be enqueued again and take the two-launch
 // chain from the pose the frame started with.  RGBDOdometry.cpp:464-467: the call returns a pose or reverts, it never aborts.
 static void odom_retrack_prepare(mmf_odom* const* odoms, int n, int so3) {
-    g_gn_latched_off.store(true);
+    // An object model whose extent did not fit its workgroups (kGnFaultExtent) says nothing about the GPU: this frame is tracked
+    // again on the two-launch chain, the model's next chain is sized by what the box needed (odom_finish_tracking has taken
+    // OdomState::gn_need over), and the one-launch chain stays in use.
+    bool extent_only = true;
+    for (int k = 0; k < n; ++k) {
+        const int fault = odoms[k]->host_result ? odoms[k]->host_result->gn_fault : 0;
+        if (fault != 0 && fault != kGnFaultExtent) extent_only = false;
+    }
+    if (!extent_only) g_gn_latched_off.store(true);
     g_gn_recoveries.fetch_add(1);
     for (int k = 0; k < n; ++k) {
         mmf_odom* o = odoms[k];
+        o->two_launch_once = true;
         if (so3)
             for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(o->last_next_image[i], o->next_image[i]);
         o->so3_prefetched = odoms[0]->retry_so3_prefetched, o->so3_stage = odoms[0]->retry_so3_stage;

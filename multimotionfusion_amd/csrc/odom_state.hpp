@@ -57,6 +57,16 @@ struct OdomState {
     float pose_out[16];  // [rot_out | trans_out; 0 0 0 1]
     float fusion_weight; // Model::computeFusionWeight(1) of this pose against the pose the chain started from (odom_fusion_weight_kernel)
     int gn_fault;  // the count barrier of a gn_iter_kernel launch timed out (a workgroup of the launch never arrived)
+    // checking mode of an object model's one-launch chain (GnIterArgs::check_sparse): correspondences icpStep accepted OUTSIDE
+    // the rectangle the chain would have walked, over all launches of the chain -- zero, or the rectangle's argument is wrong
+    unsigned gn_dbg_outside;
+    // ... and, in every mode, the level-0 rectangle of the chain's last launch {x0, y0, width, rows}, the largest number of
+    // passes a level-0 rectangle took, whether it was derived (1) or the whole image for want of a usable pose / box (0)
+    int gn_dbg_rect[6];
+    // lanes the box of the model's own depth needs at each pyramid level (gn_iter_mixed_kernel: runs of PX pixels x rows), noted by
+    // every launch that walks the model by its extents -- also by the one that finds the box does not fit (kGnFaultExtent): the
+    // host sizes the model's NEXT chain by it
+    int gn_need[3];
     OdomStats st;
     // everything above travels to the host's (pinned, device-visible) copy of this struct at the end of a chain
     // (odom_publish_kernel); this word follows it there, after a system-scope fence: the host polls it

@@ -71,6 +71,9 @@ struct PrepJob {
     // coarsest level of an object model's depth pyramid, those in the last column / row at the two finer ones
     unsigned long long* ext;
     unsigned ext_gen;
+    // non-null (PREP_TEX_TP of an object model): the job notes the pixel box and the depth range of the valid vertices it
+    // reads into these extent words (extent.hpp: aabb_note), with ext_gen
+    unsigned long long* aabb;
 };
 
 constexpr int kMaxPrepJobs = 24;  // 24 x 144 B of kernel arguments; longer job lists go out as several launches
@@ -82,8 +85,9 @@ struct PrepBatch {
 
 // transform_maps_px + pack_prev_kernel in one pass (same arithmetic; an invalid pixel's record is all NaN)
 // (v_ok / n_ok: the source vertex / normal is valid, i.e. its x is not NaN)
-__device__ __forceinline__ void transform_pack_store(int x, int y, int rows, int cols, bool v_ok, f3 vs, bool n_ok, f3 ns, m33 R, f3 t,
-                                                     float* __restrict__ vdst, float* __restrict__ ndst, float* __restrict__ packed) {
+// returns the global-frame vertex (NaN when the source is invalid)
+__device__ __forceinline__ f3 transform_pack_store(int x, int y, int rows, int cols, bool v_ok, f3 vs, bool n_ok, f3 ns, m33 R, f3 t,
+                                                   float* __restrict__ vdst, float* __restrict__ ndst, float* __restrict__ packed) {
     // (vdst / ndst: the planar copies, or null -- the chains gather from the packed records only)
     f3 vd = make_f3(qnan(), qnan(), qnan());
     if (v_ok) {
@@ -107,7 +111,12 @@ __device__ __forceinline__ void transform_pack_store(int x, int y, int rows, int
     o[0] = make_float2(vd.x, vd.y);
     o[1] = make_float2(vd.z, nd.x);
     o[2] = make_float2(nd.y, nd.z);
+    return vd;
 }
+// what the threads of a job gather for a note its workgroup leaves behind (PrepJob::aabb)
+struct PrepNote {
+    float lo[3], hi[3];
+};
 __device__ __forceinline__ bool transform_pack_px(int x, int y, int rows, int cols, const float* __restrict__ vsrc,
                                                   const float* __restrict__ nsrc, m33 R, f3 t, float* __restrict__ vdst,
                                                   float* __restrict__ ndst, float* __restrict__ packed) {
@@ -130,7 +139,7 @@ __device__ __forceinline__ bool transform_pack_px(int x, int y, int rows, int co
 }
 
 // pixel (x, y) of job J
-__device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, const void* src1, int x, int y) {
+__device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, const void* src1, int x, int y, PrepNote& note) {
     const int cols = J.cols, rows = J.rows;
     switch (J.op) {
         case PREP_VMAP:
@@ -194,6 +203,10 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
             const f3 ns = ok ? make_f3(n.x, n.y, n.z) : make_f3(qnan(), qnan(), qnan());
             transform_pack_store(x, y, rows, cols, !(vs.x != vs.x), vs, !(ns.x != ns.x), ns, R, make_f3(J.f[9], J.f[10], J.f[11]),
                                  (float*)J.dst0, (float*)J.dst1, (float*)J.dst2);
+            if (ok) {  // (extent.hpp: the pixel box and the camera-frame depth range of the valid vertices)
+                note.lo[0] = fminf(note.lo[0], (float)x), note.lo[1] = fminf(note.lo[1], (float)y), note.lo[2] = fminf(note.lo[2], v.z);
+                note.hi[0] = fmaxf(note.hi[0], (float)x), note.hi[1] = fmaxf(note.hi[1], (float)y), note.hi[2] = fmaxf(note.hi[2], v.z);
+            }
             break;
         }
         case PREP_TEX_PROJECT: {
@@ -296,7 +309,28 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
     const bool alt = J.sel != nullptr && (J.sel_total ? ((float)*J.sel / (float)J.sel_total < J.sel_ratio) : *J.sel != 0);  // wave uniform
     const void* src0 = alt ? J.alt0 : J.src0;
     const void* src1 = alt ? J.alt1 : J.src1;
-    for (int r = 0; r < J.reps; ++r) prep_job_px(J, src0, src1, x, (by * J.reps + r) * kTileY + threadIdx.y);
+    PrepNote note;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) note.lo[k] = FLT_MAX, note.hi[k] = -FLT_MAX;
+    for (int r = 0; r < J.reps; ++r) prep_job_px(J, src0, src1, x, (by * J.reps + r) * kTileY + threadIdx.y, note);
+    if (J.aabb != nullptr) {  // (uniform) the workgroup's box of valid vertices -> the model's extent words
+        __shared__ float box[kTileY][6];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                note.lo[k] = fminf(note.lo[k], __shfl_xor(note.lo[k], d));
+                note.hi[k] = fmaxf(note.hi[k], __shfl_xor(note.hi[k], d));
+            }
+        if (threadIdx.x == 0)
+            for (int k = 0; k < 3; ++k) box[threadIdx.y][k] = note.lo[k], box[threadIdx.y][3 + k] = note.hi[k];
+        __syncthreads();
+        if (threadIdx.x == 0 && threadIdx.y == 0) {
+            for (int w = 1; w < kTileY; ++w)
+                for (int k = 0; k < 3; ++k) note.lo[k] = fminf(note.lo[k], box[w][k]), note.hi[k] = fmaxf(note.hi[k], box[w][3 + k]);
+            if (note.lo[0] <= note.hi[0]) aabb_note(J.aabb, J.ext_gen, note.lo, note.hi);
+        }
+    }
 }
 
 }  // namespace mmf

@@ -908,6 +908,8 @@ __global__ void odom_begin_kernel(OdomState* st, BeginArgs a, BatchDelta bd, Beg
     st->level_break = 0;
     st->st.iterations_run = 0;
     st->gn_fault = 0;
+    st->gn_dbg_outside = 0u;
+    for (int k = 0; k < 6; ++k) st->gn_dbg_rect[k] = 0;
     for (int k = 0; k < kResShards; ++k) st->gn_acc[0][kResStride * k] = 0ull;  // the first gn_iter_kernel launch adds here
     if (!a.so3_prefetched)
         so3_begin(st, a.so3_intr, a.so3);

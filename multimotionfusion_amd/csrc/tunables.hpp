@@ -11,7 +11,7 @@ namespace mmf {
 struct Tunables {
     // ---- Gauss-Newton chain (gn_fused.hpp, mmf_hip.hip: gn_geometry, odom_fused_chain_ok) ----
     bool gn_fused = true;     // MMF_GN_FUSED=0: always the two-launch chain (producer + step)
-    int gn_fused_max = 3;     // MMF_GN_FUSED_MAX: models one one-launch chain carries (gridDim.y)
+    int gn_fused_max = 8;     // MMF_GN_FUSED_MAX: models one one-launch chain carries at most (the residency check decides below that)
     int gn_px[3] = {0, 0, 0}; // MMF_GN_PX="p0,p1,p2": pixels per lane of a level (0 = by geometry)
     int gn_groups = 256;      // MMF_GN_GROUPS: workgroups per model per launch at most
     int gn_sleep = 1;         // MMF_GN_SLEEP: s_sleep(1) repetitions between two polls of the count barrier
@@ -46,7 +46,7 @@ inline const Tunables& tunables() {
             return e ? std::atol(e) : dflt;
         };
         v.gn_fused = flag("MMF_GN_FUSED", true);
-        v.gn_fused_max = (int)num("MMF_GN_FUSED_MAX", 3);
+        v.gn_fused_max = (int)num("MMF_GN_FUSED_MAX", 8);
         if (v.gn_fused_max < 1) v.gn_fused_max = 1;
         if (const char* e = std::getenv("MMF_GN_PX")) std::sscanf(e, "%d,%d,%d", &v.gn_px[0], &v.gn_px[1], &v.gn_px[2]);
         v.gn_groups = (int)num("MMF_GN_GROUPS", 256);

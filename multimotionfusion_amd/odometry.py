@@ -91,6 +91,14 @@ class RGBDOdometry:
         self.iterations_run, self.so3_iterations_run = s.iterations_run, s.so3_iterations_run
 
     # -- test / bench hooks -------------------------------------------------------------------
+    def sparseWalk(self):
+        """(correspondences accepted outside the rectangle an object model's one-launch chain walks, was the last chain walked
+        by the model's extents) -- the first is counted in checking mode only (mmf_debug_set_sparse_check)."""
+        outside, by_extent, rect = C.c_uint(0), C.c_int(0), (C.c_int * 9)()
+        check(self.ctx.lib.mmf_debug_odom_sparse_outside(self.handle, C.byref(outside), C.byref(by_extent), rect))
+        self.sparseRect = list(rect)  # level-0 rectangle {x0, y0, width, rows}, most passes, derived, lanes needed at levels 0 / 1 / 2
+        return int(outside.value), bool(by_extent.value)
+
     _DTYPES = {"vmaps_curr": (torch.float32, 3), "nmaps_curr": (torch.float32, 3),
                "vmaps_g_prev": (torch.float32, 3), "nmaps_g_prev": (torch.float32, 3),
                "last_depth": (torch.float32, 1), "next_depth": (torch.float32, 1), "depth_pyr": (torch.float32, 1),
