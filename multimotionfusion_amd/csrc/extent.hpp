@@ -85,14 +85,26 @@ __device__ __forceinline__ bool extent_misses(const ExtentBox& e, unsigned first
 // (copy_maps_px: z != 0) -- NOT the same set as the valid depths above (verticesToDepth drops z > 6 m, cudafuncs.cu:602-613).
 // The coarser levels' vertices are averages of four valid finer ones (cudafuncs.cu:366-417): their pixels are the level-0 box
 // shifted right, their depths lie in the same range.  What it is for: gn_fused.hpp, gn_sparse_icp_box.
-constexpr int kExtentWords = 18;
-__device__ __forceinline__ unsigned aabb_key(float f) {  // monotonic in f (no NaN: only valid vertices are noted)
+__device__ __forceinline__ unsigned aabb_key_fwd(float f) {
     const unsigned b = __builtin_bit_cast(unsigned, f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-__device__ __forceinline__ float aabb_unkey(unsigned k) {
-    return __builtin_bit_cast(float, (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+__device__ __forceinline__ float aabb_unkey_fwd(unsigned k) { return __builtin_bit_cast(float, (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+constexpr int kExtentWords = 20;
+// Words [18], [19]: the smallest valid depth of the SENSOR frame's level-0 vertex map (createVMap: z != 0 && z < cutoff), noted
+// by the sensor-side preparation job that writes it (one atomic per workgroup), in slot gen & 1 -- the next frame's sensor
+// side is prepared while this frame's chain still reads its own slot.  The coarser levels' depths are weighted means of
+// finer ones (pyrDownGaussF): no smaller.  For gn_sparse_icp_box's error-image launch.
+__device__ __forceinline__ void sensor_zmin_note(unsigned long long* words, unsigned gen, float zmin) {
+    atomicMax(&words[18 + (gen & 1u)], ((unsigned long long)gen << 32) | (unsigned long long)(0xFFFFFFFFu - aabb_key_fwd(zmin)));
 }
+__device__ __forceinline__ bool sensor_zmin_load(const unsigned long long* words, unsigned gen, float& zmin) {
+    const unsigned long long w = words[18 + (gen & 1u)];
+    zmin = aabb_unkey_fwd(0xFFFFFFFFu - (unsigned)(w & 0xFFFFFFFFull));
+    return gen != 0u && (unsigned)(w >> 32) == gen;
+}
+__device__ __forceinline__ unsigned aabb_key(float f) { return aabb_key_fwd(f); }  // monotonic in f (no NaN: only valid vertices are noted)
+__device__ __forceinline__ float aabb_unkey(unsigned k) { return aabb_unkey_fwd(k); }
 // one thread: lo / hi of {x, y, z} over the valid vertices its workgroup wrote (called only when there is one)
 __device__ __forceinline__ void aabb_note(unsigned long long* words, unsigned gen, const float (&lo)[3], const float (&hi)[3]) {
     const unsigned long long g = (unsigned long long)gen << 32;

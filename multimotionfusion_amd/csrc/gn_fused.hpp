@@ -46,6 +46,8 @@ constexpr int kGnMaxGroups = 512;   // workgroups per model per launch: all resi
 constexpr int kGnArriveShift = 58;  // counter word: arrivals << 58 | count << 40 | sum diff^2 (per shard: < 2^6, 2^18, 2^40)
 constexpr int kGnMaxPolls = 1 << 17;
 constexpr int kGnMaxWaves = 8;      // the solver wave + up to seven pixel waves (the host sizes it: one workgroup per CU)
+constexpr int kGnSparseLanes = 256; // pixel lanes of a workgroup that walks an object model by its extents (gn_pixel_waves_sparse's LDS)
+constexpr int kGnStashWords = 5;    // ... and the words per pixel it keeps there
 
 struct GnIterArgs {
     IcpArgs ia;
@@ -389,13 +391,17 @@ __device__ __forceinline__ void gn_load_i16(const int16_t* __restrict__ p, int (
 // corners (all in front of the camera: projection keeps convex hulls).  Every other sensor pixel adds exact zeros to the 29
 // sums; the model's workgroups walk the rectangle only (gn_pixel_waves_sparse), in as many passes as it takes.
 // Margins: B grows by one pixel (the projection is rounded to the nearest), d by 1 % + 1 mm, the rectangle by two pixels.
-// A corner that is not in front of the camera, a pose that is not a number, or a launch that writes the error image (its
-// texels record distances WITHOUT the threshold, reduce.cu:275): the whole image.
+// The launch that writes the error image records distances WITHOUT the threshold (reduce.cu:275): there q is anywhere on the cone
+// over B, and what bounds it is the sensor's own depth range (extent.hpp: sensor_zmin_*; a sensor vertex has zs_min <= v.z <
+// cutoff): the cone's four edges, taken into the sensor camera, cut by the planes v.z = zs_min and v.z = cutoff.
+// A corner that is not in front of the camera, a pose that is not a number, a depth range that is not known: the whole image.
 struct GnSparseCtx {
-    bool box_ok, full;  // the preparation noted vertices for this frame; walk the whole image (the error-image launch)
+    bool box_ok, err;    // the preparation noted vertices for this frame; this launch writes the error images
     float lo[3], hi[3];  // pixel x, pixel y (level 0), camera-frame z of the model's valid vertices
     float Rprev[9], tprev[3];
     int px, level;       // pixels per lane of this launch, its pyramid level
+    bool zs_ok;          // the sensor frame's depth range is known: [zs_min, zs_max)
+    float zs_min, zs_max;
 };
 // one wave; lds.pose complete (written by lanes of this very wave)
 __device__ __forceinline__ void gn_sparse_icp_box(OdomState* st, const GnIterArgs& a, GnLds& lds, const GnSparseCtx& sp, int lane, int groups,
@@ -409,21 +415,32 @@ __device__ __forceinline__ void gn_sparse_icp_box(OdomState* st, const GnIterArg
         x1 = -1;  // the model predicted nothing: no pass
     } else {
         const float d = a.ia.dist_thres * 1.01f + 1e-3f;
-        const float za = sp.lo[2] - d, zb = sp.hi[2] + d;
         const int c = lane & 7;
-        // corner c of B at this level (grown by a pixel), on the near or the far plane of the slab
+        // corner c of B at this level (grown by a pixel): the direction of a cone edge in the model's camera
         const float bu = (c & 1) ? (float)((int)sp.hi[0] >> sp.level) + 1.f : (float)((int)sp.lo[0] >> sp.level) - 1.f;
         const float bv = (c & 2) ? (float)((int)sp.hi[1] >> sp.level) + 1.f : (float)((int)sp.lo[1] >> sp.level) - 1.f;
-        const float z = (c & 4) ? zb : za;
-        const float qx = (bu - a.ia.intr.cx) / a.ia.intr.fx * z, qy = (bv - a.ia.intr.cy) / a.ia.intr.fy * z, qz = z;
-        // g = Rprev q + tprev - tcurr, v = Rcurr^T g
-        const float gx = sp.Rprev[0] * qx + sp.Rprev[1] * qy + sp.Rprev[2] * qz + sp.tprev[0] - lds.pose[9];
-        const float gy = sp.Rprev[3] * qx + sp.Rprev[4] * qy + sp.Rprev[5] * qz + sp.tprev[1] - lds.pose[10];
-        const float gz = sp.Rprev[6] * qx + sp.Rprev[7] * qy + sp.Rprev[8] * qz + sp.tprev[2] - lds.pose[11];
-        const float vx = lds.pose[0] * gx + lds.pose[3] * gy + lds.pose[6] * gz;
-        const float vy = lds.pose[1] * gx + lds.pose[4] * gy + lds.pose[7] * gz;
-        const float vz = lds.pose[2] * gx + lds.pose[5] * gy + lds.pose[8] * gz;
-        const bool ok = za > 0.05f && vz > 0.05f && vz < 1e6f && fabsf(vx) < 1e6f && fabsf(vy) < 1e6f;  // (a NaN fails)
+        const float ex = (bu - a.ia.intr.cx) / a.ia.intr.fx, ey = (bv - a.ia.intr.cy) / a.ia.intr.fy;
+        // v(s) = Rcurr^T (Rprev (s e) + tprev - tcurr) = o + s w: the edge in the sensor camera
+        const float hx = sp.Rprev[0] * ex + sp.Rprev[1] * ey + sp.Rprev[2], hy = sp.Rprev[3] * ex + sp.Rprev[4] * ey + sp.Rprev[5],
+                    hz = sp.Rprev[6] * ex + sp.Rprev[7] * ey + sp.Rprev[8];
+        const float wx = lds.pose[0] * hx + lds.pose[3] * hy + lds.pose[6] * hz, wy = lds.pose[1] * hx + lds.pose[4] * hy + lds.pose[7] * hz,
+                    wz = lds.pose[2] * hx + lds.pose[5] * hy + lds.pose[8] * hz;
+        const float tx = sp.tprev[0] - lds.pose[9], ty = sp.tprev[1] - lds.pose[10], tz = sp.tprev[2] - lds.pose[11];
+        const float ox = lds.pose[0] * tx + lds.pose[3] * ty + lds.pose[6] * tz, oy = lds.pose[1] * tx + lds.pose[4] * ty + lds.pose[7] * tz,
+                    oz = lds.pose[2] * tx + lds.pose[5] * ty + lds.pose[8] * tz;
+        float s;
+        bool ok;
+        if (!sp.err) {  // the slab of model depths: s is the depth in the model's camera
+            const float za = sp.lo[2] - d, zb = sp.hi[2] + d;
+            s = (c & 4) ? zb : za;
+            ok = za > 0.05f;
+        } else {  // the sensor's depth range: s where the edge crosses the plane v.z = zs_min (a little in front of it) or cutoff
+            const float zp = (c & 4) ? sp.zs_max : sp.zs_min * 0.999f - 1e-3f;
+            s = (zp - oz) / wz;
+            ok = sp.zs_ok && sp.zs_min > 0.06f && wz > 1e-3f && s > 0.f;
+        }
+        const float vx = ox + s * wx, vy = oy + s * wy, vz = oz + s * wz;
+        ok = ok && vz > 0.05f && vz < 1e6f && fabsf(vx) < 1e6f && fabsf(vy) < 1e6f;  // (a NaN fails)
         const float u = ok ? vx * a.ia.intr.fx / vz + a.ia.intr.cx : 0.f, v = ok ? vy * a.ia.intr.fy / vz + a.ia.intr.cy : 0.f;
         float umin = fminf(fmaxf(u, -1e6f), 1e6f), vmin = fminf(fmaxf(v, -1e6f), 1e6f), umax = umin, vmax = vmin;
 #pragma unroll
@@ -443,7 +460,7 @@ __device__ __forceinline__ void gn_sparse_icp_box(OdomState* st, const GnIterArg
     const int per_pass = groups * a.lanes;
     if (lane == 0) {
         lds.sbox[6] = x0a, lds.sbox[7] = y0, lds.sbox[8] = lpr, lds.sbox[9] = nr;  // (read in checking mode only)
-        const bool whole = a.check_sparse != 0 || sp.full;
+        const bool whole = a.check_sparse != 0;
         const int rect_passes = (lpr * nr + per_pass - 1) / per_pass;
         if (whole) lpr = cols / sp.px, nr = rows;
         lds.sbox[0] = whole ? 0 : x0a, lds.sbox[1] = whole ? 0 : y0, lds.sbox[2] = lpr, lds.sbox[3] = nr;
@@ -895,6 +912,7 @@ __device__ __forceinline__ void gn_pixel_waves_sparse(OdomState* st, const GnIte
         lis[p] = a.ra.last_image[(size_t)gvv * a.ra.li_stride + gu];
         cl[p] = a.cloud4[(size_t)gvv * cols + gu];
     }
+    MMF_STAMP_PX(9);
     // ---- ICP: the sensor's vertices and normals of this lane's run in a pass ----
     float cur[6][PX];
     int si = 0, sj = 0;
@@ -917,9 +935,9 @@ __device__ __forceinline__ void gn_pixel_waves_sparse(OdomState* st, const GnIte
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- photometric: accept / reject (reduce.cu:813-836), the wave's {count, sum diff^2} ----
-    // The correspondences wait in LDS while the ICP passes run (six words per pixel: with them in registers across the pass
+    // The correspondences wait in LDS while the ICP passes run (five words per pixel: with them in registers across the pass
     // loop the kernel needs 246 registers -- one workgroup per CU instead of two, and the launch's workgroups must all be resident)
-    __shared__ unsigned stash[6 * PX][64 * (kGnMaxWaves - 1)];
+    __shared__ unsigned stash[kGnStashWords * PX][kGnSparseLanes];
     int cnt = 0, sq2 = 0;
     float perr[PX];
 #pragma unroll
@@ -931,18 +949,35 @@ __device__ __forceinline__ void gn_pixel_waves_sparse(OdomState* st, const GnIte
         perr[p] = hit ? 0.001f * vy : 0.0f;
         cnt += hit ? 1 : 0;
         sq2 += vy;
-        stash[6 * p + 0][ptid] = __builtin_bit_cast(unsigned, cl[p].x), stash[6 * p + 1][ptid] = __builtin_bit_cast(unsigned, cl[p].y);
-        stash[6 * p + 2][ptid] = __builtin_bit_cast(unsigned, cl[p].z), stash[6 * p + 3][ptid] = __builtin_bit_cast(unsigned, cl[p].w);
-        stash[6 * p + 4][ptid] = ((unsigned)valxs[p] & 0xFFFFu) | ((unsigned)valys[p] << 16);  // (Sobel sums of bytes: 16 bits each)
-        stash[6 * p + 5][ptid] = hit ? (unsigned)(idiff + 256) : 0u;                          // 0: no correspondence
+        // (1 / Z is not kept: cloud4.w IS 1.0f / z, projectPointsKernel's record -- rgb_rows divides again)
+        stash[5 * p + 0][ptid] = __builtin_bit_cast(unsigned, cl[p].x), stash[5 * p + 1][ptid] = __builtin_bit_cast(unsigned, cl[p].y);
+        stash[5 * p + 2][ptid] = __builtin_bit_cast(unsigned, cl[p].z);
+        stash[5 * p + 3][ptid] = ((unsigned)valxs[p] & 0xFFFFu) | ((unsigned)valys[p] << 16);  // (Sobel sums of bytes: 16 bits each)
+        stash[5 * p + 4][ptid] = hit ? (unsigned)(idiff + 256) : 0u;                          // 0: no correspondence
     }
     if (ERR && a.ra.err_map && live) gn_store_f32<PX>(a.ra.err_map + (size_t)i * a.ra.err_stride + j0, perr);
     cnt = wave_sum_to_lane63(cnt);
     sq2 = wave_sum_to_lane63(sq2);
+    MMF_STAMP_PX(6);
     if (lane == 63) lds.wsum[wave][0] = cnt, lds.wsum[wave][1] = sq2;
     lds_barrier();  // C: the solver wave adds the workgroup's counts to the launch's and waits for the others
     __builtin_amdgcn_sched_barrier(0);
+    MMF_STAMP_PX(7);
 
+    if (ERR) {  // the error images outside what the passes and the photometric lanes write: zeros, as the dense walk leaves there
+        const unsigned rpr = (unsigned)(cols / PX), total = rpr * (unsigned)rows, per = sgroups * (unsigned)a.lanes;
+        float zeros[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) zeros[p] = 0.f;
+        for (unsigned r = bid * (unsigned)a.lanes + (unsigned)ptid; r < total && ptid < a.lanes; r += per) {
+            const unsigned y = r / rpr;
+            const int x = (int)(r - y * rpr) * PX, yi = (int)y;
+            const bool in_rect = slpr != 0 && yi >= sy0 && yi < sy0 + (int)snr && x >= sx0 && x < sx0 + (int)slpr * PX;
+            const bool in_box = lpr != 0 && yi >= y0 && yi < y0 + nr && x >= x0a && x < x0a + lpr * PX;
+            if (a.ia.err_map && !in_rect) gn_store_f32<PX>(a.ia.err_map + (size_t)yi * a.ia.err_stride + x, zeros);
+            if (a.ra.err_map && !in_box) gn_store_f32<PX>(a.ra.err_map + (size_t)yi * a.ra.err_stride + x, zeros);
+        }
+    }
     // ---- ICP: projection, gathers, Jacobian rows (reduce.cu:257-368), pass by pass ----
     T isum[29];
 #pragma unroll
@@ -995,18 +1030,9 @@ __device__ __forceinline__ void gn_pixel_waves_sparse(OdomState* st, const GnIte
             const float added = L::hsum(isum[28]) - inl0;
             if (slive && !in_rect && added > 0.f) atomicAdd(&st->gn_dbg_outside, (unsigned)added);
         }
-        if (ERR && slive) {  // (the error-image launch walks the whole image: every texel of both images is written)
-            if (a.ia.err_map) gn_store_f32<PX>(a.ia.err_map + (size_t)si * a.ia.err_stride + sj, ierr);
-            // the photometric image outside the box the photometric lanes cover: what the dense walk writes there
-            const bool covered = lpr != 0 && si >= y0 && si < y0 + nr && sj >= x0a && sj < x0a + lpr * PX;
-            if (a.ra.err_map && !covered) {
-                float zeros[PX];
-#pragma unroll
-                for (int p = 0; p < PX; ++p) zeros[p] = 0.f;
-                gn_store_f32<PX>(a.ra.err_map + (size_t)si * a.ra.err_stride + sj, zeros);
-            }
-        }
+        if (ERR && slive && a.ia.err_map) gn_store_f32<PX>(a.ia.err_map + (size_t)si * a.ia.err_stride + sj, ierr);
     }
+    MMF_STAMP_PX(11);
     {
         float s32[32];
 #pragma unroll
@@ -1024,9 +1050,9 @@ __device__ __forceinline__ void gn_pixel_waves_sparse(OdomState* st, const GnIte
     RgbLane<PX> ph;
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
-        ph.X[p] = __builtin_bit_cast(float, stash[6 * p + 0][ptid]), ph.Y[p] = __builtin_bit_cast(float, stash[6 * p + 1][ptid]);
-        ph.Z[p] = __builtin_bit_cast(float, stash[6 * p + 2][ptid]), ph.invz[p] = __builtin_bit_cast(float, stash[6 * p + 3][ptid]);
-        const unsigned gxy = stash[6 * p + 4][ptid], dv = stash[6 * p + 5][ptid];
+        ph.X[p] = __builtin_bit_cast(float, stash[5 * p + 0][ptid]), ph.Y[p] = __builtin_bit_cast(float, stash[5 * p + 1][ptid]);
+        ph.Z[p] = __builtin_bit_cast(float, stash[5 * p + 2][ptid]), ph.invz[p] = 0.f;
+        const unsigned gxy = stash[5 * p + 3][ptid], dv = stash[5 * p + 4][ptid];
         ph.gx[p] = (int)(short)(gxy & 0xFFFFu), ph.gy[p] = (int)(short)(gxy >> 16);
         ph.c[p].diff = dv ? (float)((int)dv - 256) : 0.f;
         ph.c[p].valid = dv ? 1 : 0;
@@ -1034,7 +1060,7 @@ __device__ __forceinline__ void gn_pixel_waves_sparse(OdomState* st, const GnIte
     float psum[29];
 #pragma unroll
     for (int k = 0; k < 29; ++k) psum[k] = 0.f;
-    rgb_rows<PX>(a.sobel_scale, a.fx, a.fy, sigmaVal, live, ph, psum, lds.wtab, true);
+    rgb_rows<PX>(a.sobel_scale, a.fx, a.fy, sigmaVal, live, ph, psum, lds.wtab, false);
     {
         float s32[32];
 #pragma unroll
@@ -1071,11 +1097,17 @@ struct GnBatchGeom {
     unsigned ext_gen;      // ... the frame number they carry
     int level;             // this launch's pyramid level (extent_of_level)
     const unsigned long long* extent;  // the first model's extent words (in its slab: the others' by BatchDelta)
+    const unsigned long long* sensor;  // the extent words that hold the sensor frame's smallest depth (the leader's: shared, not shifted)
+    unsigned sensor_gen;               // ... the number it was noted under (0: unknown)
+    float sensor_cutoff;               // ... and the cut-off no sensor depth reaches (createVMap)
 };
 constexpr int kGnFaultExtent = 3;  // OdomState::gn_fault: an object model's extent does not fit its workgroups (the host walks it densely from then on)
 
+#ifndef MMF_MIXED_ATTR
+#define MMF_MIXED_ATTR
+#endif
 template <int PX, bool ERR>
-__global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_mixed_kernel(OdomState* st, GnIterArgs a, BatchDelta bd, GnBatchGeom g) {
+__global__ __launch_bounds__(64 * kGnMaxWaves) MMF_MIXED_ATTR void gn_iter_mixed_kernel(OdomState* st, GnIterArgs a, BatchDelta bd, GnBatchGeom g) {
     __shared__ GnLds lds;
     unsigned model = 0;
 #pragma unroll
@@ -1104,8 +1136,10 @@ __global__ __launch_bounds__(64 * kGnMaxWaves) void gn_iter_mixed_kernel(OdomSta
     if (wave == 0) {
         GnSparseCtx sp;
         sp.box_ok = aabb_load(ext, g.ext_gen, sp.lo, sp.hi);
-        sp.full = ERR;
+        sp.err = ERR;
         sp.px = PX, sp.level = g.level;
+        sp.zs_ok = ERR && sensor_zmin_load(g.sensor, g.sensor_gen, sp.zs_min);
+        sp.zs_max = g.sensor_cutoff;
 #pragma unroll
         for (int k = 0; k < 9; ++k) sp.Rprev[k] = st->Rprev[k];
 #pragma unroll

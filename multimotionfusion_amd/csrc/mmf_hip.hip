@@ -782,6 +782,8 @@ struct mmf_odom {
     // the number of the frame they were noted for), read by the two-launch chain's passes
     unsigned long long* extent = nullptr;
     unsigned extent_gen = 0;
+    unsigned sensor_gen = 0;     // number of the last sensor-side depth preparation (its smallest depth: extent words 18 / 19)
+    float sensor_cutoff = 0.f;   // ... and the depth cut-off its vertex maps were made with
     // an OBJECT model (set by the orchestrator): the two-launch chain walks its images with a quarter of the workgroups
     // (track_kernels.hpp: ChainGeom), batched or alone
     bool sparse = false;
@@ -1267,6 +1269,10 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
         PrepJob& j = pb.add(merge_vn ? PREP_VMAP_NMAP : PREP_VMAP, W >> lvl, H >> lvl);
         j.src0 = depth, j.dst0 = o->vmaps_curr[lvl], j.dst1 = o->nmaps_curr[lvl];
         intr_f(j, lvl, true, depth_cutoff);
+        if (lvl == 0) {  // (extent.hpp: the sensor frame's smallest valid depth, for the object models' error-image launches)
+            j.zmin = o->extent, j.zmin_gen = ++o->sensor_gen;
+            o->sensor_cutoff = depth_cutoff;
+        }
     };
     auto down_jobs = [&](PrepBuilder& pb, int lvl, const float* depth_src) {  // level lvl-1 -> lvl of every pyramid
         if (in_img) pyr(pb, PREP_PYRDOWN_U8, o->next_image[lvl - 1], o->next_image[lvl], lvl);
@@ -1544,6 +1550,9 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                                  const TrackBatch* batch = nullptr) {
     mmf_ctx* c = o->ctx;
     MMF_HIP_TRY(hipSetDevice(c->device));
+#ifdef MMF_STAMPS  // (diagnostic builds: MMF_DBG_NO_ERR=1 leaves the error images out, so that a chain's last launch is an ordinary one)
+    if (std::getenv("MMF_DBG_NO_ERR")) icp_err_dev = rgb_err_dev = nullptr;
+#endif
     const bool icp = !rgb_only && icp_weight > 0;  // :221-222
     const bool rgb = rgb_only || icp_weight < 100;
     const unsigned ny = batch ? (unsigned)batch->n : 1u;
@@ -1664,6 +1673,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
             if (mixed) {
                 for (unsigned m = 0; m < (unsigned)kMaxBatch; ++m) gg.start[m + 1] = gg.start[m] + (m < ny ? plan.groups[i][m] : 0);
                 gg.sparse_mask = plan.sparse_mask, gg.ext_gen = plan.ext_gen, gg.level = i, gg.extent = o->extent;
+                gg.sensor = o->extent, gg.sensor_gen = o->sensor_gen, gg.sensor_cutoff = o->sensor_cutoff;
             }
             for (int j = 0; j < iterations[i]; ++j) {
                 const bool last_l0 = (i == 0 && j == iterations[i] - 1);
@@ -2013,6 +2023,7 @@ static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int
         GnGeometry geo;
         if (!gn_geometry(i, cols, rows, &geo)) return false;
         // the count barrier inside the launch needs every workgroup of it resident at once
+        if (geo.lanes > kGnSparseLanes) pl.sparse_mask = 0;  // (the sparse walk keeps a workgroup's correspondences in LDS: sized for 256 lanes)
         long long total = 0;
         for (int m = 0; m < models; ++m) {
             const mmf_odom* om = batch ? batch->o[m] : o;

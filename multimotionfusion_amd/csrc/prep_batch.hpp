@@ -74,6 +74,10 @@ struct PrepJob {
     // non-null (PREP_TEX_TP of an object model): the job notes the pixel box and the depth range of the valid vertices it
     // reads into these extent words (extent.hpp: aabb_note), with ext_gen
     unsigned long long* aabb;
+    // non-null (the sensor side's level-0 PREP_VMAP / PREP_VMAP_NMAP): the job notes the smallest valid depth it reads into the
+    // extent words (extent.hpp: sensor_zmin_note) with zmin_gen
+    unsigned long long* zmin;
+    unsigned zmin_gen;
 };
 
 constexpr int kMaxPrepJobs = 24;  // 24 x 144 B of kernel arguments; longer job lists go out as several launches
@@ -145,10 +149,18 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
         case PREP_VMAP:
             create_vmap_px(x, y, (const float*)src0, cols, cols, rows, (float*)J.dst0, cols, J.f[0], J.f[1], J.f[2], J.f[3],
                            J.f[4]);
+            if (J.zmin != nullptr && x < cols && y < rows) {  // (uniform test; the depth is in the cache)
+                const float z = ((const float*)src0)[(size_t)y * cols + x];
+                if (z != 0 && z < J.f[4]) note.lo[2] = fminf(note.lo[2], z);
+            }
             break;
         case PREP_VMAP_NMAP:
             create_vmap_nmap_px(x, y, (const float*)src0, cols, rows, (float*)J.dst0, (float*)J.dst1, J.f[0], J.f[1], J.f[2], J.f[3],
                                 J.f[4]);
+            if (J.zmin != nullptr && x < cols && y < rows) {
+                const float z = ((const float*)src0)[(size_t)y * cols + x];
+                if (z != 0 && z < J.f[4]) note.lo[2] = fminf(note.lo[2], z);
+            }
             break;
         case PREP_NMAP: create_nmap_px(x, y, rows, cols, (const float*)src0, cols, (float*)J.dst0, cols); break;
         case PREP_TRANSFORM_PACK: {
@@ -313,6 +325,18 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) note.lo[k] = FLT_MAX, note.hi[k] = -FLT_MAX;
     for (int r = 0; r < J.reps; ++r) prep_job_px(J, src0, src1, x, (by * J.reps + r) * kTileY + threadIdx.y, note);
+    if (J.zmin != nullptr) {  // (uniform) the workgroup's smallest valid depth -> the sensor slot of the extent words
+        __shared__ float zlo[kTileY];
+        float z = note.lo[2];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) z = fminf(z, __shfl_xor(z, d));
+        if (threadIdx.x == 0) zlo[threadIdx.y] = z;
+        __syncthreads();
+        if (threadIdx.x == 0 && threadIdx.y == 0) {
+            for (int w = 1; w < kTileY; ++w) z = fminf(z, zlo[w]);
+            if (z < FLT_MAX) sensor_zmin_note(J.zmin, J.zmin_gen, z);
+        }
+    }
     if (J.aabb != nullptr) {  // (uniform) the workgroup's box of valid vertices -> the model's extent words
         __shared__ float box[kTileY][6];
 #pragma unroll

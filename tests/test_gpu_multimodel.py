@@ -428,6 +428,13 @@ def test_extent_walk_equals_dense_walk_frame_by_frame(gpu_ctx, fast):
                 assert np.abs(pa - pb).max() <= (2e-6 if fast or k == 0 else 1e-3), (i, k, np.abs(pa - pb).max())
                 if k > 0:
                     diffs.append(float(np.abs(pa - pb).max()))
+                    # the error images of the chain's last level-0 iteration (RGBDOdometry.cpp:367,408): A's launch walks the
+                    # rectangle the SENSOR's depth range allows and zero-fills the rest, B's the whole image
+                    for which, tol in (("icp", 2e-4), ("rgb", 0.0)):
+                        ea, eb = A.getErrorTexture(k, which).cpu().numpy(), B.getErrorTexture(k, which).cpu().numpy()
+                        assert (eb > 0).sum() > 100, (i, k, which)
+                        off = np.abs(ea - eb) > tol
+                        assert off.sum() <= (2 if fast else 0.01 * (eb > 0).sum()), (i, k, which, int(off.sum()), float(np.abs(ea - eb).max()))
                 compared += int(k > 0)
             for a_, b_ in zip(ma, mb):  # B continues from A's state
                 b_.uploadMap(a_.downloadMap())
