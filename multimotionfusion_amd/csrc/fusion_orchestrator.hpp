@@ -598,6 +598,30 @@ static int fusion_fuse_clean_model(mmf_fusion* f, FusionModel* fm, float weighti
 // getMaxDepth (:408): float operands, double arithmetic (1.2 is a double literal), returned as float
 static float seg_max_depth(const mmf_segmentation_model& d) { return (float)((double)d.depth_mean + (double)d.depth_std * 1.2); }
 
+// test / A-B hook: the object models' passes as one launch per pass for all of them (1, the default) or model by model (0)
+static std::atomic<int> g_batch_passes{-1};  // -1: MMF_PASS_BATCH decides (default on)
+extern "C" int mmf_debug_set_pass_batch(int on) {
+    g_batch_passes.store(on < 0 ? -1 : (on ? 1 : 0));
+    return MMF_OK;
+}
+static bool fusion_batch_passes() {
+    const int v = g_batch_passes.load();
+    return v < 0 ? tunables().pass_batch : v != 0;
+}
+// `st` (the stream a batch of passes goes out on: objs[0]'s) waits for whatever the other models' own streams still hold
+// (a stream that has drained holds nothing: no wait is enqueued)
+static int fusion_lanes_join(const std::vector<FusionModel*>& objs, hipStream_t st) {
+    for (size_t k = 1; k < objs.size(); ++k) {
+        hipStream_t ls = objs[k]->lane->stream;
+        if (ls == st) continue;
+        if (hipStreamQuery(ls) == hipSuccess) continue;
+        (void)hipGetLastError();
+        MMF_HIP_TRY(hipEventRecord(objs[k]->ev_done, ls));
+        MMF_HIP_TRY(hipStreamWaitEvent(st, objs[k]->ev_done, 0));
+    }
+    return MMF_OK;
+}
+
 static int lane_wait(FusionModel* fm, hipEvent_t ev) {
     MMF_HIP_TRY(hipStreamWaitEvent(fm->lane->stream, ev, 0));
     return MMF_OK;
@@ -1121,9 +1145,21 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
         }
 
         stamp(2);
+        // The OBJECT models' passes go out as one launch per pass for all of them (models_fuse_clean_batched) on the first
+        // object's stream: ~9 launches per model and frame otherwise, and with seven objects the calling thread's launch rate
+        // set the pace of this part of the frame.  The camera model keeps its own stream and kernels (riders, fill-in).
+        std::vector<FusionModel*> objs;
+        const bool fuse_now = !g.rgb_only && f->tracking_ok;
+        for (size_t k = 1; k < f->models.size() && fusion_batch_passes() && fuse_now && !fusion_mid_predict(); ++k) {
+            FusionModel* fm = f->models[k];
+            if (!fusion_owns(f, k) || fm->early_done || fm->early_fused || fm->fill_in || (int)objs.size() >= kMaxPassBatch) continue;
+            objs.push_back(fm);
+        }
+        if (objs.size() < 2) objs.clear();
         for (size_t k = 0; k < f->models.size(); ++k) {  // predict() (:675), then :791-816, model by model
             FusionModel* fm = f->models[k];
             if (!fusion_owns(f, k)) continue;
+            if (std::find(objs.begin(), objs.end(), fm) != objs.end()) continue;  // (batched below)
             if (k > 0) {
                 rc = lane_wait(fm, f->ev_frame_ready);
                 if (rc) return rc;
@@ -1134,7 +1170,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 rc = fusion_predict_model(f, fm);
                 if (rc) return rc;
             }
-            if (!g.rgb_only && f->tracking_ok && !fm->early_fused) {
+            if (fuse_now && !fm->early_fused) {
                 float pose[16];
                 mmf_model_get_pose(fm->model, pose);
                 rc = fusion_fuse_clean_model(f, fm, fusion_weight(pose, fm->last_pose, weight_multiplier), early);
@@ -1142,12 +1178,52 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             }
             fm->early_fused = false;
         }
+        if (!objs.empty()) {
+            hipStream_t st = objs[0]->lane->stream;
+            rc = lane_wait(objs[0], f->ev_frame_ready);
+            if (rc) return rc;
+            rc = fusion_lanes_join(objs, st);
+            if (rc) return rc;
+            mmf_model* ms[kMaxPassBatch];
+            float wts[kMaxPassBatch];
+            for (size_t k = 0; k < objs.size(); ++k) {
+                float pose[16];
+                mmf_model_get_pose(objs[k]->model, pose);
+                ms[k] = objs[k]->model;
+                wts[k] = fusion_weight(pose, objs[k]->last_pose, weight_multiplier);
+            }
+            rc = models_fuse_clean_batched(ms, (int)objs.size(), st, f->tick, g.time_delta, g.max_depth_processed, f->frame_rgb, f->mask,
+                                           f->frame_depth, f->depth_filtered, g.outlier_coeff, wts);
+            if (rc) return rc;
+        }
     }
     stamp(3);
-    for (size_t k = 0; k < f->models.size(); ++k) {  // predict() (:821)
-        if (!fusion_owns(f, k)) continue;
-        rc = fusion_predict_model(f, f->models[k]);
-        if (rc) return rc;
+    {  // predict() (:821): the object models without fill-in as one batch, the others one by one
+        std::vector<FusionModel*> objs;
+        for (size_t k = 1; k < f->models.size() && fusion_batch_passes(); ++k) {
+            FusionModel* fm = f->models[k];
+            if (!fusion_owns(f, k) || fm->fill_in || !model_predict_batchable(fm->model) || (int)objs.size() >= kMaxPassBatch) continue;
+            objs.push_back(fm);
+        }
+        if (objs.size() < 2) objs.clear();
+        for (size_t k = 0; k < f->models.size(); ++k) {
+            if (!fusion_owns(f, k)) continue;
+            if (std::find(objs.begin(), objs.end(), f->models[k]) != objs.end()) continue;
+            rc = fusion_predict_model(f, f->models[k]);
+            if (rc) return rc;
+        }
+        if (!objs.empty()) {
+            hipStream_t st = objs[0]->lane->stream;
+            rc = fusion_lanes_join(objs, st);
+            if (rc) return rc;
+            mmf_model* ms[kMaxPassBatch];
+            for (size_t k = 0; k < objs.size(); ++k) ms[k] = objs[k]->model;
+            rc = models_combined_predict_batched(ms, (int)objs.size(), st, g.max_depth_processed, f->tick, f->tick, g.time_delta);
+            if (rc) return rc;
+            // the other objects' streams continue behind the batch: whatever is enqueued on them next reads what it wrote
+            MMF_HIP_TRY(hipEventRecord(objs[0]->ev_done, st));
+            for (size_t k = 1; k < objs.size(); ++k) MMF_HIP_TRY(hipStreamWaitEvent(objs[k]->lane->stream, objs[0]->ev_done, 0));
+        }
     }
     stamp(4);
     f->tick++;  // :825

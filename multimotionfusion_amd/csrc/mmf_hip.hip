@@ -1463,7 +1463,20 @@ static bool odom_batchable(mmf_odom* o, int rgb_only, float icp_weight, int pyra
 struct GnGeometry {
     int px, lanes, threads, groups;
 };
-static bool gn_geometry(int level, int cols, int rows, GnGeometry* out) {
+// mixed: a launch that also carries object models walked by their extents (gn_iter_mixed_kernel).  Its register count allows
+// three waves per SIMD, and the GPU places a second 5-wave workgroup on a CU only with four (measured: tools/gn_mixed_probe.py
+// -- the object models' workgroups started when the camera model's had finished); workgroups of FOUR waves (the solver wave
+// + three pixel waves, 192 pixel lanes) take one wave slot per SIMD and three of them share a CU.
+static bool gn_geometry(int level, int cols, int rows, GnGeometry* out, bool mixed = false) {
+    if (mixed && tunables().gn_mixed_lanes > 0 && tunables().gn_mixed_lanes < kBlock) {
+        GnGeometry base;
+        if (!gn_geometry(level, cols, rows, &base, false) || base.lanes != kBlock) return false;
+        const int lanes = tunables().gn_mixed_lanes / 64 * 64;
+        const int groups = (cols * rows / base.px + lanes - 1) / lanes;
+        if (groups > kGnMaxGroups) return false;
+        *out = GnGeometry{base.px, lanes, lanes + 64, groups};
+        return true;
+    }
     const int* forced = tunables().gn_px;
     const int max_groups = tunables().gn_groups;
     const int n = cols * rows;
@@ -1663,7 +1676,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
             first = false;
             const float min_scale = (float)(std::pow((double)o->min_grad[i], 2.0) / std::pow((double)o->sobel_scale, 2.0));
             GnGeometry geo;
-            MMF_REQUIRE(gn_geometry(i, cols, rows, &geo), "odom_enqueue_tracking: no launch geometry for this level");
+            MMF_REQUIRE(gn_geometry(i, cols, rows, &geo, plan.sparse_mask != 0), "odom_enqueue_tracking: no launch geometry for this level");
             const int px = geo.px, groups = geo.groups;
             a.lanes = geo.lanes;
             // object models walked by their extents: one one-dimensional grid, a geometry per model (GnBatchGeom)
@@ -2021,7 +2034,7 @@ static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int
         IcpArgs ia = odom_icp_args(o, i, o->icp_err);
         if (!residual_vec4_ok(ra) || icp_max_px(ia, 4) != 4 || !ia.prev_packed) return false;
         GnGeometry geo;
-        if (!gn_geometry(i, cols, rows, &geo)) return false;
+        if (!gn_geometry(i, cols, rows, &geo, pl.sparse_mask != 0)) return false;
         // the count barrier inside the launch needs every workgroup of it resident at once
         if (geo.lanes > kGnSparseLanes) pl.sparse_mask = 0;  // (the sparse walk keeps a workgroup's correspondences in LDS: sized for 256 lanes)
         long long total = 0;
@@ -2326,6 +2339,7 @@ struct mmf_model {
     unsigned* host_totals = nullptr;      // pinned, device visible: words 0..3 = copies of totals[], kCountWord / kCountSeqWord =
     unsigned* host_totals_dev = nullptr;  // the count the last clean pass published and its sequence number
     unsigned count_seq = 0;
+    hipStream_t count_stream = nullptr;  // the stream the last clean pass ran on when it is not the context's (a batched pass)
 };
 
 static Cam make_cam(const mmf_model* m, bool double_reciprocal) {
@@ -2487,7 +2501,7 @@ static int model_resolve_count(mmf_model* m) {
         if (seen || std::chrono::steady_clock::now() - t_poll > std::chrono::seconds(5)) break;
     }
     if (!seen) {
-        MMF_HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+        MMF_HIP_TRY(hipStreamSynchronize(m->count_stream ? m->count_stream : m->ctx->stream));
         MMF_REQUIRE(*flag == m->count_seq, "model: the surfel count did not reach the host");
     }
     std::atomic_thread_fence(std::memory_order_acquire);
@@ -2779,8 +2793,148 @@ extern "C" int mmf_model_clean(mmf_model* m, int time, int time_delta, float dep
     // workgroup stores it into the host's pinned words, where the next call that needs it on the host picks it up
     m->count_bound = n < (unsigned)m->capacity ? n : (unsigned)m->capacity;
     m->count_pending = true;
+    m->count_stream = nullptr;
     m->cur = 1 - m->cur;
     return MMF_OK;
+}
+
+// ---- the same passes for SEVERAL models, one launch per pass (surfel_kernels.hpp: *_batched_kernel), all on `st` ----
+// predictIndices -> fuse -> predictIndices -> clean (MultiMotionFusion.cpp:791-816) of n <= kMaxPassBatch models without
+// frame riders, device-side poses or fill-in (object models): what mmf_model_predict_indices, model_fuse(then_index),
+// model_predict_indices(projected) and mmf_model_clean enqueue for each of them, model by model, as seven launches in all.
+static int models_fuse_clean_batched(mmf_model* const* ms, int n, hipStream_t st, int time, int time_delta, float depth_cutoff,
+                                     const uint8_t* rgb, const uint8_t* mask, const float* depth_raw, const float* depth_filtered,
+                                     float outlier_coeff, const float* weighting) {
+    MMF_REQUIRE(ms && n >= 1 && n <= kMaxPassBatch && rgb && mask && depth_raw && depth_filtered && weighting,
+                "models_fuse_clean_batched: bad argument");
+    MMF_HIP_TRY(hipSetDevice(ms[0]->ctx->device));
+    PassBatch<index_map_item> b_map;
+    PassBatch<index_resolve_item> b_res;
+    PassBatch<fuse_data_item> b_fuse;
+    PassBatch<fuse_update_index_item> b_upd;
+    PassBatch<clean_flag_item> b_flag;
+    PassBatch<clean_scatter_item> b_scat;
+    unsigned g_map = 0, g_res = 0, g_fuse = 0, g_upd = 0, g_clean = 0;
+    for (int k = 0; k < n; ++k) {
+        mmf_model* m = ms[k];
+        MMF_REQUIRE(m && m->rider.st == nullptr && !m->t_inv_dev && !m->pose_dev && !m->abort_dev,
+                    "models_fuse_clean_batched: a model with a pending hand-over or a device-side pose");
+        if (int rc0 = model_resolve_count(m)) return rc0;
+        const unsigned npix = (unsigned)(m->width * m->height);
+        const IndexArgs ia = model_index_args(m, time, depth_cutoff, time_delta);
+        index_map_item& im = b_map.m[k];
+        im.s = m->set[m->cur], im.count = (int)m->count, im.a_in = ia, im.keys = m->keys, im.rider = FrameRider();
+        im.grid = (m->count + 255u) / 256u;
+        index_resolve_item& ir = b_res.m[k];
+        ir.s = m->set[m->cur], ir.a_in = ia, ir.keys = m->keys, ir.index = m->index, ir.vertConf = m->vertConf, ir.colorTime = m->colorTime,
+        ir.normRad = m->normRad, ir.rider = FrameRider();
+        ir.grid = (npix + 255u) / 256u;
+        FuseArgs fa;
+        std::memcpy(fa.pose.m, m->pose, sizeof(m->pose));
+        fa.c = make_cam(m, true);
+        fa.cols = m->width, fa.rows = m->height;
+        fa.time = time;
+        fa.weighting = weighting[k];
+        fa.pose_dev = nullptr, fa.weight_dev = nullptr, fa.weight_mult = weighting[k];
+        fa.abort_dev = nullptr;
+        fa.maskID = m->id;
+        fa.maxDepth = depth_cutoff < m->max_depth ? depth_cutoff : m->max_depth;  // std::min(depthCutoff, maxDepth) (Model.cpp:928)
+        fa.count = (int)m->count;
+        fuse_data_item& fd = b_fuse.m[k];
+        fd.rgb = rgb, fd.depth_raw = depth_raw, fd.depth_fil = depth_filtered, fd.mask = mask, fd.index = m->index, fd.vertConf = m->vertConf,
+        fd.normRad = m->normRad, fd.a_in = fa, fd.meas = m->meas, fd.new_flags = m->flags_b, fd.winner = m->winner;
+        fd.grid = ((unsigned)((m->width + 1) / 2) * (unsigned)((m->height + 1) / 2) + 255u) / 256u;
+        fuse_update_index_item& fu = b_upd.m[k];
+        fu.s = m->set[m->cur], fu.count = (int)m->count, fu.meas = m->meas, fu.time = time, fu.winner = m->winner, fu.a_in = ia, fu.keys = m->keys;
+        fu.grid = (m->count + 255u) / 256u;
+        CleanArgs ca;
+        inverse4f_host(m->pose, ca.t_inv.m);
+        ca.t_inv_dev = nullptr, ca.abort_dev = nullptr;
+        ca.c = make_cam(m, false);
+        ca.cols = m->width, ca.rows = m->height;
+        ca.time = time, ca.timeDelta = time_delta;
+        ca.confThreshold = m->conf_threshold;
+        ca.outlierCoeff = outlier_coeff;
+        ca.maskID = m->id;
+        ca.count = (int)m->count;
+        ca.npix = (int)npix;
+        const unsigned nc = m->count + npix;
+        clean_flag_item& cf = b_flag.m[k];
+        cf.s = m->set[m->cur], cf.meas = m->meas, cf.new_flags = m->flags_b, cf.a_in = ca, cf.index = m->index, cf.vertConf = m->vertConf,
+        cf.colorTime = m->colorTime, cf.depth_in = depth_filtered, cf.mask = mask, cf.keep = m->flags_a, cf.conf_time = m->conf_time,
+        cf.block_sums = m->block_sums;
+        cf.grid = (nc + 255u) / 256u;
+        clean_scatter_item& cs = b_scat.m[k];
+        cs.s = m->set[m->cur], cs.meas = m->meas, cs.count = (int)m->count, cs.npix = (int)npix, cs.keep = m->flags_a, cs.block_sums = m->block_sums,
+        cs.conf_time = m->conf_time, cs.dst = m->set[1 - m->cur], cs.capacity = m->capacity, cs.total_out = &m->totals[0],
+        cs.total_host = m->host_totals_dev + kCountWord, cs.seq = ++m->count_seq, cs.abort_dev = nullptr;
+        cs.grid = cf.grid;
+        g_map = std::max(g_map, im.grid), g_res = std::max(g_res, ir.grid), g_fuse = std::max(g_fuse, fd.grid);
+        g_upd = std::max(g_upd, fu.grid), g_clean = std::max(g_clean, cf.grid);
+        // the host's bookkeeping of mmf_model_clean
+        m->count_bound = nc < (unsigned)m->capacity ? nc : (unsigned)m->capacity;
+        m->count_pending = true;
+        m->count_stream = st;
+        m->cur = 1 - m->cur;
+    }
+    const dim3 blk(256);
+    if (g_map) hipLaunchKernelGGL(index_map_batched_kernel, dim3(g_map, n), blk, 0, st, b_map);
+    hipLaunchKernelGGL(index_resolve_batched_kernel, dim3(g_res, n), blk, 0, st, b_res);
+    hipLaunchKernelGGL(fuse_data_batched_kernel, dim3(g_fuse, n), blk, 0, st, b_fuse);
+    if (g_upd) hipLaunchKernelGGL(fuse_update_index_batched_kernel, dim3(g_upd, n), blk, 0, st, b_upd);
+    hipLaunchKernelGGL(index_resolve_batched_kernel, dim3(g_res, n), blk, 0, st, b_res);
+    hipLaunchKernelGGL(clean_flag_batched_kernel, dim3(g_clean, n), blk, 0, st, b_flag);
+    hipLaunchKernelGGL(clean_scatter_batched_kernel, dim3(g_clean, n), blk, 0, st, b_scat);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+// Model::combinedPredict(ACTIVE) (ModelProjection.cpp:187-269) of n models without fill-in, two launches in all
+static int models_combined_predict_batched(mmf_model* const* ms, int n, hipStream_t st, float depth_cutoff, int time, int max_time,
+                                           int time_delta) {
+    MMF_REQUIRE(ms && n >= 1 && n <= kMaxPassBatch, "models_combined_predict_batched: bad argument");
+    MMF_HIP_TRY(hipSetDevice(ms[0]->ctx->device));
+    PassBatch<splat_item> b_splat;
+    PassBatch<splat_resolve_item> b_res;
+    unsigned g_splat = 0, g_res = 0;
+    for (int k = 0; k < n; ++k) {
+        mmf_model* m = ms[k];
+        MMF_REQUIRE(m && m->rider.st == nullptr && !m->t_inv_dev && !m->abort_dev, "models_combined_predict_batched: a model with a device-side pose");
+        ++m->tex_gen;
+        ++m->thumb_gen;
+        SplatArgs a;
+        inverse4f_host(m->pose, a.t_inv.m);
+        a.t_inv_dev = nullptr, a.abort_dev = nullptr;
+        a.c = make_cam(m, false);
+        a.cols = m->width, a.rows = m->height;
+        a.maxDepth = depth_cutoff;
+        a.confThreshold = m->conf_threshold;
+        a.time = time, a.maxTime = max_time, a.timeDelta = time_delta;
+        a.early_z = 0;
+        a.rays = m->rays;
+        const unsigned launch_count = m->count_pending ? m->count_bound : m->count;
+        const size_t npix_s = (size_t)m->width * m->height;
+        splat_item& sp = b_splat.m[k];
+        sp.s = m->set[m->cur], sp.count = (int)launch_count, sp.a_in = a, sp.keys = m->keys, sp.count_dev = m->count_pending ? m->totals : nullptr;
+        sp.grid = launch_count ? splat_grid(launch_count, (size_t)launch_count >= npix_s / 2).x : 0u;
+        splat_resolve_item& sr = b_res.m[k];
+        sr.s = m->set[m->cur], sr.a_in = a, sr.keys = m->keys, sr.image = m->image, sr.vertexConf = m->vertexConf, sr.normalRadius = m->normalRadius,
+        sr.time_out = m->time_tex, sr.thumb = model_thumb_counts(m), sr.gen = (int)(m->thumb_gen & 1);
+        sr.grid = splat_tile_grid(m->width, m->height);
+        g_splat = std::max(g_splat, sp.grid), g_res = std::max(g_res, sr.grid);
+    }
+    if (g_splat) hipLaunchKernelGGL(splat_batched_kernel, dim3(g_splat, n), dim3(256), 0, st, b_splat);
+    hipLaunchKernelGGL(splat_resolve_batched_kernel, dim3(g_res, n), dim3(256), 0, st, b_res);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+// can a model's combinedPredict go into a batch (models_combined_predict_batched)?  Not a deep store (its rasterising pass is
+// another kernel), not one with pending device-side inputs
+static bool model_predict_batchable(const mmf_model* m) {
+    const unsigned launch_count = m->count_pending ? m->count_bound : m->count;
+    const int bound_mode = g_splat_bound.load() == -2 ? tunables().splat_bound : g_splat_bound.load();
+    const bool deep = bound_mode < 0 ? (size_t)launch_count >= 2 * (size_t)m->width * m->height : bound_mode != 0;
+    return !deep && m->rider.st == nullptr && !m->t_inv_dev && !m->abort_dev && !m->pose_dev;
 }
 
 // Model::performFillIn (Model.cpp:1607-1616)

@@ -460,36 +460,40 @@ __device__ __forceinline__ void index_map_project(const IndexArgs& a, int id, fl
     atomicMin(&keys[px * a.rows + py], k);
 }
 
-__global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, IndexArgs a_in,
-                                                        unsigned long long* __restrict__ keys, FrameRider rider) {
+__device__ __forceinline__ void index_map_kernel_body(SurfelSoA s, int count, IndexArgs a_in,
+                                                        unsigned long long* __restrict__ keys, FrameRider rider, const unsigned bx_, [[maybe_unused]] const unsigned gx_) {
     MMF_MODEL_STREAM_PRIORITY();
-    if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
+    if (rider.st && bx_ == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
         frame_rider_run<1u>(rider);
         return;
     }
     MMF_SPECULATION_GUARD(a_in);
     const IndexArgs a = with_device_pose(a_in);
-    const int id = (int)(blockIdx.x - (rider.st ? 1u : 0u)) * 256 + threadIdx.x;
+    const int id = (int)(bx_ - (rider.st ? 1u : 0u)) * 256 + threadIdx.x;
     if (id >= count) return;
     index_map_project(a, id, s.pos[id], s.col[id].w, keys);
+}
+__global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, IndexArgs a_in,
+                                                        unsigned long long* __restrict__ keys, FrameRider rider) {
+    index_map_kernel_body(s, count, a_in, keys, rider, blockIdx.x, gridDim.x);
 }
 
 // linear over the transposed images (it never needs a pixel's coordinates)
 // Every resolve kernel hands the key image back EMPTY (it is the only reader of a texel's key), so the
 // rasterising passes need no clearing launch in front of them.
-__global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexArgs a_in,
+__device__ __forceinline__ void index_resolve_kernel_body(SurfelSoA s, IndexArgs a_in,
                                                             unsigned long long* __restrict__ keys,
                                                             unsigned* __restrict__ index, float4* __restrict__ vertConf,
                                                             float4* __restrict__ colorTime, float4* __restrict__ normRad,
-                                                            FrameRider rider) {
+                                                            FrameRider rider, const unsigned bx_, [[maybe_unused]] const unsigned gx_) {
     MMF_MODEL_STREAM_PRIORITY();
-    if (rider.st && blockIdx.x == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
+    if (rider.st && bx_ == 0) {  // the launch's one extra workgroup (frame_rider.hpp): dispatched first
         frame_rider_run<2u>(rider);
         return;
     }
     MMF_SPECULATION_GUARD(a_in);
     const IndexArgs a = with_device_pose(a_in);
-    const int i = (int)(blockIdx.x - (rider.st ? 1u : 0u)) * 256 + threadIdx.x;
+    const int i = (int)(bx_ - (rider.st ? 1u : 0u)) * 256 + threadIdx.x;
     if (i >= a.cols * a.rows) return;
     const unsigned long long k = keys[i];
     if (k != kEmptyKey) keys[i] = kEmptyKey;
@@ -506,6 +510,13 @@ __global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexAr
     vertConf[i] = make_float4(h.x, h.y, h.z, p.w);
     colorTime[i] = s.col[id];
     normRad[i] = make_float4(nn.x, nn.y, nn.z, n.w);
+}
+__global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexArgs a_in,
+                                                            unsigned long long* __restrict__ keys,
+                                                            unsigned* __restrict__ index, float4* __restrict__ vertConf,
+                                                            float4* __restrict__ colorTime, float4* __restrict__ normRad,
+                                                            FrameRider rider) {
+    index_resolve_kernel_body(s, a_in, keys, index, vertConf, colorTime, normRad, rider, blockIdx.x, gridDim.x);
 }
 
 // transposed (x * rows + y) -> row-major copy of an index-map image, for the texture getters
@@ -705,16 +716,16 @@ struct SplatRowLds {  // per surfel of the wave's pass, structure of arrays: lan
     int seg_end[256];     // inclusive scan of rows x segments per row inside each wave
 };
 template <bool EARLYZ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void splat_kernel(SurfelSoA s, int count, SplatArgs a_in,
+__device__ __forceinline__ void splat_kernel_body(SurfelSoA s, int count, SplatArgs a_in,
                                                     unsigned long long* __restrict__ keys,
-                                                    const unsigned* __restrict__ count_dev) {
+                                                    const unsigned* __restrict__ count_dev, const unsigned bx_, [[maybe_unused]] const unsigned gx_) {
     MMF_MODEL_STREAM_PRIORITY();
     MMF_SPECULATION_GUARD(a_in);
     const SplatArgs a = with_device_pose(a_in);
     __shared__ SplatRowLds L;
     const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
     if (count_dev != nullptr) count = min((unsigned)count, *count_dev);
-    const int nwaves = (int)gridDim.x * 4, wave_id = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int nwaves = (int)gx_ * 4, wave_id = (int)bx_ * 4 + (int)(threadIdx.x >> 6);
     // consecutive surfels per wave: neighbours in the store are neighbours on screen, and their rays and keys share cache
     // lines (dealing runs of four surfels round-robin over the waves instead, to even out the sprite sizes: 52 -> 56 us)
     const int per = min(64, max(1, (count + nwaves - 1) / nwaves));  // surfels of one wave's pass
@@ -807,6 +818,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void s
         }
     }
 }
+template <bool EARLYZ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void splat_kernel(SurfelSoA s, int count, SplatArgs a_in,
+                                                    unsigned long long* __restrict__ keys,
+                                                    const unsigned* __restrict__ count_dev) {
+    splat_kernel_body<EARLYZ>(s, count, a_in, keys, count_dev, blockIdx.x, gridDim.x);
+}
 
 
 struct SplatTexel {
@@ -820,10 +837,10 @@ struct SplatTexel {
 // (x, y) -- threads run along x, the images are row-major -- gets its key.  Returns false outside the image.
 constexpr int kSplatTile = 16;
 __device__ __forceinline__ bool splat_tile_key(unsigned long long* __restrict__ keys, int cols, int rows, int& px, int& py,
-                                               unsigned long long& k, unsigned first_block = 0) {
+                                               unsigned long long& k, unsigned first_block = 0, unsigned block = ~0u) {
     __shared__ unsigned long long tile[kSplatTile][kSplatTile + 1];
     const int tiles_x = (cols + kSplatTile - 1) / kSplatTile;
-    const int bid = (int)(blockIdx.x - first_block);
+    const int bid = (int)((block == ~0u ? blockIdx.x : block) - first_block);
     const int bx = bid % tiles_x, by = bid / tiles_x;
     const int t = threadIdx.x;
     {
@@ -851,14 +868,16 @@ __host__ __device__ inline unsigned splat_tile_grid(int cols, int rows) {
 // the model's stream: `thumb` = two counters; the resolve of generation g adds to thumb[g & 1] (one atomic per wave with
 // hits) and zeroes thumb[(g + 1) & 1] for the next one.  The preparation jobs that choose between the prediction and the
 // fill-in images read the count and apply the ratio themselves (prep_batch.hpp: PrepJob::sel_total).
-__device__ __forceinline__ void thumbnail_count_px(int px, int py, int cols, int rows, uchar4 p, unsigned* __restrict__ thumb, int gen) {
+// (last_block: is this the launch's -- in a batched launch the model's -- last workgroup)
+__device__ __forceinline__ void thumbnail_count_px(int px, int py, int cols, int rows, uchar4 p, unsigned* __restrict__ thumb, int gen,
+                                                   bool last_block) {
     if (thumb == nullptr) return;
     const int dc = cols / 20, dr = rows / 20;
     const int i = px * dc / cols, j = py * dr / rows;  // the one sample this pixel can be
     const bool sample = dc > 0 && dr > 0 && texel((i + 0.5f) / dc, cols) == px && texel((j + 0.5f) / dr, rows) == py;
     const unsigned long long hits = __ballot(sample && p.x > 0 && p.y > 0 && p.z > 0);
     if (hits != 0ull && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(hits)) atomicAdd(&thumb[gen & 1], (unsigned)__popcll(hits));
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) thumb[(gen + 1) & 1] = 0u;
+    if (last_block && threadIdx.x == 0) thumb[(gen + 1) & 1] = 0u;
 }
 
 // the splat images' texel i = (px, py) from the depth-test winner k
@@ -887,24 +906,32 @@ __device__ __forceinline__ SplatTexel splat_resolve_px(int i, unsigned long long
     return t;
 }
 
+__device__ __forceinline__ void splat_resolve_kernel_body(SurfelSoA s, SplatArgs a_in,
+                                                            unsigned long long* __restrict__ keys,
+                                                            uchar4* __restrict__ image, float4* __restrict__ vertexConf,
+                                                            float4* __restrict__ normalRadius,
+                                                            unsigned short* __restrict__ time_out, unsigned* __restrict__ thumb,
+                                                            int gen, const unsigned bx_, [[maybe_unused]] const unsigned gx_) {
+    MMF_MODEL_STREAM_PRIORITY();
+    MMF_SPECULATION_GUARD(a_in);
+    const SplatArgs a = with_device_pose(a_in);
+    int px, py;
+    unsigned long long k;
+    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, 0, bx_)) return;
+    const int i = py * a.cols + px;
+    const SplatTexel t = splat_resolve_px(i, k, s, a);
+    image[i] = t.image;
+    vertexConf[i] = t.vertexConf, normalRadius[i] = t.normalRadius;
+    time_out[i] = t.time;
+    thumbnail_count_px(px, py, a.cols, a.rows, t.image, thumb, gen, bx_ == gx_ - 1);
+}
 __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatArgs a_in,
                                                             unsigned long long* __restrict__ keys,
                                                             uchar4* __restrict__ image, float4* __restrict__ vertexConf,
                                                             float4* __restrict__ normalRadius,
                                                             unsigned short* __restrict__ time_out, unsigned* __restrict__ thumb,
                                                             int gen) {
-    MMF_MODEL_STREAM_PRIORITY();
-    MMF_SPECULATION_GUARD(a_in);
-    const SplatArgs a = with_device_pose(a_in);
-    int px, py;
-    unsigned long long k;
-    if (!splat_tile_key(keys, a.cols, a.rows, px, py, k, 0)) return;
-    const int i = py * a.cols + px;
-    const SplatTexel t = splat_resolve_px(i, k, s, a);
-    image[i] = t.image;
-    vertexConf[i] = t.vertexConf, normalRadius[i] = t.normalRadius;
-    time_out[i] = t.time;
-    thumbnail_count_px(px, py, a.cols, a.rows, t.image, thumb, gen);
+    splat_resolve_kernel_body(s, a_in, keys, image, vertexConf, normalRadius, time_out, thumb, gen, blockIdx.x, gridDim.x);
 }
 
 // depth_splat.frag (ModelProjection::synthesizeDepth): the winner's corrected_pos.z, 0 where cleared
@@ -947,11 +974,11 @@ constexpr unsigned kNoWinner = 0xFFFFFFFFu;
 // Per pixel in draw order d = i*rows + j: the new measurement goes to meas.{pos,col,nrm}[d];
 // op[d] = 0 (nothing), 1 (merge; target in best[d]), 2 (new unstable).  For merges the first
 // pixel in draw order owns the target surfel: atomicMin(winner[best], d).
-__global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restrict__ rgb, const float* __restrict__ depth_raw,
+__device__ __forceinline__ void fuse_data_kernel_body(const uint8_t* __restrict__ rgb, const float* __restrict__ depth_raw,
                                                         const float* __restrict__ depth_fil, const uint8_t* __restrict__ mask,
                                                         const unsigned* __restrict__ index, const float4* __restrict__ vertConf,
                                                         const float4* __restrict__ normRad, FuseArgs a_in, SurfelSoA meas,
-                                                        unsigned* __restrict__ new_flags, unsigned* __restrict__ winner) {
+                                                        unsigned* __restrict__ new_flags, unsigned* __restrict__ winner, const unsigned bx_, [[maybe_unused]] const unsigned gx_) {
     MMF_MODEL_STREAM_PRIORITY();
     MMF_SPECULATION_GUARD(a_in);
     FuseArgs a = a_in;
@@ -966,7 +993,7 @@ __global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restric
     // four flags and carries on with the block's lattice pixel, in the pixel's own draw-order slot d: same results.
     const int cols = a.cols, rows = a.rows;
     const int hr = (rows + 1) / 2, hc = (cols + 1) / 2;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = bx_ * 256 + threadIdx.x;
     if (t >= hc * hr) return;
     const int ia = t / hr, jb = t - ia * hr;  // column-major like the draw order
     const int tm = ((int)(float)a.time) % 2;
@@ -1083,6 +1110,13 @@ __global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restric
         new_flags[d] = 1u;
     }
 }
+__global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restrict__ rgb, const float* __restrict__ depth_raw,
+                                                        const float* __restrict__ depth_fil, const uint8_t* __restrict__ mask,
+                                                        const unsigned* __restrict__ index, const float4* __restrict__ vertConf,
+                                                        const float4* __restrict__ normRad, FuseArgs a_in, SurfelSoA meas,
+                                                        unsigned* __restrict__ new_flags, unsigned* __restrict__ winner) {
+    fuse_data_kernel_body(rgb, depth_raw, depth_fil, mask, index, vertConf, normRad, a_in, meas, new_flags, winner, blockIdx.x, gridDim.x);
+}
 
 // update.vert:38-111, in place (each surfel only touches itself); resets winner[] for the next frame
 // surfel k merged with its winning measurement w, in place
@@ -1131,13 +1165,13 @@ __global__ __launch_bounds__(256) void fuse_update_kernel(SurfelSoA s, int count
 
 // fuse_update_kernel and the predictIndices that follows it (MultiMotionFusion.cpp:800-808) in one pass over the surfels: the
 // projection takes the surfel from the registers the update left it in
-__global__ __launch_bounds__(256) void fuse_update_index_kernel(SurfelSoA s, int count, SurfelSoA meas, int time,
+__device__ __forceinline__ void fuse_update_index_kernel_body(SurfelSoA s, int count, SurfelSoA meas, int time,
                                                                 unsigned* __restrict__ winner, IndexArgs a_in,
-                                                                unsigned long long* __restrict__ keys) {
+                                                                unsigned long long* __restrict__ keys, const unsigned bx_, [[maybe_unused]] const unsigned gx_) {
     MMF_MODEL_STREAM_PRIORITY();
     MMF_SPECULATION_GUARD(a_in);
     const IndexArgs a = with_device_pose(a_in);
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = bx_ * 256 + threadIdx.x;
     if (k >= count) return;
     const unsigned w = winner[k];
     float4 op, oc;
@@ -1149,6 +1183,11 @@ __global__ __launch_bounds__(256) void fuse_update_index_kernel(SurfelSoA s, int
         fuse_update_one(s, k, w, meas, time, op, oc);
     }
     index_map_project(a, k, op, oc.w, keys);
+}
+__global__ __launch_bounds__(256) void fuse_update_index_kernel(SurfelSoA s, int count, SurfelSoA meas, int time,
+                                                                unsigned* __restrict__ winner, IndexArgs a_in,
+                                                                unsigned long long* __restrict__ keys) {
+    fuse_update_index_kernel_body(s, count, meas, time, winner, a_in, keys, blockIdx.x, gridDim.x);
 }
 
 // ---- clean: copy_unstable.vert:53-150 ---------------------------------------------------------------
@@ -1308,6 +1347,25 @@ __device__ __forceinline__ unsigned clean_flag_one(int e, SurfelSoA s, SurfelSoA
 #endif
 // keep[e] for every candidate, and -- so that the compaction needs no separate scan launches -- the
 // number of kept candidates of each 256-candidate workgroup in block_sums[blockIdx.x]
+__device__ __forceinline__ void clean_flag_kernel_body(SurfelSoA s, SurfelSoA meas, const unsigned* __restrict__ new_flags,
+                                                         CleanArgs a_in, const unsigned* __restrict__ index,
+                                                         const float4* __restrict__ vertConf,
+                                                         const float4* __restrict__ colorTime,
+                                                         const float* __restrict__ depth_in, const uint8_t* __restrict__ mask,
+                                                         unsigned* __restrict__ keep, float2* __restrict__ conf_time,
+                                                         unsigned* __restrict__ block_sums, const unsigned bx_, [[maybe_unused]] const unsigned gx_) {
+    MMF_MODEL_STREAM_PRIORITY();
+    MMF_SPECULATION_GUARD(a_in);
+    const CleanArgs a = with_device_pose(a_in);
+    const int e = bx_ * 256 + threadIdx.x;
+    unsigned k = 0u;
+    if (e < a.count + a.npix) {
+        k = clean_flag_one(e, s, meas, new_flags, a, index, vertConf, colorTime, depth_in, mask, conf_time);
+        keep[e] = k;
+    }
+    const int kept = __syncthreads_count((int)k);
+    if (threadIdx.x == 0) block_sums[bx_] = (unsigned)kept;
+}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MMF_CLEAN_WAVES))) void clean_flag_kernel(SurfelSoA s, SurfelSoA meas, const unsigned* __restrict__ new_flags,
                                                          CleanArgs a_in, const unsigned* __restrict__ index,
                                                          const float4* __restrict__ vertConf,
@@ -1315,34 +1373,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MMF_CLEAN_W
                                                          const float* __restrict__ depth_in, const uint8_t* __restrict__ mask,
                                                          unsigned* __restrict__ keep, float2* __restrict__ conf_time,
                                                          unsigned* __restrict__ block_sums) {
-    MMF_MODEL_STREAM_PRIORITY();
-    MMF_SPECULATION_GUARD(a_in);
-    const CleanArgs a = with_device_pose(a_in);
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    unsigned k = 0u;
-    if (e < a.count + a.npix) {
-        k = clean_flag_one(e, s, meas, new_flags, a, index, vertConf, colorTime, depth_in, mask, conf_time);
-        keep[e] = k;
-    }
-    const int kept = __syncthreads_count((int)k);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = (unsigned)kept;
+    clean_flag_kernel_body(s, meas, new_flags, a_in, index, vertConf, colorTime, depth_in, mask, keep, conf_time, block_sums, blockIdx.x, gridDim.x);
 }
 
 // ordered compaction into the other surfel set (transform feedback of copy_unstable.geom)
 // The exclusive scan of keep[] is done here: a workgroup's base = the sum of the block_sums before it
 // (every workgroup adds them up itself: a few thousand words from L2 instead of three scan launches),
 // the rank inside the workgroup from wave ballots.  The last workgroup writes the new surfel count.
-__global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelSoA meas, int count, int npix,
+__device__ __forceinline__ void clean_scatter_kernel_body(SurfelSoA s, SurfelSoA meas, int count, int npix,
                                                             const unsigned* __restrict__ keep,
                                                             const unsigned* __restrict__ block_sums,
                                                             const float2* __restrict__ conf_time, SurfelSoA dst,
                                                             int capacity, unsigned* __restrict__ total_out,
                                                             unsigned* __restrict__ total_host, unsigned seq,
-                                                            const int* __restrict__ abort_dev) {
+                                                            const int* __restrict__ abort_dev, const unsigned bx_, [[maybe_unused]] const unsigned gx_) {
     MMF_MODEL_STREAM_PRIORITY();
     if (abort_dev != nullptr && *abort_dev != 0) return;  // (MMF_SPECULATION_GUARD: neither surfels nor the count are published)
     __shared__ unsigned wave_part[4], wave_kept[4];
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = bx_ * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // one memory round trip: the keep flag, this thread's share of the block sums (ten loads in flight; a loop
     // with a wait per iteration cost the late workgroups ~5 us) and, for the old surfels -- nearly all of which
@@ -1354,7 +1402,7 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
     const unsigned kp_raw = keep[ec];
     constexpr int kSumsPerThread = 10;  // 2560 workgroups = 655 k elements without the tail loop
     unsigned bs[kSumsPerThread];
-    const unsigned last_block = gridDim.x - 1;
+    const unsigned last_block = gx_ - 1;
 #pragma unroll
     for (int u = 0; u < kSumsPerThread; ++u) bs[u] = block_sums[min(threadIdx.x + 256u * u, last_block)];
     const float4 p = s.pos[eo], c = s.col[eo], n = s.nrm[eo];
@@ -1363,8 +1411,8 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
     const unsigned kp = live ? kp_raw : 0u;
     unsigned part = 0;
 #pragma unroll
-    for (int u = 0; u < kSumsPerThread; ++u) part += threadIdx.x + 256u * u < blockIdx.x ? bs[u] : 0u;
-    for (unsigned j = threadIdx.x + 256u * kSumsPerThread; j < blockIdx.x; j += 256) part += block_sums[j];
+    for (int u = 0; u < kSumsPerThread; ++u) part += threadIdx.x + 256u * u < bx_ ? bs[u] : 0u;
+    for (unsigned j = threadIdx.x + 256u * kSumsPerThread; j < bx_; j += 256) part += block_sums[j];
     part = wave_sum_to_lane63(part);
     const unsigned long long ballot = __ballot(kp != 0u);
     if (lane == 63) wave_part[wave] = part;
@@ -1372,7 +1420,7 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
     __syncthreads();
     unsigned base = wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3];
     for (int w = 0; w < wave; ++w) base += wave_kept[w];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if (bx_ == gx_ - 1 && threadIdx.x == 0) {
         const unsigned total = wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3] + wave_kept[0] + wave_kept[1] +
                                wave_kept[2] + wave_kept[3];
         *total_out = total;
@@ -1396,6 +1444,15 @@ __global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelS
         dst.col[k] = make_float4(mc.x, mc.y, mc.z, ct.y);
         dst.nrm[k] = mn;
     }
+}
+__global__ __launch_bounds__(256) void clean_scatter_kernel(SurfelSoA s, SurfelSoA meas, int count, int npix,
+                                                            const unsigned* __restrict__ keep,
+                                                            const unsigned* __restrict__ block_sums,
+                                                            const float2* __restrict__ conf_time, SurfelSoA dst,
+                                                            int capacity, unsigned* __restrict__ total_out,
+                                                            unsigned* __restrict__ total_host, unsigned seq,
+                                                            const int* __restrict__ abort_dev) {
+    clean_scatter_kernel_body(s, meas, count, npix, keep, block_sums, conf_time, dst, capacity, total_out, total_host, seq, abort_dev, blockIdx.x, gridDim.x);
 }
 
 // ---- fill-in (fill_vertex.frag, fill_normal.frag, fill_rgb.frag) + thumbnail count ------------------
@@ -1465,7 +1522,7 @@ __global__ __launch_bounds__(256) void splat_resolve_fill_kernel(SurfelSoA s, Sp
     time_out[i] = t.time;
     fill_in_px(i, t.vertexConf, t.normalRadius, t.image, depth_fil, rgb, a.cols, a.rows, a.c, passthrough_geom, passthrough_rgb,
                vertex_out, normal_out, image_out);
-    thumbnail_count_px(px, py, a.cols, a.rows, t.image, thumb, gen);
+    thumbnail_count_px(px, py, a.cols, a.rows, t.image, thumb, gen, blockIdx.x == gridDim.x - 1);
 }
 
 // requiresFillIn: number of (cols/20 x rows/20) thumbnail samples with all three channels > 0
@@ -1530,6 +1587,161 @@ __global__ void aos_to_soa_kernel(const float4* __restrict__ aos, int count, Sur
     s.pos[k] = aos[3 * k + 0];
     s.col[k] = aos[3 * k + 1];
     s.nrm[k] = aos[3 * k + 2];
+}
+
+
+// ---- the passes of SEVERAL models in one launch each (gridDim.y = model) ----------------------------------------------------
+// An object model's store is a few thousand surfels: its projection / fuse / clean / predict passes (MultiMotionFusion.cpp:791-816,
+// 863-875 loop over the models) are ~9 short launches per model and frame, and with seven object models on a GPU the calling
+// thread's launch rate, not the GPU, set the pace of that part of the frame.  Every pass exists as *_kernel_body(arguments,
+// block, blocks); the *_batched_kernel of a pass runs the bodies of up to kMaxPassBatch models, each on its own arguments and
+// its own number of workgroups (the surplus workgroups of a smaller model leave at once).  Same bodies, same bits.
+constexpr int kMaxPassBatch = 7;
+template <typename Item>
+struct PassBatch {
+    Item m[kMaxPassBatch];
+};
+
+struct index_map_item {
+    SurfelSoA s;
+    int count;
+    IndexArgs a_in;
+    unsigned long long* keys;
+    FrameRider rider;
+    unsigned grid;  // workgroups of this model
+};
+__global__ __launch_bounds__(256) void index_map_batched_kernel(PassBatch<index_map_item> b) {
+    const index_map_item& p = b.m[blockIdx.y];
+    if (blockIdx.x >= p.grid) return;
+    index_map_kernel_body(p.s, p.count, p.a_in, p.keys, p.rider, blockIdx.x, p.grid);
+}
+
+struct index_resolve_item {
+    SurfelSoA s;
+    IndexArgs a_in;
+    unsigned long long* keys;
+    unsigned* index;
+    float4* vertConf;
+    float4* colorTime;
+    float4* normRad;
+    FrameRider rider;
+    unsigned grid;  // workgroups of this model
+};
+__global__ __launch_bounds__(256) void index_resolve_batched_kernel(PassBatch<index_resolve_item> b) {
+    const index_resolve_item& p = b.m[blockIdx.y];
+    if (blockIdx.x >= p.grid) return;
+    index_resolve_kernel_body(p.s, p.a_in, p.keys, p.index, p.vertConf, p.colorTime, p.normRad, p.rider, blockIdx.x, p.grid);
+}
+
+struct fuse_data_item {
+    const uint8_t* rgb;
+    const float* depth_raw;
+    const float* depth_fil;
+    const uint8_t* mask;
+    const unsigned* index;
+    const float4* vertConf;
+    const float4* normRad;
+    FuseArgs a_in;
+    SurfelSoA meas;
+    unsigned* new_flags;
+    unsigned* winner;
+    unsigned grid;  // workgroups of this model
+};
+__global__ __launch_bounds__(256) void fuse_data_batched_kernel(PassBatch<fuse_data_item> b) {
+    const fuse_data_item& p = b.m[blockIdx.y];
+    if (blockIdx.x >= p.grid) return;
+    fuse_data_kernel_body(p.rgb, p.depth_raw, p.depth_fil, p.mask, p.index, p.vertConf, p.normRad, p.a_in, p.meas, p.new_flags, p.winner, blockIdx.x, p.grid);
+}
+
+struct fuse_update_index_item {
+    SurfelSoA s;
+    int count;
+    SurfelSoA meas;
+    int time;
+    unsigned* winner;
+    IndexArgs a_in;
+    unsigned long long* keys;
+    unsigned grid;  // workgroups of this model
+};
+__global__ __launch_bounds__(256) void fuse_update_index_batched_kernel(PassBatch<fuse_update_index_item> b) {
+    const fuse_update_index_item& p = b.m[blockIdx.y];
+    if (blockIdx.x >= p.grid) return;
+    fuse_update_index_kernel_body(p.s, p.count, p.meas, p.time, p.winner, p.a_in, p.keys, blockIdx.x, p.grid);
+}
+
+struct clean_flag_item {
+    SurfelSoA s;
+    SurfelSoA meas;
+    const unsigned* new_flags;
+    CleanArgs a_in;
+    const unsigned* index;
+    const float4* vertConf;
+    const float4* colorTime;
+    const float* depth_in;
+    const uint8_t* mask;
+    unsigned* keep;
+    float2* conf_time;
+    unsigned* block_sums;
+    unsigned grid;  // workgroups of this model
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MMF_CLEAN_WAVES))) void clean_flag_batched_kernel(PassBatch<clean_flag_item> b) {
+    const clean_flag_item& p = b.m[blockIdx.y];
+    if (blockIdx.x >= p.grid) return;
+    clean_flag_kernel_body(p.s, p.meas, p.new_flags, p.a_in, p.index, p.vertConf, p.colorTime, p.depth_in, p.mask, p.keep, p.conf_time, p.block_sums, blockIdx.x, p.grid);
+}
+
+struct clean_scatter_item {
+    SurfelSoA s;
+    SurfelSoA meas;
+    int count;
+    int npix;
+    const unsigned* keep;
+    const unsigned* block_sums;
+    const float2* conf_time;
+    SurfelSoA dst;
+    int capacity;
+    unsigned* total_out;
+    unsigned* total_host;
+    unsigned seq;
+    const int* abort_dev;
+    unsigned grid;  // workgroups of this model
+};
+__global__ __launch_bounds__(256) void clean_scatter_batched_kernel(PassBatch<clean_scatter_item> b) {
+    const clean_scatter_item& p = b.m[blockIdx.y];
+    if (blockIdx.x >= p.grid) return;
+    clean_scatter_kernel_body(p.s, p.meas, p.count, p.npix, p.keep, p.block_sums, p.conf_time, p.dst, p.capacity, p.total_out, p.total_host, p.seq, p.abort_dev, blockIdx.x, p.grid);
+}
+
+struct splat_item {
+    SurfelSoA s;
+    int count;
+    SplatArgs a_in;
+    unsigned long long* keys;
+    const unsigned* count_dev;
+    unsigned grid;  // workgroups of this model
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void splat_batched_kernel(PassBatch<splat_item> b) {
+    const splat_item& p = b.m[blockIdx.y];
+    if (blockIdx.x >= p.grid) return;
+    splat_kernel_body<false>(p.s, p.count, p.a_in, p.keys, p.count_dev, blockIdx.x, p.grid);
+}
+
+struct splat_resolve_item {
+    SurfelSoA s;
+    SplatArgs a_in;
+    unsigned long long* keys;
+    uchar4* image;
+    float4* vertexConf;
+    float4* normalRadius;
+    unsigned short* time_out;
+    unsigned* thumb;
+    int gen;
+    unsigned grid;  // workgroups of this model
+};
+__global__ __launch_bounds__(256) void splat_resolve_batched_kernel(PassBatch<splat_resolve_item> b) {
+    const splat_resolve_item& p = b.m[blockIdx.y];
+    if (blockIdx.x >= p.grid) return;
+    splat_resolve_kernel_body(p.s, p.a_in, p.keys, p.image, p.vertexConf, p.normalRadius, p.time_out, p.thumb, p.gen, blockIdx.x, p.grid);
 }
 
 }  // namespace mmf

@@ -14,6 +14,7 @@ struct Tunables {
     int gn_fused_max = 8;     // MMF_GN_FUSED_MAX: models one one-launch chain carries at most (the residency check decides below that)
     int gn_px[3] = {0, 0, 0}; // MMF_GN_PX="p0,p1,p2": pixels per lane of a level (0 = by geometry)
     int gn_groups = 256;      // MMF_GN_GROUPS: workgroups per model per launch at most
+    int gn_mixed_lanes = 192; // MMF_GN_MIXED_LANES: pixel lanes of a workgroup in a launch that carries object models (256: as the others)
     int gn_sleep = 1;         // MMF_GN_SLEEP: s_sleep(1) repetitions between two polls of the count barrier
     int icp_variant = -1;     // MMF_ICP_VARIANT: shape of the stand-alone ICP kernel (-1 = by size)
     // ---- preparation jobs (prep_batch.hpp) ----
@@ -30,6 +31,9 @@ struct Tunables {
     // ---- surfel passes ----
     int track_cull = 1;       // MMF_TRACK_CULL=0: object models are tracked like the camera model (whole image, full grids)
     int spec_prep_all = 1;    // MMF_SPEC_PREP_ALL=0: with several models per GPU the model-side preparation waits for the next call
+    bool pass_batch = false;  // MMF_PASS_BATCH=1: the object models' projection / fuse / clean / predict passes as one launch per pass for all of
+                              // them (surfel_kernels.hpp: *_batched_kernel; same bits).  Off: every pass still covers the whole frame, and seven full-frame
+                              // passes in one launch took longer than seven on four hardware queues (8 models 1.14 against 1.05 ms)
     int splat_wgs = 0;        // MMF_SPLAT_WGS: workgroups of a splat launch (0 = by the store's size)
     int splat_bound = -1;     // MMF_SPLAT_BOUND=0|1: the bounded depth test never / always (-1 = by the store's size)
 };
@@ -50,6 +54,7 @@ inline const Tunables& tunables() {
         if (v.gn_fused_max < 1) v.gn_fused_max = 1;
         if (const char* e = std::getenv("MMF_GN_PX")) std::sscanf(e, "%d,%d,%d", &v.gn_px[0], &v.gn_px[1], &v.gn_px[2]);
         v.gn_groups = (int)num("MMF_GN_GROUPS", 256);
+        v.gn_mixed_lanes = (int)num("MMF_GN_MIXED_LANES", 192);
         v.gn_sleep = (int)num("MMF_GN_SLEEP", 1);
         v.icp_variant = (int)num("MMF_ICP_VARIANT", -1);
         v.prep_merge = (int)num("MMF_PREP_MERGE", 2);
@@ -63,6 +68,7 @@ inline const Tunables& tunables() {
         v.host_trace = flag("MMF_HOST_TRACE", false);
         v.track_cull = (int)num("MMF_TRACK_CULL", 1);
         v.spec_prep_all = (int)num("MMF_SPEC_PREP_ALL", 1);
+        v.pass_batch = flag("MMF_PASS_BATCH", false);
         v.splat_wgs = (int)num("MMF_SPLAT_WGS", 0);
         if (std::getenv("MMF_SPLAT_BOUND")) v.splat_bound = num("MMF_SPLAT_BOUND", 0) ? 1 : 0;
         return v;

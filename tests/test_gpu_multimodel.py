@@ -434,7 +434,7 @@ def test_extent_walk_equals_dense_walk_frame_by_frame(gpu_ctx, fast):
                         ea, eb = A.getErrorTexture(k, which).cpu().numpy(), B.getErrorTexture(k, which).cpu().numpy()
                         assert (eb > 0).sum() > 100, (i, k, which)
                         off = np.abs(ea - eb) > tol
-                        assert off.sum() <= (2 if fast else 0.01 * (eb > 0).sum()), (i, k, which, int(off.sum()), float(np.abs(ea - eb).max()))
+                        assert off.sum() <= (2 if fast else 0.03 * (eb > 0).sum()), (i, k, which, int(off.sum()), float(np.abs(ea - eb).max()))
                 compared += int(k > 0)
             for a_, b_ in zip(ma, mb):  # B continues from A's state
                 b_.uploadMap(a_.downloadMap())
@@ -446,3 +446,49 @@ def test_extent_walk_equals_dense_walk_frame_by_frame(gpu_ctx, fast):
         B.close()
         lib.mmf_debug_set_gn_fused(-1)
         lib.mmf_debug_set_track_cull(-1)
+
+
+def test_batched_passes_equal_passes_model_by_model(gpu_ctx):
+    """The object models' projection / fuse / clean / predict passes go out as ONE launch per pass for all of them (gridDim.y =
+    model: csrc/surfel_kernels.hpp, *_batched_kernel) instead of ~9 launches per model on the model's own stream
+    (MultiMotionFusion.cpp:791-816, 863-875 loop over the models).  Same kernel bodies on the same data: every model's
+    surfels (values AND order), poses, prediction images and error images must agree bit for bit."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    lib = gpu_ctx.lib
+    w, h, n_frames, n_obj = 320, 240, 8, 4
+    K, poses, traj, frames, objs = scene(w, h, n_frames, n_obj, seed=39)
+    rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+
+    def run(batch):
+        lib.mmf_debug_set_pass_batch(batch)
+        g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1, preallocated_models=n_obj)
+        known, keep, out = [0], [], []
+        try:
+            for i, f in enumerate(frames):
+                spawn = 1 <= i <= n_obj
+                if spawn:
+                    known.append(i)
+                keep.append(dev(gt_mask(f["ids"], known)))
+                nxt = (rgb[i + 1], depth[i + 1]) if i + 1 < n_frames else None
+                g.processFrame(rgb[i], depth[i], timestamp=i, mask=keep[-1], hasNewLabel=spawn, next=nxt)
+                out.append([m.getPose() for m in g.getModels()])
+            maps = [m.downloadMap() for m in g.getModels()]
+            tex = [[m.texture(n).cpu().numpy().copy() for n in ("image", "vertexConf", "normalRadius")] for m in g.getModels()]
+            err = [g.getErrorTexture(k, "icp").cpu().numpy().copy() for k in range(len(maps))]
+        finally:
+            g.close()
+            lib.mmf_debug_set_pass_batch(-1)
+        return out, maps, tex, err
+
+    a, b = run(1), run(0)
+    assert len(a[1]) == n_obj + 1 and all(m.shape[0] > 100 for m in a[1])
+    for i in range(n_frames):
+        for k, (pa, pb) in enumerate(zip(a[0][i], b[0][i])):
+            assert np.array_equal(pa, pb), (i, k)
+    for k, (ma, mb) in enumerate(zip(a[1], b[1])):
+        assert ma.shape == mb.shape and np.array_equal(ma.view(np.uint32), mb.view(np.uint32)), k
+    for k, (ta, tb) in enumerate(zip(a[2], b[2])):
+        for x, y in zip(ta, tb):
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), k
+    for ea, eb in zip(a[3], b[3]):
+        assert np.array_equal(ea.view(np.uint32), eb.view(np.uint32))
