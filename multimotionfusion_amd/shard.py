@@ -99,6 +99,58 @@ def gather_poses(pose: np.ndarray, icp_error: float, icp_count: float, device) -
     return torch.stack(out).cpu().numpy()
 
 
+class PoseRing:
+    """torch.distributed twin of mmf_shard_gather_poses_begin / _end (csrc/shard_rccl.hpp): the pose exchange as a ring of up to
+    three all-gathers in flight.  begin() snapshots the slot table of the model list AS IT IS THEN (who owns which slot) and posts
+    the gather of this rank's records; end() waits for the OLDEST exchange in flight and returns {model id: [18] record} of the
+    models OTHER ranks own -- keyed by id, so a model that has left the caller's list in the meantime is simply not applied,
+    and one that moved in the list is found where it is now.  A fourth begin() first completes the oldest exchange (its records
+    are returned by that begin()).  Documented staleness (include/mmf_hip.h): another rank's pose is up to two frames old."""
+    RING = 3
+
+    def __init__(self, device):
+        self.device = device
+        self.ring = []  # oldest first: (work handle or None, per-rank tensors, slots, ids[world][slots])
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+
+    def begin(self, model_ids, records):
+        """model_ids: the active list's ids in list order; records: {model id: 18 floats} of the models this rank owns."""
+        applied = self.end() if len(self.ring) >= self.RING else {}
+        slots, table = slot_table(model_ids, self.world)
+        ids = [[int(model_ids[k]) if k >= 0 else -1 for k in table[r]] for r in range(self.world)]
+        send = torch.zeros((slots, 18), dtype=torch.float32)
+        for j, mid in enumerate(ids[self.rank]):
+            if mid >= 0:
+                send[j] = torch.as_tensor(np.asarray(records[mid], np.float32).reshape(18))
+        send = send.to(self.device)
+        if self.world == 1:
+            work, parts = None, [send]
+        else:
+            parts = [torch.empty_like(send) for _ in range(self.world)]
+            work = dist.all_gather(parts, send, async_op=True)
+        self.ring.append((work, parts, slots, ids))
+        return applied
+
+    def end(self):
+        if not self.ring:
+            return {}
+        work, parts, slots, ids = self.ring.pop(0)
+        if work is not None:
+            work.wait()
+        out = {}
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            for j in range(slots):
+                if ids[r][j] >= 0:
+                    out[ids[r][j]] = parts[r][j].cpu().numpy().copy()
+        return out
+
+    def in_flight(self):
+        return len(self.ring)
+
+
 class Shard:
     """The C-level shard (mmf_shard_*): the same two exchanges -- frame broadcast, pose all-gather -- run by
     libmmf_hip.so on the context's stream over RCCL, for front-ends that are not PyTorch programs.  `unique_id` is the

@@ -135,3 +135,58 @@ def test_single_process_paths_are_noops():
     out = shard.gather_poses(np.eye(4), 0.5, 7.0, torch.device("cpu"))
     assert out.shape == (1, 18) and out[0, 16] == 0.5 and out[0, 17] == 7.0
     assert shard.model_owner(0, 8) == 0 and shard.model_owner(9, 8) == 1
+
+
+def _ring_worker(rank, world, port, out_dir):
+    """the pose exchange as a ring (begin / end, three in flight) over gloo, with a model leaving the list mid-ring"""
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimotionfusion_amd import shard
+    ring = shard.PoseRing(torch.device("cpu"))
+
+    def rec(model_id, frame):  # what the owner would send: any function of (id, frame) will do
+        v = np.zeros(18, np.float32)
+        v[:16] = np.eye(4, dtype=np.float32).reshape(16)
+        v[3], v[16], v[17] = 100.0 * model_id + frame, 0.5 * frame, 1000.0 + model_id
+        return v
+
+    lists = {0: [0, 1, 2, 3], 1: [0, 1, 2, 3], 2: [0, 1, 2, 3], 3: [0, 2, 3], 4: [0, 2, 3], 5: [0, 2, 3, 4]}  # model 1 leaves at frame 3
+    applied_log = []
+    known = {}  # this rank's bookkeeping of the OTHER ranks' models: id -> (frame of the record it holds)
+    for frame in range(6):
+        ids = lists[frame]
+        mine = {m: rec(m, frame) for m in ids if shard.model_owner(m, world) == rank}
+        got = ring.begin(ids, mine)  # a fourth begin completes the oldest exchange first
+        assert ring.in_flight() <= shard.PoseRing.RING
+        if frame < 3:
+            assert got == {} and ring.in_flight() == frame + 1
+        else:
+            assert ring.in_flight() == 3
+        for mid, r in got.items():
+            if mid in ids:  # (mmf_shard_gather_poses_end: fusion_find(f, id) -- a model that has left is not applied)
+                known[mid] = int(round(float(r[3]) - 100.0 * mid))
+                assert r[17] == 1000.0 + mid and shard.model_owner(mid, world) != rank
+            applied_log.append((frame, mid, mid in ids))
+    # frames 3, 4, 5 completed the exchanges of frames 0, 1, 2: the records of model 1 (owner: rank 1) arrive at rank 0 after
+    # it has left rank 0's list and are dropped there
+    if rank == 0:
+        assert [(f, m) for f, m, ok in applied_log if not ok] == [(3, 1), (4, 1), (5, 1)], applied_log
+        assert known == {3: 2}  # rank 1's surviving model, as of frame 2 (three frames old at frame 5: two in flight + this one)
+    else:
+        assert all(ok for _, _, ok in applied_log) and known == {0: 2, 2: 2}
+    while ring.in_flight():  # drain: the exchanges of frames 3, 4, 5 (lists without model 1; model 4 appears in the last)
+        for mid, r in ring.end().items():
+            known[mid] = int(round(float(r[3]) - 100.0 * mid))
+    assert known == ({3: 5} if rank == 0 else {0: 5, 2: 5, 4: 5}), (rank, known)
+    np.save(os.path.join(out_dir, f"ring{rank}.npy"), np.array(sorted(known.items())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pose_ring_world2(tmp_path):
+    """begin / end with three in flight, and a model that leaves the list while its records are still in the ring"""
+    port = _free_port()
+    mp.spawn(_ring_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert np.load(tmp_path / "ring0.npy").tolist() == [[3, 5]] and np.load(tmp_path / "ring1.npy").tolist() == [[0, 5], [2, 5], [4, 5]]
