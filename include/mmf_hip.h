@@ -543,11 +543,12 @@ int mmf_debug_set_mid_predict(int on);
  * evaluates a fragment there and skips what cannot win; same images).  1 = always, 0 = never, -1 = when the store holds two
  * surfels per pixel or more (the default).  Process wide. */
 int mmf_debug_set_splat_bound(int mode);
-/* test / A-B hook: the projection / fuse / clean / predict passes of the OBJECT models of a frame as one launch per pass for all of
- * them (1; csrc/surfel_kernels.hpp: *_batched_kernel -- the same kernel bodies, gridDim.y = model) or model by model on the
- * models' own streams (0), -1 = the default (MMF_PASS_BATCH, off: measured slower while every pass covers the whole frame).  Same maps
- * and images, bit for bit.  Process wide. */
-int mmf_debug_set_pass_batch(int on);
+/* test / A-B hook: the projection / fuse / clean / predict passes of the OBJECT models of a frame: 0 = model by model on the models' own
+ * streams (the default), 1 = one launch per pass for all of them, each covering the whole frame (csrc/surfel_kernels.hpp:
+ * *_batched_kernel -- the same kernel bodies, gridDim.y = model), 2 = one launch per pass restricted to where each model is
+ * (csrc/pass_rect.hpp: the boxes of its key-image writes, of its non-zero images and of its id in the id image), -1 = the
+ * default (MMF_PASS_BATCH).  Same maps and images, bit for bit, in all three.  Process wide. */
+int mmf_debug_set_pass_batch(int mode);
 /* test / A-B hook: object models in the producer + step chain (csrc/extent.hpp, ChainGeom: their passes skip the blocks outside
  * the model's own depth and walk the images with a quarter of the workgroups).  1 = on, 0 = every model is tracked like the
  * camera model, -1 = the default (MMF_TRACK_CULL, on).  Process wide. */

@@ -71,6 +71,8 @@ struct mmf_fusion {
     bool mask_is_zero = false;
     int tick = 1;                     // MultiMotionFusion.cpp:36
     unsigned extent_seq = 0;          // number of the frame whose model-side preparation notes extents (extent.hpp): only ever grows
+    unsigned long long* mask_boxes = nullptr;  // pass_rect.hpp: the boxes of the ids of the frame's id image (device, 256 x 4 words)
+    unsigned mask_gen = 0;
     int tracking_ok = 1;
     const uint8_t* frame_rgb = nullptr;  // this frame's inputs (device), kept for predict()
     const float* frame_depth = nullptr;
@@ -323,6 +325,7 @@ extern "C" void mmf_fusion_destroy(mmf_fusion* f) {
     (void)hipFree(f->filtered[0]);
     (void)hipFree(f->filtered[1]);
     (void)hipFree(f->mask);
+    (void)hipFree(f->mask_boxes);
     (void)hipFree(f->side_partials);
     (void)hipFree(f->side_ticket);
     if (f->stager.thread.joinable()) {
@@ -600,13 +603,28 @@ static float seg_max_depth(const mmf_segmentation_model& d) { return (float)((do
 
 // test / A-B hook: the object models' passes as one launch per pass for all of them (1, the default) or model by model (0)
 static std::atomic<int> g_batch_passes{-1};  // -1: MMF_PASS_BATCH decides (default on)
-extern "C" int mmf_debug_set_pass_batch(int on) {
-    g_batch_passes.store(on < 0 ? -1 : (on ? 1 : 0));
+extern "C" int mmf_debug_set_pass_batch(int mode) {
+    g_batch_passes.store(mode < 0 ? -1 : (mode > 2 ? 2 : mode));
     return MMF_OK;
 }
-static bool fusion_batch_passes() {
+// 0: model by model; 1: one launch per pass, each covering the whole frame (*_batched_kernel); 2: one launch per pass,
+// restricted to where the models are (pass_rect.hpp)
+static int fusion_batch_mode() {
     const int v = g_batch_passes.load();
-    return v < 0 ? tunables().pass_batch : v != 0;
+    return v < 0 ? tunables().pass_batch : v;
+}
+static bool fusion_batch_passes() { return fusion_batch_mode() != 0; }
+// the boxes of the ids of the frame's id image (pass_rect.hpp: mask_boxes_kernel), on `st`
+static int fusion_note_mask_boxes(mmf_fusion* f, hipStream_t st) {
+    if (!f->mask_boxes) {
+        MMF_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->mask_boxes), 256 * 4 * sizeof(unsigned long long)));
+        MMF_HIP_TRY(hipMemsetAsync(f->mask_boxes, 0, 256 * 4 * sizeof(unsigned long long), st));
+    }
+    ++f->mask_gen;
+    const int tiles = ((f->width + 63) / 64) * ((f->height + 15) / 16);
+    hipLaunchKernelGGL(mask_boxes_kernel, dim3(tiles), dim3(256), 0, st, f->mask, f->width, f->height, f->mask_boxes, f->mask_gen);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
 }
 // `st` (the stream a batch of passes goes out on: objs[0]'s) waits for whatever the other models' own streams still hold
 // (a stream that has drained holds nothing: no wait is enqueued)
@@ -1192,8 +1210,15 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 ms[k] = objs[k]->model;
                 wts[k] = fusion_weight(pose, objs[k]->last_pose, weight_multiplier);
             }
-            rc = models_fuse_clean_batched(ms, (int)objs.size(), st, f->tick, g.time_delta, g.max_depth_processed, f->frame_rgb, f->mask,
-                                           f->frame_depth, f->depth_filtered, g.outlier_coeff, wts);
+            if (fusion_batch_mode() >= 2) {
+                rc = fusion_note_mask_boxes(f, st);
+                if (rc) return rc;
+                rc = models_fuse_clean_rect(ms, (int)objs.size(), st, f->tick, g.time_delta, g.max_depth_processed, f->frame_rgb, f->mask,
+                                            f->frame_depth, f->depth_filtered, g.outlier_coeff, wts, f->mask_boxes, f->mask_gen);
+            } else {
+                rc = models_fuse_clean_batched(ms, (int)objs.size(), st, f->tick, g.time_delta, g.max_depth_processed, f->frame_rgb, f->mask,
+                                               f->frame_depth, f->depth_filtered, g.outlier_coeff, wts);
+            }
             if (rc) return rc;
         }
     }
@@ -1218,7 +1243,8 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             if (rc) return rc;
             mmf_model* ms[kMaxPassBatch];
             for (size_t k = 0; k < objs.size(); ++k) ms[k] = objs[k]->model;
-            rc = models_combined_predict_batched(ms, (int)objs.size(), st, g.max_depth_processed, f->tick, f->tick, g.time_delta);
+            rc = fusion_batch_mode() >= 2 ? models_combined_predict_rect(ms, (int)objs.size(), st, g.max_depth_processed, f->tick, f->tick, g.time_delta)
+                                          : models_combined_predict_batched(ms, (int)objs.size(), st, g.max_depth_processed, f->tick, f->tick, g.time_delta);
             if (rc) return rc;
             // the other objects' streams continue behind the batch: whatever is enqueued on them next reads what it wrote
             MMF_HIP_TRY(hipEventRecord(objs[0]->ev_done, st));

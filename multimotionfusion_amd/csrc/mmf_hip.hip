@@ -2280,6 +2280,7 @@ extern "C" int mmf_odom_time_icp_kernel(mmf_odom* o, int level, int reps, int va
 // Surfel model (Core/Model/Model.{h,cpp} + Core/Model/ModelProjection.{h,cpp}), pure HIP
 // =============================================================================================
 #include "surfel_kernels.hpp"
+#include "pass_rect.hpp"
 
 constexpr int kCountWord = 8, kCountSeqWord = 9;  // in mmf_model::host_totals
 
@@ -2340,6 +2341,12 @@ struct mmf_model {
     unsigned* host_totals_dev = nullptr;  // the count the last clean pass published and its sequence number
     unsigned count_seq = 0;
     hipStream_t count_stream = nullptr;  // the stream the last clean pass ran on when it is not the context's (a batched pass)
+    // pass_rect.hpp: where this model's key image was written and where its images are non-zero (device), the numbers of its
+    // projection / index-resolve / prediction-resolve launches, and whether the non-zero boxes describe the images (a
+    // full-frame pass leaves them unknown: the next restricted resolve then covers the whole image once)
+    PassBoxes* boxes = nullptr;
+    unsigned kgen = 0, igen = 0, sgen = 0;
+    bool idx_nz_known = false, spl_nz_known = false;
 };
 
 static Cam make_cam(const mmf_model* m, bool double_reciprocal) {
@@ -2407,6 +2414,8 @@ extern "C" int mmf_model_create(mmf_ctx* c, int width, int height, float cx, flo
         return fail(MMF_ERR_HIP, std::string("mmf_model_create: hipMalloc: ") + hipGetErrorString(e));
     }
     MMF_HIP_TRY(hipMemsetAsync(m->slab, 0, m->slab_bytes, c->stream));
+    MMF_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->boxes), sizeof(PassBoxes)));
+    MMF_HIP_TRY(hipMemsetAsync(m->boxes, 0, sizeof(PassBoxes), c->stream));
     char* b = static_cast<char*>(m->slab);
     for (int s = 0; s < 2; ++s)
         m->set[s] = SurfelSoA{(float4*)(b + o_set[s][0]), (float4*)(b + o_set[s][1]), (float4*)(b + o_set[s][2])};
@@ -2460,6 +2469,7 @@ extern "C" void mmf_model_destroy(mmf_model* m) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     (void)hipFree(m->slab);
+    (void)hipFree(m->boxes);
     (void)hipHostFree(m->host_totals);
     delete m;
 }
@@ -2598,6 +2608,7 @@ static int model_predict_indices(mmf_model* m, int time, float depth_cutoff, int
     MMF_HIP_TRY(hipSetDevice(c->device));
     const size_t npix = (size_t)m->width * m->height;
     const IndexArgs a = model_index_args(m, time, depth_cutoff, time_delta);
+    m->idx_nz_known = false;  // (pass_rect.hpp: a full-frame resolve; the non-zero box is not kept)
     // frame_rider.hpp: when this is the frame's first projection, its first launch carries the tracking result's hand-over
     // to the host and its second the fusion weight (each a few microseconds on one extra workgroup, shorter than its carrier)
     FrameRider publish = m->rider, weight = m->rider;
@@ -2659,6 +2670,7 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     MMF_HIP_TRY(hipSetDevice(c->device));
     ++m->tex_gen;
     ++m->thumb_gen;
+    m->spl_nz_known = false;  // (pass_rect.hpp)
     SplatArgs a;
     inverse4f_host(m->pose, a.t_inv.m);
     a.t_inv_dev = m->t_inv_dev;
@@ -2820,6 +2832,7 @@ static int models_fuse_clean_batched(mmf_model* const* ms, int n, hipStream_t st
         MMF_REQUIRE(m && m->rider.st == nullptr && !m->t_inv_dev && !m->pose_dev && !m->abort_dev,
                     "models_fuse_clean_batched: a model with a pending hand-over or a device-side pose");
         if (int rc0 = model_resolve_count(m)) return rc0;
+        m->idx_nz_known = false;
         const unsigned npix = (unsigned)(m->width * m->height);
         const IndexArgs ia = model_index_args(m, time, depth_cutoff, time_delta);
         index_map_item& im = b_map.m[k];
@@ -2902,6 +2915,7 @@ static int models_combined_predict_batched(mmf_model* const* ms, int n, hipStrea
         MMF_REQUIRE(m && m->rider.st == nullptr && !m->t_inv_dev && !m->abort_dev, "models_combined_predict_batched: a model with a device-side pose");
         ++m->tex_gen;
         ++m->thumb_gen;
+        m->spl_nz_known = false;
         SplatArgs a;
         inverse4f_host(m->pose, a.t_inv.m);
         a.t_inv_dev = nullptr, a.abort_dev = nullptr;
@@ -2925,6 +2939,139 @@ static int models_combined_predict_batched(mmf_model* const* ms, int n, hipStrea
     }
     if (g_splat) hipLaunchKernelGGL(splat_batched_kernel, dim3(g_splat, n), dim3(256), 0, st, b_splat);
     hipLaunchKernelGGL(splat_resolve_batched_kernel, dim3(g_res, n), dim3(256), 0, st, b_res);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+// ---- the same passes RESTRICTED to where the models are (pass_rect.hpp): nine launches for all of them ----
+// mask_boxes: the id image's boxes of this frame (mask_boxes_kernel, generation mask_gen), device
+static int models_fuse_clean_rect(mmf_model* const* ms, int n, hipStream_t st, int time, int time_delta, float depth_cutoff,
+                                  const uint8_t* rgb, const uint8_t* mask, const float* depth_raw, const float* depth_filtered,
+                                  float outlier_coeff, const float* weighting, const unsigned long long* mask_boxes, unsigned mask_gen) {
+    MMF_REQUIRE(ms && n >= 1 && n <= kMaxPassBatch && rgb && mask && depth_raw && depth_filtered && weighting && mask_boxes,
+                "models_fuse_clean_rect: bad argument");
+    MMF_HIP_TRY(hipSetDevice(ms[0]->ctx->device));
+    PassBatch<index_map_box_item> b_map;
+    PassBatch<index_resolve_rect_item> b_res1, b_res2;
+    PassBatch<fuse_data_rect_item> b_fuse;
+    PassBatch<fuse_update_index_box_item> b_upd;
+    PassBatch<clean_rect_item> b_clean;
+    unsigned g_map = 0, g_upd = 0;
+    for (int k = 0; k < n; ++k) {
+        mmf_model* m = ms[k];
+        MMF_REQUIRE(m && m->boxes && m->rider.st == nullptr && !m->t_inv_dev && !m->pose_dev && !m->abort_dev,
+                    "models_fuse_clean_rect: a model with a pending hand-over or a device-side pose");
+        if (int rc0 = model_resolve_count(m)) return rc0;
+        const unsigned npix = (unsigned)(m->width * m->height);
+        const IndexArgs ia = model_index_args(m, time, depth_cutoff, time_delta);
+        // predictIndices: projection (generation kgen + 1) and its resolve
+        index_map_box_item& im = b_map.m[k];
+        im.s = m->set[m->cur], im.count = (int)m->count, im.a = ia, im.keys = m->keys, im.boxes = m->boxes, im.kgen = ++m->kgen;
+        im.grid = (m->count + 255u) / 256u;
+        index_resolve_rect_item& r1 = b_res1.m[k];
+        r1.s = m->set[m->cur], r1.a = ia, r1.keys = m->keys, r1.index = m->index, r1.vertConf = m->vertConf, r1.colorTime = m->colorTime,
+        r1.normRad = m->normRad, r1.boxes = m->boxes, r1.kgen = m->kgen, r1.igen = ++m->igen, r1.prev_whole = m->idx_nz_known ? 0 : 1;
+        m->idx_nz_known = true;
+        // fuse: data association over the id's box, then the update pass with the next projection (generation kgen + 1)
+        FuseArgs fa;
+        std::memcpy(fa.pose.m, m->pose, sizeof(m->pose));
+        fa.c = make_cam(m, true);
+        fa.cols = m->width, fa.rows = m->height;
+        fa.time = time;
+        fa.weighting = weighting[k];
+        fa.pose_dev = nullptr, fa.weight_dev = nullptr, fa.weight_mult = weighting[k];
+        fa.abort_dev = nullptr;
+        fa.maskID = m->id;
+        fa.maxDepth = depth_cutoff < m->max_depth ? depth_cutoff : m->max_depth;  // std::min(depthCutoff, maxDepth) (Model.cpp:928)
+        fa.count = (int)m->count;
+        fuse_data_rect_item& fd = b_fuse.m[k];
+        fd.rgb = rgb, fd.depth_raw = depth_raw, fd.depth_fil = depth_filtered, fd.mask = mask, fd.index = m->index, fd.vertConf = m->vertConf,
+        fd.normRad = m->normRad, fd.a = fa, fd.meas = m->meas, fd.new_flags = m->flags_b, fd.winner = m->winner;
+        fd.mask_box = mask_boxes + 4 * (size_t)m->id, fd.mask_gen = mask_gen;
+        fuse_update_index_box_item& fu = b_upd.m[k];
+        fu.s = m->set[m->cur], fu.count = (int)m->count, fu.meas = m->meas, fu.time = time, fu.winner = m->winner, fu.a = ia, fu.keys = m->keys,
+        fu.boxes = m->boxes, fu.kgen = ++m->kgen;
+        fu.grid = (m->count + 255u) / 256u;
+        index_resolve_rect_item& r2 = b_res2.m[k];
+        r2 = r1;
+        r2.kgen = m->kgen, r2.igen = ++m->igen, r2.prev_whole = 0;
+        // clean
+        CleanArgs ca;
+        inverse4f_host(m->pose, ca.t_inv.m);
+        ca.t_inv_dev = nullptr, ca.abort_dev = nullptr;
+        ca.c = make_cam(m, false);
+        ca.cols = m->width, ca.rows = m->height;
+        ca.time = time, ca.timeDelta = time_delta;
+        ca.confThreshold = m->conf_threshold;
+        ca.outlierCoeff = outlier_coeff;
+        ca.maskID = m->id;
+        ca.count = (int)m->count;
+        ca.npix = (int)npix;
+        clean_rect_item& cl = b_clean.m[k];
+        cl.s = m->set[m->cur], cl.meas = m->meas, cl.new_flags = m->flags_b, cl.a = ca, cl.index = m->index, cl.vertConf = m->vertConf,
+        cl.colorTime = m->colorTime, cl.depth_in = depth_filtered, cl.mask = mask, cl.keep = m->flags_a, cl.conf_time = m->conf_time,
+        cl.block_sums = m->block_sums, cl.dst = m->set[1 - m->cur], cl.capacity = m->capacity, cl.total_out = &m->totals[0],
+        cl.total_host = m->host_totals_dev + kCountWord, cl.seq = ++m->count_seq, cl.mask_box = fd.mask_box, cl.mask_gen = mask_gen;
+        g_map = std::max(g_map, im.grid), g_upd = std::max(g_upd, fu.grid);
+        // the host's bookkeeping of mmf_model_clean (the count's bound: every pixel could still be a candidate)
+        const unsigned nc = m->count + npix;
+        m->count_bound = nc < (unsigned)m->capacity ? nc : (unsigned)m->capacity;
+        m->count_pending = true;
+        m->count_stream = st;
+        m->cur = 1 - m->cur;
+    }
+    const dim3 blk(256), rect(kRectGroups, n);
+    if (g_map) hipLaunchKernelGGL(index_map_box_batched_kernel, dim3(g_map, n), blk, 0, st, b_map);
+    hipLaunchKernelGGL(index_resolve_rect_batched_kernel, rect, blk, 0, st, b_res1);
+    hipLaunchKernelGGL(fuse_data_rect_batched_kernel, rect, blk, 0, st, b_fuse);
+    if (g_upd) hipLaunchKernelGGL(fuse_update_index_box_batched_kernel, dim3(g_upd, n), blk, 0, st, b_upd);
+    hipLaunchKernelGGL(index_resolve_rect_batched_kernel, rect, blk, 0, st, b_res2);
+    hipLaunchKernelGGL(clean_flag_rect_batched_kernel, rect, blk, 0, st, b_clean);
+    hipLaunchKernelGGL(clean_scatter_rect_batched_kernel, rect, blk, 0, st, b_clean);
+    MMF_HIP_TRY(hipGetLastError());
+    return MMF_OK;
+}
+
+static int models_combined_predict_rect(mmf_model* const* ms, int n, hipStream_t st, float depth_cutoff, int time, int max_time,
+                                        int time_delta) {
+    MMF_REQUIRE(ms && n >= 1 && n <= kMaxPassBatch, "models_combined_predict_rect: bad argument");
+    MMF_HIP_TRY(hipSetDevice(ms[0]->ctx->device));
+    PassBatch<splat_box_item> b_splat;
+    PassBatch<splat_resolve_rect_item> b_res;
+    unsigned g_splat = 0;
+    for (int k = 0; k < n; ++k) {
+        mmf_model* m = ms[k];
+        MMF_REQUIRE(m && m->boxes && m->rider.st == nullptr && !m->t_inv_dev && !m->abort_dev, "models_combined_predict_rect: a model with a device-side pose");
+        ++m->tex_gen;
+        ++m->thumb_gen;
+        SplatArgs a;
+        inverse4f_host(m->pose, a.t_inv.m);
+        a.t_inv_dev = nullptr, a.abort_dev = nullptr;
+        a.c = make_cam(m, false);
+        a.cols = m->width, a.rows = m->height;
+        a.maxDepth = depth_cutoff;
+        a.confThreshold = m->conf_threshold;
+        a.time = time, a.maxTime = max_time, a.timeDelta = time_delta;
+        a.early_z = 0;
+        a.rays = m->rays;
+        const unsigned launch_count = m->count_pending ? m->count_bound : m->count;
+        const size_t npix_s = (size_t)m->width * m->height;
+        splat_box_item& sp = b_splat.m[k];
+        sp.s = m->set[m->cur], sp.count = (int)launch_count, sp.a = a, sp.keys = m->keys, sp.count_dev = m->count_pending ? m->totals : nullptr;
+        sp.boxes = m->boxes, sp.kgen = ++m->kgen;
+        // The bound right after clean() is count + every pixel; the waves deal the surfels out whatever the grid is, and every
+        // wave with a surfel notes its sprites' box: size the grid by what the store can plausibly hold (the count before the
+        // clean pass, doubled, + 8192) -- 4 000 one-surfel waves noting into four words took 180 us
+        const size_t plausible = std::min<size_t>(launch_count, (size_t)m->count * 2 + 8192);
+        sp.grid = launch_count ? splat_grid(plausible, plausible >= npix_s / 2).x : 0u;
+        splat_resolve_rect_item& sr = b_res.m[k];
+        sr.s = m->set[m->cur], sr.a = a, sr.keys = m->keys, sr.image = m->image, sr.vertexConf = m->vertexConf, sr.normalRadius = m->normalRadius,
+        sr.time_out = m->time_tex, sr.thumb = model_thumb_counts(m), sr.gen = (int)(m->thumb_gen & 1);
+        sr.boxes = m->boxes, sr.kgen = m->kgen, sr.sgen = ++m->sgen, sr.prev_whole = m->spl_nz_known ? 0 : 1;
+        m->spl_nz_known = true;
+        g_splat = std::max(g_splat, sp.grid);
+    }
+    if (g_splat) hipLaunchKernelGGL(splat_box_batched_kernel, dim3(g_splat, n), dim3(256), 0, st, b_splat);
+    hipLaunchKernelGGL(splat_resolve_rect_batched_kernel, dim3(kRectGroups, n), dim3(256), 0, st, b_res);
     MMF_HIP_TRY(hipGetLastError());
     return MMF_OK;
 }

@@ -439,18 +439,18 @@ struct IndexArgs {
     int time, timeDelta;
 };
 
-// index.vert: surfel `id` (position p, timestamp ts) into the key image
-__device__ __forceinline__ void index_map_project(const IndexArgs& a, int id, float4 p, float ts,
-                                                  unsigned long long* __restrict__ keys) {
+// index.vert: surfel `id` (position p, timestamp ts) into the key image; true: it wrote, at pixel (px, py)
+__device__ __forceinline__ bool index_map_project_xy(const IndexArgs& a, int id, float4 p, float ts,
+                                                     unsigned long long* __restrict__ keys, int& px, int& py) {
     const v3 h = m4point(a.t_inv, V3(p.x, p.y, p.z));
-    if (h.z > a.maxDepth || h.z < 0 || (float)a.time - ts > (float)a.timeDelta) return;
+    if (h.z > a.maxDepth || h.z < 0 || (float)a.time - ts > (float)a.timeDelta) return false;
     const float xn = ((((a.c.fx * h.x) / h.z) + a.c.cx) - (a.cols * 0.5f)) / (a.cols * 0.5f);
     const float yn = ((((a.c.fy * h.y) / h.z) + a.c.cy) - (a.rows * 0.5f)) / (a.rows * 0.5f);
     const float zn = h.z / a.maxDepth;
-    if (!(xn >= -1 && xn <= 1 && yn >= -1 && yn <= 1 && zn >= -1 && zn <= 1)) return;
+    if (!(xn >= -1 && xn <= 1 && yn >= -1 && yn <= 1 && zn >= -1 && zn <= 1)) return false;
     const float xw = (xn + 1.0f) * (a.cols * 0.5f), yw = (yn + 1.0f) * (a.rows * 0.5f);
-    const int px = (int)floorf(xw), py = (int)floorf(yw);
-    if (px < 0 || py < 0 || px >= a.cols || py >= a.rows) return;
+    px = (int)floorf(xw), py = (int)floorf(yw);
+    if (px < 0 || py < 0 || px >= a.cols || py >= a.rows) return false;
     const unsigned long long k = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | (unsigned)id;
     // the index map and its key image are stored TRANSPOSED (pixel (x, y) at x * rows + y): surfels are
     // kept in the reference's draw order, which is column-major over the image, so neighbouring lanes
@@ -458,6 +458,12 @@ __device__ __forceinline__ void index_map_project(const IndexArgs& a, int id, fl
     // look-ups of fuse_data_kernel / clean_flag_kernel (row-major storage made each of those a
     // one-cache-line-per-lane access: 47 us for clean_flag_kernel at 640x480)
     atomicMin(&keys[px * a.rows + py], k);
+    return true;
+}
+__device__ __forceinline__ void index_map_project(const IndexArgs& a, int id, float4 p, float ts,
+                                                  unsigned long long* __restrict__ keys) {
+    int px, py;
+    (void)index_map_project_xy(a, id, p, ts, keys, px, py);
 }
 
 __device__ __forceinline__ void index_map_kernel_body(SurfelSoA s, int count, IndexArgs a_in,
@@ -478,6 +484,27 @@ __global__ __launch_bounds__(256) void index_map_kernel(SurfelSoA s, int count, 
     index_map_kernel_body(s, count, a_in, keys, rider, blockIdx.x, gridDim.x);
 }
 
+// texel i of the (transposed) index-map images from its key; the key goes back empty
+__device__ __forceinline__ void index_resolve_texel(int i, const SurfelSoA& s, const IndexArgs& a, unsigned long long* __restrict__ keys,
+                                                    unsigned* __restrict__ index, float4* __restrict__ vertConf, float4* __restrict__ colorTime,
+                                                    float4* __restrict__ normRad) {
+    const unsigned long long k = keys[i];
+    if (k != kEmptyKey) keys[i] = kEmptyKey;
+    if (k == kEmptyKey) {
+        index[i] = 0;
+        vertConf[i] = colorTime[i] = normRad[i] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const unsigned id = (unsigned)k;
+    const float4 p = s.pos[id], n = s.nrm[id];
+    const v3 h = m4point(a.t_inv, V3(p.x, p.y, p.z));
+    const v3 nn = v3normalize(m4dir(a.t_inv, V3(n.x, n.y, n.z)));
+    index[i] = id;
+    vertConf[i] = make_float4(h.x, h.y, h.z, p.w);
+    colorTime[i] = s.col[id];
+    normRad[i] = make_float4(nn.x, nn.y, nn.z, n.w);
+}
+
 // linear over the transposed images (it never needs a pixel's coordinates)
 // Every resolve kernel hands the key image back EMPTY (it is the only reader of a texel's key), so the
 // rasterising passes need no clearing launch in front of them.
@@ -495,21 +522,7 @@ __device__ __forceinline__ void index_resolve_kernel_body(SurfelSoA s, IndexArgs
     const IndexArgs a = with_device_pose(a_in);
     const int i = (int)(bx_ - (rider.st ? 1u : 0u)) * 256 + threadIdx.x;
     if (i >= a.cols * a.rows) return;
-    const unsigned long long k = keys[i];
-    if (k != kEmptyKey) keys[i] = kEmptyKey;
-    if (k == kEmptyKey) {
-        index[i] = 0;
-        vertConf[i] = colorTime[i] = normRad[i] = make_float4(0, 0, 0, 0);
-        return;
-    }
-    const unsigned id = (unsigned)k;
-    const float4 p = s.pos[id], n = s.nrm[id];
-    const v3 h = m4point(a.t_inv, V3(p.x, p.y, p.z));
-    const v3 nn = v3normalize(m4dir(a.t_inv, V3(n.x, n.y, n.z)));
-    index[i] = id;
-    vertConf[i] = make_float4(h.x, h.y, h.z, p.w);
-    colorTime[i] = s.col[id];
-    normRad[i] = make_float4(nn.x, nn.y, nn.z, n.w);
+    index_resolve_texel(i, s, a, keys, index, vertConf, colorTime, normRad);
 }
 __global__ __launch_bounds__(256) void index_resolve_kernel(SurfelSoA s, IndexArgs a_in,
                                                             unsigned long long* __restrict__ keys,
@@ -715,12 +728,42 @@ struct SplatRowLds {  // per surfel of the wave's pass, structure of arrays: lan
     unsigned dmin[256];
     int seg_end[256];     // inclusive scan of rows x segments per row inside each wave
 };
-template <bool EARLYZ>
+// (pass_rect.hpp) all 64 lanes of a wave: lanes with `valid` carry a box [x0, x1] x [y0, y1]; one set of generation-tagged
+// atomics (extent.hpp's words) per wave that has one
+__device__ __forceinline__ int wave_min_all(int v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = min(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ int wave_max_all(int v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ void box_note_wave(unsigned long long* w, unsigned gen, bool valid, int x0, int x1, int y0, int y1) {
+    const int a = wave_min_all(valid ? x0 : 0x7FFF), b = wave_max_all(valid ? x1 : -1);
+    const int c = wave_min_all(valid ? y0 : 0x7FFF), d = wave_max_all(valid ? y1 : -1);
+    if ((threadIdx.x & 63u) != 0u || b < a || d < c) return;
+    const unsigned long long g = (unsigned long long)gen << 32;
+    // look first: the words only ever rise, so a value that is there already needs no atomic -- after the first few waves of a
+    // launch hardly any wave still widens the box (a rasterising pass of 4 000 one-surfel waves: 16 000 atomics on four
+    // addresses, 300 us, without the look)
+    const unsigned long long v0 = g | (unsigned long long)(0xFFFF - a), v1 = g | (unsigned long long)b, v2 = g | (unsigned long long)(0xFFFF - c),
+                             v3w = g | (unsigned long long)d;
+    if (__hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v0) atomicMax(&w[0], v0);
+    if (__hip_atomic_load(&w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v1) atomicMax(&w[1], v1);
+    if (__hip_atomic_load(&w[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v2) atomicMax(&w[2], v2);
+    if (__hip_atomic_load(&w[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v3w) atomicMax(&w[3], v3w);
+}
+// BOX: the pass also notes the box of its sprites (what it may write of the key image) into key_box, generation kgen
+template <bool EARLYZ, bool BOX = false>
 __device__ __forceinline__ void splat_kernel_body(SurfelSoA s, int count, SplatArgs a_in,
                                                     unsigned long long* __restrict__ keys,
-                                                    const unsigned* __restrict__ count_dev, const unsigned bx_, [[maybe_unused]] const unsigned gx_) {
+                                                    const unsigned* __restrict__ count_dev, const unsigned bx_, [[maybe_unused]] const unsigned gx_,
+                                                    [[maybe_unused]] unsigned long long* key_box = nullptr, [[maybe_unused]] unsigned kgen = 0u) {
     MMF_MODEL_STREAM_PRIORITY();
     MMF_SPECULATION_GUARD(a_in);
+    int bx0 = 0x7FFF, bx1 = -1, by0 = 0x7FFF, by1 = -1;  // (BOX) this lane's sprites
     const SplatArgs a = with_device_pose(a_in);
     __shared__ SplatRowLds L;
     const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
@@ -741,6 +784,7 @@ __device__ __forceinline__ void splat_kernel_body(SurfelSoA s, int count, SplatA
             f = splat_setup(p, col, n, a);
         }
         const int h = f.ok ? max(f.y1 - f.y0 + 1, 0) : 0, w = f.ok ? max(f.x1 - f.x0 + 1, 0) : 0;
+        if (BOX && h > 0 && w > 0) bx0 = min(bx0, f.x0), bx1 = max(bx1, f.x1), by0 = min(by0, f.y0), by1 = max(by1, f.y1);
         const int nseg = (w + kSplatSeg - 1) / kSplatSeg;
         int scan = h * nseg;
 #pragma unroll
@@ -817,6 +861,7 @@ __device__ __forceinline__ void splat_kernel_body(SurfelSoA s, int count, SplatA
                 if (draw[k]) atomicMin(&keys[(size_t)(pb + k) * a.rows + py], ((unsigned long long)d24v[k] << 32) | sid);
         }
     }
+    if (BOX) box_note_wave(key_box, kgen, bx1 >= bx0 && by1 >= by0, bx0, bx1, by0, by1);
 }
 template <bool EARLYZ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void splat_kernel(SurfelSoA s, int count, SplatArgs a_in,
@@ -974,6 +1019,11 @@ constexpr unsigned kNoWinner = 0xFFFFFFFFu;
 // Per pixel in draw order d = i*rows + j: the new measurement goes to meas.{pos,col,nrm}[d];
 // op[d] = 0 (nothing), 1 (merge; target in best[d]), 2 (new unstable).  For merges the first
 // pixel in draw order owns the target surfel: atomicMin(winner[best], d).
+__device__ __forceinline__ void fuse_data_thread(const int t, const uint8_t* __restrict__ rgb, const float* __restrict__ depth_raw,
+                                                 const float* __restrict__ depth_fil, const uint8_t* __restrict__ mask,
+                                                 const unsigned* __restrict__ index, const float4* __restrict__ vertConf,
+                                                 const float4* __restrict__ normRad, const FuseArgs& a, SurfelSoA meas,
+                                                 unsigned* __restrict__ new_flags, unsigned* __restrict__ winner);
 __device__ __forceinline__ void fuse_data_kernel_body(const uint8_t* __restrict__ rgb, const float* __restrict__ depth_raw,
                                                         const float* __restrict__ depth_fil, const uint8_t* __restrict__ mask,
                                                         const unsigned* __restrict__ index, const float4* __restrict__ vertConf,
@@ -987,13 +1037,20 @@ __device__ __forceinline__ void fuse_data_kernel_body(const uint8_t* __restrict_
         for (int k = 0; k < 16; ++k) a.pose.m[k] = a_in.pose_dev[k];
         a.weighting = *a_in.weight_dev * a_in.weight_mult;  // (computeFusionWeight's last operation)
     }
+    fuse_data_thread((int)(bx_ * 256 + threadIdx.x), rgb, depth_raw, depth_fil, mask, index, vertConf, normRad, a, meas, new_flags, winner);
+}
+// thread t of the pass (t < ceil(cols / 2) * ceil(rows / 2), column-major over the 2 x 2 blocks); `a`: the pose resolved
+__device__ __forceinline__ void fuse_data_thread(const int t, const uint8_t* __restrict__ rgb, const float* __restrict__ depth_raw,
+                                                 const float* __restrict__ depth_fil, const uint8_t* __restrict__ mask,
+                                                 const unsigned* __restrict__ index, const float4* __restrict__ vertConf,
+                                                 const float4* __restrict__ normRad, const FuseArgs& a, SurfelSoA meas,
+                                                 unsigned* __restrict__ new_flags, unsigned* __restrict__ winner) {
     // One thread per 2 x 2 block of pixels: data.vert:116 keeps one pixel in four -- (int)x and (int)y both of the frame's
     // parity, i.e. one lattice point per block ((int)(uv_coord(i, n) * n) == i for every i: the error of that product is
     // ~1e-5) -- so a thread per PIXEL left every other wave empty and the rest half empty.  The thread clears its block's
     // four flags and carries on with the block's lattice pixel, in the pixel's own draw-order slot d: same results.
     const int cols = a.cols, rows = a.rows;
     const int hr = (rows + 1) / 2, hc = (cols + 1) / 2;
-    const int t = bx_ * 256 + threadIdx.x;
     if (t >= hc * hr) return;
     const int ia = t / hr, jb = t - ia * hr;  // column-major like the draw order
     const int tm = ((int)(float)a.time) % 2;
@@ -1211,7 +1268,8 @@ __device__ __forceinline__ unsigned clean_flag_one(int e, SurfelSoA s, SurfelSoA
                                                    const float4* __restrict__ vertConf,
                                                    const float4* __restrict__ colorTime,
                                                    const float* __restrict__ depth_in, const uint8_t* __restrict__ mask,
-                                                   float2* __restrict__ conf_time) {
+                                                   float2* __restrict__ conf_time, int e_store = -1) {
+    // (e_store: where the candidate's {confidence, timestamp} go when the caller numbers its candidates differently: pass_rect.hpp)
     float4 vpos, vcol, vnrm;
     if (e < a.count) {
         vpos = s.pos[e], vcol = s.col[e], vnrm = s.nrm[e];
@@ -1338,7 +1396,7 @@ __device__ __forceinline__ unsigned clean_flag_one(int e, SurfelSoA s, SurfelSoA
         if (mask[t] != a.maskID && (wDepth > localPos.z - 0.05f && wDepth < localPos.z + 0.05f))
             vpos.w *= (0.5f + 0.5f * (1 - a.outlierCoeff / 10.0f));
     }
-    conf_time[e] = make_float2(vpos.w, vcol.w);
+    conf_time[e_store >= 0 ? e_store : e] = make_float2(vpos.w, vcol.w);
     return test ? 1u : 0u;
 }
 

@@ -450,9 +450,11 @@ def test_extent_walk_equals_dense_walk_frame_by_frame(gpu_ctx, fast):
 
 def test_batched_passes_equal_passes_model_by_model(gpu_ctx):
     """The object models' projection / fuse / clean / predict passes go out as ONE launch per pass for all of them (gridDim.y =
-    model: csrc/surfel_kernels.hpp, *_batched_kernel) instead of ~9 launches per model on the model's own stream
-    (MultiMotionFusion.cpp:791-816, 863-875 loop over the models).  Same kernel bodies on the same data: every model's
-    surfels (values AND order), poses, prediction images and error images must agree bit for bit."""
+    model) instead of ~9 launches per model on the model's own stream (MultiMotionFusion.cpp:791-816, 863-875 loop over the
+    models) -- restricted to where each model is (csrc/pass_rect.hpp: the boxes of its key-image writes, of its non-zero
+    images and of its id in the id image) or covering the whole frame (csrc/surfel_kernels.hpp, *_batched_kernel).  Same
+    per-texel code on the same data: every model's surfels (values AND order), poses, prediction images -- all of the
+    image, also where the restricted passes never go -- and error images must agree bit for bit."""
     from multimotionfusion_amd.fusion import MultiMotionFusion
     lib = gpu_ctx.lib
     w, h, n_frames, n_obj = 320, 240, 8, 4
@@ -473,14 +475,25 @@ def test_batched_passes_equal_passes_model_by_model(gpu_ctx):
                 g.processFrame(rgb[i], depth[i], timestamp=i, mask=keep[-1], hasNewLabel=spawn, next=nxt)
                 out.append([m.getPose() for m in g.getModels()])
             maps = [m.downloadMap() for m in g.getModels()]
-            tex = [[m.texture(n).cpu().numpy().copy() for n in ("image", "vertexConf", "normalRadius")] for m in g.getModels()]
+            def tex_of(m, n):  # (the index-map getters copy on the MODEL's stream: wait for the device before reading)
+                t = m.texture(n)
+                torch.cuda.synchronize()
+                return t.cpu().numpy().copy()
+            tex = [[tex_of(m, n) for n in ("image", "vertexConf", "normalRadius", "index", "vertConf", "normRad")] for m in g.getModels()]
             err = [g.getErrorTexture(k, "icp").cpu().numpy().copy() for k in range(len(maps))]
         finally:
             g.close()
             lib.mmf_debug_set_pass_batch(-1)
         return out, maps, tex, err
 
-    a, b = run(1), run(0)
+    a, b = run(2), run(0)  # restricted to where the models are (csrc/pass_rect.hpp: the default) against model by model
+    c = run(1)             # ... and the batched launches that cover the whole frame
+    for x, y in ((a, c),):
+        for i in range(n_frames):
+            for pa, pb in zip(x[0][i], y[0][i]):
+                assert np.array_equal(pa, pb), i
+        for ma, mb in zip(x[1], y[1]):
+            assert ma.shape == mb.shape and np.array_equal(ma.view(np.uint32), mb.view(np.uint32))
     assert len(a[1]) == n_obj + 1 and all(m.shape[0] > 100 for m in a[1])
     for i in range(n_frames):
         for k, (pa, pb) in enumerate(zip(a[0][i], b[0][i])):
