@@ -549,6 +549,11 @@ int mmf_debug_set_splat_bound(int mode);
  * (csrc/pass_rect.hpp: the boxes of its key-image writes, of its non-zero images and of its id in the id image), -1 = the
  * default (MMF_PASS_BATCH).  Same maps and images, bit for bit, in all three.  Process wide. */
 int mmf_debug_set_pass_batch(int mode);
+/* test / A-B hook: an OBJECT model's model-side preparation (Model::initICPModel / initRGBModel's pyramids, records and point
+ * clouds) covers only the box its prediction is non-zero in -- the hull of that box now and at its previous preparation, so
+ * that every buffer stays what a whole-frame preparation writes (1, the default) -- or the whole frame (0); -1 = the default
+ * (MMF_PREP_RECT).  Same buffers, bit for bit.  Process wide. */
+int mmf_debug_set_prep_rect(int on);
 /* test / A-B hook: object models in the producer + step chain (csrc/extent.hpp, ChainGeom: their passes skip the blocks outside
  * the model's own depth and walk the images with a quarter of the workgroups).  1 = on, 0 = every model is tracked like the
  * camera model, -1 = the default (MMF_TRACK_CULL, on).  Process wide. */

@@ -127,4 +127,23 @@ __device__ __forceinline__ bool aabb_load(const unsigned long long* words, unsig
     return ok;
 }
 
+
+// ---- boxes kept as plain ints {x0, y0, x1, y1} (one writer per launch, read by later launches) ----
+__device__ __forceinline__ ExtentBox box_of_ints(const int* p) { return ExtentBox{p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void box_to_ints(int* p, const ExtentBox& e) {
+    const bool none = e.x1 < e.x0 || e.y1 < e.y0;
+    p[0] = none ? 1 : e.x0, p[1] = none ? 1 : e.y0, p[2] = none ? 0 : e.x1, p[3] = none ? 0 : e.y1;
+}
+__device__ __forceinline__ ExtentBox box_clip(ExtentBox e, int cols, int rows) {
+    e.x0 = max(e.x0, 0), e.y0 = max(e.y0, 0), e.x1 = min(e.x1, cols - 1), e.y1 = min(e.y1, rows - 1);
+    return e;
+}
+// Per surfel model, device resident (pass_rect.hpp; prep_batch.hpp reads spl_nz): where the key image was last written and
+// where the model's images are non-zero.
+struct PassBoxes {
+    unsigned long long key[2][4];  // [g & 1]: box of the key-image writes of projection launch g (the words above, generation g)
+    int idx_nz[2][4];              // [g & 1]: where the index-map images are non-zero after resolve g: {x0, y0, x1, y1}, x1 < x0 = nowhere
+    int spl_nz[2][4];              // likewise the prediction images
+};
+
 }  // namespace mmf

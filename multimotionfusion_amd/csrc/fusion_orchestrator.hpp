@@ -551,6 +551,13 @@ static void odom_alias_sensor_side(mmf_odom* o, const mmf_odom* primary) {
     o->depth_l0 = primary->depth_l0;
 }
 
+// where an OBJECT model's latest prediction is non-zero (device, PassBoxes::spl_nz of its last resolve), for a model-side
+// preparation that may then leave the rest of the frame alone; null: unknown, or not such a model
+static const int* fusion_pred_box(const FusionModel* fm, int side) {
+    const mmf_model* m = fm->model;
+    if (side != PREP_MODEL_SIDE || fm->fill_in || !fm->odom->sparse || !m->boxes || !m->spl_nz_known) return nullptr;
+    return m->boxes->spl_nz[m->sgen & 1u];
+}
 // the covered thumbnail samples of a model's latest prediction (thumbnail_count_px)
 static const int* fusion_thumb_count(const mmf_model* m) {
     return reinterpret_cast<const int*>(&m->totals[4 + (m->thumb_gen & 1)]);
@@ -855,7 +862,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                                      (const float*)m->normalRadius, pi, 4, pose,
                                      fm->fill_in ? fusion_thumb_count(m) : nullptr, (const float*)m->fill_vertex,
                                      (const float*)m->fill_normal, (const uint8_t*)m->fill_image, side, (m->width / 20) * (m->height / 20),
-                                     0.75f, fm->odom->sparse ? ext_gen : 0u);
+                                     0.75f, fm->odom->sparse ? ext_gen : 0u, fusion_pred_box(fm, side));
             };
             bool batch_ok = batched;
             if (batched) {
@@ -1336,7 +1343,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                                      (const float*)m->normalRadius, pi, 4, fm->spec_pose,
                                      fm->fill_in ? fusion_thumb_count(m) : nullptr, (const float*)m->fill_vertex,
                                      (const float*)m->fill_normal, (const uint8_t*)m->fill_image, PREP_MODEL_SIDE,
-                                     (m->width / 20) * (m->height / 20), 0.75f, fm->odom->sparse ? ext_gen : 0u);
+                                     (m->width / 20) * (m->height / 20), 0.75f, fm->odom->sparse ? ext_gen : 0u, fusion_pred_box(fm, PREP_MODEL_SIDE));
                 fm->spec_tex_gen = m->tex_gen;
                 fm->spec_f2f = g.frame_to_frame_rgb;
                 fm->spec_valid = true;

@@ -782,6 +782,12 @@ struct mmf_odom {
     // the number of the frame they were noted for), read by the two-launch chain's passes
     unsigned long long* extent = nullptr;
     unsigned extent_gen = 0;
+    // prep_batch.hpp (PrepJob::rect_*): the box an object model's model-side preparation last found its prediction non-zero
+    // in (device: two slots of four ints, the preparation's number & 1), and whether it describes the buffers (any
+    // preparation of the whole frame leaves it unknown)
+    int* prep_box = nullptr;
+    unsigned prep_gen = 0;
+    bool prep_box_known = false;
     unsigned sensor_gen = 0;     // number of the last sensor-side depth preparation (its smallest depth: extent words 18 / 19)
     float sensor_cutoff = 0.f;   // ... and the depth cut-off its vertex maps were made with
     // an OBJECT model (set by the orchestrator): the two-launch chain walks its images with a quarter of the workgroups
@@ -895,7 +901,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     size_t o_state = carve(sizeof(OdomState));
     const size_t o_pf = carve(sizeof(float) * kMaxGrid * kPartialStride), o_pi = carve(sizeof(float) * kMaxIcpGrid * kPartialStride),
                  o_pr = carve(sizeof(int2) * kMaxGrid), o_tk = carve(sizeof(unsigned) * kTicketWords), o_ei = carve(n0 * 4),
-                 o_er = carve(n0 * 4), o_ex = carve(kExtentWords * sizeof(unsigned long long));
+                 o_er = carve(n0 * 4), o_ex = carve(kExtentWords * sizeof(unsigned long long) + 64);  // (+ prep_box)
     o->slab_bytes = off;
     hipError_t e = hipMalloc(&o->slab, o->slab_bytes);
     if (e != hipSuccess) {
@@ -931,6 +937,7 @@ extern "C" int mmf_odom_create(mmf_ctx* c, int width, int height, float cx, floa
     o->gn_partials_res = (int2*)(base + o_pr), o->gn_ticket = (unsigned*)(base + o_tk);
     o->icp_err = (float*)(base + o_ei), o->rgb_err = (float*)(base + o_er);
     o->extent = (unsigned long long*)(base + o_ex);
+    o->prep_box = (int*)(base + o_ex + kExtentWords * sizeof(unsigned long long));
     MMF_HIP_TRY(hipHostMalloc(&o->host_result, sizeof(OdomState), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(o->host_result, 0, sizeof(OdomState));
     MMF_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&o->host_result_dev), o->host_result, 0));
@@ -1146,7 +1153,7 @@ struct PrepBuilder {  // the jobs of one stage (possibly of several models); lau
                 PrepJob& j = b.job[b.njobs++];
                 j = jobs[k];
                 j.first_block = blocks;
-                blocks += j.gx * ((j.rows + kTileY * j.reps - 1) / (kTileY * j.reps));
+                blocks += j.rect_now ? j.rect_groups : j.gx * ((j.rows + kTileY * j.reps - 1) / (kTileY * j.reps));
             }
             q.launch(prep_batch_kernel, dim3(blocks), tile_block(), b);
         }
@@ -1182,14 +1189,24 @@ struct PrepStages {  // the four dependent launches of a frame's preparation
 // (mmf_fusion_prefetch_frame); PREP_ALL is both groups in the same four launches.
 enum PrepSide { PREP_INPUT_IMAGE = 1, PREP_INPUT_DEPTH = 2, PREP_MODEL_SIDE = 4, PREP_ALL = 7 };
 
+static std::atomic<int> g_prep_rect{-1};  // -1: MMF_PREP_RECT decides (default on); 0 / 1: mmf_debug_set_prep_rect
+extern "C" int mmf_debug_set_prep_rect(int on) {
+    g_prep_rect.store(on < 0 ? -1 : (on ? 1 : 0));
+    return MMF_OK;
+}
 static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* depth_filtered, float depth_cutoff, const uint8_t* rgb,
                                  int rgb_channels, const float* pred_vertex, const float* pred_normal,
                                  const uint8_t* pred_image, int pred_channels, const float pose[16],
                                  const int* sel = nullptr, const float* alt_vertex = nullptr,
                                  const float* alt_normal = nullptr, const uint8_t* alt_image = nullptr,
-                                 int side = PREP_ALL, int sel_total = 0, float sel_ratio = 0.f, unsigned ext_gen = 0) {
+                                 int side = PREP_ALL, int sel_total = 0, float sel_ratio = 0.f, unsigned ext_gen = 0,
+                                 const int* pred_box = nullptr) {
+    // pred_box (device, level-0 pixels {x0, y0, x1, y1}; an OBJECT model's model side only): where the prediction's images are
+    // non-zero -- the jobs then cover the hull of that box and of the one the previous preparation saw (PrepJob::rect_*)
     const bool in_img = (side & PREP_INPUT_IMAGE) != 0, in_depth = (side & PREP_INPUT_DEPTH) != 0;
     const bool model_side = (side & PREP_MODEL_SIDE) != 0;
+    size_t jobs_before[4];
+    for (int k = 0; k < 4; ++k) jobs_before[k] = stages.stage[k].jobs.size();
     const int W = o->width, H = o->height;
     const size_t n0 = (size_t)W * H;
     // camera-frame model pyramids (before the transform into the global frame) live in the two 4*N-float
@@ -1362,7 +1379,29 @@ static void odom_prepare_collect(PrepStages& stages, mmf_odom* o, const float* d
         PrepBuilder& pb = stages.stage[3];
         level_jobs(pb, 2);
     }
-    if (model_side) o->prep_batched = true;
+    if (model_side) {
+        const bool rect_on = g_prep_rect.load() < 0 ? tunables().prep_rect : g_prep_rect.load() != 0;
+        const bool rect = pred_box != nullptr && side == PREP_MODEL_SIDE && sel == nullptr && rect_on && o->prep_box != nullptr;
+        if (rect) {
+            const unsigned g = ++o->prep_gen;
+            bool first = true;
+            for (int k = 0; k < 4; ++k)
+                for (size_t q = jobs_before[k]; q < stages.stage[k].jobs.size(); ++q) {
+                    PrepJob& j = stages.stage[k].jobs[q];
+                    int lvl = 0;
+                    while ((W >> lvl) > j.cols && lvl < MMF_NUM_PYRS - 1) ++lvl;
+                    j.rect_now = pred_box, j.rect_prev = o->prep_box_known ? o->prep_box + 4 * ((g + 1u) & 1u) : nullptr;
+                    j.rect_level = lvl;
+                    j.rect_groups = lvl == 0 ? 48 : (lvl == 1 ? 32 : 16);
+                    j.rect_store = first ? o->prep_box + 4 * (g & 1u) : nullptr;
+                    first = false;
+                }
+            o->prep_box_known = true;
+        } else {
+            o->prep_box_known = false;
+        }
+        o->prep_batched = true;
+    }
     if (in_img) o->grad_pending = true;
     if (sel && sel_total)  // *sel is a count (PrepJob::sel_total)
         for (PrepBuilder& pb : stages.stage)
@@ -2691,6 +2730,24 @@ static int model_combined_predict(mmf_model* m, float depth_cutoff, int time, in
     const bool deep = bound_mode < 0 ? deep_store : bound_mode != 0;
     a.early_z = deep ? 1 : 0;
     a.rays = m->rays;
+    // An OBJECT model (no fill-in, no deep store): the rasterising pass also notes the box of its sprites and the resolve keeps it
+    // as the box the prediction is non-zero in (PassBoxes::spl_nz) -- the model-side preparation that follows walks that box
+    // instead of the frame.  The grid is sized by what the store can plausibly hold rather than by the bound (see
+    // models_combined_predict_rect).
+    const bool keep_box = m->boxes != nullptr && !(fill_rgb && fill_depth) && !deep && m->id != 0;
+    if (keep_box) {
+        ++m->kgen, ++m->sgen;
+        const size_t plausible = std::min<size_t>(launch_count, (size_t)m->count * 2 + 8192);
+        if (launch_count)
+            hipLaunchKernelGGL(splat_box_kernel, splat_grid(plausible, plausible >= npix_s / 2), dim3(256), 0, c->stream, m->set[m->cur],
+                               (int)launch_count, a, m->keys, m->count_pending ? m->totals : nullptr, m->boxes, m->kgen);
+        hipLaunchKernelGGL(splat_resolve_keep_box_kernel, dim3(splat_tile_grid(m->width, m->height)), dim3(256), 0, c->stream, m->set[m->cur], a, m->keys,
+                           m->image, m->vertexConf, m->normalRadius, m->time_tex, model_thumb_counts(m), (int)(m->thumb_gen & 1), m->boxes, m->kgen,
+                           m->sgen);
+        m->spl_nz_known = true;
+        MMF_HIP_TRY(hipGetLastError());
+        return MMF_OK;
+    }
     if (launch_count)
         hipLaunchKernelGGL(deep ? splat_kernel<true> : splat_kernel<false>, splat_grid(launch_count, (size_t)launch_count >= npix_s / 2), dim3(256), 0, c->stream,
                            m->set[m->cur], (int)launch_count, a, m->keys, m->count_pending ? m->totals : nullptr);

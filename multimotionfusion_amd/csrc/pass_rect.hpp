@@ -20,22 +20,7 @@
 
 namespace mmf {
 
-struct PassBoxes {                 // per model, device resident
-    unsigned long long key[2][4];  // [g & 1]: box of the key-image writes of projection launch g (extent.hpp's words, generation g)
-    int idx_nz[2][4];              // [g & 1]: where the index-map images are non-zero after resolve g: {x0, y0, x1, y1}, x1 < x0 = nowhere
-    int spl_nz[2][4];              // likewise the prediction images
-};
 constexpr int kRectGroups = 128;   // workgroups per model of a rect launch (an object's box of 200 x 200: one or two strides each)
-
-__device__ __forceinline__ ExtentBox box_of_ints(const int* p) { return ExtentBox{p[0], p[1], p[2], p[3]}; }
-__device__ __forceinline__ void box_to_ints(int* p, const ExtentBox& e) {
-    const bool none = e.x1 < e.x0 || e.y1 < e.y0;
-    p[0] = none ? 1 : e.x0, p[1] = none ? 1 : e.y0, p[2] = none ? 0 : e.x1, p[3] = none ? 0 : e.y1;
-}
-__device__ __forceinline__ ExtentBox box_clip(ExtentBox e, int cols, int rows) {
-    e.x0 = max(e.x0, 0), e.y0 = max(e.y0, 0), e.x1 = min(e.x1, cols - 1), e.y1 = min(e.y1, rows - 1);
-    return e;
-}
 
 // ---- the id image's boxes: one launch per frame for all ids (the segmentation's result is an input of processFrame) ----
 // boxes[id][4] (id 0, the background, is not noted).  64 x 16 pixel tiles; per tile the ids present are few.

@@ -78,6 +78,15 @@ struct PrepJob {
     // extent words (extent.hpp: sensor_zmin_note) with zmin_gen
     unsigned long long* zmin;
     unsigned zmin_gen;
+    // rect_now != nullptr (the model-side jobs of an OBJECT model): the job covers only the tiles that can differ from what
+    // its outputs already hold -- the hull of the box the prediction's images are non-zero in NOW (rect_now: level-0 pixels
+    // {x0, y0, x1, y1}, PassBoxes::spl_nz) and of that box at the model's previous preparation (rect_prev; null: unknown, the
+    // whole image), taken to the job's level with the pyramid windows' reach -- on rect_groups workgroups that stride over
+    // them.  Outside the hull the inputs are empty now and were empty then: the outputs there are the "nothing here" values
+    // already.  rect_store: the job's first workgroup keeps rect_now there for the next preparation.
+    const int *rect_now, *rect_prev;
+    int* rect_store;
+    int rect_level, rect_groups;
 };
 
 constexpr int kMaxPrepJobs = 24;  // 24 x 144 B of kernel arguments; longer job lists go out as several launches
@@ -316,15 +325,32 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
     for (int k = 1; k < b.njobs; ++k) j = (int)blockIdx.x >= b.job[k].first_block ? k : j;  // wave uniform
     const PrepJob& J = b.job[j];
     const int local = (int)blockIdx.x - J.first_block;
-    const int by = local / J.gx, bx = local - by * J.gx;
-    const int x = bx * kTileX + threadIdx.x;
     const bool alt = J.sel != nullptr && (J.sel_total ? ((float)*J.sel / (float)J.sel_total < J.sel_ratio) : *J.sel != 0);  // wave uniform
     const void* src0 = alt ? J.alt0 : J.src0;
     const void* src1 = alt ? J.alt1 : J.src1;
     PrepNote note;
 #pragma unroll
     for (int k = 0; k < 3; ++k) note.lo[k] = FLT_MAX, note.hi[k] = -FLT_MAX;
-    for (int r = 0; r < J.reps; ++r) prep_job_px(J, src0, src1, x, (by * J.reps + r) * kTileY + threadIdx.y, note);
+    if (J.rect_now != nullptr) {  // (uniform) an object model's job: the tiles of the hull only
+        const ExtentBox now = box_of_ints(J.rect_now);
+        ExtentBox hull = J.rect_prev ? extent_hull(now, box_of_ints(J.rect_prev)) : ExtentBox{0, 0, (J.cols << J.rect_level) - 1, (J.rows << J.rect_level) - 1};
+        if (J.rect_store != nullptr && local == 0 && threadIdx.x == 0 && threadIdx.y == 0) box_to_ints(J.rect_store, now);
+        if (!(hull.x1 < hull.x0 || hull.y1 < hull.y0)) {
+            // a destination pixel of level l + 1 reads sources within +-2 of twice its coordinates (5 x 5 pyramid windows; 2 x 2 resize)
+            for (int l = 0; l < J.rect_level; ++l) hull = ExtentBox{(hull.x0 - 4) >> 1, (hull.y0 - 4) >> 1, (hull.x1 + 4) >> 1, (hull.y1 + 4) >> 1};
+            hull = box_clip(hull, J.cols, J.rows);
+            const int th = kTileY * J.reps;
+            const int tx0 = hull.x0 / kTileX, ty0 = hull.y0 / th, tw = hull.x1 / kTileX - tx0 + 1, ntiles = tw * (hull.y1 / th - ty0 + 1);
+            for (int t = local; t < ntiles; t += J.rect_groups) {
+                const int ty = t / tw, x = (tx0 + t - ty * tw) * kTileX + (int)threadIdx.x;
+                for (int r = 0; r < J.reps; ++r) prep_job_px(J, src0, src1, x, ((ty0 + ty) * J.reps + r) * kTileY + (int)threadIdx.y, note);
+            }
+        }
+    } else {
+        const int by = local / J.gx, bx = local - by * J.gx;
+        const int x = bx * kTileX + threadIdx.x;
+        for (int r = 0; r < J.reps; ++r) prep_job_px(J, src0, src1, x, (by * J.reps + r) * kTileY + threadIdx.y, note);
+    }
     if (J.zmin != nullptr) {  // (uniform) the workgroup's smallest valid depth -> the sensor slot of the extent words
         __shared__ float zlo[kTileY];
         float z = note.lo[2];

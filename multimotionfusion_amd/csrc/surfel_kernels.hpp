@@ -18,6 +18,7 @@
 // The arithmetic follows oracle/mmf_oracle_surfel.c statement by statement (assumptions A1-A5
 // about the fixed-function GL state are listed there); built without FMA contraction.
 #pragma once
+#include "extent.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -863,6 +864,12 @@ __device__ __forceinline__ void splat_kernel_body(SurfelSoA s, int count, SplatA
     }
     if (BOX) box_note_wave(key_box, kgen, bx1 >= bx0 && by1 >= by0, bx0, bx1, by0, by1);
 }
+// the same pass, noting the box of its sprites (an object model's prediction: the preparation that follows walks that box only)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void splat_box_kernel(SurfelSoA s, int count, SplatArgs a_in,
+                                                    unsigned long long* __restrict__ keys, const unsigned* __restrict__ count_dev,
+                                                    PassBoxes* boxes, unsigned kgen) {
+    splat_kernel_body<false, true>(s, count, a_in, keys, count_dev, blockIdx.x, gridDim.x, boxes->key[kgen & 1u], kgen);
+}
 template <bool EARLYZ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void splat_kernel(SurfelSoA s, int count, SplatArgs a_in,
                                                     unsigned long long* __restrict__ keys,
@@ -969,6 +976,16 @@ __device__ __forceinline__ void splat_resolve_kernel_body(SurfelSoA s, SplatArgs
     vertexConf[i] = t.vertexConf, normalRadius[i] = t.normalRadius;
     time_out[i] = t.time;
     thumbnail_count_px(px, py, a.cols, a.rows, t.image, thumb, gen, bx_ == gx_ - 1);
+}
+// the same resolve behind splat_box_kernel: one thread also keeps the sprites' box as the box the images are non-zero in
+__global__ __launch_bounds__(256) void splat_resolve_keep_box_kernel(SurfelSoA s, SplatArgs a_in, unsigned long long* __restrict__ keys,
+                                                                     uchar4* __restrict__ image, float4* __restrict__ vertexConf,
+                                                                     float4* __restrict__ normalRadius, unsigned short* __restrict__ time_out,
+                                                                     unsigned* __restrict__ thumb, int gen, PassBoxes* boxes, unsigned kgen,
+                                                                     unsigned sgen) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !(a_in.abort_dev != nullptr && *a_in.abort_dev != 0))
+        box_to_ints(boxes->spl_nz[sgen & 1u], box_clip(extent_load(boxes->key[kgen & 1u], kgen), a_in.cols, a_in.rows));
+    splat_resolve_kernel_body(s, a_in, keys, image, vertexConf, normalRadius, time_out, thumb, gen, blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(256) void splat_resolve_kernel(SurfelSoA s, SplatArgs a_in,
                                                             unsigned long long* __restrict__ keys,

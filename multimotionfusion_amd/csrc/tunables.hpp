@@ -23,6 +23,7 @@ struct Tunables {
     bool prep_l0_late = true; // MMF_PREP_L0_LATE=0: the model side's level-0 jobs in its first launch
     long prep_big = -1;       // MMF_PREP_BIG=<pixels>|0: from how many pixels a job's workgroups take four tiles each
     bool prep_planar = false; // MMF_PREP_PLANAR=1: also write the planar model maps and the AoS point cloud
+    bool prep_rect = true;    // MMF_PREP_RECT=0: an object model's model-side preparation covers the whole frame (else: the box its prediction is non-zero in)
     // ---- orchestrator (fusion_orchestrator.hpp) ----
     int early_image = 2;      // MMF_EARLY_IMAGE=start|chain|off: where the next frame's image side is enqueued
     bool fuse_index = true;   // MMF_FUSE_INDEX=0: fuse's update pass and the index map's projection as two launches
@@ -63,6 +64,7 @@ inline const Tunables& tunables() {
         v.prep_l0_late = flag("MMF_PREP_L0_LATE", true);
         v.prep_big = num("MMF_PREP_BIG", -1);
         v.prep_planar = flag("MMF_PREP_PLANAR", false);
+        v.prep_rect = flag("MMF_PREP_RECT", true);
         if (const char* e = std::getenv("MMF_EARLY_IMAGE")) v.early_image = std::strcmp(e, "off") == 0 ? 0 : (std::strcmp(e, "chain") == 0 ? 1 : 2);
         v.fuse_index = flag("MMF_FUSE_INDEX", true);
         v.host_up_events = flag("MMF_HOST_UP_EVENTS", false);

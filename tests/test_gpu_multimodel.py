@@ -505,3 +505,54 @@ def test_batched_passes_equal_passes_model_by_model(gpu_ctx):
             assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), k
     for ea, eb in zip(a[3], b[3]):
         assert np.array_equal(ea.view(np.uint32), eb.view(np.uint32))
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_object_preparation_by_box_equals_whole_frame_preparation(gpu_ctx, fused):
+    """An object model's model-side preparation (the pyramids, global-frame records and point clouds of initICPModel /
+    initRGBModel, csrc/prep_batch.hpp) covers only the hull of the box its prediction is non-zero in now and at its previous
+    preparation; told not to (mmf_debug_set_prep_rect(0)) it covers the frame.  The buffers must be the same everywhere:
+    poses, maps and error images bit for bit under the one-launch chain (which reads them near the boxes) AND under the
+    two-launch chain (which reads all of them), and the downloadable pyramid levels themselves."""
+    from multimotionfusion_amd.fusion import MultiMotionFusion
+    lib = gpu_ctx.lib
+    w, h, n_frames, n_obj = 320, 240, 8, 3
+    K, poses, traj, frames, objs = scene(w, h, n_frames, n_obj, seed=41)
+    rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+
+    def run(rect):
+        lib.mmf_debug_set_gn_fused(fused)
+        lib.mmf_debug_set_prep_rect(rect)
+        g = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"], enable_multiple_models=1, preallocated_models=n_obj)
+        known, keep, out, bufs = [0], [], [], []
+        try:
+            for i, f in enumerate(frames):
+                spawn = 1 <= i <= n_obj
+                if spawn:
+                    known.append(i)
+                keep.append(dev(gt_mask(f["ids"], known)))
+                nxt = (rgb[i + 1], depth[i + 1]) if i + 1 < n_frames else None
+                g.processFrame(rgb[i], depth[i], timestamp=i, mask=keep[-1], hasNewLabel=spawn, next=nxt)
+                out.append([m.getPose() for m in g.getModels()])
+                torch.cuda.synchronize()
+                bufs.append([[g.getModelOdometry(k).download(nm, lvl) for nm in ("last_depth", "last_image") for lvl in range(3)]
+                             for k in range(len(g.getModels()))])
+            maps = [m.downloadMap() for m in g.getModels()]
+            err = [g.getErrorTexture(k, "icp").cpu().numpy().copy() for k in range(len(maps))]
+        finally:
+            g.close()
+            lib.mmf_debug_set_prep_rect(-1)
+            lib.mmf_debug_set_gn_fused(-1)
+        return out, maps, err, bufs
+
+    a, b = run(1), run(0)
+    for i in range(n_frames):
+        for k, (pa, pb) in enumerate(zip(a[0][i], b[0][i])):
+            assert np.array_equal(pa, pb), (i, k, np.abs(pa - pb).max())
+        for k, (ba, bb) in enumerate(zip(a[3][i], b[3][i])):
+            for j, (x, y) in enumerate(zip(ba, bb)):
+                assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (i, k, j)
+    for ma, mb in zip(a[1], b[1]):
+        assert ma.shape == mb.shape and np.array_equal(ma.view(np.uint32), mb.view(np.uint32))
+    for ea, eb in zip(a[2], b[2]):
+        assert np.array_equal(ea.view(np.uint32), eb.view(np.uint32))

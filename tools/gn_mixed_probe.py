@@ -56,7 +56,8 @@ print(f"{models} models: {nb} workgroups stamped their last slot; by extent:", [
 s = s[:nb]
 t0 = s[1:, 5].min()
 q = lambda v: " ".join(f"{np.percentile(v, p):6.2f}" for p in (0, 50, 90, 100))  # noqa: E731
-for name, sel in (("camera model (workgroups 1..239)", s[1:240]), ("object models (workgroups 240..)", s[240:])):
+cam = -(-(W * H // 5) // 192)  # the camera model's workgroups in a launch that carries object models: 192 pixel lanes x 5 pixels
+for name, sel in ((f"camera model (workgroups 1..{cam - 1})", s[1:cam]), (f"object models (workgroups {cam}..)", s[cam:])):
     if len(sel) == 0:
         continue
     print(f"  {name}: us after the first workgroup's start:                     min    p50    p90    max")
