@@ -610,20 +610,25 @@ def test_the_first_prediction_of_a_frame_is_never_read(gpu_ctx):
         assert np.array_equal(ref_map.view(np.uint32), got_map.view(np.uint32))
 
 
-@pytest.mark.parametrize("hint", [False, True])
-def test_a_chain_that_gives_up_is_tracked_again(gpu_ctx, hint):
+@pytest.mark.parametrize("hint,fault_at,host", [(False, 3, False), (True, 3, False), (True, 1, False), (False, 1, False), (True, 1, True),
+                                                 (True, 3, True), (False, 2, True)])
+def test_a_chain_that_gives_up_is_tracked_again(gpu_ctx, hint, fault_at, host):
     """The one-launch Gauss-Newton chain spins on its own workgroups; when a launch gives up (forced here: its count barrier
     polls zero times, as if another process held part of the GPU) the frame must come out as if the two-launch chain had
     tracked it -- same pose, same map, although the projections, the fuse and the clean pass had been enqueued ahead of the
-    pose -- and the process stops using the one-launch chain.  Reference: RGBDOdometry.cpp:464-467 (the call returns a pose)."""
+    pose -- and the process stops using the one-launch chain.  Reference: RGBDOdometry.cpp:464-467 (the call returns a pose).
+    fault_at 1: the FIRST tracked frame (whatever was or was not prepared ahead of it); host: frames handed over in host memory
+    (mmf_fusion_process_frame_host_next: the staging ring and the upload stream are part of what a re-tracked frame goes back
+    through) -- the round-4 advisor's cases of the speculation rollback."""
     import ctypes as C
-    from multimotionfusion_amd.fusion import MultiMotionFusion
+    from multimotionfusion_amd.fusion import HostFrame, MultiMotionFusion
     lib = gpu_ctx.lib
-    w, h, n, fault_at = 320, 240, 7, 3
+    w, h, n = 320, 240, 7
     K = synth.intrinsics(w, h)
     poses = synth.trajectory(n, seed=23)
     frames = [synth.render(p, w, h, seed=i) for i, p in enumerate(poses)]
     rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
+    hf = [HostFrame(f["rgb"], f["depth"]) for f in frames]
 
     def status():
         rec, use = C.c_int(0), C.c_int(0)
@@ -642,8 +647,11 @@ def test_a_chain_that_gives_up_is_tracked_again(gpu_ctx, hint):
                     lib.mmf_debug_force_gn_fault(1)
                 else:
                     lib.mmf_debug_set_gn_fused(0)  # the frames a recovery leaves to the two-launch chain
-            nxt = (rgb[i + 1], depth[i + 1]) if hint and i + 1 < n else None
-            g.processFrame(rgb[i], depth[i], timestamp=i, next=nxt)
+            if host:
+                g.processFrameHost(hf[i], timestamp=i, next=hf[i + 1] if hint and i + 1 < n else None)
+            else:
+                nxt = (rgb[i + 1], depth[i + 1]) if hint and i + 1 < n else None
+                g.processFrame(rgb[i], depth[i], timestamp=i, next=nxt)
             out.append(np.asarray(g.getCurrPose()).copy())
             if forced and i == fault_at:
                 assert status() == (rec0 + 1, 0), "the chain's give-up was not noticed"
