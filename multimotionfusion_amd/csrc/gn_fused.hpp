@@ -27,6 +27,10 @@
 //     launch -- or gn_final_kernel -- reads 7.4 KB of totals instead of a 256-byte record per workgroup (round 3: 61 KB
 //     fetched by every workgroup, 0.8 us of a 640x480 launch).
 //
+// Several models of a frame share ONE launch per iteration (gn_iter_mixed_kernel, further down): the camera model walks the
+// image as described here, an object model walks the box of its own depth and the rectangle of sensor pixels its prediction
+// can reach under the iteration's pose (gn_sparse_icp_box, gn_pixel_waves_sparse), with 4-wave workgroups for everybody.
+//
 // PX = 1, 2, 4 or 5 pixels per lane, chosen by the host per level (gn_geometry) so that a launch has at most one
 // workgroup per CU with exactly four pixel waves wherever the level allows: 640x480 = 240 workgroups x 256 lanes x 5.
 // Per-pixel arithmetic is the very code of the two-launch chain (icp_project_v / icp_rows_v, rgb_rows), so Jacobian rows,
