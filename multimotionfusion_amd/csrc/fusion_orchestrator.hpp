@@ -64,7 +64,7 @@ struct mmf_fusion {
     // thresholds, poses handed in through mmf_fusion_set_model_pose) -- their owners run on other GPUs
     int shard_rank = 0, shard_world = 1;
     double t_tracking_s = 0, t_frame_s = 0;  // host wall clock of the last processFrame: tracking phase, whole call
-    double trace_us[6] = {0, 0, 0, 0, 0, 0};  // MMF_HOST_TRACE
+    double trace_us[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // MMF_HOST_TRACE
     long trace_calls = 0;
     float* depth_filtered = nullptr;  // = filtered[cur]
     uint8_t* mask = nullptr;          // textures[MASK]: all zeros unless enableMultipleModels
@@ -804,6 +804,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 for (int i = 0; i < MMF_NUM_PYRS; ++i) std::swap(go->last_next_image[i], go->next_image[i]);
                 if (rc) return rc;
             }
+            stamp(6);
             std::vector<FusionModel*> tracked;
             for (size_t k = 0; k < n_models; ++k) {  // :312-387, enqueue only
                 FusionModel* fm = f->models[k];
@@ -845,6 +846,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 fm->tracking = true;
                 tracked.push_back(fm);
             }
+            stamp(7);
             if (so3_stage)  // every chain enqueued below starts from the prefetched pre-alignment
                 for (FusionModel* fm : tracked) fm->odom->so3_prefetched = true, fm->odom->so3_stage = so3_stage;
             // ONE chain of launches for all tracked models (gridDim.y = model) when every level runs on the fused
@@ -883,6 +885,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 }
                 rc = stages.launch(st);
                 if (rc) return rc;
+                stamp(8);
                 // (a PREP_ALL collect above prepared this frame's image side as well; NOT when the pending gradients are the
                 // next frame's, from the image side enqueued ahead a few lines up)
                 if (one_pass && !prefetched) odom_adopt_gradients(global->odom);
@@ -1354,10 +1357,10 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     }
     stamp(5);
     if (host_trace && ++f->trace_calls % 100 == 0) {
-        std::fprintf(stderr, "host us from call start: chains enqueued %.0f, poses here %.0f, segmentation handled %.0f, per-model passes enqueued %.0f, "
-                             "final predicts enqueued %.0f, end %.0f\n",
-                     f->trace_us[0] / 100, f->trace_us[1] / 100, f->trace_us[2] / 100, f->trace_us[3] / 100, f->trace_us[4] / 100,
-                     f->trace_us[5] / 100);
+        std::fprintf(stderr, "host us from call start: next image side enqueued %.0f, lanes waiting %.0f, preparation enqueued %.0f (batched chains), chains enqueued %.0f, "
+                             "poses here %.0f, segmentation handled %.0f, per-model passes enqueued %.0f, final predicts enqueued %.0f, end %.0f\n",
+                     f->trace_us[6] / 100, f->trace_us[7] / 100, f->trace_us[8] / 100, f->trace_us[0] / 100, f->trace_us[1] / 100, f->trace_us[2] / 100,
+                     f->trace_us[3] / 100, f->trace_us[4] / 100, f->trace_us[5] / 100);
         for (double& a : f->trace_us) a = 0;
     }
     f->t_frame_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

@@ -1104,6 +1104,8 @@ struct GnBatchGeom {
     const unsigned long long* sensor;  // the extent words that hold the sensor frame's smallest depth (the leader's: shared, not shifted)
     unsigned sensor_gen;               // ... the number it was noted under (0: unknown)
     float sensor_cutoff;               // ... and the cut-off no sensor depth reaches (createVMap)
+    int rotate;  // the grid's first workgroup is number `rotate` of the list start[] describes (tunables: gn_obj_first: the object
+                 // models' workgroups, which have the longer way to go, are dispatched before the camera model's)
 };
 constexpr int kGnFaultExtent = 3;  // OdomState::gn_fault: an object model's extent does not fit its workgroups (the host walks it densely from then on)
 
@@ -1114,9 +1116,11 @@ template <int PX, bool ERR>
 __global__ __launch_bounds__(64 * kGnMaxWaves) MMF_MIXED_ATTR void gn_iter_mixed_kernel(OdomState* st, GnIterArgs a, BatchDelta bd, GnBatchGeom g) {
     __shared__ GnLds lds;
     unsigned model = 0;
+    int vb = (int)blockIdx.x + g.rotate;
+    vb = vb >= g.start[kMaxBatch] ? vb - g.start[kMaxBatch] : vb;
 #pragma unroll
-    for (int m = 1; m < kMaxBatch; ++m) model = ((int)blockIdx.x >= g.start[m] && g.start[m] < g.start[m + 1]) ? (unsigned)m : model;  // (uniform)
-    const unsigned bid = blockIdx.x - (unsigned)g.start[model], groups = (unsigned)(g.start[model + 1] - g.start[model]);
+    for (int m = 1; m < kMaxBatch; ++m) model = (vb >= g.start[m] && g.start[m] < g.start[m + 1]) ? (unsigned)m : model;  // (uniform)
+    const unsigned bid = (unsigned)(vb - g.start[model]), groups = (unsigned)(g.start[model + 1] - g.start[model]);
     gn_batch_shift(st, a, bd, model);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (!((g.sparse_mask >> model) & 1u)) {

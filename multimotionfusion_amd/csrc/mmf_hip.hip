@@ -34,8 +34,10 @@
 using namespace mmf;
 
 // The enqueue side of a chain of dependent kernel launches: launches go out in call order on one stream, the first error
-// is kept (`flush`).  (Rounds 2-3 could replay such a chain as a hipGraph; a graph launch reaches the GPU ~10 us later than
-// the first kernel of a launch-by-launch chain and the replay is gone: LABNOTES.md.)
+// is kept (`flush`).  (Rounds 2-3 and again round 5 could replay such a chain as a hipGraph -- one host call per chain, the
+// arguments of the nodes that changed replaced.  With one model a graph launch reaches the GPU ~10 us later than the first
+// kernel of a launch-by-launch chain; with eight models it takes the call's start from 330 to 80 us of the calling thread's
+// time and the frame is no shorter: LABNOTES.md.)
 struct Enqueuer {
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
@@ -1510,10 +1512,10 @@ static bool gn_geometry(int level, int cols, int rows, GnGeometry* out, bool mix
     if (mixed && tunables().gn_mixed_lanes > 0 && tunables().gn_mixed_lanes < kBlock) {
         GnGeometry base;
         if (!gn_geometry(level, cols, rows, &base, false) || base.lanes != kBlock) return false;
-        const int lanes = tunables().gn_mixed_lanes / 64 * 64;
+        const int lanes = std::max(32, tunables().gn_mixed_lanes);
         const int groups = (cols * rows / base.px + lanes - 1) / lanes;
         if (groups > kGnMaxGroups) return false;
-        *out = GnGeometry{base.px, lanes, lanes + 64, groups};
+        *out = GnGeometry{base.px, lanes, (lanes + 63) / 64 * 64 + 64, groups};
         return true;
     }
     const int* forced = tunables().gn_px;
@@ -1597,6 +1599,7 @@ static std::atomic<int> g_gn_recoveries{0};
 constexpr int kGnRetry = 0x6e726574;
 static int gn_retry_twice() { return fail(MMF_ERR_STATE, "odometry: tracking gave up twice (the two-launch chain reported a fault)"); }
 
+static bool odom_sparse_on() { return (g_track_cull.load() < 0 ? tunables().track_cull : g_track_cull.load()) != 0; }
 static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float rot[9], int rgb_only, float icp_weight,
                                  int pyramid, int fast_odom, int so3, float* icp_err_dev, float* rgb_err_dev,
                                  const TrackBatch* batch = nullptr) {
@@ -1631,7 +1634,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     // quarter of the workgroups; in the one-launch chain (gn_fused.hpp: gn_iter_mixed_kernel) they walk their extents with a
     // fraction of the workgroups, which is what lets ALL models of a frame be resident in one launch.
     // MMF_TRACK_CULL=0 / mmf_debug_set_track_cull(0): every model like the first.
-    const bool sparse_on = (g_track_cull.load() < 0 ? tunables().track_cull : g_track_cull.load()) != 0;
+    const bool sparse_on = odom_sparse_on();
     bool two_launch_once = false;  // (odom_retrack_prepare: this frame is being tracked again)
     for (unsigned m = 0; m < ny; ++m) {
         mmf_odom* om = batch ? batch->o[m] : o;
@@ -1726,6 +1729,7 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
                 for (unsigned m = 0; m < (unsigned)kMaxBatch; ++m) gg.start[m + 1] = gg.start[m] + (m < ny ? plan.groups[i][m] : 0);
                 gg.sparse_mask = plan.sparse_mask, gg.ext_gen = plan.ext_gen, gg.level = i, gg.extent = o->extent;
                 gg.sensor = o->extent, gg.sensor_gen = o->sensor_gen, gg.sensor_cutoff = o->sensor_cutoff;
+                gg.rotate = tunables().gn_obj_first ? gg.start[1] : 0;  // (the first model of a batch is the camera model)
             }
             for (int j = 0; j < iterations[i]; ++j) {
                 const bool last_l0 = (i == 0 && j == iterations[i] - 1);

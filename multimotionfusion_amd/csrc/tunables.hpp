@@ -16,6 +16,7 @@ struct Tunables {
     int gn_groups = 256;      // MMF_GN_GROUPS: workgroups per model per launch at most
     int gn_mixed_lanes = 192; // MMF_GN_MIXED_LANES: pixel lanes of a workgroup in a launch that carries object models (256: as the others)
     int gn_sleep = 1;         // MMF_GN_SLEEP: s_sleep(1) repetitions between two polls of the count barrier
+    bool gn_obj_first = true; // MMF_GN_OBJ_FIRST=0: a shared launch dispatches the camera model's workgroups first
     int icp_variant = -1;     // MMF_ICP_VARIANT: shape of the stand-alone ICP kernel (-1 = by size)
     // ---- preparation jobs (prep_batch.hpp) ----
     int prep_merge = 2;       // MMF_PREP_MERGE=0|1|2: four / three / two model-side preparation stages
@@ -58,6 +59,7 @@ inline const Tunables& tunables() {
         v.gn_groups = (int)num("MMF_GN_GROUPS", 256);
         v.gn_mixed_lanes = (int)num("MMF_GN_MIXED_LANES", 192);
         v.gn_sleep = (int)num("MMF_GN_SLEEP", 1);
+        v.gn_obj_first = flag("MMF_GN_OBJ_FIRST", true);
         v.icp_variant = (int)num("MMF_ICP_VARIANT", -1);
         v.prep_merge = (int)num("MMF_PREP_MERGE", 2);
         v.prep_vn = flag("MMF_PREP_VN", true);

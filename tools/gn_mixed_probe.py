@@ -54,16 +54,22 @@ s = stamps.cpu().numpy().reshape(-1, 16)
 nb = int(np.count_nonzero(s[:, 13]))
 print(f"{models} models: {nb} workgroups stamped their last slot; by extent:", [g.getModelOdometry(m).sparseWalk()[1] for m in range(models)])
 s = s[:nb]
-t0 = s[1:, 5].min()
+t0 = s[:, 0][s[:, 0] > 0].min()  # the first "state loaded" of the launch
 q = lambda v: " ".join(f"{np.percentile(v, p):6.2f}" for p in (0, 50, 90, 100))  # noqa: E731
 cam = -(-(W * H // 5) // 192)  # the camera model's workgroups in a launch that carries object models: 192 pixel lanes x 5 pixels
-for name, sel in ((f"camera model (workgroups 1..{cam - 1})", s[1:cam]), (f"object models (workgroups {cam}..)", s[cam:])):
+obj_first = os.environ.get("MMF_GN_OBJ_FIRST", "1") != "0"  # (tunables.hpp: the object models' workgroups are dispatched first)
+cam_wgs, obj_wgs = (s[nb - cam:], s[:nb - cam]) if obj_first else (s[:cam], s[cam:])
+for name, sel in ((f"camera model ({cam} workgroups, dispatched {'last' if obj_first else 'first'})", cam_wgs), ("object models", obj_wgs)):
     if len(sel) == 0:
         continue
-    print(f"  {name}: us after the first workgroup's start:                     min    p50    p90    max")
+    print(f"  {name}: us after the launch's first 'state loaded':                     min    p50    p90    max")
     for slot, what in sorted(SLOTS, key=lambda sn: np.median(sel[:, sn[0]])):
         if np.count_nonzero(sel[:, slot]) == 0:
             continue
         print(f"    {what:66s} {q((sel[:, slot] - t0) * 0.01)}")
+if os.environ.get("MMF_PROBE_DUMP"):  # per workgroup, in dispatch order: start, pose in LDS, arrival, sums added
+    print("block  state_loaded  B  accept  arrived  sums_added   (us)")
+    for b in range(nb):
+        print(f"{b:5d} " + " ".join(f"{(s[b, k] - t0) * 0.01:7.2f}" for k in (0, 8, 6, 10, 13)))
 g.close()
 ctx.close()
