@@ -702,9 +702,11 @@ def main():
         chain_b = gn_chain_bytes(W, H)
         gn_chain = {"bytes": chain_b, "us": tm["chain_us"], "GBps": chain_b / max(tm["chain_us"], 1e-9) / 1e3,
                     "frac": chain_b / max(tm["chain_us"], 1e-9) / 1e3 / HBM_PEAK_GBPS, "per_level": per_level,
-                    "what": "one getIncrementalTransformation of one model on the device (odom_begin .. last solve): SO3 pre-alignment "
+                    "what": "one getIncrementalTransformation of one model on the device (first launch .. last solve): SO3 pre-alignment "
                             "(unless prefetched) + 19 Gauss-Newton iterations (" + ("one launch each" if fused else "producer + step launch each") +
-                            "; per_level.producer_us is that launch); bytes = 110 B/px x (10 N0 + 5 N1 + 4 N2)"}
+                            "; per_level.producer_us is that launch); bytes = 110 B/px x (10 N0 + 5 N1 + 4 N2).  The 4-5 us of "
+                            "odom_begin_kernel are inside when it is a launch of its own and outside when it rode the last launch of the "
+                            "preparation enqueued ahead of the frame (hinted frames: csrc/track_kernels.hpp, prep_batch_begin_kernel)"}
         # the stand-alone ICP reduction kernel (the function-level icpStep entry point), back-to-back launches
         us_icp = odom.timeIcpKernel(0, 200)
         icp_standalone = {"kernel": "icp_kernel2<2,1,256,packed> level 0", "us_per_launch_back_to_back": us_icp,

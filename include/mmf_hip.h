@@ -554,6 +554,13 @@ int mmf_debug_set_pass_batch(int mode);
  * that every buffer stays what a whole-frame preparation writes (1, the default) -- or the whole frame (0); -1 = the default
  * (MMF_PREP_RECT).  Same buffers, bit for bit.  Process wide. */
 int mmf_debug_set_prep_rect(int on);
+/* test / A-B hook: when a frame's model side is prepared at the end of the call before it (one model per process, the next frame
+ * handed in), the beginning of its tracking (odom_begin_kernel: RGBDOdometry.cpp:221-228, 237, 252-255, 316-328) rides the
+ * preparation's last launch on one more workgroup (1, the default: csrc/track_kernels.hpp, prep_batch_begin_kernel) or is a launch
+ * of its own in front of the first Gauss-Newton iteration (0); -1 = the default (MMF_BEGIN_RIDER).  Same bits.  Process wide.
+ * mmf_debug_begin_rider_count: chains of this process that found their beginning done. */
+int mmf_debug_set_begin_rider(int on);
+int mmf_debug_begin_rider_count(void);
 /* test / A-B hook: object models in the producer + step chain (csrc/extent.hpp, ChainGeom: their passes skip the blocks outside
  * the model's own depth and walk the images with a quarter of the workgroups).  1 = on, 0 = every model is tracked like the
  * camera model, -1 = the default (MMF_TRACK_CULL, on).  Process wide. */

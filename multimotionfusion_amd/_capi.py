@@ -211,6 +211,8 @@ SIGNATURES = {
     "mmf_debug_set_sparse_check": (_i, [_i]),
     "mmf_debug_set_pass_batch": (_i, [_i]),
     "mmf_debug_set_prep_rect": (_i, [_i]),
+    "mmf_debug_set_begin_rider": (_i, [_i]),
+    "mmf_debug_begin_rider_count": (_i, []),
     "mmf_debug_set_sparse_groups": (_i, [_i]),
     "mmf_debug_odom_sparse_outside": (_i, [_vp, C.POINTER(C.c_uint), C.POINTER(_i), C.POINTER(_i)]),
     "mmf_gn_chain_status": (_i, [C.POINTER(_i), C.POINTER(_i)]),

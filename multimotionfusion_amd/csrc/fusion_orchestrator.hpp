@@ -767,6 +767,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                                fm->model->tex_gen == fm->spec_tex_gen && fm->spec_f2f == g.frame_to_frame_rgb &&
                                fm->odom->prep_batched;
                 fm->spec_valid = false;
+                fm->odom->begin_spec_ok = fm->spec_hit;  // (the tracking's beginning rode that preparation: odom_begin_rider)
                 fm->early_done = fm->early_fused = false;
             }
             const bool one_pass = n_models == 1 && !have_init && fusion_owns(f, 0) && !global->spec_hit;
@@ -1320,7 +1321,19 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                                  only->fill_in ? fusion_thumb_count(m) : nullptr, (const float*)m->fill_vertex,
                                  (const float*)m->fill_normal, (const uint8_t*)m->fill_image, PREP_MODEL_SIDE,
                                  (m->width / 20) * (m->height / 20), 0.75f);
-            rc = stages.launch(st);
+            // ... and the beginning of that tracking (odom_begin_kernel: the pose it starts from is this one, the pre-alignment
+            // of the next frame sits staged since the start of this call) on one more workgroup of the preparation's last launch
+            BeginRider rider;
+            bool ride = false;
+            if (only == global && !stages.empty() && fr->next_rgb && f->image_pre_rgb == fr->next_rgb && !g.rgb_only) {
+                const OdomState* stage = (g.so3 && f->so3_stage_ready >= 0) ? f->so3_stage[f->so3_stage_ready] : nullptr;
+                if (!g.so3 || stage != nullptr) {
+                    if (stage) MMF_HIP_TRY(fusion_wait_unless_done(st, f->ev_prefetch2_done));  // (the staged pre-alignment is complete)
+                    ride = odom_begin_rider(only->odom, only->spec_pose, g.rgb_only, g.icp_weight, g.pyramid, g.fast_odom, g.so3, stage, &rider);
+                }
+            }
+            if (!ride) only->odom->begin_spec_valid = false;
+            rc = stages.launch(st, ride ? &rider : nullptr);
             if (rc) return rc;
             only->spec_tex_gen = m->tex_gen;
             only->spec_f2f = g.frame_to_frame_rgb;

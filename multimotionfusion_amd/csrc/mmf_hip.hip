@@ -829,6 +829,10 @@ struct mmf_odom {
     // such launches from different streams can each hold part of the GPU and wait for the rest forever, so an owner that
     // keeps several chains in flight at once (the orchestrator without batching) clears this and gets the two-launch chain.
     bool exclusive_chain = true;
+    // the beginning of the next tracking already ran, with these arguments, on the last launch of the preparation enqueued ahead
+    // of it (track_kernels.hpp: prep_batch_begin_kernel); begin_spec_ok: the caller vouches that nothing touched the state since
+    bool begin_spec_valid = false, begin_spec_ok = false;
+    BeginArgs begin_spec;
     bool retry_so3_prefetched = false;  // what the last odom_enqueue_tracking consumed (a chain that gives up is enqueued again)
     const OdomState* retry_so3_stage = nullptr;
     bool pending_icp = false, pending_so3 = false;  // mode of the tracking call that is in flight (enqueue -> finish)
@@ -1145,7 +1149,8 @@ struct PrepBuilder {  // the jobs of one stage (possibly of several models); lau
         j.reps = (size_t)cols * rows >= prep_big_job() ? 4 : 1;  // (PrepJob::reps)
         return j;
     }
-    int launch(Enqueuer& q) {
+    // rider: the beginning of the tracking these jobs prepare, on one more workgroup of the stage's LAST launch (BeginRider)
+    int launch(Enqueuer& q, const BeginRider* rider = nullptr) {
         for (size_t first = 0; first < jobs.size(); first += kMaxPrepJobs) {
             PrepBatch b;
             b.njobs = 0;
@@ -1157,7 +1162,13 @@ struct PrepBuilder {  // the jobs of one stage (possibly of several models); lau
                 j.first_block = blocks;
                 blocks += j.rect_now ? j.rect_groups : j.gx * ((j.rows + kTileY * j.reps - 1) / (kTileY * j.reps));
             }
-            q.launch(prep_batch_kernel, dim3(blocks), tile_block(), b);
+            if (rider && first + kMaxPrepJobs >= jobs.size()) {
+                BeginRider r = *rider;
+                r.prep_blocks = blocks;
+                q.launch(prep_batch_begin_kernel, dim3(blocks + 1), tile_block(), b, r);
+            } else {
+                q.launch(prep_batch_kernel, dim3(blocks), tile_block(), b);
+            }
         }
         jobs.clear();
         return MMF_OK;
@@ -1168,16 +1179,24 @@ struct PrepStages {  // the four dependent launches of a frame's preparation
     void set_critical(bool on) {
         for (PrepBuilder& pb : stage) pb.critical = on;
     }
-    int launch(Enqueuer& q) {  // recorded; the caller flushes
-        for (PrepBuilder& pb : stage)
-            if (int rc = pb.launch(q)) return rc;
+    int launch(Enqueuer& q, const BeginRider* rider = nullptr) {  // recorded; the caller flushes.  rider: on the last launch
+        int last = -1;
+        for (int k = 0; k < 4; ++k)
+            if (!stage[k].jobs.empty()) last = k;
+        for (int k = 0; k < 4; ++k)
+            if (int rc = stage[k].launch(q, k == last ? rider : nullptr)) return rc;
         return MMF_OK;
     }
-    int launch(hipStream_t stream) {
+    int launch(hipStream_t stream, const BeginRider* rider = nullptr) {
         Enqueuer q(stream);
-        if (int rc = launch(q)) return rc;
+        if (int rc = launch(q, rider)) return rc;
         MMF_HIP_TRY(q.flush());
         return MMF_OK;
+    }
+    bool empty() const {
+        for (const PrepBuilder& pb : stage)
+            if (!pb.jobs.empty()) return false;
+        return true;
     }
 };
 
@@ -1600,6 +1619,33 @@ constexpr int kGnRetry = 0x6e726574;
 static int gn_retry_twice() { return fail(MMF_ERR_STATE, "odometry: tracking gave up twice (the two-launch chain reported a fault)"); }
 
 static bool odom_sparse_on() { return (g_track_cull.load() < 0 ? tunables().track_cull : g_track_cull.load()) != 0; }
+static void odom_begin_rider_used();
+// what odom_begin_kernel is told (RGBDOdometry.cpp:221-228, 237, 252-255, 316-328); every byte defined (the blocks are compared)
+static BeginArgs odom_begin_args(const mmf_odom* o, const float trans[3], const float rot[9], int rgb_only, float icp_weight, int pyramid,
+                                 int fast_odom, int so3, bool so3_prefetched, const OdomState* so3_stage, bool fused_chain) {
+    const bool icp = !rgb_only && icp_weight > 0;  // :221-222
+    const bool rgb = rgb_only || icp_weight < 100;
+    const int iterations[MMF_NUM_PYRS] = {fast_odom ? 3 : 10, pyramid ? 5 : 0, pyramid ? 4 : 0};  // :312-314
+    int first_iter_level = MMF_NUM_PYRS - 1;  // the coarsest level that runs iterations
+    while (first_iter_level > 0 && !iterations[first_iter_level]) --first_iter_level;
+    BeginArgs b;
+    std::memset(&b, 0, sizeof(b));
+    std::memcpy(b.trans, trans, sizeof(b.trans));
+    std::memcpy(b.rot, rot, sizeof(b.rot));
+    b.rgb_only = rgb_only ? 1 : 0;
+    b.icp = icp ? 1 : 0;
+    b.rgb = rgb ? 1 : 0;
+    b.so3 = so3 ? 1 : 0;
+    b.icp_weight = icp_weight;
+    b.so3_intr = level_intr(o->fx, o->fy, o->cx, o->cy, 2);
+    b.so3_prefetched = (so3 && so3_prefetched) ? 1 : 0;
+    b.so3_stage = b.so3_prefetched ? so3_stage : nullptr;
+    // nothing runs between the beginning and the first level's begin unless the SO3 loop does: one launch
+    b.fold_level_begin = (!so3 || so3_prefetched) ? 1 : 0;
+    // the one-launch chain has no per-level begin: its first launch reads what this one prepares
+    b.first_intr = level_intr(o->fx, o->fy, o->cx, o->cy, fused_chain ? first_iter_level : MMF_NUM_PYRS - 1);
+    return b;
+}
 static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float rot[9], int rgb_only, float icp_weight,
                                  int pyramid, int fast_odom, int so3, float* icp_err_dev, float* rgb_err_dev,
                                  const TrackBatch* batch = nullptr) {
@@ -1659,27 +1705,20 @@ static int odom_enqueue_tracking(mmf_odom* o, const float trans[3], const float 
     int first_iter_level = MMF_NUM_PYRS - 1;  // the coarsest level that runs iterations
     while (first_iter_level > 0 && !iterations[first_iter_level]) --first_iter_level;
 
-    BeginArgs b;
-    std::memcpy(b.trans, trans, sizeof(b.trans));
-    std::memcpy(b.rot, rot, sizeof(b.rot));
-    b.rgb_only = rgb_only ? 1 : 0;
-    b.icp = icp ? 1 : 0;
-    b.rgb = rgb ? 1 : 0;
-    b.so3 = so3 ? 1 : 0;
-    b.icp_weight = icp_weight;
-    b.so3_intr = level_intr(o->fx, o->fy, o->cx, o->cy, 2);
-    b.so3_prefetched = (so3 && o->so3_prefetched) ? 1 : 0;
-    b.so3_stage = b.so3_prefetched ? o->so3_stage : nullptr;
+    const BeginArgs b = odom_begin_args(o, trans, rot, rgb_only, icp_weight, pyramid, fast_odom, so3, o->so3_prefetched, o->so3_stage, fused_chain);
     // nothing runs between the beginning and the first level's begin unless the SO3 loop does: one launch
-    const bool fold_first_level = !so3 || o->so3_prefetched;
-    b.fold_level_begin = fold_first_level ? 1 : 0;
-    // the one-launch chain has no per-level begin: its first launch reads what this one prepares
-    b.first_intr = level_intr(o->fx, o->fy, o->cx, o->cy, fused_chain ? first_iter_level : MMF_NUM_PYRS - 1);
+    const bool fold_first_level = b.fold_level_begin != 0;
     o->n_timed = 0;
     if (o->timing) MMF_HIP_TRY(hipEventRecord(o->ev_chain[0], c->stream));
     // from here to the last step: kernels only, enqueued one by one in call order (Enqueuer keeps the first error)
     Enqueuer q(c->stream);
-    q.launch(odom_begin_kernel, dim3(ny), dim3(64), o->state, b, bd, poses);
+    // (the beginning may have run already, on the last launch of the preparation enqueued ahead of this frame: odom_begin_rider)
+    const bool begun = o->begin_spec_valid && o->begin_spec_ok && !batch && std::memcmp(&b, &o->begin_spec, sizeof(b)) == 0;
+    o->begin_spec_valid = o->begin_spec_ok = false;
+    if (!begun)
+        q.launch(odom_begin_kernel, dim3(ny), dim3(64), o->state, b, bd, poses);
+    else
+        odom_begin_rider_used();
 
     o->retry_so3_prefetched = o->so3_prefetched, o->retry_so3_stage = o->so3_stage;  // (odom_retrack_prepare)
     const bool so3_ran_here = so3 && !o->so3_prefetched;  // in the leader's state: shared with the others at the first level begin
@@ -2089,6 +2128,34 @@ static bool odom_fused_chain_ok(mmf_odom* o, int rgb_only, float icp_weight, int
         if (total > gn_resident_groups(o->ctx, geo.px, geo.threads, pl.sparse_mask != 0)) return false;
     }
     if (plan) *plan = pl;
+    return true;
+}
+
+// The beginning of the NEXT tracking of one model, to ride the last launch of the preparation that is being enqueued ahead of
+// it (track_kernels.hpp: prep_batch_begin_kernel): `pose` = where that tracking will start (the model's pose now), so3_stage =
+// the staged pre-alignment of that frame (null: none, the tracking runs it itself).  odom_enqueue_tracking skips its own
+// odom_begin_kernel when it is about to pass these very arguments and the caller says the state was left alone (begin_spec_ok).
+static std::atomic<int> g_begin_rider{-1};      // -1: MMF_BEGIN_RIDER decides (default on); 0 / 1: mmf_debug_set_begin_rider
+static std::atomic<int> g_begin_riders_used{0};  // chains that found their beginning done (mmf_debug_begin_rider_count)
+extern "C" int mmf_debug_set_begin_rider(int on) {
+    g_begin_rider.store(on < 0 ? -1 : (on ? 1 : 0));
+    return MMF_OK;
+}
+extern "C" int mmf_debug_begin_rider_count(void) { return g_begin_riders_used.load(); }
+static void odom_begin_rider_used() { g_begin_riders_used.fetch_add(1); }
+static bool odom_begin_rider(mmf_odom* o, const float pose[16], int rgb_only, float icp_weight, int pyramid, int fast_odom, int so3,
+                             const OdomState* so3_stage, BeginRider* out) {
+    o->begin_spec_valid = o->begin_spec_ok = false;
+    const int forced = g_begin_rider.load();
+    if (!(forced < 0 ? tunables().begin_rider : forced != 0) || o->two_launch_once) return false;
+    const bool fused = odom_fused_chain_ok(o, rgb_only, icp_weight, pyramid, fast_odom, nullptr, odom_sparse_on(), nullptr);
+    const float trans[3] = {pose[3], pose[7], pose[11]};
+    const float rot[9] = {pose[0], pose[1], pose[2], pose[4], pose[5], pose[6], pose[8], pose[9], pose[10]};
+    std::memset(out, 0, sizeof(*out));
+    out->st = o->state;
+    out->a = odom_begin_args(o, trans, rot, rgb_only, icp_weight, pyramid, fast_odom, so3, so3_stage != nullptr, so3_stage, fused);
+    o->begin_spec = out->a;
+    o->begin_spec_valid = true;
     return true;
 }
 

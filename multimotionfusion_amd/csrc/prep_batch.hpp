@@ -319,12 +319,13 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
     }
 }
 
-__global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
+// workgroup `block` of the launch (64 x 4 threads)
+__device__ __forceinline__ void prep_batch_body(const PrepBatch& b, int block) {
     if (b.critical) __builtin_amdgcn_s_setprio(3);
     int j = 0;
-    for (int k = 1; k < b.njobs; ++k) j = (int)blockIdx.x >= b.job[k].first_block ? k : j;  // wave uniform
+    for (int k = 1; k < b.njobs; ++k) j = block >= b.job[k].first_block ? k : j;  // wave uniform
     const PrepJob& J = b.job[j];
-    const int local = (int)blockIdx.x - J.first_block;
+    const int local = block - J.first_block;
     const bool alt = J.sel != nullptr && (J.sel_total ? ((float)*J.sel / (float)J.sel_total < J.sel_ratio) : *J.sel != 0);  // wave uniform
     const void* src0 = alt ? J.alt0 : J.src0;
     const void* src1 = alt ? J.alt1 : J.src1;
@@ -382,5 +383,6 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) {
         }
     }
 }
+__global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) { prep_batch_body(b, (int)blockIdx.x); }
 
 }  // namespace mmf

@@ -15,6 +15,7 @@
 #include "icp_kernels.hpp"
 #include "odom_state.hpp"
 #include "pose_algebra.hpp"
+#include "prep_batch.hpp"
 #include "frame_rider.hpp"
 
 namespace mmf {
@@ -884,19 +885,12 @@ __device__ __forceinline__ void so3_share(OdomState* dst, const OdomState* src) 
     so3_store(dst, s);
 }
 
-// RGBDOdometry.cpp:221-228, 237, 252-255, 316-328.  Batched: block m = model m, poses from `poses`.
-__global__ void odom_begin_kernel(OdomState* st, BeginArgs a, BatchDelta bd, BeginPoses poses) {
-    if (threadIdx.x < 64) {  // the first gn_iter_kernel launch adds its sums here
-        OdomState* sm = gridDim.x > 1 ? batch_shift(st, bd.d[blockIdx.x]) : st;
-        for (int x = 0; x < kGnSumShards; ++x) sm->gn_sum[0][x][threadIdx.x] = 0ll;
-    }
-    if (threadIdx.x != 0) return;
-    const OdomState* leader = st;
-    if (gridDim.x > 1) {
-        st = batch_shift(st, bd.d[blockIdx.x]);
-        for (int k = 0; k < 9; ++k) a.rot[k] = poses.rot[blockIdx.x][k];
-        for (int k = 0; k < 3; ++k) a.trans[k] = poses.trans[blockIdx.x][k];
-    }
+// RGBDOdometry.cpp:221-228, 237, 252-255, 316-328 for one model (64 lanes; lane 0 does the bookkeeping).
+// leader: the state a prefetched pre-alignment sits in when there is no staging state (the first model's); follower: not that model
+__device__ __forceinline__ void odom_begin_model(OdomState* st, const OdomState* leader, const BeginArgs& a, bool follower, int lane) {
+    if (lane < 64)  // the first gn_iter_kernel launch adds its sums here
+        for (int x = 0; x < kGnSumShards; ++x) st->gn_sum[0][x][lane] = 0ll;
+    if (lane != 0) return;
     for (int k = 0; k < 9; ++k) st->Rprev[k] = st->Rcurr[k] = a.rot[k];
     for (int k = 0; k < 3; ++k) st->tprev[k] = st->tcurr[k] = a.trans[k];
     inverse3f(st->Rprev, st->Rprev_inv);
@@ -915,9 +909,37 @@ __global__ void odom_begin_kernel(OdomState* st, BeginArgs a, BatchDelta bd, Beg
         so3_begin(st, a.so3_intr, a.so3);
     else if (a.so3_stage)
         so3_share(st, a.so3_stage);
-    else if (blockIdx.x > 0)
+    else if (follower)
         so3_share(st, leader);  // the prefetched pre-alignment sits complete in the leader's state (nobody writes it here)
     if (a.fold_level_begin) gn_level_begin(st, 1, a.first_intr);
+}
+// Batched: block m = model m, poses from `poses`.
+__global__ void odom_begin_kernel(OdomState* st, BeginArgs a, BatchDelta bd, BeginPoses poses) {
+    OdomState* sm = st;
+    if (gridDim.x > 1) {
+        sm = batch_shift(st, bd.d[blockIdx.x]);
+        for (int k = 0; k < 9; ++k) a.rot[k] = poses.rot[blockIdx.x][k];
+        for (int k = 0; k < 3; ++k) a.trans[k] = poses.trans[blockIdx.x][k];
+    }
+    odom_begin_model(sm, st, a, blockIdx.x > 0, (int)threadIdx.x);
+}
+// The last launch of a frame's model-side preparation (prep_batch.hpp) with the beginning of the tracking it prepares on one
+// more workgroup: when a frame is prepared at the end of the call before it (fusion_orchestrator.hpp: FusionModel::spec_valid)
+// the pose it starts from, the mode and the staged pre-alignment are known as well, and odom_begin_kernel -- 4-5 us of one
+// lane's bookkeeping between the preparation and the first Gauss-Newton launch on the stream a frame waits for -- runs beside
+// the preparation's last stage instead.  odom_enqueue_tracking skips its own launch when the arguments it would pass are
+// these, bit for bit.
+struct BeginRider {
+    OdomState* st;
+    int prep_blocks;  // workgroups of the preparation in this launch; the one after them is the rider's
+    BeginArgs a;
+};
+__global__ __launch_bounds__(256) void prep_batch_begin_kernel(PrepBatch b, BeginRider r) {
+    if ((int)blockIdx.x < r.prep_blocks) {
+        prep_batch_body(b, (int)blockIdx.x);
+        return;
+    }
+    if (threadIdx.y == 0) odom_begin_model(r.st, r.st, r.a, false, (int)threadIdx.x);
 }
 
 // share_so3: the SO3 loop has just run in the leader's state (block 0's)

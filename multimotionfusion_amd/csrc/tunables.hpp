@@ -24,6 +24,7 @@ struct Tunables {
     bool prep_l0_late = true; // MMF_PREP_L0_LATE=0: the model side's level-0 jobs in its first launch
     long prep_big = -1;       // MMF_PREP_BIG=<pixels>|0: from how many pixels a job's workgroups take four tiles each
     bool prep_planar = false; // MMF_PREP_PLANAR=1: also write the planar model maps and the AoS point cloud
+    bool begin_rider = true;  // MMF_BEGIN_RIDER=0: odom_begin_kernel always as a launch of its own (else: on the last launch of a preparation enqueued ahead of the frame)
     bool prep_rect = true;    // MMF_PREP_RECT=0: an object model's model-side preparation covers the whole frame (else: the box its prediction is non-zero in)
     // ---- orchestrator (fusion_orchestrator.hpp) ----
     int early_image = 2;      // MMF_EARLY_IMAGE=start|chain|off: where the next frame's image side is enqueued
@@ -67,6 +68,7 @@ inline const Tunables& tunables() {
         v.prep_big = num("MMF_PREP_BIG", -1);
         v.prep_planar = flag("MMF_PREP_PLANAR", false);
         v.prep_rect = flag("MMF_PREP_RECT", true);
+        v.begin_rider = flag("MMF_BEGIN_RIDER", true);
         if (const char* e = std::getenv("MMF_EARLY_IMAGE")) v.early_image = std::strcmp(e, "off") == 0 ? 0 : (std::strcmp(e, "chain") == 0 ? 1 : 2);
         v.fuse_index = flag("MMF_FUSE_INDEX", true);
         v.host_up_events = flag("MMF_HOST_UP_EVENTS", false);

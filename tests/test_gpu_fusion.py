@@ -351,16 +351,28 @@ def test_prefetched_frames_give_the_same_bits(gpu_ctx, w, h):
         assert np.array_equal(b.getCurrPose(), ref_poses[i]), i
     assert np.array_equal(b.getBackgroundModel().downloadMap().view(np.uint32), ref_map.view(np.uint32))
     b.close()
-    # the same through mmf_frame::next_*: the prefetch is enqueued inside processFrame while it waits for its pose
-    c = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
-    for i in range(n):
-        nxt = (rgb[i + 1], depth[i + 1]) if i + 1 < n else None
-        if i == 3:
-            nxt = (rgb[0], depth[0])  # a hint that turns out wrong: discarded by the next call
-        c.processFrame(rgb[i], depth[i], timestamp=i, next=nxt)
-        assert np.array_equal(c.getCurrPose(), ref_poses[i]), i
-    assert np.array_equal(c.getBackgroundModel().downloadMap().view(np.uint32), ref_map.view(np.uint32))
-    c.close()
+    # the same through mmf_frame::next_*: the prefetch is enqueued inside processFrame while it waits for its pose.  The model
+    # side of the next frame is then prepared at the end of the call, and the beginning of its tracking (odom_begin_kernel) rides
+    # that preparation's last launch (csrc/track_kernels.hpp: prep_batch_begin_kernel) -- unless told not to: same bits either way
+    for rider in (1, 0):
+        gpu_ctx.lib.mmf_debug_set_begin_rider(rider)
+        used = gpu_ctx.lib.mmf_debug_begin_rider_count()
+        try:
+            c = MultiMotionFusion(gpu_ctx, w, h, K["cx"], K["cy"], K["fx"], K["fy"])
+            for i in range(n):
+                nxt = (rgb[i + 1], depth[i + 1]) if i + 1 < n else None
+                if i == 3:
+                    nxt = (rgb[0], depth[0])  # a hint that turns out wrong: discarded by the next call
+                c.processFrame(rgb[i], depth[i], timestamp=i, next=nxt)
+                assert np.array_equal(c.getCurrPose(), ref_poses[i]), (rider, i)
+            assert np.array_equal(c.getBackgroundModel().downloadMap().view(np.uint32), ref_map.view(np.uint32))
+            c.close()
+        finally:
+            gpu_ctx.lib.mmf_debug_set_begin_rider(-1)
+        used = gpu_ctx.lib.mmf_debug_begin_rider_count() - used
+        # frames 1, 2, 3 and 5 start behind a correct hint and a model side prepared at the end of the call before (frame 0 only
+        # initialises the map; frame 4's hint was wrong)
+        assert used == (4 if rider else 0), (rider, used)
 
 
 def test_prefetch_with_frames_that_are_not_tracked(gpu_ctx):
