@@ -806,14 +806,22 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 if (rc) return rc;
             }
             stamp(6);
+            // Several models in one chain (below): an object model's stream gets its next work behind that chain -- it waits for
+            // an event recorded there -- so the wait for the frame's sensor side here would be a second barrier packet per stream
+            // and two host calls per model at the point of the call where the GPU waits for the calling thread.
+            int will_track = 0;
+            for (size_t k = 0; k < n_models; ++k) will_track += fusion_owns(f, k) ? 1 : 0;
+            const bool will_batch = will_track > 1 && will_track <= kMaxBatch && !have_init && g.batch_tracking;
             std::vector<FusionModel*> tracked;
             for (size_t k = 0; k < n_models; ++k) {  // :312-387, enqueue only
                 FusionModel* fm = f->models[k];
                 fm->tracking = false;
                 if (!fusion_owns(f, k)) continue;
                 if (k > 0) {
-                    rc = lane_wait(fm, f->ev_frame_ready);
-                    if (rc) return rc;
+                    if (!will_batch) {
+                        rc = lane_wait(fm, f->ev_frame_ready);
+                        if (rc) return rc;
+                    }
                     odom_alias_sensor_side(fm->odom, global->odom);
                 }
                 bool do_icp = true;
@@ -872,6 +880,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 FusionModel* lead = tracked[0];
                 hipStream_t st = lead->lane->stream;
                 for (size_t k = 1; k < tracked.size(); ++k) {  // the other models' last work (previous frame's predict) precedes
+                    // (a model prepared at the end of the last call, behind the join of all streams there, and untouched since:
+                    // nothing enqueued below reads what its stream may still hold)
+                    if (tracked[k]->spec_hit) continue;
                     MMF_HIP_TRY(hipEventRecord(tracked[k]->ev_done, tracked[k]->lane->stream));
                     MMF_HIP_TRY(hipStreamWaitEvent(st, tracked[k]->ev_done, 0));
                 }
@@ -909,7 +920,10 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     rc = odom_enqueue_tracking(lead->odom, tb.poses.trans[0], tb.poses.rot[0], g.rgb_only, g.icp_weight, g.pyramid,
                                                g.fast_odom, g.so3, lead->icp_error, lead->rgb_error, &tb);
                     if (rc) return rc;
-                    for (size_t k = 1; k < tracked.size(); ++k) {  // the lanes continue after the chain
+                    // the lanes continue after the chain.  With a segmentation every lane waits for ev_frame_ready before its
+                    // passes anyway, and that event is recorded on this very stream (the camera model's) behind the chain (the mask's upload, below):
+                    // an event and a wait per model here would be fourteen host calls and seven barrier packets for nothing
+                    for (size_t k = 1; k < tracked.size() && !(g.enable_multiple_models && st == c->stream); ++k) {
                         MMF_HIP_TRY(hipEventRecord(tracked[k]->ev_done, st));
                         MMF_HIP_TRY(hipStreamWaitEvent(tracked[k]->lane->stream, tracked[k]->ev_done, 0));
                     }
@@ -917,6 +931,10 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             }
             for (size_t k = 0; k < tracked.size() && !batch_ok; ++k) {
                 FusionModel* fm = tracked[k];
+                if (will_batch && fm != global) {  // (the wait skipped above)
+                    rc = lane_wait(fm, f->ev_frame_ready);
+                    if (rc) return rc;
+                }
                 if (fm->spec_hit) {  // the model side was prepared at the end of the last frame; the sensor side by the prefetch
                     fm->odom->depth_l0 = f->depth_filtered;  // (or just above)
                 } else if (!batched) {  // (a failed batch has prepared every model already)
@@ -1035,7 +1053,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                     int rc2 = odom_enqueue_tracking(lead->odom, tb.poses.trans[0], tb.poses.rot[0], g.rgb_only, g.icp_weight, g.pyramid,
                                                     g.fast_odom, g.so3, lead->icp_error, lead->rgb_error, &tb);
                     if (rc2) return rc2;
-                    for (size_t k = 1; k < tracked.size(); ++k) {
+                    for (size_t k = 1; k < tracked.size() && !(g.enable_multiple_models && lead->lane->stream == c->stream); ++k) {  // (as above)
                         MMF_HIP_TRY(hipEventRecord(tracked[k]->ev_done, lead->lane->stream));
                         MMF_HIP_TRY(hipStreamWaitEvent(tracked[k]->lane->stream, tracked[k]->ev_done, 0));
                     }
