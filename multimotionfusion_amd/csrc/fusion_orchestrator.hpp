@@ -615,12 +615,19 @@ extern "C" int mmf_debug_set_pass_batch(int mode) {
     return MMF_OK;
 }
 // 0: model by model; 1: one launch per pass, each covering the whole frame (*_batched_kernel); 2: one launch per pass,
-// restricted to where the models are (pass_rect.hpp)
-static int fusion_batch_mode() {
-    const int v = g_batch_passes.load();
-    return v < 0 ? tunables().pass_batch : v;
+// restricted to where the models are (pass_rect.hpp).  Neither the hook nor MMF_PASS_BATCH says: by the number of object
+// models this GPU runs -- model by model on the models' own streams up to three of them, restricted launches from four on
+// (measured, LABNOTES r5: 8 models 0.69-0.70 against 0.76-0.78 ms, 5 models 0.60-0.62 against 0.65-0.67, 4 models 0.575-0.58
+// against 0.55-0.59)
+constexpr int kRectPassObjects = 4;
+static int fusion_batch_mode(const mmf_fusion* f) {
+    int v = g_batch_passes.load();
+    if (v < 0) v = tunables().pass_batch;
+    if (v >= 0) return v;
+    int objects = 0;
+    for (size_t k = 1; k < f->models.size(); ++k) objects += fusion_owns(f, k) ? 1 : 0;
+    return objects >= kRectPassObjects ? 2 : 0;
 }
-static bool fusion_batch_passes() { return fusion_batch_mode() != 0; }
 // the boxes of the ids of the frame's id image (pass_rect.hpp: mask_boxes_kernel), on `st`
 static int fusion_note_mask_boxes(mmf_fusion* f, hipStream_t st) {
     if (!f->mask_boxes) {
@@ -1197,7 +1204,8 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
         // set the pace of this part of the frame.  The camera model keeps its own stream and kernels (riders, fill-in).
         std::vector<FusionModel*> objs;
         const bool fuse_now = !g.rgb_only && f->tracking_ok;
-        for (size_t k = 1; k < f->models.size() && fusion_batch_passes() && fuse_now && !fusion_mid_predict(); ++k) {
+        const int pass_mode = fusion_batch_mode(f);
+        for (size_t k = 1; k < f->models.size() && pass_mode != 0 && fuse_now && !fusion_mid_predict(); ++k) {
             FusionModel* fm = f->models[k];
             if (!fusion_owns(f, k) || fm->early_done || fm->early_fused || fm->fill_in || (int)objs.size() >= kMaxPassBatch) continue;
             objs.push_back(fm);
@@ -1239,7 +1247,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
                 ms[k] = objs[k]->model;
                 wts[k] = fusion_weight(pose, objs[k]->last_pose, weight_multiplier);
             }
-            if (fusion_batch_mode() >= 2) {
+            if (pass_mode >= 2) {
                 rc = fusion_note_mask_boxes(f, st);
                 if (rc) return rc;
                 rc = models_fuse_clean_rect(ms, (int)objs.size(), st, f->tick, g.time_delta, g.max_depth_processed, f->frame_rgb, f->mask,
@@ -1254,7 +1262,8 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
     stamp(3);
     {  // predict() (:821): the object models without fill-in as one batch, the others one by one
         std::vector<FusionModel*> objs;
-        for (size_t k = 1; k < f->models.size() && fusion_batch_passes(); ++k) {
+        const int pass_mode = fusion_batch_mode(f);
+        for (size_t k = 1; k < f->models.size() && pass_mode != 0; ++k) {
             FusionModel* fm = f->models[k];
             if (!fusion_owns(f, k) || fm->fill_in || !model_predict_batchable(fm->model) || (int)objs.size() >= kMaxPassBatch) continue;
             objs.push_back(fm);
@@ -1272,7 +1281,7 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             if (rc) return rc;
             mmf_model* ms[kMaxPassBatch];
             for (size_t k = 0; k < objs.size(); ++k) ms[k] = objs[k]->model;
-            rc = fusion_batch_mode() >= 2 ? models_combined_predict_rect(ms, (int)objs.size(), st, g.max_depth_processed, f->tick, f->tick, g.time_delta)
+            rc = pass_mode >= 2 ? models_combined_predict_rect(ms, (int)objs.size(), st, g.max_depth_processed, f->tick, f->tick, g.time_delta)
                                           : models_combined_predict_batched(ms, (int)objs.size(), st, g.max_depth_processed, f->tick, f->tick, g.time_delta);
             if (rc) return rc;
             // the other objects' streams continue behind the batch: whatever is enqueued on them next reads what it wrote

@@ -34,10 +34,11 @@ struct Tunables {
     // ---- surfel passes ----
     int track_cull = 1;       // MMF_TRACK_CULL=0: object models are tracked like the camera model (whole image, full grids)
     int spec_prep_all = 1;    // MMF_SPEC_PREP_ALL=0: with several models per GPU the model-side preparation waits for the next call
-    int pass_batch = 0;       // MMF_PASS_BATCH=0|1|2: the object models' projection / fuse / clean / predict passes model by model on the models' own
+    int pass_batch = -1;      // MMF_PASS_BATCH=0|1|2: the object models' projection / fuse / clean / predict passes model by model on the models' own
                               // streams / as one launch per pass covering the whole frame / as one launch per pass restricted to where the models
-                              // are (pass_rect.hpp).  All bit-identical.  Measured (LABNOTES r5): 2 does 9 % less GPU work with a fifth of the launches
-                              // and is no faster -- the camera model's own passes and the calling thread's launch rate bound that part of the frame
+                              // are (pass_rect.hpp).  All bit-identical.  -1 (default): 2 from four object models on a GPU, else 0 -- the restricted
+                              // launches do 9 % less GPU work with a fifth of the launches, which pays once the calling thread's ~11 launches per
+                              // model are what the GPU waits for (LABNOTES r5)
     int splat_wgs = 0;        // MMF_SPLAT_WGS: workgroups of a splat launch (0 = by the store's size)
     int splat_bound = -1;     // MMF_SPLAT_BOUND=0|1: the bounded depth test never / always (-1 = by the store's size)
 };
@@ -75,7 +76,7 @@ inline const Tunables& tunables() {
         v.host_trace = flag("MMF_HOST_TRACE", false);
         v.track_cull = (int)num("MMF_TRACK_CULL", 1);
         v.spec_prep_all = (int)num("MMF_SPEC_PREP_ALL", 1);
-        v.pass_batch = (int)num("MMF_PASS_BATCH", 0);
+        v.pass_batch = (int)num("MMF_PASS_BATCH", -1);
         v.splat_wgs = (int)num("MMF_SPLAT_WGS", 0);
         if (std::getenv("MMF_SPLAT_BOUND")) v.splat_bound = num("MMF_SPLAT_BOUND", 0) ? 1 : 0;
         return v;

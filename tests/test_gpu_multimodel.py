@@ -448,7 +448,8 @@ def test_extent_walk_equals_dense_walk_frame_by_frame(gpu_ctx, fast):
         lib.mmf_debug_set_track_cull(-1)
 
 
-def test_batched_passes_equal_passes_model_by_model(gpu_ctx):
+@pytest.mark.parametrize("n_obj", [4, 6])
+def test_batched_passes_equal_passes_model_by_model(gpu_ctx, n_obj):
     """The object models' projection / fuse / clean / predict passes go out as ONE launch per pass for all of them (gridDim.y =
     model) instead of ~9 launches per model on the model's own stream (MultiMotionFusion.cpp:791-816, 863-875 loop over the
     models) -- restricted to where each model is (csrc/pass_rect.hpp: the boxes of its key-image writes, of its non-zero
@@ -457,7 +458,7 @@ def test_batched_passes_equal_passes_model_by_model(gpu_ctx):
     image, also where the restricted passes never go -- and error images must agree bit for bit."""
     from multimotionfusion_amd.fusion import MultiMotionFusion
     lib = gpu_ctx.lib
-    w, h, n_frames, n_obj = 320, 240, 8, 4
+    w, h, n_frames = 320, 240, n_obj + 4
     K, poses, traj, frames, objs = scene(w, h, n_frames, n_obj, seed=39)
     rgb, depth = [dev(f["rgb"]) for f in frames], [dev(f["depth"]) for f in frames]
 
@@ -486,8 +487,11 @@ def test_batched_passes_equal_passes_model_by_model(gpu_ctx):
             lib.mmf_debug_set_pass_batch(-1)
         return out, maps, tex, err
 
-    a, b = run(2), run(0)  # restricted to where the models are (csrc/pass_rect.hpp: the default) against model by model
-    c = run(1)             # ... and the batched launches that cover the whole frame
+    # restricted to where the models are (csrc/pass_rect.hpp) against model by model ... and the batched launches that cover the
+    # whole frame.  Six objects: the DEFAULT (-1: model by model up to three object models on a GPU, restricted launches from the
+    # fourth on -- the mode changes in the middle of the sequence, when the fourth object is spawned) against model by model
+    a, b = run(2 if n_obj == 4 else -1), run(0)
+    c = run(1) if n_obj == 4 else a
     for x, y in ((a, c),):
         for i in range(n_frames):
             for pa, pb in zip(x[0][i], y[0][i]):
