@@ -33,7 +33,7 @@ python3 $R/tools/kstats.py $(ls $O/prof_4m/*results.db | head -1) 100 gn_iter > 
 python3 $R/tools/gn_mixed_probe.py 8 > $O/r05_gn_mixed_probe.txt 2>&1
 python3 $R/tools/gn_mixed_probe.py 2 >> $O/r05_gn_mixed_probe.txt 2>&1
 python3 $R/tools/mm_sparse_probe.py 8 24 > $O/r05_sparse_walk_probe.txt 2>&1
-{ for m in 2 4 8; do for c in MMF_PASS_BATCH=0 MMF_PASS_BATCH=1 MMF_PASS_BATCH=2 MMF_PREP_RECT=0 MMF_GN_MIXED_LANES=256 MMF_GN_FUSED=0; do echo "$m models $c: $(env $c timeout -k 10 200 python3 $R/tools/profile_frames.py 200 640x480 $m 1 2>&1 | grep 'ms per frame')"; done; done; } > $O/r05_multi_model_ab.txt 2>&1
+{ for m in 2 4 8; do for c in MMF_NOP=1 MMF_PASS_BATCH=0 MMF_PASS_BATCH=1 MMF_PASS_BATCH=2 MMF_GN_OBJ_FIRST=0 MMF_PREP_RECT=0 MMF_GN_MIXED_LANES=256 MMF_GN_FUSED=0; do echo "$m models $c: $(env $c timeout -k 10 200 python3 $R/tools/profile_frames.py 200 640x480 $m 1 2>&1 | grep 'ms per frame')"; done; done; } > $O/r05_multi_model_ab.txt 2>&1
 (cd $R && python3 -c "import __graft_entry__ as g; g.smoke()") > $O/r05_smoke.txt 2>&1
 cd $R
 python3 tools/host_frames.py > $O/r05_host_frames.txt 2>&1
