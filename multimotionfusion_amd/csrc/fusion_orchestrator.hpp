@@ -800,7 +800,12 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             //   =off: at the end of the call with the depth side.
             // so3_stage: this frame's own pre-alignment ran ahead as well -- inside the chain it reads the LAST frame's level-2
             // image, the half of the image ring the next frame's pyramid is written to.
-            const int early_image = tunables().early_image;
+            // (-1, the default: `start` with one or two models on this GPU -- the GPU is still busy when the call begins --,
+            // `chain` from three on: there the GPU waits for the chain's first launch when the call begins, and sixteen
+            // launches enqueued in front of it are 50-80 us of that wait: 4 models 0.617 -> 0.558 ms, 8 models 0.70 -> 0.69)
+            int owned_models = 0;
+            for (size_t k = 0; k < n_models; ++k) owned_models += fusion_owns(f, k) ? 1 : 0;
+            const int early_image = tunables().early_image >= 0 ? tunables().early_image : (owned_models >= 3 ? 1 : 2);
             const bool next_from_host = f->host_next.slot >= 0 && f->up_dev[0] != nullptr;  // (a frame still being uploaded)
             const bool image_early_any = fr->next_rgb && fr->next_depth && f->side2 && g.so3 && so3_stage != nullptr;
             const bool image_early_ok = image_early_any && !next_from_host;

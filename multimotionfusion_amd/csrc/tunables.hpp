@@ -27,7 +27,7 @@ struct Tunables {
     bool begin_rider = true;  // MMF_BEGIN_RIDER=0: odom_begin_kernel always as a launch of its own (else: on the last launch of a preparation enqueued ahead of the frame)
     bool prep_rect = true;    // MMF_PREP_RECT=0: an object model's model-side preparation covers the whole frame (else: the box its prediction is non-zero in)
     // ---- orchestrator (fusion_orchestrator.hpp) ----
-    int early_image = 2;      // MMF_EARLY_IMAGE=start|chain|off: where the next frame's image side is enqueued
+    int early_image = -1;     // MMF_EARLY_IMAGE=start|chain|off: where the next frame's image side is enqueued (2 / 1 / 0; -1: by the number of models)
     bool fuse_index = true;   // MMF_FUSE_INDEX=0: fuse's update pass and the index map's projection as two launches
     bool host_up_events = false;  // MMF_HOST_UP_EVENTS=1: host frames: always order a ring slot's upload by events
     bool host_trace = false;  // MMF_HOST_TRACE=1: the calling thread's timeline (stderr, every 100 calls)
