@@ -1370,13 +1370,14 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             only->spec_tex_gen = m->tex_gen;
             only->spec_f2f = g.frame_to_frame_rgb;
             only->spec_valid = true;
-        } else if (owned > 3 && f->shard_world <= 1 && g.batch_tracking && owned <= kMaxBatch && tunables().spec_prep_all) {
+        } else if (owned >= std::max(2, tunables().spec_prep_all) && f->shard_world <= 1 && g.batch_tracking && owned <= kMaxBatch && tunables().spec_prep_all) {
             // Several models on this GPU: the same for all of them, in the launches they will share (the batched chain's
             // preparation: one set of stages, every model's jobs).  At the start of the next call these ~50 jobs were what the
             // calling thread enqueued first -- 130 us of it and as much of the GPU's -- while the GPU had nothing else to do; here
             // they queue up behind the frame's last passes.  A model whose pose or prediction changes before it is tracked
-            // (a pose initialisation, a caller's predict()) is prepared again then (spec_hit).  From four models on: with two or
-            // three (the one-launch chain) the call's start is short and the early preparation measured 6 % slower.
+            // (a pose initialisation, a caller's predict()) is prepared again then (spec_hit).  From two models on (round 4: from
+            // four -- with two or three the early preparation measured 6 % slower while every model's stream was joined by an
+            // event in front of the chain; a model prepared HERE needs no such wait, and it is 4-7 % faster: LABNOTES r5).
             PrepStages stages;
             stages.set_critical(true);
             const unsigned ext_gen = ++f->extent_seq;

@@ -33,7 +33,7 @@ struct Tunables {
     bool host_trace = false;  // MMF_HOST_TRACE=1: the calling thread's timeline (stderr, every 100 calls)
     // ---- surfel passes ----
     int track_cull = 1;       // MMF_TRACK_CULL=0: object models are tracked like the camera model (whole image, full grids)
-    int spec_prep_all = 1;    // MMF_SPEC_PREP_ALL=0: with several models per GPU the model-side preparation waits for the next call
+    int spec_prep_all = 2;    // MMF_SPEC_PREP_ALL=<n>: from n models per GPU on the next frame's model-side preparation of all models is enqueued at the end of the frame (0: never)
     int pass_batch = -1;      // MMF_PASS_BATCH=0|1|2: the object models' projection / fuse / clean / predict passes model by model on the models' own
                               // streams / as one launch per pass covering the whole frame / as one launch per pass restricted to where the models
                               // are (pass_rect.hpp).  All bit-identical.  -1 (default): 2 from four object models on a GPU, else 0 -- the restricted
@@ -75,7 +75,7 @@ inline const Tunables& tunables() {
         v.host_up_events = flag("MMF_HOST_UP_EVENTS", false);
         v.host_trace = flag("MMF_HOST_TRACE", false);
         v.track_cull = (int)num("MMF_TRACK_CULL", 1);
-        v.spec_prep_all = (int)num("MMF_SPEC_PREP_ALL", 1);
+        v.spec_prep_all = (int)num("MMF_SPEC_PREP_ALL", 2);
         v.pass_batch = (int)num("MMF_PASS_BATCH", -1);
         v.splat_wgs = (int)num("MMF_SPLAT_WGS", 0);
         if (std::getenv("MMF_SPLAT_BOUND")) v.splat_bound = num("MMF_SPLAT_BOUND", 0) ? 1 : 0;
