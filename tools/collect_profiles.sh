@@ -33,12 +33,13 @@ python3 $R/tools/kstats.py $(ls $O/prof_4m/*results.db | head -1) 100 gn_iter > 
 python3 $R/tools/gn_mixed_probe.py 8 > $O/r05_gn_mixed_probe.txt 2>&1
 python3 $R/tools/gn_mixed_probe.py 2 >> $O/r05_gn_mixed_probe.txt 2>&1
 python3 $R/tools/mm_sparse_probe.py 8 24 > $O/r05_sparse_walk_probe.txt 2>&1
-{ for m in 2 4 8; do for c in MMF_NOP=1 MMF_PASS_BATCH=0 MMF_PASS_BATCH=1 MMF_PASS_BATCH=2 MMF_GN_OBJ_FIRST=0 MMF_PREP_RECT=0 MMF_GN_MIXED_LANES=256 MMF_GN_FUSED=0; do echo "$m models $c: $(env $c timeout -k 10 200 python3 $R/tools/profile_frames.py 200 640x480 $m 1 2>&1 | grep 'ms per frame')"; done; done; } > $O/r05_multi_model_ab.txt 2>&1
+{ for m in 2 4 8; do for c in MMF_NOP=1 MMF_PASS_BATCH=0 MMF_PASS_BATCH=2 MMF_EARLY_IMAGE=start MMF_SPEC_PREP_ALL=4 MMF_GN_OBJ_FIRST=0 MMF_PREP_RECT=0 MMF_GN_MIXED_LANES=256 MMF_GN_FUSED=0; do echo "$m models $c: $(env $c timeout -k 10 200 python3 $R/tools/profile_frames.py 200 640x480 $m 1 2>&1 | grep 'ms per frame')"; done; done; } > $O/r05_multi_model_ab.txt 2>&1
 (cd $R && python3 -c "import __graft_entry__ as g; g.smoke()") > $O/r05_smoke.txt 2>&1
 cd $R
 python3 tools/host_frames.py > $O/r05_host_frames.txt 2>&1
 echo "probes done"
 MMF_BENCH_WORKLOAD=config5 python bench.py --no-cpu-baseline --no-extras 2>> $O/bench.err | grep '^{"metric"' > $O/r05_bench_config5_n1.json
 MMF_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>> $O/bench.err | grep '^{"metric"' > $O/r05_bench_gloo_n2.json
+bash $R/tools/mm_trace.sh 8 r05tl > /dev/null 2>&1; cp $R/gpurun_out/mmt_r05tl_timeline.txt $O/r05_timeline_8models.txt; cd $R
 rm -rf $O/prof_bench $O/prof_headline $O/prof_8m $O/prof_4m $O/pmc_f $O/pmc_w
 ls -la $O
