@@ -559,6 +559,10 @@ int mmf_debug_set_prep_rect(int on);
  * preparation's last launch on one more workgroup (1, the default: csrc/track_kernels.hpp, prep_batch_begin_kernel) or is a launch
  * of its own in front of the first Gauss-Newton iteration (0); -1 = the default (MMF_BEGIN_RIDER).  Same bits.  Process wide.
  * mmf_debug_begin_rider_count: chains of this process that found their beginning done. */
+/* test / A-B hook: every XCD works on one contiguous eighth of a surfel pass's blocks (1, the default: csrc/surfel_kernels.hpp,
+ * xcd_block) or the blocks are dealt round-robin as the workgroups are (0); -1 = the default (MMF_XCD).  Same bits.  Synchronises
+ * the device; process wide. */
+int mmf_debug_set_xcd(int on);
 int mmf_debug_set_begin_rider(int on);
 int mmf_debug_begin_rider_count(void);
 /* test / A-B hook: object models in the producer + step chain (csrc/extent.hpp, ChainGeom: their passes skip the blocks outside

@@ -47,4 +47,20 @@ __device__ __forceinline__ int float2int_rn(float x) {
     return (int)rintf(x);
 }
 
+// ---- which XCD works on which blocks ------------------------------------------------------------
+// The workgroups of a launch are dealt to the eight XCDs round-robin by their index, and every XCD has an L2 of its own.
+// Neighbouring blocks of a pass over the IMAGE share cache lines -- the 3 x 3 window texels of fuse_data_kernel, the key
+// image's lines under fuse_update_index_kernel's projection -- and dealt out round-robin the neighbours sit on eight different
+// L2s, each of which fetches the shared lines again.  xcd_block maps a workgroup's index to the block it works on so that
+// every XCD gets ONE contiguous eighth of the blocks: fuse_data_kernel 15.9 -> 13.7 us, fuse_update_index_kernel 11.7 -> 9.9
+// (LABNOTES r5; the passes over the STORE in its own order -- clean_flag, clean_scatter -- gain nothing or lose a microsecond
+// and keep the plain order).  A permutation of who does what: results are the same bits (MMF_XCD=0 / mmf_debug_set_xcd(0):
+// the identity).
+__device__ int g_xcd_blocks = 1;
+__device__ __forceinline__ unsigned xcd_block(unsigned bx, unsigned nb) {
+    if (nb < 16u || !g_xcd_blocks) return bx;
+    const unsigned x = bx & 7u, slot = bx >> 3, q = nb >> 3, r = nb & 7u;
+    return x * q + min(x, r) + slot;
+}
+
 }  // namespace mmf

@@ -114,6 +114,7 @@ struct mmf_ctx {
     int cu_count = 0;  // compute units of the device (the one-launch Gauss-Newton chain needs its grid resident at once)
 };
 
+static std::atomic<int> g_xcd_forced{-1};  // mmf_debug_set_xcd
 extern "C" int mmf_ctx_create(int device, void* stream, int private_stream, mmf_ctx** out) {
     MMF_REQUIRE(out != nullptr, "mmf_ctx_create: out is null");
     int count = 0;
@@ -151,7 +152,20 @@ extern "C" int mmf_ctx_create(int device, void* stream, int private_stream, mmf_
     MMF_HIP_TRY(hipEventCreate(&c->ev0));
     MMF_HIP_TRY(hipEventCreate(&c->ev1));
     MMF_HIP_TRY(hipStreamSynchronize(c->stream));
+    {  // (surfel_kernels.hpp: xcd_block)
+        const int on = g_xcd_forced.load() < 0 ? (tunables().xcd_blocks ? 1 : 0) : g_xcd_forced.load();
+        MMF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_blocks), &on, sizeof(on)));
+    }
     *out = c;
+    return MMF_OK;
+}
+// test / A-B hook: every XCD works on one contiguous eighth of a surfel pass's blocks (1, the default) or the blocks are dealt
+// round-robin as the workgroups are (0); -1 = the default (MMF_XCD).  A device-wide word: set while no pass is running.
+extern "C" int mmf_debug_set_xcd(int on) {
+    g_xcd_forced.store(on < 0 ? -1 : (on ? 1 : 0));
+    const int v = on < 0 ? (tunables().xcd_blocks ? 1 : 0) : (on ? 1 : 0);
+    MMF_HIP_TRY(hipDeviceSynchronize());
+    MMF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_blocks), &v, sizeof(v)));
     return MMF_OK;
 }
 

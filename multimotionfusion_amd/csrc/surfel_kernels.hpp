@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(256) void fuse_data_kernel(const uint8_t* __restric
                                                         const unsigned* __restrict__ index, const float4* __restrict__ vertConf,
                                                         const float4* __restrict__ normRad, FuseArgs a_in, SurfelSoA meas,
                                                         unsigned* __restrict__ new_flags, unsigned* __restrict__ winner) {
-    fuse_data_kernel_body(rgb, depth_raw, depth_fil, mask, index, vertConf, normRad, a_in, meas, new_flags, winner, blockIdx.x, gridDim.x);
+    fuse_data_kernel_body(rgb, depth_raw, depth_fil, mask, index, vertConf, normRad, a_in, meas, new_flags, winner, xcd_block(blockIdx.x, gridDim.x), gridDim.x);
 }
 
 // update.vert:38-111, in place (each surfel only touches itself); resets winner[] for the next frame
@@ -1261,7 +1261,7 @@ __device__ __forceinline__ void fuse_update_index_kernel_body(SurfelSoA s, int c
 __global__ __launch_bounds__(256) void fuse_update_index_kernel(SurfelSoA s, int count, SurfelSoA meas, int time,
                                                                 unsigned* __restrict__ winner, IndexArgs a_in,
                                                                 unsigned long long* __restrict__ keys) {
-    fuse_update_index_kernel_body(s, count, meas, time, winner, a_in, keys, blockIdx.x, gridDim.x);
+    fuse_update_index_kernel_body(s, count, meas, time, winner, a_in, keys, xcd_block(blockIdx.x, gridDim.x), gridDim.x);
 }
 
 // ---- clean: copy_unstable.vert:53-150 ---------------------------------------------------------------

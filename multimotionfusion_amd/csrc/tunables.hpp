@@ -39,6 +39,7 @@ struct Tunables {
                               // are (pass_rect.hpp).  All bit-identical.  -1 (default): 2 from four object models on a GPU, else 0 -- the restricted
                               // launches do 9 % less GPU work with a fifth of the launches, which pays once the calling thread's ~11 launches per
                               // model are what the GPU waits for (LABNOTES r5)
+    bool xcd_blocks = true;   // MMF_XCD=0: the blocks of a surfel pass are dealt to the XCDs round-robin, as the workgroups are (else: a contiguous eighth per XCD)
     int splat_wgs = 0;        // MMF_SPLAT_WGS: workgroups of a splat launch (0 = by the store's size)
     int splat_bound = -1;     // MMF_SPLAT_BOUND=0|1: the bounded depth test never / always (-1 = by the store's size)
 };
@@ -77,6 +78,7 @@ inline const Tunables& tunables() {
         v.track_cull = (int)num("MMF_TRACK_CULL", 1);
         v.spec_prep_all = (int)num("MMF_SPEC_PREP_ALL", 2);
         v.pass_batch = (int)num("MMF_PASS_BATCH", -1);
+        v.xcd_blocks = flag("MMF_XCD", true);
         v.splat_wgs = (int)num("MMF_SPLAT_WGS", 0);
         if (std::getenv("MMF_SPLAT_BOUND")) v.splat_bound = num("MMF_SPLAT_BOUND", 0) ? 1 : 0;
         return v;
