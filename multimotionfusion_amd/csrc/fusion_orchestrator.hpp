@@ -823,7 +823,9 @@ static int fusion_process_frame_impl(mmf_fusion* f, const mmf_frame* fr) {
             // and two host calls per model at the point of the call where the GPU waits for the calling thread.
             int will_track = 0;
             for (size_t k = 0; k < n_models; ++k) will_track += fusion_owns(f, k) ? 1 : 0;
-            const bool will_batch = will_track > 1 && will_track <= kMaxBatch && !have_init && g.batch_tracking;
+            // (only where the camera model leads the chain: its stream is the one the sensor side and the end-of-frame preparation
+            // are ordered on; a rank of a sharded run that holds object models only keeps every wait)
+            const bool will_batch = will_track > 1 && will_track <= kMaxBatch && !have_init && g.batch_tracking && fusion_owns(f, 0);
             std::vector<FusionModel*> tracked;
             for (size_t k = 0; k < n_models; ++k) {  // :312-387, enqueue only
                 FusionModel* fm = f->models[k];
