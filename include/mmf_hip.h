@@ -544,10 +544,11 @@ int mmf_debug_set_mid_predict(int on);
  * surfels per pixel or more (the default).  Process wide. */
 int mmf_debug_set_splat_bound(int mode);
 /* test / A-B hook: the projection / fuse / clean / predict passes of the OBJECT models of a frame: 0 = model by model on the models' own
- * streams (the default), 1 = one launch per pass for all of them, each covering the whole frame (csrc/surfel_kernels.hpp:
+ * streams, 1 = one launch per pass for all of them, each covering the whole frame (csrc/surfel_kernels.hpp:
  * *_batched_kernel -- the same kernel bodies, gridDim.y = model), 2 = one launch per pass restricted to where each model is
  * (csrc/pass_rect.hpp: the boxes of its key-image writes, of its non-zero images and of its id in the id image), -1 = the
- * default (MMF_PASS_BATCH).  Same maps and images, bit for bit, in all three.  Process wide. */
+ * default (MMF_PASS_BATCH, or by the number of object models a GPU runs: 2 from four on, 0 below).  Same maps and images, bit
+ * for bit, in all three, also across a frame in which the mode changes.  Process wide. */
 int mmf_debug_set_pass_batch(int mode);
 /* test / A-B hook: an OBJECT model's model-side preparation (Model::initICPModel / initRGBModel's pyramids, records and point
  * clouds) covers only the box its prediction is non-zero in -- the hull of that box now and at its previous preparation, so

@@ -608,8 +608,8 @@ static int fusion_fuse_clean_model(mmf_fusion* f, FusionModel* fm, float weighti
 // getMaxDepth (:408): float operands, double arithmetic (1.2 is a double literal), returned as float
 static float seg_max_depth(const mmf_segmentation_model& d) { return (float)((double)d.depth_mean + (double)d.depth_std * 1.2); }
 
-// test / A-B hook: the object models' passes as one launch per pass for all of them (1, the default) or model by model (0)
-static std::atomic<int> g_batch_passes{-1};  // -1: MMF_PASS_BATCH decides (default on)
+// test / A-B hook: how the object models' passes go out (fusion_batch_mode)
+static std::atomic<int> g_batch_passes{-1};  // -1: MMF_PASS_BATCH / the number of object models decide
 extern "C" int mmf_debug_set_pass_batch(int mode) {
     g_batch_passes.store(mode < 0 ? -1 : (mode > 2 ? 2 : mode));
     return MMF_OK;
