@@ -564,6 +564,8 @@ int mmf_debug_set_prep_rect(int on);
  * xcd_block) or the blocks are dealt round-robin as the workgroups are (0); -1 = the default (MMF_XCD).  Same bits.  Synchronises
  * the device; process wide. */
 int mmf_debug_set_xcd(int on);
+/* the block workgroup `block` of a launch of `blocks` works on under that mapping (a host function: needs no device) */
+unsigned mmf_debug_xcd_block(unsigned block, unsigned blocks);
 int mmf_debug_set_begin_rider(int on);
 int mmf_debug_begin_rider_count(void);
 /* test / A-B hook: object models in the producer + step chain (csrc/extent.hpp, ChainGeom: their passes skip the blocks outside

@@ -212,6 +212,7 @@ SIGNATURES = {
     "mmf_debug_set_pass_batch": (_i, [_i]),
     "mmf_debug_set_prep_rect": (_i, [_i]),
     "mmf_debug_set_xcd": (_i, [_i]),
+    "mmf_debug_xcd_block": (C.c_uint, [C.c_uint, C.c_uint]),
     "mmf_debug_set_begin_rider": (_i, [_i]),
     "mmf_debug_begin_rider_count": (_i, []),
     "mmf_debug_set_sparse_groups": (_i, [_i]),

@@ -56,11 +56,12 @@ __device__ __forceinline__ int float2int_rn(float x) {
 // (LABNOTES r5; the passes over the STORE in its own order -- clean_flag, clean_scatter -- gain nothing or lose a microsecond
 // and keep the plain order).  A permutation of who does what: results are the same bits (MMF_XCD=0 / mmf_debug_set_xcd(0):
 // the identity).
-__device__ int g_xcd_blocks = 1;
-__device__ __forceinline__ unsigned xcd_block(unsigned bx, unsigned nb) {
-    if (nb < 16u || !g_xcd_blocks) return bx;
+__host__ __device__ inline unsigned xcd_block_of(unsigned bx, unsigned nb) {  // (a permutation of [0, nb): tests/test_capi_exports.py)
+    if (nb < 16u) return bx;
     const unsigned x = bx & 7u, slot = bx >> 3, q = nb >> 3, r = nb & 7u;
-    return x * q + min(x, r) + slot;
+    return x * q + (x < r ? x : r) + slot;
 }
+__device__ int g_xcd_blocks = 1;
+__device__ __forceinline__ unsigned xcd_block(unsigned bx, unsigned nb) { return g_xcd_blocks ? xcd_block_of(bx, nb) : bx; }
 
 }  // namespace mmf

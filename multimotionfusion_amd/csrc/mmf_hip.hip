@@ -161,6 +161,7 @@ extern "C" int mmf_ctx_create(int device, void* stream, int private_stream, mmf_
 }
 // test / A-B hook: every XCD works on one contiguous eighth of a surfel pass's blocks (1, the default) or the blocks are dealt
 // round-robin as the workgroups are (0); -1 = the default (MMF_XCD).  A device-wide word: set while no pass is running.
+extern "C" unsigned mmf_debug_xcd_block(unsigned block, unsigned blocks) { return xcd_block_of(block, blocks); }  // (host: no device needed)
 extern "C" int mmf_debug_set_xcd(int on) {
     g_xcd_forced.store(on < 0 ? -1 : (on ? 1 : 0));
     const int v = on < 0 ? (tunables().xcd_blocks ? 1 : 0) : (on ? 1 : 0);

@@ -42,6 +42,28 @@ def test_no_device_is_reported_not_emulated():
         Context(0)
 
 
+def test_xcd_block_mapping_is_a_permutation_with_one_contiguous_run_per_xcd():
+    """csrc/device_math.hpp: xcd_block.  The workgroups of a launch go to the eight XCDs round-robin by their index; the surfel
+    passes whose neighbouring blocks share cache lines give every XCD ONE contiguous run of the blocks.  Host logic, no device:
+    the mapping must be a permutation of the blocks (every block worked on exactly once -- clean's ordered compaction and the
+    rasterising passes rely on it), order preserving within an XCD, and contiguous per XCD."""
+    from multimotionfusion_amd import _capi
+    lib = _capi.load()
+    import random
+    rng = random.Random(7)
+    for nb in [1, 7, 15, 16, 17, 23, 24, 63, 64, 65, 300, 961, 1200, 2161] + [rng.randrange(16, 5000) for _ in range(60)]:
+        to = [lib.mmf_debug_xcd_block(b, nb) for b in range(nb)]
+        assert sorted(to) == list(range(nb)), nb
+        if nb < 16:
+            assert to == list(range(nb))
+            continue
+        for x in range(8):
+            mine = [to[b] for b in range(x, nb, 8)]  # the blocks of XCD x, in dispatch order
+            assert mine == list(range(mine[0], mine[0] + len(mine))), (nb, x)
+        starts = [to[x] for x in range(8)]
+        assert starts == sorted(starts) and starts[0] == 0, (nb, starts)
+
+
 def test_product_never_imports_the_oracle():
     """oracle/ is test infrastructure: nothing under multimotionfusion_amd/ may reference it."""
     pkg = os.path.join(REPO, "multimotionfusion_amd")
