@@ -1165,18 +1165,32 @@ struct PrepBuilder {  // the jobs of one stage (possibly of several models); lau
         return j;
     }
     // rider: the beginning of the tracking these jobs prepare, on one more workgroup of the stage's LAST launch (BeginRider)
+    template <int CAP>
+    static int fill(PrepBatchT<CAP>& b, const std::vector<PrepJob>& jobs, size_t first, bool critical) {
+        b.njobs = 0;
+        b.critical = critical ? 1 : 0;
+        int blocks = 0;
+        for (size_t k = first; k < jobs.size() && b.njobs < CAP; ++k) {
+            PrepJob& j = b.job[b.njobs++];
+            j = jobs[k];
+            j.first_block = blocks;
+            blocks += j.rect_now ? j.rect_groups : j.gx * ((j.rows + kTileY * j.reps - 1) / (kTileY * j.reps));
+        }
+        return blocks;
+    }
     int launch(Enqueuer& q, const BeginRider* rider = nullptr) {
+        if (jobs.size() > (size_t)kMaxPrepJobs && !rider) {  // several models' jobs: the wide table (prep_batch.hpp)
+            for (size_t first = 0; first < jobs.size(); first += kMaxPrepJobsWide) {
+                PrepBatchWide b;
+                const int blocks = fill(b, jobs, first, critical);
+                q.launch(prep_batch_wide_kernel, dim3(blocks), tile_block(), b);
+            }
+            jobs.clear();
+            return MMF_OK;
+        }
         for (size_t first = 0; first < jobs.size(); first += kMaxPrepJobs) {
             PrepBatch b;
-            b.njobs = 0;
-            b.critical = critical ? 1 : 0;
-            int blocks = 0;
-            for (size_t k = first; k < jobs.size() && b.njobs < kMaxPrepJobs; ++k) {
-                PrepJob& j = b.job[b.njobs++];
-                j = jobs[k];
-                j.first_block = blocks;
-                blocks += j.rect_now ? j.rect_groups : j.gx * ((j.rows + kTileY * j.reps - 1) / (kTileY * j.reps));
-            }
+            const int blocks = fill(b, jobs, first, critical);
             if (rider && first + kMaxPrepJobs >= jobs.size()) {
                 BeginRider r = *rider;
                 r.prep_blocks = blocks;

@@ -89,12 +89,19 @@ struct PrepJob {
     int rect_level, rect_groups;
 };
 
-constexpr int kMaxPrepJobs = 24;  // 24 x 144 B of kernel arguments; longer job lists go out as several launches
-struct PrepBatch {
+constexpr int kMaxPrepJobs = 24;  // 24 x 232 B of kernel arguments: what one model's stage (and a sensor side) needs
+// Several models' jobs of a stage share a launch (eight models: 24 + 64 jobs in two stages): the wide table carries a stage
+// of eight models in ONE launch -- as three launches of 24 the second stage was three launch latencies for jobs that do not
+// depend on each other (8 models: 31 + 22 + 14 + 11 us on the stream the next chain waits for).  Longer lists go out in chunks.
+constexpr int kMaxPrepJobsWide = 72;
+template <int CAP>
+struct PrepBatchT {
     int njobs;
     int critical;  // 1: on the model's stream (what a frame waits for): its waves ask for issue priority over side-stream work
-    PrepJob job[kMaxPrepJobs];
+    PrepJob job[CAP];
 };
+using PrepBatch = PrepBatchT<kMaxPrepJobs>;
+using PrepBatchWide = PrepBatchT<kMaxPrepJobsWide>;
 
 // transform_maps_px + pack_prev_kernel in one pass (same arithmetic; an invalid pixel's record is all NaN)
 // (v_ok / n_ok: the source vertex / normal is valid, i.e. its x is not NaN)
@@ -320,7 +327,8 @@ __device__ __forceinline__ void prep_job_px(const PrepJob& J, const void* src0, 
 }
 
 // workgroup `block` of the launch (64 x 4 threads)
-__device__ __forceinline__ void prep_batch_body(const PrepBatch& b, int block) {
+template <int CAP>
+__device__ __forceinline__ void prep_batch_body(const PrepBatchT<CAP>& b, int block) {
     if (b.critical) __builtin_amdgcn_s_setprio(3);
     int j = 0;
     for (int k = 1; k < b.njobs; ++k) j = block >= b.job[k].first_block ? k : j;  // wave uniform
@@ -384,5 +392,6 @@ __device__ __forceinline__ void prep_batch_body(const PrepBatch& b, int block) {
     }
 }
 __global__ __launch_bounds__(256) void prep_batch_kernel(PrepBatch b) { prep_batch_body(b, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void prep_batch_wide_kernel(PrepBatchWide b) { prep_batch_body(b, (int)blockIdx.x); }
 
 }  // namespace mmf
