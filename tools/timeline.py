@@ -6,7 +6,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-starts = [i for i, r in enumerate(rows) if "odom_begin_kernel" in r["Kernel_Name"]]
+# a frame starts where its tracking begins: odom_begin_kernel, or -- when that rode the last launch of the preparation enqueued
+# ahead of the frame -- that launch (prep_batch_begin_kernel)
+starts = [i for i, r in enumerate(rows) if "odom_begin_kernel" in r["Kernel_Name"] or "prep_batch_begin_kernel" in r["Kernel_Name"]]
 i0, i1 = starts[which], starts[which + 1]
 t0 = int(rows[i0]["Start_Timestamp"])
 j = i0
